@@ -1,0 +1,249 @@
+"""Golden-vector case table shared by make_goldens.py (runs the REAL reference,
+CPU container only) and the parity tests (oracle on CPU, HIP path on GPU).
+
+A case = policy + MODEL overrides + frame size + batch geometry + mode.
+Weights are not stored: they are regenerated from state_dict key names by
+oracle.thirdparty.synth_state_dict (seeded, construction-order independent).
+Inputs ARE stored in the .npz next to the expected outputs.
+"""
+import numpy as np
+import torch
+
+CASES = {
+    # BASELINE.json configs[0]: the reference's own CPU-runnable case
+    "seq2seq_act_128": dict(
+        policy="Seq2SeqPolicy", hw=128, N=2, T=1, lengths=[40, 33], mode="eval", call="act",
+    ),
+    "seq2seq_update_64": dict(
+        policy="Seq2SeqPolicy", hw=64, N=2, T=3, lengths=[9, 4], mode="train", call="update",
+        overrides={"SEQ2SEQ.use_prev_action": True, "PROGRESS_MONITOR.use": True},
+    ),
+    "seq2seq_lstm_state_64": dict(
+        policy="Seq2SeqPolicy", hw=64, N=3, T=2, lengths=[5, 11, 1], mode="eval", call="dist",
+        overrides={"STATE_ENCODER.rnn_type": "LSTM", "INSTRUCTION_ENCODER.rnn_type": "GRU"},
+    ),
+    "cma_act_64": dict(
+        policy="CMAPolicy", hw=64, N=3, T=1, lengths=[7, 5, 12], mode="eval", call="act",
+    ),
+    "cma_act_train_bn_64": dict(
+        policy="CMAPolicy", hw=64, N=4, T=1, lengths=[7, 5, 12, 3], mode="train", call="act",
+    ),
+    "cma_update_64": dict(
+        policy="CMAPolicy", hw=64, N=2, T=3, lengths=[6, 10], mode="train", call="update",
+        overrides={"PROGRESS_MONITOR.use": True, "PROGRESS_MONITOR.alpha": 0.5},
+    ),
+    "cma_cached_feats": dict(
+        policy="CMAPolicy", hw=256, N=2, T=4, lengths=[8, 3], mode="train", call="update",
+        cached=True,
+    ),
+    "cma_norm_ablate_64": dict(
+        policy="CMAPolicy", hw=64, N=2, T=1, lengths=[4, 9], mode="eval", call="dist",
+        overrides={"normalize_rgb": True, "ablate_depth": True},
+    ),
+    "waypoint_64": dict(
+        policy="WaypointPolicy", hw=64, N=2, T=1, lengths=[9, 14], mode="eval", call="waypoint",
+    ),
+    "waypoint_discrete_64": dict(
+        policy="WaypointPolicy", hw=64, N=2, T=1, lengths=[3, 6], mode="eval", call="waypoint",
+        overrides={"WAYPOINT.continuous_distance": False, "WAYPOINT.continuous_offset": False},
+    ),
+}
+
+VOCAB = 2504
+
+
+def build_inputs(case):
+    """Seeded synthetic inputs (BASELINE.md section 3 recipe)."""
+    c = case
+    g = torch.Generator().manual_seed(1)
+    N, T, hw = c["N"], c["T"], c["hw"]
+    B = N * T
+    pano = c["policy"] == "WaypointPolicy"
+    obs = {}
+    tok = torch.zeros(N, 200, dtype=torch.long)
+    for i, L in enumerate(c["lengths"]):
+        tok[i, :L] = torch.randint(1, VOCAB, (L,), generator=g)
+    obs["instruction"] = tok.repeat(T, 1)  # time-major rows: row = t*N + n
+    if c.get("cached"):
+        # hooks at dagger_trainer.py:300-314 cache the CNN trunk outputs
+        obs["rgb_features"] = torch.rand(B, 2048, 4, 4, generator=g) * 2.0
+        obs["depth_features"] = torch.rand(B, 128, 4, 4, generator=g)
+    elif pano:
+        obs["rgb"] = torch.randint(0, 256, (B, 12, hw, hw, 3), generator=g).float()
+        obs["depth"] = torch.rand(B, 12, hw, hw, 1, generator=g)
+        obs["rgb_history"] = torch.randint(0, 256, (B, hw, hw, 3), generator=g).float()
+        obs["depth_history"] = torch.rand(B, hw, hw, 1, generator=g)
+        obs["angle_features"] = torch.randn(B, 12, 4, generator=g)
+    else:
+        obs["rgb"] = torch.randint(0, 256, (B, hw, hw, 3), generator=g).float()
+        obs["depth"] = torch.rand(B, hw, hw, 1, generator=g)
+    obs["progress"] = torch.rand(B, 1, generator=g)
+    masks = torch.ones(T, N, 1, dtype=torch.uint8)
+    masks[0] = 0  # collate_fn: not_done_masks[0] = 0 (dagger_trainer.py:90-111)
+    if T > 2:
+        masks[2, 0] = 0  # an episode boundary mid-sequence
+    if T == 1 and N > 1:
+        masks[0, 1:] = 1  # act(): mix of fresh and running episodes
+    masks = masks.view(B, 1)
+    extra = {}
+    if pano:
+        prev = {
+            "pano": torch.randint(0, 12, (B, 1), generator=g),
+            "offset": (torch.rand(B, 1, generator=g) - 0.5) * 0.4,
+            "distance": 0.25 + torch.rand(B, 1, generator=g) * 2.0,
+        }
+        if not c.get("overrides", {}).get("WAYPOINT.continuous_offset", True):
+            prev["offset"] = torch.randint(0, 7, (B, 1), generator=g)
+            prev["distance"] = torch.randint(0, 6, (B, 1), generator=g)
+        extra["hidden"] = 256
+    else:
+        prev = torch.randint(0, 4, (B, 1), generator=g)
+        extra["hidden"] = 512
+    extra["targets"] = torch.randint(0, 4, (T, N), generator=g)
+    w = torch.rand(T, N, generator=g) + 0.5
+    if T > 1:
+        w[-1, 0] = 0.0  # padded step of a shorter episode
+    extra["weights"] = w
+    extra["h0"] = 0.1 * torch.randn(N, 2, extra["hidden"], generator=g)
+    return obs, prev, masks, extra
+
+
+def to_numpy_tree(d, prefix=""):
+    out = {}
+    for k, v in d.items():
+        if isinstance(v, dict):
+            out.update(to_numpy_tree(v, prefix + k + "/"))
+        elif isinstance(v, torch.Tensor):
+            out[prefix + k] = v.detach().cpu().numpy()
+        elif v is None:
+            continue
+        else:
+            out[prefix + k] = np.asarray(v)
+    return out
+
+
+def build_policy(ns, case, make_config, make_spaces, synth_state_dict):
+    """ns: namespace exposing Seq2SeqPolicy / CMAPolicy / WaypointPolicy."""
+    cfg = make_config(case["policy"], **case.get("overrides", {}))
+    pano = case["policy"] == "WaypointPolicy"
+    obs_space, act_space = make_spaces(case["hw"], case["hw"], pano=pano)
+    policy = getattr(ns, case["policy"]).from_config(cfg, obs_space, act_space)
+    policy.load_state_dict(synth_state_dict(policy))
+    if case["mode"] == "eval":
+        policy.eval()
+    # mode == "train": leave exactly as constructed (Net.__init__ ends with
+    # self.train(): frozen CNN's BatchNorm runs on batch statistics, App. B-1)
+    return policy, cfg
+
+
+_BN_PROBES = [
+    "net.rgb_encoder.cnn.1.running_mean",
+    "net.rgb_encoder.cnn.1.running_var",
+    "net.rgb_encoder.cnn.1.num_batches_tracked",
+    "net.rgb_encoder.cnn.7.1.bn2.running_mean",
+    "net.rgb_encoder.cnn.7.1.bn2.running_var",
+]
+
+
+def run_case(policy, case, obs, prev, masks, extra, update_fn=None, aux=None):
+    """Runs one case through any implementation of the policy surface and
+    returns {name: tensor}.  `update_fn(policy, obs, prev, masks, targets,
+    weights) -> (loss, action_loss, aux_loss)` must leave .grad populated and
+    NOT step (step_grad=False)."""
+    out = {}
+    L = policy.net.num_recurrent_layers
+    h0 = extra["h0"][:, :L].contiguous()
+    call = case["call"]
+    dev = h0.device
+    if call == "act":
+        with torch.no_grad():
+            a, h = policy.act(obs, h0, prev, masks, deterministic=True)
+            out["actions"], out["rnn_states"] = a, h
+            out["logits"] = policy.build_distribution(obs, h0, prev, masks).logits
+    elif call == "dist":
+        with torch.no_grad():
+            out["logits"] = policy.build_distribution(obs, h0, prev, masks).logits
+    elif call == "update":
+        if aux is not None:
+            aux.activate()
+        loss, al, xl = update_fn(policy, obs, prev, masks, extra["targets"], extra["weights"])
+        if aux is not None:
+            aux.deactivate()
+        out["loss"] = torch.tensor([loss, al, xl], dtype=torch.float64)
+        names, norms = [], []
+        for n, p in policy.named_parameters():
+            if p.grad is not None:
+                names.append(n)
+                norms.append(p.grad.double().norm().item())
+        out["grad_names"] = np.array(names)
+        out["grad_norms"] = torch.tensor(norms, dtype=torch.float64)
+        out["grad_action_w"] = policy.action_distribution.linear.weight.grad
+        if hasattr(policy.net, "state_q"):
+            out["grad_state_q_w"] = policy.net.state_q.weight.grad
+        out["grad_ins_w_hh"] = policy.net.instruction_encoder.encoder_rnn.weight_hh_l0.grad
+    elif call == "waypoint":
+        with torch.no_grad():
+            pa = {k: v.clone() for k, v in prev.items()}
+            (value, _acts, elems, modes, variances, logp, h, pdist) = policy.act(
+                obs, h0, pa, masks, deterministic=True
+            )
+            out.update(value=value, logp=logp, rnn_states=h, pano_logits=pdist.logits)
+            for k, v in elems.items():
+                out["elem_" + k] = v
+            for k, v in modes.items():
+                out["mode_" + k] = v
+            for k, v in variances.items():
+                out["var_" + k] = v
+            pa = {k: v.clone() for k, v in prev.items()}
+            v2, lp2, ent, h2 = policy.evaluate_actions(obs, h0, pa, masks, elems)
+            out.update(ev_value=v2, ev_logp=lp2, ev_rnn_states=h2)
+            for k, v in ent.items():
+                out["ent_" + k] = v
+            pa = {k: v.clone() for k, v in prev.items()}
+            out["get_value"] = policy.get_value(obs, h0, pa, masks)
+    else:
+        raise ValueError(call)
+    if case["mode"] == "train" and not case.get("cached"):
+        sd = policy.state_dict()
+        for k in _BN_PROBES:
+            if k in sd:
+                out["bn/" + k] = sd[k].detach().clone().float()
+    return {k: (v.detach().cpu() if isinstance(v, torch.Tensor) else v) for k, v in out.items()}
+
+
+def save_case(path, case_name, obs, prev, masks, extra, outputs):
+    blob = {}
+    ins = dict(obs=dict(obs), masks=masks, extra=extra)
+    ins["prev"] = prev if isinstance(prev, dict) else {"_": prev}
+    for k in list(ins["obs"].keys()):
+        if k.startswith("rgb") and not k.endswith("features"):
+            ins["obs"][k] = ins["obs"][k].to(torch.uint8)  # integer-valued: exact
+    blob.update(to_numpy_tree(ins, "in/"))
+    blob.update(to_numpy_tree(outputs, "out/"))
+    np.savez_compressed(path, **blob)
+
+
+def load_case(path, device="cpu"):
+    z = np.load(path, allow_pickle=False)
+    obs, prev, extra, outs = {}, {}, {}, {}
+    masks = None
+    for k in z.files:
+        v = z[k]
+        if k.startswith("out/"):
+            outs[k[4:]] = v if v.dtype.kind in "US" else torch.from_numpy(v)
+            continue
+        t = torch.from_numpy(v)
+        if k.startswith("in/obs/"):
+            name = k[7:]
+            if t.dtype == torch.uint8:
+                t = t.float()
+            obs[name] = t.to(device)
+        elif k.startswith("in/prev/"):
+            prev[k[8:]] = t.to(device)
+        elif k == "in/masks":
+            masks = t.to(device)
+        elif k.startswith("in/extra/"):
+            extra[k[9:]] = t.to(device) if t.dim() > 0 else int(t)
+    if list(prev.keys()) == ["_"]:
+        prev = prev["_"]
+    return obs, prev, masks, extra, outs
