@@ -1,0 +1,201 @@
+/*
+ * vlnce_hip.h -- C ABI of libvlnce_hip.so: hand-written CDNA4 (gfx950) kernels
+ * for VLN-CE's per-step policy hot path (vlnce_baselines/models/ of the
+ * reference).  The reference is pure Python on torch/cuDNN and has no FFI of
+ * its own; each entry point below names the torch operator call site in the
+ * reference that it replaces (file:line relative to /root/reference).
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on error; the message is
+ *     available through vlnce_last_error() (thread-local).
+ *   - all pointers are DEVICE pointers valid on `stream`; the library never
+ *     allocates, never synchronises and keeps no mutable global state besides
+ *     the error string.  Workspaces are caller-allocated.
+ *   - activations are fp32, channels-last: images [N,H,W,C], matrices row-major.
+ *   - `stream` is a hipStream_t passed as void* (0 = default stream).
+ */
+#ifndef VLNCE_HIP_H
+#define VLNCE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* vlnce_stream_t;
+
+enum { VLNCE_ACT_NONE = 0, VLNCE_ACT_RELU = 1, VLNCE_ACT_SIGMOID = 2, VLNCE_ACT_TANH = 3 };
+
+int vlnce_version(void);
+const char* vlnce_last_error(void);
+
+/* ---------------------------------------------------------------- conv / GEMM
+ * Implicit-GEMM convolution on v_mfma_f32_32x32x2_f32 (exact fp32):
+ *   Y[m, co] = epilogue( sum_{r,q,ci} prologue(X[n, ho*s-p+r, wo*s-p+q, ci]) * W[co, r, q, ci] )
+ * with m = (n*Ho + ho)*Wo + wo.  Replaces nn.Conv2d(+BatchNorm2d/+ReLU/+add) of
+ * the torchvision trunk (models/encoders/resnet_encoders.py:136-139,199) and of
+ * habitat's GroupNorm ResNetEncoder (resnet_encoders.py:31-43,95).
+ */
+typedef struct {
+  int N, H, W, Cin;   /* input  [N,H,W,Cin], pixel stride ldx floats (>= Cin) */
+  int Cout, KH, KW;   /* weight [Cout,KH,KW,Cin] ("OHWI"), contiguous          */
+  int stride, pad;
+  int Ho, Wo;         /* output [N,Ho,Wo,Cout], row stride ldy floats (>= Cout) */
+  int ldx, ldy;
+} vlnce_conv_desc;
+
+typedef struct {
+  /* input transform applied in the A-operand loader BEFORE zero padding:
+   *   x' = act(x * in_scale[ci] + in_shift[ci]);  NULL = identity.
+   * Used for the RGB stem's /255 (+ImageNet mean/std, resnet_encoders.py:171-192)
+   * and to apply the previous layer's BatchNorm+ReLU on the fly. */
+  const float* in_scale;
+  const float* in_shift;
+  int in_relu;
+} vlnce_prologue;
+
+typedef struct {
+  const float* scale;     /* [Cout] per-channel multiplier or NULL (folded eval-BN gamma/sqrt(var+eps)) */
+  const float* shift;     /* [Cout] per-channel add or NULL (bias / folded BN shift)                    */
+  const float* residual;  /* [M,Cout] (row stride ldr) added before the activation, or NULL            */
+  int ldr;
+  int act;                /* VLNCE_ACT_*                                                               */
+  int accumulate;         /* Y += result (after activation) instead of Y = result                      */
+  /* train-mode BatchNorm: per-(M-tile, channel) partial statistics of the RAW
+   * accumulator (before scale/shift): float2 {sum, M2 about the tile mean}.
+   * Layout [tiles_m][Cout][2]; tiles_m from vlnce_conv2d_tiles_m(). NULL = off. */
+  float* stat_partial;
+} vlnce_epilogue;
+
+int vlnce_conv2d_tiles_m(const vlnce_conv_desc* d);   /* rows of stat_partial  */
+int vlnce_conv2d_tile_rows(const vlnce_conv_desc* d); /* BM chosen for `d`      */
+
+int vlnce_conv2d_fwd(const float* x, const float* w_ohwi, float* y,
+                     const vlnce_conv_desc* d, const vlnce_prologue* pro,
+                     const vlnce_epilogue* epi, vlnce_stream_t stream);
+
+/* General GEMM  C[M,N] = act( op(A)[M,K] * op(B)[K,N] * scale[n] + shift[n] + R )
+ *   transA = 0: A is [M,K] row-major (lda)     transA = 1: A is stored [K,M] (lda)
+ *   transB = 0: B is [N,K] row-major (ldb)  -- i.e. an nn.Linear weight
+ *   transB = 1: B is stored [K,N] row-major (ldb)
+ * Replaces nn.Linear / 1x1 nn.Conv1d forward and their dgrad/wgrad
+ * (cma_policy.py:103-119,140-170; seq2seq_policy.py:109-121;
+ * waypoint_predictors.py:76-180; policy.py:19-21).
+ */
+int vlnce_gemm(const float* A, int lda, int transA, const float* B, int ldb, int transB,
+               float* C, int ldc, int M, int N, int K,
+               const vlnce_epilogue* epi, vlnce_stream_t stream);
+
+/* column sums: out[n] (+)= sum_m X[m,n]  (bias gradients) */
+int vlnce_colsum(const float* x, int ldx, int M, int N, float* out, int accumulate,
+                 vlnce_stream_t stream);
+
+/* ------------------------------------------------------------- normalisation
+ * BatchNorm2d (torchvision trunk; eps 1e-5, momentum 0.1; SURVEY App. B-1:
+ * runs on batch statistics whenever the policy was not .eval()'d).
+ * vlnce_bn_finalize reduces the conv epilogue's partials (Chan's parallel
+ * variance, fp64 combine) into per-channel scale/shift and updates the running
+ * statistics exactly like torch (unbiased running_var). */
+int vlnce_bn_finalize(const float* stat_partial, int tiles_m, int tile_rows, int M, int C,
+                      const float* gamma, const float* beta, float eps, float momentum,
+                      float* running_mean, float* running_var, /* may be NULL */
+                      float* scale_out, float* shift_out,
+                      float* mean_out, float* rstd_out, /* may be NULL; saved for backward */
+                      vlnce_stream_t stream);
+
+/* y = act(x * scale[s, c] + shift[s, c] + residual)   with s = row / rows_per_sample
+ * (rows_per_sample = 0 => one scale/shift vector for all rows: BatchNorm apply;
+ *  > 0 => per-sample vectors [Nsamples, C]: GroupNorm apply). */
+int vlnce_scale_shift_act(const float* x, const float* scale, const float* shift,
+                          int rows_per_sample, const float* residual, float* y,
+                          long M, int C, int act, vlnce_stream_t stream);
+
+/* GroupNorm (habitat depth trunk: ngroups 16, and GroupNorm(1,C) in the
+ * compression block; eps 1e-5).  Two launches: partial sums per
+ * (sample, pixel-chunk, channel) then a finalize that emits per-(sample,channel)
+ * scale/shift for vlnce_scale_shift_act. */
+int vlnce_gn_chunks(int HW);
+int vlnce_gn_partial(const float* x, int Nimg, int HW, int C, float* partial /* [N,chunks,C,2] */,
+                     vlnce_stream_t stream);
+int vlnce_gn_finalize(const float* partial, int Nimg, int HW, int C, int groups,
+                      const float* gamma, const float* beta, float eps,
+                      float* scale_out, float* shift_out, /* [N,C] */
+                      float* mean_out, float* rstd_out,   /* [N,groups] or NULL */
+                      vlnce_stream_t stream);
+
+/* ------------------------------------------------------------------ pooling
+ * NHWC. maxpool 3x3/s2/p1 (torchvision + habitat stems), avg_pool2d(2)
+ * (ResNetEncoder.forward), adaptive_avg_pool2d -> (OH,OW)
+ * (resnet_encoders.py:154-162; also the global 1x1 pool). */
+int vlnce_maxpool3x3s2(const float* x, float* y, int N, int H, int W, int C, int Ho, int Wo,
+                       vlnce_stream_t stream);
+int vlnce_avgpool2x2(const float* x, float* y, int N, int H, int W, int C, vlnce_stream_t stream);
+int vlnce_adaptive_avgpool(const float* x, float* y, int N, int H, int W, int C, int OH, int OW,
+                           int ldy, vlnce_stream_t stream);
+
+/* ---------------------------------------------------------------- attention
+ * One query per batch row against P keys:  logits[i] = <q, K[i]>;
+ *   mask_mode 1 (additive, CMANet._attn cma_policy.py:207-217): logits -= mask*1e8
+ *   mask_mode 2 (multiplicative, DotProductAttention utils.py:173-177): logits *= mask
+ *   attn = softmax(logits * scale);  out = sum_i attn[i] * V[i]
+ * K: [B,P,Dk] (row stride ldk), V: [B,P,Dv] (row stride ldv), mask: uint8 [B,P] or NULL.
+ * attn_out [B,P] is saved for the backward.  P <= 1024. */
+int vlnce_attn_fwd(const float* q, const float* K, int ldk, const float* V, int ldv,
+                   const uint8_t* mask, int mask_mode, float scale,
+                   float* out, float* attn_out, int B, int P, int Dk, int Dv,
+                   vlnce_stream_t stream);
+int vlnce_attn_bwd(const float* dout, const float* q, const float* K, int ldk,
+                   const float* V, int ldv, const uint8_t* mask, int mask_mode, float scale,
+                   const float* attn, float* dq, float* dK, int lddk, float* dV, int lddv,
+                   int B, int P, int Dk, int Dv, vlnce_stream_t stream);
+/* mask[b,i] = all_c(x[b,i,c] == 0)   (text_mask, cma_policy.py:260) */
+int vlnce_rowzero_mask(const float* x, int ld, long rows, int C, uint8_t* mask,
+                       vlnce_stream_t stream);
+
+/* --------------------------------------------------------- recurrent cells
+ * GRU / LSTM pointwise gate stage (torch.nn.GRU/LSTM semantics, gate order
+ * r,z,n / i,f,g,o) with the done-mask already applied to h_prev by the caller
+ * through `mask` (h_prev_eff = h_prev * mask[b]); gi = x W_ih^T + b_ih and
+ * gh = h_prev_eff W_hh^T + b_hh come from vlnce_gemm.  Replaces habitat's
+ * RNNStateEncoder single/seq forward (seq2seq_policy.py:164, cma_policy.py:
+ * 249-256,287-294, waypoint_predictors.py:420-427,532-545). */
+int vlnce_gru_gates_fwd(const float* gi, const float* gh, const float* h_prev,
+                        const uint8_t* mask, /* [B] or NULL */
+                        float* h_out, float* gates_out /* [B,3H] r,z,n saved */,
+                        float* hn_out /* [B,H] saved W_hn h + b_hn */,
+                        int B, int H, vlnce_stream_t stream);
+int vlnce_gru_gates_bwd(const float* dh_out, const float* gates, const float* hn,
+                        const float* h_prev, const uint8_t* mask,
+                        float* dgi, float* dgh, float* dh_prev, int B, int H,
+                        vlnce_stream_t stream);
+int vlnce_lstm_gates_fwd(const float* gi, const float* gh, const float* c_prev,
+                         const uint8_t* mask, float* h_out, float* c_out,
+                         float* gates_out /* [B,4H] i,f,g,o activated */, int B, int H,
+                         vlnce_stream_t stream);
+int vlnce_lstm_gates_bwd(const float* dh_out, const float* dc_out, const float* gates,
+                         const float* c_prev, const float* c_out, const uint8_t* mask,
+                         float* dgates /* [B,4H] */, float* dc_prev, int B, int H,
+                         vlnce_stream_t stream);
+
+/* ---------------------------------------------------------------- utilities */
+/* y[b, c] = mean_p x[b, p, c]   (AdaptiveAvgPool1d(1) of rgb_linear, cma_policy.py:104) */
+int vlnce_mean_rows(const float* x, float* y, int B, int P, int C, vlnce_stream_t stream);
+/* x[b, :] *= mask[b]  (done-mask zeroing of the recurrent state; out may alias x) */
+int vlnce_mask_rows(const float* x, const uint8_t* mask, float* out, int B, int H,
+                    vlnce_stream_t stream);
+
+/* out[b, :] = mask[b] ? a[b, :] : b[b, :]  (NULL operand = zeros): packed-sequence
+ * semantics of the instruction RNN (steps past a sample's length keep the state
+ * and emit zeros, instruction_encoder.py:80-94). */
+int vlnce_select_rows(const uint8_t* mask, const float* a, const float* b, float* out, int B, int H,
+                      vlnce_stream_t stream);
+/* dz = dy * act'(.) written through the activation output y (ReLU/Sigmoid/Tanh backward). */
+int vlnce_act_bwd(const float* dy, const float* y, float* dz, long n, int act,
+                  vlnce_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VLNCE_HIP_H */

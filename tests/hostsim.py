@@ -1,0 +1,271 @@
+"""TEST INFRASTRUCTURE ONLY.  A tensor-level simulator of the C ABI
+(include/vlnce_hip.h) written with torch CPU ops, installed in place of
+vlnce_amd._lib.HipLib by the `hostsim` fixture so the *host-side* logic of the
+package (module wiring, layouts, weight packing, autograd pairing, sequence
+handling) can be exercised in the GPU-less container against the golden
+vectors.  It never ships in the product path: the package itself has no CPU
+fallback and raises when libvlnce_hip.so or a GPU is missing.
+
+Every method documents the contract of the kernel it stands in for; the GPU
+tests check the real kernels against the same contracts.
+"""
+import torch
+import torch.nn.functional as F
+
+
+def _act(v, act):
+    if act == 1:
+        return torch.relu(v)
+    if act == 2:
+        return torch.sigmoid(v)
+    if act == 3:
+        return torch.tanh(v)
+    return v
+
+
+def _mat(t, rows, cols, ld):
+    return t.as_strided((rows, cols), (ld, 1))
+
+
+class HostSim:
+    name = "hostsim"
+    TILE_ROWS = 128
+
+    # ---- conv / gemm
+    def conv2d_tiles(self, g):
+        M = g["N"] * g["Ho"] * g["Wo"]
+        return (M + self.TILE_ROWS - 1) // self.TILE_ROWS, self.TILE_ROWS
+
+    def conv2d_fwd(self, x, w, y, g, in_scale=None, in_shift=None, in_relu=0, scale=None,
+                   shift=None, residual=None, ldr=0, act=0, accumulate=0, stat_partial=None):
+        N, H, W, Cin, Cout = g["N"], g["H"], g["W"], g["Cin"], g["Cout"]
+        xi = x.as_strided((N, H, W, Cin), (H * W * g["ldx"], W * g["ldx"], g["ldx"], 1))
+        if in_scale is not None:
+            xi = xi * in_scale + in_shift
+            if in_relu:
+                xi = torch.relu(xi)
+        wk = w.view(Cout, g["KH"], g["KW"], Cin).permute(0, 3, 1, 2)
+        raw = F.conv2d(xi.permute(0, 3, 1, 2), wk, stride=g["stride"], padding=g["pad"])
+        raw = raw.permute(0, 2, 3, 1).reshape(-1, Cout)
+        M = raw.size(0)
+        if stat_partial is not None:
+            tm, tr = self.conv2d_tiles(g)
+            for t in range(tm):
+                blk = raw[t * tr:(t + 1) * tr]
+                stat_partial[t, :, 0] = blk.sum(0)
+                stat_partial[t, :, 1] = ((blk - blk.mean(0)) ** 2).sum(0)
+        v = raw
+        if scale is not None:
+            v = v * scale
+        if shift is not None:
+            v = v + shift
+        if residual is not None:
+            v = v + _mat(residual, M, Cout, ldr)
+        v = _act(v, act)
+        out = _mat(y, M, Cout, g["ldy"])
+        if accumulate:
+            out += v
+        else:
+            out.copy_(v)
+
+    def gemm(self, A, lda, transA, B, ldb, transB, Cm, ldc, M, N, K, scale=None, shift=None,
+             residual=None, ldr=0, act=0, accumulate=0):
+        a = _mat(A, K, M, lda).t() if transA else _mat(A, M, K, lda)
+        b = _mat(B, K, N, ldb) if transB else _mat(B, N, K, ldb).t()
+        v = a @ b
+        if scale is not None:
+            v = v * scale
+        if shift is not None:
+            v = v + shift
+        if residual is not None:
+            v = v + _mat(residual, M, N, ldr)
+        v = _act(v, act)
+        out = _mat(Cm, M, N, ldc)
+        if accumulate:
+            out += v
+        else:
+            out.copy_(v)
+
+    def colsum(self, x, ldx, M, N, out, accumulate=0):
+        s = _mat(x, M, N, ldx).sum(0)
+        if accumulate:
+            out += s
+        else:
+            out.copy_(s)
+
+    # ---- norms
+    def bn_finalize(self, partial, tiles_m, tile_rows, M, Cc, gamma, beta, eps, momentum,
+                    running_mean, running_var, scale_out, shift_out, mean_out=None, rstd_out=None):
+        p = partial.double()
+        n_t = torch.full((tiles_m,), float(tile_rows), dtype=torch.float64)
+        n_t[-1] = M - tile_rows * (tiles_m - 1)
+        mean = p[:, :, 0].sum(0) / M
+        m2 = (p[:, :, 1] + n_t[:, None] * (p[:, :, 0] / n_t[:, None] - mean) ** 2).sum(0)
+        var = m2 / M
+        rstd = 1.0 / torch.sqrt(var + eps)
+        sc = (gamma.double() if gamma is not None else 1.0) * rstd.float().double()
+        scale_out.copy_(sc.float())
+        shift_out.copy_(((beta if beta is not None else 0.0) - mean.float() * scale_out))
+        if mean_out is not None:
+            mean_out.copy_(mean.float())
+        if rstd_out is not None:
+            rstd_out.copy_(rstd.float())
+        if running_mean is not None:
+            unb = m2 / max(M - 1, 1)
+            running_mean.mul_(1 - momentum).add_(momentum * mean.float())
+            running_var.mul_(1 - momentum).add_(momentum * unb.float())
+
+    def scale_shift_act(self, x, scale, shift, rows_per_sample, residual, y, M, Cc, act):
+        v = x.reshape(M, Cc)
+        if rows_per_sample > 0:
+            S = M // rows_per_sample
+            v = v.view(S, rows_per_sample, Cc) * scale.view(S, 1, Cc) + shift.view(S, 1, Cc)
+            v = v.view(M, Cc)
+        else:
+            v = v * scale + shift
+        if residual is not None:
+            v = v + residual.reshape(M, Cc)
+        y.view(M, Cc).copy_(_act(v, act))
+
+    def gn_chunks(self, HW):
+        return (HW + 127) // 128
+
+    def gn_partial(self, x, Nimg, HW, Cc, partial):
+        xv = x.reshape(Nimg, HW, Cc)
+        for c in range(self.gn_chunks(HW)):
+            blk = xv[:, c * 128:(c + 1) * 128]
+            partial[:, c, :, 0] = blk.sum(1)
+            partial[:, c, :, 1] = (blk * blk).sum(1)
+
+    def gn_finalize(self, partial, Nimg, HW, Cc, groups, gamma, beta, eps, scale_out, shift_out,
+                    mean_out=None, rstd_out=None):
+        cpg = Cc // groups
+        p = partial.double().sum(1).view(Nimg, groups, cpg, 2).sum(2)
+        cnt = HW * cpg
+        mean = p[..., 0] / cnt
+        var = (p[..., 1] / cnt - mean * mean).clamp_min(0)
+        rstd = (1.0 / torch.sqrt(var + eps)).float()
+        sc = rstd.repeat_interleave(cpg, dim=1) * (gamma if gamma is not None else 1.0)
+        scale_out.copy_(sc)
+        shift_out.copy_((beta if beta is not None else 0.0)
+                        - mean.float().repeat_interleave(cpg, dim=1) * sc)
+        if mean_out is not None:
+            mean_out.copy_(mean.float())
+        if rstd_out is not None:
+            rstd_out.copy_(rstd)
+
+    # ---- pools
+    def maxpool3x3s2(self, x, y, N, H, W, Cc, Ho, Wo):
+        y.copy_(F.max_pool2d(x.permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1))
+
+    def avgpool2x2(self, x, y, N, H, W, Cc):
+        y.copy_(F.avg_pool2d(x.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1))
+
+    def adaptive_avgpool(self, x, y, N, H, W, Cc, OH, OW, ldy):
+        v = F.adaptive_avg_pool2d(x.permute(0, 3, 1, 2), (OH, OW)).permute(0, 2, 3, 1)
+        _mat(y, N * OH * OW, Cc, ldy).copy_(v.reshape(-1, Cc))
+
+    def mean_rows(self, x, y, B, P, Cc):
+        y.copy_(x.reshape(B, P, Cc).mean(1))
+
+    # ---- attention
+    @staticmethod
+    def _kv(t, B, P, D, ld):
+        return t.as_strided((B, P, D), (P * ld, ld, 1))
+
+    def attn_fwd(self, q, K, ldk, V, ldv, mask, mask_mode, scale, out, attn_out, B, P, Dk, Dv):
+        k = self._kv(K, B, P, Dk, ldk)
+        v = self._kv(V, B, P, Dv, ldv)
+        logits = torch.einsum("bd,bpd->bp", q, k)
+        if mask is not None and mask_mode == 1:
+            logits = logits - mask.float() * 1e8
+        if mask is not None and mask_mode == 2:
+            logits = logits * mask.float()
+        a = torch.softmax(logits * scale, dim=1)
+        if attn_out is not None:
+            attn_out.copy_(a)
+        out.copy_(torch.einsum("bp,bpd->bd", a, v))
+
+    def attn_bwd(self, dout, q, K, ldk, V, ldv, mask, mask_mode, scale, attn, dq, dK, lddk, dV,
+                 lddv, B, P, Dk, Dv):
+        k = self._kv(K, B, P, Dk, ldk)
+        v = self._kv(V, B, P, Dv, ldv)
+        da = torch.einsum("bd,bpd->bp", dout, v)
+        dl = attn * (da - (attn * da).sum(1, keepdim=True)) * scale
+        if mask is not None and mask_mode == 2:
+            dl = dl * mask.float()
+        if dV is not None:
+            self._kv(dV, B, P, Dv, lddv).copy_(attn.unsqueeze(2) * dout.unsqueeze(1))
+        if dK is not None:
+            self._kv(dK, B, P, Dk, lddk).copy_(dl.unsqueeze(2) * q.unsqueeze(1))
+        if dq is not None:
+            dq.copy_(torch.einsum("bp,bpd->bd", dl, k))
+
+    def rowzero_mask(self, x, ld, rows, Cc, mask):
+        mask.view(-1).copy_((_mat(x, rows, Cc, ld) == 0).all(1).to(torch.uint8))
+
+    # ---- recurrent cells
+    def gru_gates_fwd(self, gi, gh, h_prev, mask, h_out, gates_out, hn_out, B, H):
+        hp = h_prev if mask is None else h_prev * mask.view(B, 1).float()
+        ir, iz, inn = gi.view(B, 3 * H).split(H, 1)
+        hr, hz, hn = gh.view(B, 3 * H).split(H, 1)
+        r, z = torch.sigmoid(ir + hr), torch.sigmoid(iz + hz)
+        n = torch.tanh(inn + r * hn)
+        h_out.copy_((1 - z) * n + z * hp)
+        if gates_out is not None:
+            gates_out.copy_(torch.cat([r, z, n], 1))
+        if hn_out is not None:
+            hn_out.copy_(hn)
+
+    def gru_gates_bwd(self, dh_out, gates, hn, h_prev, mask, dgi, dgh, dh_prev, B, H):
+        mk = 1.0 if mask is None else mask.view(B, 1).float()
+        hp = h_prev * mk
+        r, z, n = gates.split(H, 1)
+        dn = dh_out * (1 - z)
+        dz = dh_out * (hp - n)
+        dnp = dn * (1 - n * n)
+        drp = dnp * hn * r * (1 - r)
+        dzp = dz * z * (1 - z)
+        dgi.copy_(torch.cat([drp, dzp, dnp], 1))
+        dgh.copy_(torch.cat([drp, dzp, dnp * r], 1))
+        dh_prev.copy_(dh_out * z * mk)
+
+    def lstm_gates_fwd(self, gi, gh, c_prev, mask, h_out, c_out, gates_out, B, H):
+        cp = c_prev if mask is None else c_prev * mask.view(B, 1).float()
+        i, f, g, o = (gi + gh).view(B, 4 * H).split(H, 1)
+        i, f, g, o = torch.sigmoid(i), torch.sigmoid(f), torch.tanh(g), torch.sigmoid(o)
+        c = f * cp + i * g
+        c_out.copy_(c)
+        h_out.copy_(o * torch.tanh(c))
+        if gates_out is not None:
+            gates_out.copy_(torch.cat([i, f, g, o], 1))
+
+    def lstm_gates_bwd(self, dh_out, dc_out, gates, c_prev, c_out, mask, dgates, dc_prev, B, H):
+        mk = 1.0 if mask is None else mask.view(B, 1).float()
+        cp = c_prev * mk
+        i, f, g, o = gates.split(H, 1)
+        tc = torch.tanh(c_out)
+        dh = dh_out if dh_out is not None else torch.zeros_like(c_out)
+        dc = (dc_out if dc_out is not None else 0) + dh * o * (1 - tc * tc)
+        dgates.copy_(torch.cat([dc * g * i * (1 - i), dc * cp * f * (1 - f), dc * i * (1 - g * g),
+                                dh * tc * o * (1 - o)], 1))
+        dc_prev.copy_(dc * f * mk)
+
+    def mask_rows(self, x, mask, out, B, H):
+        out.copy_(x.view(B, H) * mask.view(B, 1).float())
+
+    def select_rows(self, mask, a, b, out, B, H):
+        z = torch.zeros(B, H)
+        out.copy_(torch.where(mask.view(B, 1) != 0, a if a is not None else z,
+                              b if b is not None else z))
+
+    def act_bwd(self, dy, y, dz, n, act):
+        if act == 1:
+            r = dy * (y > 0)
+        elif act == 2:
+            r = dy * y * (1 - y)
+        elif act == 3:
+            r = dy * (1 - y * y)
+        else:
+            r = dy
+        dz.copy_(r)

@@ -1,0 +1,62 @@
+"""CPU tier: the package's HOST logic (module wiring, channels-last layouts,
+weight repacking, autograd pairing, sequence / packed-sequence handling,
+BatchNorm running-stat bookkeeping) run through tests/hostsim.py -- a
+tensor-level simulator of the C ABI -- against the golden vectors produced by
+the real reference.  The kernels themselves are checked on the GPU tier."""
+import os
+
+import pytest
+import torch
+
+import cases
+import hostsim
+import vlnce_amd
+from vlnce_amd import _lib
+from oracle import thirdparty as tp
+from test_oracle_golden import compare
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+torch.distributions.Distribution.set_default_validate_args(False)
+
+IL_CASES = [n for n, c in cases.CASES.items() if c["policy"] in vlnce_amd.baseline_registry._policies]
+
+
+@pytest.fixture()
+def sim(monkeypatch):
+    monkeypatch.setattr(_lib, "_LIB", hostsim.HostSim())
+    yield
+    assert _lib._LIB.name == "hostsim"
+
+
+def product_update(policy, obs, prev, masks, targets, weights):
+    from vlnce_amd.il_harness import update_agent
+
+    hs = policy.net.model_config.STATE_ENCODER.hidden_size
+    loss, al, xl = update_agent(policy, None, obs, prev, masks, targets, weights, hs,
+                                step_grad=False)
+    return loss.item(), al.item(), (xl.item() if isinstance(xl, torch.Tensor) else xl)
+
+
+@pytest.mark.parametrize("name", IL_CASES)
+def test_host_logic_matches_golden(sim, name):
+    case = cases.CASES[name]
+    obs, prev, masks, extra, gold = cases.load_case(os.path.join(GOLD, name + ".npz"))
+    policy, _ = cases.build_policy(vlnce_amd, case, vlnce_amd.make_config, vlnce_amd.make_spaces,
+                                   tp.synth_state_dict)
+    outs = cases.run_case(policy, case, obs, prev, masks, extra, product_update,
+                          vlnce_amd.AuxLosses)
+    compare(outs, gold, atol=1e-4, rtol=1e-4)
+
+
+def test_no_cpu_fallback_without_library(monkeypatch):
+    monkeypatch.setattr(_lib, "_LIB", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libvlnce_hip.so")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _lib.HipLib(_lib.LIB_PATH)
+
+
+def test_cpu_tensors_are_rejected_by_the_binding():
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("library not built")
+    with pytest.raises(RuntimeError, match="not on a GPU"):
+        _lib._ptr(torch.zeros(4))

@@ -1,0 +1,243 @@
+"""ctypes binding of libvlnce_hip.so (C ABI in include/vlnce_hip.h).
+
+`HipLib` exposes one method per C entry point, taking torch tensors where the
+C function takes device pointers (None -> NULL) and launching on torch's
+current HIP stream.  There is NO fallback: if the shared library is missing
+or a tensor is not on a GPU the call raises.  (tests/hostsim.py swaps in a
+tensor-level simulator of this class to exercise the *host* logic on CPU; it
+lives under tests/ and is never importable from the product.)
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvlnce_hip.so")
+
+_P = C.c_void_p
+_I = C.c_int
+_F = C.c_float
+_L = C.c_long
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, _I) for n in
+                ("N", "H", "W", "Cin", "Cout", "KH", "KW", "stride", "pad", "Ho", "Wo", "ldx", "ldy")]
+
+
+class Prologue(C.Structure):
+    _fields_ = [("in_scale", _P), ("in_shift", _P), ("in_relu", _I)]
+
+
+class Epilogue(C.Structure):
+    _fields_ = [("scale", _P), ("shift", _P), ("residual", _P), ("ldr", _I), ("act", _I),
+                ("accumulate", _I), ("stat_partial", _P)]
+
+
+_SIGNATURES = {
+    "vlnce_version": (_I, []),
+    "vlnce_last_error": (C.c_char_p, []),
+    "vlnce_conv2d_tiles_m": (_I, [C.POINTER(ConvDesc)]),
+    "vlnce_conv2d_tile_rows": (_I, [C.POINTER(ConvDesc)]),
+    "vlnce_conv2d_fwd": (_I, [_P, _P, _P, C.POINTER(ConvDesc), C.POINTER(Prologue),
+                              C.POINTER(Epilogue), _P]),
+    "vlnce_gemm": (_I, [_P, _I, _I, _P, _I, _I, _P, _I, _I, _I, _I, C.POINTER(Epilogue), _P]),
+    "vlnce_colsum": (_I, [_P, _I, _I, _I, _P, _I, _P]),
+    "vlnce_bn_finalize": (_I, [_P, _I, _I, _I, _I, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P]),
+    "vlnce_scale_shift_act": (_I, [_P, _P, _P, _I, _P, _P, _L, _I, _I, _P]),
+    "vlnce_gn_chunks": (_I, [_I]),
+    "vlnce_gn_partial": (_I, [_P, _I, _I, _I, _P, _P]),
+    "vlnce_gn_finalize": (_I, [_P, _I, _I, _I, _I, _P, _P, _F, _P, _P, _P, _P, _P]),
+    "vlnce_maxpool3x3s2": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "vlnce_avgpool2x2": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "vlnce_adaptive_avgpool": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "vlnce_attn_fwd": (_I, [_P, _P, _I, _P, _I, _P, _I, _F, _P, _P, _I, _I, _I, _I, _P]),
+    "vlnce_attn_bwd": (_I, [_P, _P, _P, _I, _P, _I, _P, _I, _F, _P, _P, _P, _I, _P, _I,
+                            _I, _I, _I, _I, _P]),
+    "vlnce_rowzero_mask": (_I, [_P, _I, _L, _I, _P, _P]),
+    "vlnce_gru_gates_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
+    "vlnce_gru_gates_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
+    "vlnce_lstm_gates_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
+    "vlnce_lstm_gates_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
+    "vlnce_mean_rows": (_I, [_P, _P, _I, _I, _I, _P]),
+    "vlnce_mask_rows": (_I, [_P, _P, _P, _I, _I, _P]),
+    "vlnce_select_rows": (_I, [_P, _P, _P, _P, _I, _I, _P]),
+    "vlnce_act_bwd": (_I, [_P, _P, _P, _L, _I, _P]),
+}
+
+
+def exported_symbols():
+    return sorted(_SIGNATURES)
+
+
+def load_cdll(path=LIB_PATH):
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{path} not found: build it with `python __graft_entry__.py` (hipcc, gfx950). "
+            "The VLN-CE policy path has no CPU fallback."
+        )
+    dll = C.CDLL(path)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(dll, name)  # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    return dll
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("libvlnce_hip: tensor is not on a GPU (no CPU fallback)")
+    return t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+class HipLib:
+    """Tensor-level view of the C ABI."""
+
+    name = "hip"
+
+    def __init__(self, path=LIB_PATH):
+        self.dll = load_cdll(path)
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError(f"{what} failed (rc={rc}): {self.dll.vlnce_last_error().decode()}")
+
+    # ---- conv / gemm
+    @staticmethod
+    def _desc(g):
+        return ConvDesc(*[int(g[k]) for k, _ in ConvDesc._fields_])
+
+    def conv2d_tiles(self, g):
+        d = self._desc(g)
+        return self.dll.vlnce_conv2d_tiles_m(C.byref(d)), self.dll.vlnce_conv2d_tile_rows(C.byref(d))
+
+    def conv2d_fwd(self, x, w, y, g, in_scale=None, in_shift=None, in_relu=0, scale=None,
+                   shift=None, residual=None, ldr=0, act=0, accumulate=0, stat_partial=None):
+        d = self._desc(g)
+        pro = Prologue(_ptr(in_scale), _ptr(in_shift), int(in_relu))
+        epi = Epilogue(_ptr(scale), _ptr(shift), _ptr(residual), int(ldr), int(act),
+                       int(accumulate), _ptr(stat_partial))
+        self._check(self.dll.vlnce_conv2d_fwd(_ptr(x), _ptr(w), _ptr(y), C.byref(d), C.byref(pro),
+                                              C.byref(epi), _stream()), "vlnce_conv2d_fwd")
+
+    def gemm(self, A, lda, transA, B, ldb, transB, Cm, ldc, M, N, K, scale=None, shift=None,
+             residual=None, ldr=0, act=0, accumulate=0):
+        epi = Epilogue(_ptr(scale), _ptr(shift), _ptr(residual), int(ldr), int(act),
+                       int(accumulate), None)
+        self._check(self.dll.vlnce_gemm(_ptr(A), lda, transA, _ptr(B), ldb, transB, _ptr(Cm), ldc,
+                                        M, N, K, C.byref(epi), _stream()), "vlnce_gemm")
+
+    def colsum(self, x, ldx, M, N, out, accumulate=0):
+        self._check(self.dll.vlnce_colsum(_ptr(x), ldx, M, N, _ptr(out), accumulate, _stream()),
+                    "vlnce_colsum")
+
+    # ---- norms
+    def bn_finalize(self, partial, tiles_m, tile_rows, M, Cc, gamma, beta, eps, momentum,
+                    running_mean, running_var, scale_out, shift_out, mean_out=None, rstd_out=None):
+        self._check(self.dll.vlnce_bn_finalize(
+            _ptr(partial), tiles_m, tile_rows, M, Cc, _ptr(gamma), _ptr(beta), eps, momentum,
+            _ptr(running_mean), _ptr(running_var), _ptr(scale_out), _ptr(shift_out),
+            _ptr(mean_out), _ptr(rstd_out), _stream()), "vlnce_bn_finalize")
+
+    def scale_shift_act(self, x, scale, shift, rows_per_sample, residual, y, M, Cc, act):
+        self._check(self.dll.vlnce_scale_shift_act(
+            _ptr(x), _ptr(scale), _ptr(shift), rows_per_sample, _ptr(residual), _ptr(y), M, Cc,
+            act, _stream()), "vlnce_scale_shift_act")
+
+    def gn_chunks(self, HW):
+        return self.dll.vlnce_gn_chunks(HW)
+
+    def gn_partial(self, x, Nimg, HW, Cc, partial):
+        self._check(self.dll.vlnce_gn_partial(_ptr(x), Nimg, HW, Cc, _ptr(partial), _stream()),
+                    "vlnce_gn_partial")
+
+    def gn_finalize(self, partial, Nimg, HW, Cc, groups, gamma, beta, eps, scale_out, shift_out,
+                    mean_out=None, rstd_out=None):
+        self._check(self.dll.vlnce_gn_finalize(
+            _ptr(partial), Nimg, HW, Cc, groups, _ptr(gamma), _ptr(beta), eps, _ptr(scale_out),
+            _ptr(shift_out), _ptr(mean_out), _ptr(rstd_out), _stream()), "vlnce_gn_finalize")
+
+    # ---- pools
+    def maxpool3x3s2(self, x, y, N, H, W, Cc, Ho, Wo):
+        self._check(self.dll.vlnce_maxpool3x3s2(_ptr(x), _ptr(y), N, H, W, Cc, Ho, Wo, _stream()),
+                    "vlnce_maxpool3x3s2")
+
+    def avgpool2x2(self, x, y, N, H, W, Cc):
+        self._check(self.dll.vlnce_avgpool2x2(_ptr(x), _ptr(y), N, H, W, Cc, _stream()),
+                    "vlnce_avgpool2x2")
+
+    def adaptive_avgpool(self, x, y, N, H, W, Cc, OH, OW, ldy):
+        self._check(self.dll.vlnce_adaptive_avgpool(_ptr(x), _ptr(y), N, H, W, Cc, OH, OW, ldy,
+                                                    _stream()), "vlnce_adaptive_avgpool")
+
+    def mean_rows(self, x, y, B, P, Cc):
+        self._check(self.dll.vlnce_mean_rows(_ptr(x), _ptr(y), B, P, Cc, _stream()),
+                    "vlnce_mean_rows")
+
+    # ---- attention
+    def attn_fwd(self, q, K, ldk, V, ldv, mask, mask_mode, scale, out, attn_out, B, P, Dk, Dv):
+        self._check(self.dll.vlnce_attn_fwd(_ptr(q), _ptr(K), ldk, _ptr(V), ldv, _ptr(mask),
+                                            mask_mode, scale, _ptr(out), _ptr(attn_out), B, P, Dk,
+                                            Dv, _stream()), "vlnce_attn_fwd")
+
+    def attn_bwd(self, dout, q, K, ldk, V, ldv, mask, mask_mode, scale, attn, dq, dK, lddk, dV,
+                 lddv, B, P, Dk, Dv):
+        self._check(self.dll.vlnce_attn_bwd(_ptr(dout), _ptr(q), _ptr(K), ldk, _ptr(V), ldv,
+                                            _ptr(mask), mask_mode, scale, _ptr(attn), _ptr(dq),
+                                            _ptr(dK), lddk, _ptr(dV), lddv, B, P, Dk, Dv,
+                                            _stream()), "vlnce_attn_bwd")
+
+    def rowzero_mask(self, x, ld, rows, Cc, mask):
+        self._check(self.dll.vlnce_rowzero_mask(_ptr(x), ld, rows, Cc, _ptr(mask), _stream()),
+                    "vlnce_rowzero_mask")
+
+    # ---- recurrent cells
+    def gru_gates_fwd(self, gi, gh, h_prev, mask, h_out, gates_out, hn_out, B, H):
+        self._check(self.dll.vlnce_gru_gates_fwd(_ptr(gi), _ptr(gh), _ptr(h_prev), _ptr(mask),
+                                                 _ptr(h_out), _ptr(gates_out), _ptr(hn_out), B, H,
+                                                 _stream()), "vlnce_gru_gates_fwd")
+
+    def gru_gates_bwd(self, dh_out, gates, hn, h_prev, mask, dgi, dgh, dh_prev, B, H):
+        self._check(self.dll.vlnce_gru_gates_bwd(_ptr(dh_out), _ptr(gates), _ptr(hn), _ptr(h_prev),
+                                                 _ptr(mask), _ptr(dgi), _ptr(dgh), _ptr(dh_prev),
+                                                 B, H, _stream()), "vlnce_gru_gates_bwd")
+
+    def lstm_gates_fwd(self, gi, gh, c_prev, mask, h_out, c_out, gates_out, B, H):
+        self._check(self.dll.vlnce_lstm_gates_fwd(_ptr(gi), _ptr(gh), _ptr(c_prev), _ptr(mask),
+                                                  _ptr(h_out), _ptr(c_out), _ptr(gates_out), B, H,
+                                                  _stream()), "vlnce_lstm_gates_fwd")
+
+    def lstm_gates_bwd(self, dh_out, dc_out, gates, c_prev, c_out, mask, dgates, dc_prev, B, H):
+        self._check(self.dll.vlnce_lstm_gates_bwd(_ptr(dh_out), _ptr(dc_out), _ptr(gates),
+                                                  _ptr(c_prev), _ptr(c_out), _ptr(mask),
+                                                  _ptr(dgates), _ptr(dc_prev), B, H, _stream()),
+                    "vlnce_lstm_gates_bwd")
+
+    def mask_rows(self, x, mask, out, B, H):
+        self._check(self.dll.vlnce_mask_rows(_ptr(x), _ptr(mask), _ptr(out), B, H, _stream()),
+                    "vlnce_mask_rows")
+
+    def select_rows(self, mask, a, b, out, B, H):
+        self._check(self.dll.vlnce_select_rows(_ptr(mask), _ptr(a), _ptr(b), _ptr(out), B, H,
+                                               _stream()), "vlnce_select_rows")
+
+    def act_bwd(self, dy, y, dz, n, act):
+        self._check(self.dll.vlnce_act_bwd(_ptr(dy), _ptr(y), _ptr(dz), n, act, _stream()),
+                    "vlnce_act_bwd")
+
+
+_LIB = None
+
+
+def get_lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = HipLib()
+    return _LIB

@@ -1,0 +1,168 @@
+"""Cross-modal attention policy (reference: vlnce_baselines/models/
+cma_policy.py:24-309; arXiv 2004.02857).  Same module / parameter names; the
+arithmetic runs on the HIP kernels with visual and text features kept as
+[B, positions, channels] rows (the reference's [B, C, P] tensors permuted)."""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .encoders import resnet_encoders
+from .encoders.instruction_encoder import InstructionEncoder
+from .policy import ILPolicy, Net
+from .registry import baseline_registry
+from .rnn_state_encoder import build_rnn_state_encoder
+from .seq2seq_policy import prev_action_index, register_progress_loss
+
+
+@baseline_registry.register_policy
+class CMAPolicy(ILPolicy):
+    def __init__(self, observation_space, action_space, model_config):
+        super().__init__(
+            CMANet(observation_space=observation_space, model_config=model_config,
+                   num_actions=action_space.n),
+            action_space.n,
+        )
+
+    @classmethod
+    def from_config(cls, config, observation_space, action_space):
+        return cls(observation_space=observation_space, action_space=action_space,
+                   model_config=config.MODEL)
+
+
+def rows_of(feature_map):
+    """logical [B, C, h, w] (NHWC memory) -> [B, h*w, C] rows without a copy."""
+    b, c = feature_map.shape[:2]
+    return feature_map.permute(0, 2, 3, 1).reshape(b, -1, c)
+
+
+def nchw_flat_weight(linear, c, p):
+    """nn.Linear over the reference's Flatten of [B, C, P] (column c*P + p) re-indexed
+    for [B, P, C] rows (column p*C + c)."""
+    w = linear.weight
+    return w.view(w.size(0), c, p).permute(0, 2, 1).reshape(w.size(0), p * c)
+
+
+class CMANet(Net):
+    def __init__(self, observation_space, model_config, num_actions):
+        super().__init__()
+        self.model_config = model_config
+        model_config.defrost()
+        model_config.INSTRUCTION_ENCODER.final_state_only = False
+        model_config.freeze()
+        self.instruction_encoder = InstructionEncoder(model_config.INSTRUCTION_ENCODER)
+        assert model_config.DEPTH_ENCODER.cnn_type in ["VlnResnetDepthEncoder"]
+        self.depth_encoder = getattr(resnet_encoders, model_config.DEPTH_ENCODER.cnn_type)(
+            observation_space,
+            output_size=model_config.DEPTH_ENCODER.output_size,
+            checkpoint=model_config.DEPTH_ENCODER.ddppo_checkpoint,
+            backbone=model_config.DEPTH_ENCODER.backbone,
+            trainable=model_config.DEPTH_ENCODER.trainable,
+            spatial_output=True,
+        )
+        assert model_config.RGB_ENCODER.cnn_type in ["TorchVisionResNet18", "TorchVisionResNet50"]
+        self.rgb_encoder = getattr(resnet_encoders, model_config.RGB_ENCODER.cnn_type)(
+            model_config.RGB_ENCODER.output_size,
+            normalize_visual_inputs=model_config.normalize_rgb,
+            trainable=model_config.RGB_ENCODER.trainable,
+            spatial_output=True,
+        )
+        self.prev_action_embedding = nn.Embedding(num_actions + 1, 32)
+        hidden_size = model_config.STATE_ENCODER.hidden_size
+        self._hidden_size = hidden_size
+        r_out = model_config.RGB_ENCODER.output_size
+        d_out = model_config.DEPTH_ENCODER.output_size
+        self.rgb_linear = nn.Sequential(
+            nn.AdaptiveAvgPool1d(1), nn.Flatten(),
+            nn.Linear(self.rgb_encoder.output_shape[0], r_out), nn.ReLU(True))
+        self.depth_linear = nn.Sequential(
+            nn.Flatten(), nn.Linear(int(np.prod(self.depth_encoder.output_shape)), d_out),
+            nn.ReLU(True))
+        self.state_encoder = build_rnn_state_encoder(
+            input_size=d_out + r_out + self.prev_action_embedding.embedding_dim,
+            hidden_size=hidden_size, rnn_type=model_config.STATE_ENCODER.rnn_type, num_layers=1)
+        self._output_size = (hidden_size + r_out + d_out + self.instruction_encoder.output_size)
+        self.rgb_kv = nn.Conv1d(self.rgb_encoder.output_shape[0], hidden_size // 2 + r_out, 1)
+        self.depth_kv = nn.Conv1d(self.depth_encoder.output_shape[0], hidden_size // 2 + d_out, 1)
+        self.state_q = nn.Linear(hidden_size, hidden_size // 2)
+        self.text_k = nn.Conv1d(self.instruction_encoder.output_size, hidden_size // 2, 1)
+        self.text_q = nn.Linear(self.instruction_encoder.output_size, hidden_size // 2)
+        self.register_buffer("_scale", torch.tensor(1.0 / ((hidden_size // 2) ** 0.5)))
+        self._scale_f = 1.0 / ((hidden_size // 2) ** 0.5)
+        self.second_state_compress = nn.Sequential(
+            nn.Linear(self._output_size + self.prev_action_embedding.embedding_dim, hidden_size),
+            nn.ReLU(True))
+        self.second_state_encoder = build_rnn_state_encoder(
+            input_size=hidden_size, hidden_size=hidden_size,
+            rnn_type=model_config.STATE_ENCODER.rnn_type, num_layers=1)
+        self._output_size = hidden_size
+        self.progress_monitor = nn.Linear(self.output_size, 1)
+        if model_config.PROGRESS_MONITOR.use:
+            nn.init.kaiming_normal_(self.progress_monitor.weight, nonlinearity="tanh")
+            nn.init.constant_(self.progress_monitor.bias, 0)
+        self.train()
+
+    @property
+    def output_size(self):
+        return self._output_size
+
+    @property
+    def is_blind(self):
+        return self.rgb_encoder.is_blind or self.depth_encoder.is_blind
+
+    @property
+    def num_recurrent_layers(self):
+        return (self.state_encoder.num_recurrent_layers
+                + self.second_state_encoder.num_recurrent_layers)
+
+    def _attn(self, q, k, v, mask=None):
+        """softmax((q.k - 1e8 mask) * scale) . v  over [B, P, C] rows (cma_policy.py:207-217)."""
+        return ops.attention(q, k, v, mask, 1, self._scale_f)
+
+    def forward(self, observations, rnn_states, prev_actions, masks):
+        mc = self.model_config
+        ins = self.instruction_encoder(observations).permute(0, 2, 1)  # [B, L, 2H]
+        dep = rows_of(self.depth_encoder(observations))  # [B, P, 192]
+        rgb = rows_of(self.rgb_encoder(observations))  # [B, 16, 2112]
+        act = F.embedding(prev_action_index(prev_actions, masks),
+                          self.prev_action_embedding.weight)
+        if mc.ablate_instruction:
+            ins = ins * 0
+        if mc.ablate_depth:
+            dep = dep * 0
+        if mc.ablate_rgb:
+            rgb = rgb * 0
+        B, L, Ci = ins.shape
+        P_r, C_r = rgb.shape[1:]
+        P_d, C_d = dep.shape[1:]
+        half = self._hidden_size // 2
+
+        rgb_in = ops.linear(ops.mean_rows(rgb), self.rgb_linear[2].weight,
+                            self.rgb_linear[2].bias, ops.ACT_RELU)
+        depth_in = ops.linear(dep.reshape(B, P_d * C_d),
+                              nchw_flat_weight(self.depth_linear[1], C_d, P_d),
+                              self.depth_linear[1].bias, ops.ACT_RELU)
+        state_in = torch.cat([rgb_in, depth_in, act], dim=1)
+        n1 = self.state_encoder.num_recurrent_layers
+        state, h1 = self.state_encoder(state_in, rnn_states[:, 0:n1], masks)
+
+        text_state_q = ops.linear(state, self.state_q.weight, self.state_q.bias)
+        text_state_k = ops.linear(ins, self.text_k.weight.view(half, Ci), self.text_k.bias)
+        ins_c = ins.contiguous()
+        text_mask = ops.rowzero_mask(ins_c.detach())  # (instruction_embedding == 0).all(dim=1)
+        text_embedding = self._attn(text_state_q, text_state_k, ins_c, text_mask)
+
+        rgb_kv = ops.linear(rgb, self.rgb_kv.weight.view(-1, C_r), self.rgb_kv.bias)
+        depth_kv = ops.linear(dep, self.depth_kv.weight.view(-1, C_d), self.depth_kv.bias)
+        text_q = ops.linear(text_embedding, self.text_q.weight, self.text_q.bias)
+        rgb_embedding = self._attn(text_q, rgb_kv[..., :half], rgb_kv[..., half:])
+        depth_embedding = self._attn(text_q, depth_kv[..., :half], depth_kv[..., half:])
+
+        x = torch.cat([state, text_embedding, rgb_embedding, depth_embedding, act], dim=1)
+        x = ops.linear(x, self.second_state_compress[0].weight,
+                       self.second_state_compress[0].bias, ops.ACT_RELU)
+        x, h2 = self.second_state_encoder(x, rnn_states[:, n1:], masks)
+        rnn_states_out = torch.cat([h1, h2], dim=1)
+        register_progress_loss(self, x, observations)
+        return x, rnn_states_out

@@ -1,0 +1,184 @@
+// Single-query dot-product attention (one workgroup per batch row).
+//   logits[i] = <q, K[i]>  -> mask -> * scale -> softmax -> out = sum_i attn[i] V[i]
+// K and V rows are each read exactly once, so they are streamed straight from
+// HBM with float4 loads (no LDS staging: nothing is reused); the P logits live
+// in LDS and the row reductions are wavefront shuffles.
+#include "common.h"
+
+namespace {
+
+constexpr int MAXP = 1024;
+
+__device__ __forceinline__ float block_reduce(float v, float* sbuf, bool is_max) {
+  v = is_max ? wave_max(v) : wave_sum(v);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sbuf[w] = v;
+  __syncthreads();
+  float r = sbuf[0];
+  for (int i = 1; i < 4; ++i) r = is_max ? fmaxf(r, sbuf[i]) : r + sbuf[i];
+  return r;
+}
+
+__global__ __launch_bounds__(256) void attn_fwd_kernel(
+    const float* __restrict__ q, const float* __restrict__ K, int ldk, const float* __restrict__ V,
+    int ldv, const uint8_t* __restrict__ mask, int mask_mode, float scale, float* __restrict__ out,
+    float* __restrict__ attn_out, int P, int Dk, int Dv) {
+  __shared__ float logits[MAXP];
+  __shared__ float sbuf[4];
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* qb = q + (long)b * Dk;
+  const float* Kb = K + (long)b * P * ldk;
+  const float* Vb = V + (long)b * P * ldv;
+  const bool vec = ((Dk & 3) == 0) && ((ldk & 3) == 0) &&
+                   ((reinterpret_cast<uintptr_t>(K) | reinterpret_cast<uintptr_t>(q)) & 15) == 0;
+  for (int i = wave; i < P; i += 4) {
+    const float* kr = Kb + (long)i * ldk;
+    float s = 0.f;
+    if (vec) {
+      for (int c = lane * 4; c < Dk; c += 256) {
+        const f32x4 kv = *reinterpret_cast<const f32x4*>(kr + c);
+        const f32x4 qv = *reinterpret_cast<const f32x4*>(qb + c);
+        s += kv.x * qv.x + kv.y * qv.y + kv.z * qv.z + kv.w * qv.w;
+      }
+    } else {
+      for (int c = lane; c < Dk; c += 64) s += kr[c] * qb[c];
+    }
+    s = wave_sum(s);
+    if (lane == 0) {
+      if (mask != nullptr) {
+        const float mk = (float)mask[(long)b * P + i];
+        if (mask_mode == 1) s = s - mk * 1e8f;
+        if (mask_mode == 2) s = s * mk;
+      }
+      logits[i] = s * scale;
+    }
+  }
+  __syncthreads();
+  float mx = -INFINITY;
+  for (int i = tid; i < P; i += 256) mx = fmaxf(mx, logits[i]);
+  mx = block_reduce(mx, sbuf, true);
+  float sum = 0.f;
+  for (int i = tid; i < P; i += 256) {
+    const float e = expf(logits[i] - mx);
+    logits[i] = e;
+    sum += e;
+  }
+  sum = block_reduce(sum, sbuf, false);
+  const float inv = 1.f / sum;
+  __syncthreads();
+  for (int i = tid; i < P; i += 256) {
+    const float a = logits[i] * inv;
+    logits[i] = a;
+    if (attn_out) attn_out[(long)b * P + i] = a;
+  }
+  __syncthreads();
+  for (int c = tid; c < Dv; c += 256) {
+    float acc = 0.f;
+    for (int i = 0; i < P; ++i) acc += logits[i] * Vb[(long)i * ldv + c];
+    out[(long)b * Dv + c] = acc;
+  }
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_kernel(
+    const float* __restrict__ dout, const float* __restrict__ q, const float* __restrict__ K,
+    int ldk, const float* __restrict__ V, int ldv, const uint8_t* __restrict__ mask, int mask_mode,
+    float scale, const float* __restrict__ attn, float* __restrict__ dq, float* __restrict__ dK,
+    int lddk, float* __restrict__ dV, int lddv, int P, int Dk, int Dv) {
+  __shared__ float dl[MAXP];  // d(attn) then d(logit)
+  __shared__ float sbuf[4];
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* dob = dout + (long)b * Dv;
+  const float* ab = attn + (long)b * P;
+  const float* Vb = V + (long)b * P * ldv;
+  const float* Kb = K + (long)b * P * ldk;
+  const float* qb = q + (long)b * Dk;
+  // d attn[i] = <dout, V[i]>,  dV[i] = attn[i] * dout
+  for (int i = wave; i < P; i += 4) {
+    const float a = ab[i];
+    float s = 0.f;
+    for (int c = lane; c < Dv; c += 64) {
+      const float g = dob[c];
+      s += g * Vb[(long)i * ldv + c];
+      if (dV) dV[((long)b * P + i) * lddv + c] = a * g;
+    }
+    s = wave_sum(s);
+    if (lane == 0) dl[i] = s;
+  }
+  __syncthreads();
+  float dot = 0.f;
+  for (int i = tid; i < P; i += 256) dot += ab[i] * dl[i];
+  dot = block_reduce(dot, sbuf, false);
+  __syncthreads();
+  for (int i = tid; i < P; i += 256) {
+    float g = ab[i] * (dl[i] - dot) * scale;
+    if (mask != nullptr && mask_mode == 2) g *= (float)mask[(long)b * P + i];
+    dl[i] = g;
+  }
+  __syncthreads();
+  // dK[i] = dl[i] * q ; dq = sum_i dl[i] * K[i]
+  for (int c = tid; c < Dk; c += 256) {
+    const float qc = qb[c];
+    float acc = 0.f;
+    for (int i = 0; i < P; ++i) {
+      const float g = dl[i];
+      acc += g * Kb[(long)i * ldk + c];
+      if (dK) dK[((long)b * P + i) * lddk + c] = g * qc;
+    }
+    if (dq) dq[(long)b * Dk + c] = acc;
+  }
+}
+
+__global__ __launch_bounds__(256) void rowzero_mask_kernel(const float* __restrict__ x, int ld,
+                                                           long rows, int C,
+                                                           uint8_t* __restrict__ mask) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* r = x + row * ld;
+  int nz = 0;
+  for (int c = lane; c < C; c += 64) nz |= (r[c] != 0.0f) ? 1 : 0;
+  const unsigned long long any = __ballot(nz);
+  if (lane == 0) mask[row] = any ? 0 : 1;
+}
+
+}  // namespace
+
+extern "C" int vlnce_attn_fwd(const float* q, const float* K, int ldk, const float* V, int ldv,
+                              const uint8_t* mask, int mask_mode, float scale, float* out,
+                              float* attn_out, int B, int P, int Dk, int Dv,
+                              vlnce_stream_t stream) {
+  VLNCE_CHECK_ARG(q && K && V && out, "attn_fwd: null argument");
+  VLNCE_CHECK_ARG(B > 0 && P > 0 && P <= MAXP && Dk > 0 && Dv > 0, "attn_fwd: bad shape (P<=%d)",
+                  MAXP);
+  VLNCE_CHECK_ARG(mask_mode >= 0 && mask_mode <= 2, "attn_fwd: bad mask_mode");
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3(B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     q, K, ldk, V, ldv, mask, mask_mode, scale, out, attn_out, P, Dk, Dv);
+  VLNCE_CHECK_LAUNCH("attn_fwd");
+  return 0;
+}
+
+extern "C" int vlnce_attn_bwd(const float* dout, const float* q, const float* K, int ldk,
+                              const float* V, int ldv, const uint8_t* mask, int mask_mode,
+                              float scale, const float* attn, float* dq, float* dK, int lddk,
+                              float* dV, int lddv, int B, int P, int Dk, int Dv,
+                              vlnce_stream_t stream) {
+  VLNCE_CHECK_ARG(dout && q && K && V && attn, "attn_bwd: null argument");
+  VLNCE_CHECK_ARG(B > 0 && P > 0 && P <= MAXP, "attn_bwd: bad shape");
+  hipLaunchKernelGGL(attn_bwd_kernel, dim3(B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     dout, q, K, ldk, V, ldv, mask, mask_mode, scale, attn, dq, dK, lddk, dV, lddv,
+                     P, Dk, Dv);
+  VLNCE_CHECK_LAUNCH("attn_bwd");
+  return 0;
+}
+
+extern "C" int vlnce_rowzero_mask(const float* x, int ld, long rows, int C, uint8_t* mask,
+                                  vlnce_stream_t stream) {
+  VLNCE_CHECK_ARG(x && mask && rows > 0 && C > 0, "rowzero_mask: bad argument");
+  hipLaunchKernelGGL(rowzero_mask_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), x, ld, rows, C, mask);
+  VLNCE_CHECK_LAUNCH("rowzero_mask");
+  return 0;
+}

@@ -1,0 +1,617 @@
+// fp32 implicit-GEMM convolution / general GEMM on v_mfma_f32_32x32x2_f32.
+//
+//   C[M,N] = epilogue( A[M,K] * B[K,N] )
+//
+// A is gathered on the fly (im2col of a channels-last image, or a plain /
+// transposed matrix), B is an nn.Linear-style [N,K] weight or a [K,N] matrix.
+// Design (MI355X_MICROARCH / cdna_hip_programming guides):
+//   * 256 threads = 4 wave64; block tile BM x BN, K-tile 32; each wave owns a
+//     (BM/WM) x (BN/WN) sub-tile made of 32x32 MFMA tiles (16 acc VGPRs each).
+//   * operands go global -> registers -> LDS (register staging: the im2col
+//     gather needs zero-fill + an optional per-channel prologue, which LDS-DMA
+//     cannot do), double-buffered LDS, ONE barrier per K-tile; the global loads
+//     of tile t+1 are issued before the MFMAs of tile t and written to LDS after.
+//   * LDS rows are K-contiguous with a 36-float pitch: every lane fetches its
+//     MFMA operands for four k-steps with one conflict-free ds_read_b128.
+//     The k order inside a group of 8 is permuted identically for A and B
+//     (lanes 0-31 take k 0..3, lanes 32-63 take k 4..7), which a dot product
+//     does not care about.
+//   * exact fp32: the MFMA is a k-ordered fmaf chain, no reduced precision.
+//   * blockIdx -> tile map is XCD-aware: each XCD (private L2) gets a
+//     contiguous run of tiles with the N-tile index fastest, so blocks that
+//     share an A row-panel hit the same L2.
+#include "common.h"
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int LDP = 36;  // LDS row pitch in floats (32 + 4 pad)
+
+enum { A_IM2COL_V4 = 0, A_IM2COL_S = 1, A_TRANS = 2 };
+enum { B_NK_V4 = 0, B_NK_S = 1, B_KN = 2 };
+
+struct IgemmParams {
+  const float* A;
+  const float* B;
+  float* C;
+  int M, N, K;
+  int H, W, Cin, KH, KW, stride, pad, Ho, Wo;  // im2col geometry (plain GEMM: 1x1 "image" row)
+  int lda, ldb, ldc;
+  const float* in_scale;
+  const float* in_shift;
+  int in_relu;
+  const float* scale;
+  const float* shift;
+  const float* residual;
+  int ldr;
+  int act;
+  int accumulate;
+  float* stat_partial;
+  int tiles_m, tiles_n;
+};
+
+__device__ __forceinline__ f32x4 ldg4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+
+template <int BM, int BN, int WM, int WN, int AMODE, int BMODE>
+__global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
+  constexpr int WTM = BM / WM;  // rows per wave
+  constexpr int WTN = BN / WN;
+  constexpr int MT = WTM / 32;
+  constexpr int NT = WTN / 32;
+  constexpr int A_TILE = BM * LDP;
+  constexpr int B_TILE = BN * LDP;
+  constexpr int STAGE = A_TILE + B_TILE;
+  static_assert(WM * WN == 4, "4 waves");
+  static_assert(MT >= 1 && NT >= 1, "tile");
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+
+  // ---- XCD-aware tile mapping (bijective for any grid size)
+  int tile;
+  {
+    const int bid = blockIdx.x, nwg = gridDim.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tile_m = tile / p.tiles_n;
+  const int tile_n = tile - tile_m * p.tiles_n;
+  const int m0 = tile_m * BM;
+  const int n0 = tile_n * BN;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WN;
+  const int wn = wave - wm * WN;
+  const int half = lane >> 5;
+  const int l31 = lane & 31;
+
+  // ------------------------------------------------------------------ A loader state
+  constexpr int A_ROWS = BM / 32;  // row-major modes: 32 rows x 8 float4 per pass
+  const int lrow = tid >> 3;
+  const int lk4 = (tid & 7) * 4;
+  int a_off[A_ROWS];
+  int a_hw[A_ROWS];
+  // current (r, q, ci) of this thread's first k in the K-tile (im2col v4 mode)
+  int k_r = 0, k_q = 0, k_ci = 0;
+  if constexpr (AMODE == A_IM2COL_V4 || AMODE == A_IM2COL_S) {
+    const int HoWo = p.Ho * p.Wo;
+#pragma unroll
+    for (int i = 0; i < A_ROWS; ++i) {
+      const int m = m0 + i * 32 + lrow;
+      if (m < p.M) {
+        const int img = m / HoWo;
+        const int rem = m - img * HoWo;
+        const int ho = rem / p.Wo;
+        const int wo = rem - ho * p.Wo;
+        const int hi0 = ho * p.stride - p.pad;
+        const int wi0 = wo * p.stride - p.pad;
+        a_off[i] = (img * p.H + hi0) * p.W + wi0;
+        a_hw[i] = (hi0 << 16) | (wi0 & 0xffff);
+      } else {
+        a_off[i] = 0;
+        a_hw[i] = (int)0x80008000;  // hi0 = wi0 = -32768: never valid
+      }
+    }
+    if constexpr (AMODE == A_IM2COL_V4) {
+      const int tap = lk4 / p.Cin;
+      k_ci = lk4 - tap * p.Cin;
+      k_r = tap / p.KW;
+      k_q = tap - k_r * p.KW;
+    }
+  }
+
+  f32x4 a_reg[A_ROWS];
+  constexpr int B_ROWS = BN / 32;
+  f32x4 b_reg[B_ROWS];
+
+  auto load_a = [&](int k0) {
+    if constexpr (AMODE == A_IM2COL_V4) {
+      f32x4 s4, t4;
+      const bool tap_ok = k_r < p.KH;
+      if (p.in_scale != nullptr && tap_ok) {
+        s4 = ldg4(p.in_scale + k_ci);
+        t4 = ldg4(p.in_shift + k_ci);
+      }
+#pragma unroll
+      for (int i = 0; i < A_ROWS; ++i) {
+        const int hi = (a_hw[i] >> 16) + k_r;
+        const int wi = (int)(short)(a_hw[i] & 0xffff) + k_q;
+        const bool ok = tap_ok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (ok) {
+          const long pix = (long)a_off[i] + k_r * p.W + k_q;
+          v = ldg4(p.A + pix * p.lda + k_ci);
+          if (p.in_scale != nullptr) {
+            v = v * s4 + t4;
+            if (p.in_relu) {
+              v.x = fmaxf(v.x, 0.f);
+              v.y = fmaxf(v.y, 0.f);
+              v.z = fmaxf(v.z, 0.f);
+              v.w = fmaxf(v.w, 0.f);
+            }
+          }
+        }
+        a_reg[i] = v;
+      }
+      // advance (r, q, ci) by one K-tile
+      k_ci += BK;
+      while (k_ci >= p.Cin) {
+        k_ci -= p.Cin;
+        if (++k_q == p.KW) {
+          k_q = 0;
+          ++k_r;
+        }
+      }
+    } else if constexpr (AMODE == A_IM2COL_S) {
+      int er[4], eq[4], eci[4];
+      float es[4], et[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int k = k0 + lk4 + e;
+        const int tap = k / p.Cin;
+        eci[e] = k - tap * p.Cin;
+        er[e] = tap / p.KW;
+        eq[e] = tap - er[e] * p.KW;
+        es[e] = 1.f;
+        et[e] = 0.f;
+        if (p.in_scale != nullptr && k < p.K) {
+          es[e] = p.in_scale[eci[e]];
+          et[e] = p.in_shift[eci[e]];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < A_ROWS; ++i) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int hi = (a_hw[i] >> 16) + er[e];
+          const int wi = (int)(short)(a_hw[i] & 0xffff) + eq[e];
+          const bool ok =
+              er[e] < p.KH && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+          float x = 0.f;
+          if (ok) {
+            const long pix = (long)a_off[i] + er[e] * p.W + eq[e];
+            x = p.A[pix * p.lda + eci[e]];
+            if (p.in_scale != nullptr) {
+              x = x * es[e] + et[e];
+              if (p.in_relu) x = fmaxf(x, 0.f);
+            }
+          }
+          v[e] = x;
+        }
+        a_reg[i] = f32x4{v[0], v[1], v[2], v[3]};
+      }
+    } else {  // A_TRANS: A[m][k] stored at A[k*lda + m]; tile read as BK x BM, m contiguous
+      constexpr int TPR = BM / 4;        // threads per k-row
+      constexpr int KPP = 256 / TPR;     // k rows per pass
+      const int km = tid / TPR;
+      const int m4 = (tid - km * TPR) * 4;
+      const bool vec = ((p.lda & 3) == 0) && ((p.M & 3) == 0);
+#pragma unroll
+      for (int i = 0; i < A_ROWS; ++i) {
+        const int k = k0 + i * KPP + km;
+        const int m = m0 + m4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (k < p.K) {
+          const float* src = p.A + (long)k * p.lda + m;
+          if (vec && m + 3 < p.M) {
+            v = ldg4(src);
+          } else {
+            if (m + 0 < p.M) v.x = src[0];
+            if (m + 1 < p.M) v.y = src[1];
+            if (m + 2 < p.M) v.z = src[2];
+            if (m + 3 < p.M) v.w = src[3];
+          }
+        }
+        a_reg[i] = v;
+      }
+    }
+  };
+
+  auto load_b = [&](int k0) {
+    if constexpr (BMODE == B_NK_V4) {
+      const int k = k0 + lk4;
+#pragma unroll
+      for (int i = 0; i < B_ROWS; ++i) {
+        const int n = n0 + i * 32 + lrow;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (n < p.N && k < p.K) v = ldg4(p.B + (long)n * p.ldb + k);
+        b_reg[i] = v;
+      }
+    } else if constexpr (BMODE == B_NK_S) {
+      const int k = k0 + lk4;
+#pragma unroll
+      for (int i = 0; i < B_ROWS; ++i) {
+        const int n = n0 + i * 32 + lrow;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (n < p.N) {
+          const float* src = p.B + (long)n * p.ldb + k;
+          if (k + 0 < p.K) v.x = src[0];
+          if (k + 1 < p.K) v.y = src[1];
+          if (k + 2 < p.K) v.z = src[2];
+          if (k + 3 < p.K) v.w = src[3];
+        }
+        b_reg[i] = v;
+      }
+    } else {  // B_KN: B[k][n] at B[k*ldb + n]
+      constexpr int TPR = BN / 4;
+      constexpr int KPP = 256 / TPR;
+      const int kn = tid / TPR;
+      const int n4 = (tid - kn * TPR) * 4;
+      const bool vec = ((p.ldb & 3) == 0) && ((p.N & 3) == 0);
+#pragma unroll
+      for (int i = 0; i < B_ROWS; ++i) {
+        const int k = k0 + i * KPP + kn;
+        const int n = n0 + n4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (k < p.K) {
+          const float* src = p.B + (long)k * p.ldb + n;
+          if (vec && n + 3 < p.N) {
+            v = ldg4(src);
+          } else {
+            if (n + 0 < p.N) v.x = src[0];
+            if (n + 1 < p.N) v.y = src[1];
+            if (n + 2 < p.N) v.z = src[2];
+            if (n + 3 < p.N) v.w = src[3];
+          }
+        }
+        b_reg[i] = v;
+      }
+    }
+  };
+
+  auto store_ab = [&](float* stage) {
+    float* As = stage;
+    float* Bs = stage + A_TILE;
+    if constexpr (AMODE == A_TRANS) {
+      constexpr int TPR = BM / 4;
+      constexpr int KPP = 256 / TPR;
+      const int km = tid / TPR;
+      const int m4 = (tid - km * TPR) * 4;
+#pragma unroll
+      for (int i = 0; i < A_ROWS; ++i) {
+        const int kk = i * KPP + km;
+        As[(m4 + 0) * LDP + kk] = a_reg[i].x;
+        As[(m4 + 1) * LDP + kk] = a_reg[i].y;
+        As[(m4 + 2) * LDP + kk] = a_reg[i].z;
+        As[(m4 + 3) * LDP + kk] = a_reg[i].w;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < A_ROWS; ++i)
+        *reinterpret_cast<f32x4*>(As + (i * 32 + lrow) * LDP + lk4) = a_reg[i];
+    }
+    if constexpr (BMODE == B_KN) {
+      constexpr int TPR = BN / 4;
+      constexpr int KPP = 256 / TPR;
+      const int kn = tid / TPR;
+      const int n4 = (tid - kn * TPR) * 4;
+#pragma unroll
+      for (int i = 0; i < B_ROWS; ++i) {
+        const int kk = i * KPP + kn;
+        Bs[(n4 + 0) * LDP + kk] = b_reg[i].x;
+        Bs[(n4 + 1) * LDP + kk] = b_reg[i].y;
+        Bs[(n4 + 2) * LDP + kk] = b_reg[i].z;
+        Bs[(n4 + 3) * LDP + kk] = b_reg[i].w;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < B_ROWS; ++i)
+        *reinterpret_cast<f32x4*>(Bs + (i * 32 + lrow) * LDP + lk4) = b_reg[i];
+    }
+  };
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int KT = (p.K + BK - 1) / BK;
+  load_a(0);
+  load_b(0);
+  store_ab(smem);
+  __syncthreads();
+
+  for (int t = 0; t < KT; ++t) {
+    float* cur = smem + (t & 1) * STAGE;
+    const bool more = (t + 1) < KT;
+    if (more) {
+      load_a((t + 1) * BK);
+      load_b((t + 1) * BK);
+    }
+    const float* Aw = cur + (wm * WTM + l31) * LDP + 4 * half;
+    const float* Bw = cur + A_TILE + (wn * WTN + l31) * LDP + 4 * half;
+#pragma unroll
+    for (int g = 0; g < BK / 8; ++g) {
+      f32x4 af[MT], bf[NT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const f32x4*>(Aw + i * 32 * LDP + 8 * g);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) bf[j] = *reinterpret_cast<const f32x4*>(Bw + j * 32 * LDP + 8 * g);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
+    }
+    if (more) store_ab(smem + ((t + 1) & 1) * STAGE);
+    __syncthreads();
+  }
+
+  // ------------------------------------------------------------------ BN statistics of the raw tile
+  if (p.stat_partial != nullptr) {
+    float* red = smem;  // [WM][BN] floats, reused twice; all MFMA reads are behind the last barrier
+    const int rows_valid = min(BM, p.M - m0);
+    float csum[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          if (row < rows_valid) s += acc[i][j][r];
+        }
+      s += __shfl_xor(s, 32, 64);
+      csum[j] = s;
+      if (half == 0) red[wm * BN + wn * WTN + j * 32 + l31] = s;
+    }
+    __syncthreads();
+    float cmean[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < WM; ++w) s += red[w * BN + wn * WTN + j * 32 + l31];
+      csum[j] = s;
+      cmean[j] = s / (float)rows_valid;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          const float d = acc[i][j][r] - cmean[j];
+          if (row < rows_valid) s += d * d;
+        }
+      s += __shfl_xor(s, 32, 64);
+      if (half == 0) red[wm * BN + wn * WTN + j * 32 + l31] = s;
+    }
+    __syncthreads();
+    if (wm == 0 && half == 0) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        float m2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < WM; ++w) m2 += red[w * BN + wn * WTN + j * 32 + l31];
+        const int col = n0 + wn * WTN + j * 32 + l31;
+        if (col < p.N) {
+          float* dst = p.stat_partial + ((long)tile_m * p.N + col) * 2;
+          dst[0] = csum[j];
+          dst[1] = m2;
+        }
+      }
+    }
+  }
+
+  // ------------------------------------------------------------------ epilogue
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int col = n0 + wn * WTN + j * 32 + l31;
+    if (col >= p.N) continue;
+    const float sc = p.scale ? p.scale[col] : 1.f;
+    const float sh = p.shift ? p.shift[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (row < p.M) {
+          float v = acc[i][j][r] * sc + sh;
+          if (p.residual) v += p.residual[(long)row * p.ldr + col];
+          v = apply_act(v, p.act);
+          float* dst = p.C + (long)row * p.ldc + col;
+          if (p.accumulate) v += *dst;
+          *dst = v;
+        }
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WM, int WN, int AMODE, int BMODE>
+int launch(const IgemmParams& p, hipStream_t stream) {
+  constexpr int smem_bytes = 2 * (BM + BN) * LDP * (int)sizeof(float);
+  auto kern = igemm_kernel<BM, BN, WM, WN, AMODE, BMODE>;
+  static bool attr_set = false;  // per instantiation
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
+    if (e != hipSuccess) {
+      vlnce_set_error("igemm: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      return 2;
+    }
+    attr_set = true;
+  }
+  IgemmParams q = p;
+  q.tiles_m = ceil_div(p.M, BM);
+  q.tiles_n = ceil_div(p.N, BN);
+  const long nwg = (long)q.tiles_m * q.tiles_n;
+  if (nwg <= 0 || nwg > 0x7fffffffL) {
+    vlnce_set_error("igemm: bad grid %ld", nwg);
+    return 1;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), smem_bytes, stream, q);
+  VLNCE_CHECK_LAUNCH("igemm");
+  return 0;
+}
+
+// tile choice: biggest tile that still yields >= ~2 workgroups per CU
+struct TileChoice {
+  int bm, bn;
+};
+TileChoice choose_tile(long M, int N) {
+  const long want = 512;
+  auto tiles = [&](int bm, int bn) { return (long)ceil_div(M, bm) * ceil_div(N, bn); };
+  if (N > 64 && M > 64 && tiles(128, 128) >= want) return {128, 128};
+  if (M > 64 && tiles(128, 64) >= want) return {128, 64};
+  return {64, 64};
+}
+
+template <int AMODE, int BMODE>
+int dispatch_tiles(const IgemmParams& p, hipStream_t s) {
+  const TileChoice t = choose_tile(p.M, p.N);
+  if (t.bm == 128 && t.bn == 128) return launch<128, 128, 2, 2, AMODE, BMODE>(p, s);
+  if (t.bm == 128 && t.bn == 64) return launch<128, 64, 2, 2, AMODE, BMODE>(p, s);
+  return launch<64, 64, 2, 2, AMODE, BMODE>(p, s);
+}
+template <int AMODE, int BMODE>
+int dispatch_small(const IgemmParams& p, hipStream_t s) {
+  return launch<64, 64, 2, 2, AMODE, BMODE>(p, s);
+}
+
+void fill_epilogue(IgemmParams& p, const vlnce_epilogue* e) {
+  p.scale = e ? e->scale : nullptr;
+  p.shift = e ? e->shift : nullptr;
+  p.residual = e ? e->residual : nullptr;
+  p.ldr = e ? e->ldr : 0;
+  p.act = e ? e->act : 0;
+  p.accumulate = e ? e->accumulate : 0;
+  p.stat_partial = e ? e->stat_partial : nullptr;
+}
+
+bool aligned16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
+
+}  // namespace
+
+extern "C" int vlnce_conv2d_tile_rows(const vlnce_conv_desc* d) {
+  const long M = (long)d->N * d->Ho * d->Wo;
+  return choose_tile(M, d->Cout).bm;
+}
+
+extern "C" int vlnce_conv2d_tiles_m(const vlnce_conv_desc* d) {
+  const long M = (long)d->N * d->Ho * d->Wo;
+  return ceil_div(M, choose_tile(M, d->Cout).bm);
+}
+
+extern "C" int vlnce_conv2d_fwd(const float* x, const float* w, float* y, const vlnce_conv_desc* d,
+                                const vlnce_prologue* pro, const vlnce_epilogue* epi,
+                                vlnce_stream_t stream) {
+  VLNCE_CHECK_ARG(x && w && y && d, "conv2d_fwd: null argument");
+  VLNCE_CHECK_ARG(d->N > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0,
+                  "conv2d_fwd: bad shape");
+  VLNCE_CHECK_ARG(d->H < 32768 && d->W < 32768, "conv2d_fwd: H/W must be < 32768");
+  const int ho = (d->H + 2 * d->pad - d->KH) / d->stride + 1;
+  const int wo = (d->W + 2 * d->pad - d->KW) / d->stride + 1;
+  VLNCE_CHECK_ARG(ho == d->Ho && wo == d->Wo, "conv2d_fwd: Ho/Wo mismatch (%d,%d) vs (%d,%d)", ho,
+                  wo, d->Ho, d->Wo);
+  const long M = (long)d->N * d->Ho * d->Wo;
+  VLNCE_CHECK_ARG(M < 0x7fffffffL && (long)d->N * d->H * d->W < 0x7fffffffL,
+                  "conv2d_fwd: too many pixels for 32-bit row indices");
+  IgemmParams p{};
+  p.A = x;
+  p.B = w;
+  p.C = y;
+  p.M = (int)M;
+  p.N = d->Cout;
+  p.K = d->KH * d->KW * d->Cin;
+  p.H = d->H;
+  p.W = d->W;
+  p.Cin = d->Cin;
+  p.KH = d->KH;
+  p.KW = d->KW;
+  p.stride = d->stride;
+  p.pad = d->pad;
+  p.Ho = d->Ho;
+  p.Wo = d->Wo;
+  p.lda = d->ldx ? d->ldx : d->Cin;
+  p.ldb = p.K;
+  p.ldc = d->ldy ? d->ldy : d->Cout;
+  p.in_scale = pro ? pro->in_scale : nullptr;
+  p.in_shift = pro ? pro->in_shift : nullptr;
+  p.in_relu = pro ? pro->in_relu : 0;
+  VLNCE_CHECK_ARG((p.in_scale == nullptr) == (p.in_shift == nullptr),
+                  "conv2d_fwd: in_scale and in_shift must come together");
+  fill_epilogue(p, epi);
+  const bool v4 = (d->Cin % 4 == 0) && (p.lda % 4 == 0) && aligned16(x) && aligned16(w) &&
+                  (!p.in_scale || (aligned16(p.in_scale) && aligned16(p.in_shift)));
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (v4) return dispatch_tiles<A_IM2COL_V4, B_NK_V4>(p, s);
+  return dispatch_tiles<A_IM2COL_S, B_NK_S>(p, s);
+}
+
+extern "C" int vlnce_gemm(const float* A, int lda, int transA, const float* B, int ldb, int transB,
+                          float* C, int ldc, int M, int N, int K, const vlnce_epilogue* epi,
+                          vlnce_stream_t stream) {
+  VLNCE_CHECK_ARG(A && B && C, "gemm: null argument");
+  VLNCE_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm: bad shape %d %d %d", M, N, K);
+  VLNCE_CHECK_ARG(!(epi && epi->stat_partial), "gemm: stat_partial is a conv-only option");
+  IgemmParams p{};
+  p.A = A;
+  p.B = B;
+  p.C = C;
+  p.M = M;
+  p.N = N;
+  p.K = K;
+  // plain matrix as a 1x1-conv over an "image" of M pixels with K channels, folded
+  // into rows of 1024 pixels so the loader's 16-bit (h, w) fields never overflow
+  VLNCE_CHECK_ARG((long)M < 32767L * 1024L, "gemm: M too large");
+  p.W = M < 1024 ? M : 1024;
+  p.H = ceil_div(M, p.W);
+  p.Cin = K;
+  p.KH = p.KW = 1;
+  p.stride = 1;
+  p.pad = 0;
+  p.Ho = p.H;
+  p.Wo = p.W;
+  p.lda = lda;
+  p.ldb = ldb;
+  p.ldc = ldc;
+  fill_epilogue(p, epi);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (!transA) {
+    const bool av4 = (K % 4 == 0) && (lda % 4 == 0) && aligned16(A);
+    if (!transB) {
+      const bool bv4 = (K % 4 == 0) && (ldb % 4 == 0) && aligned16(B);
+      if (av4 && bv4) return dispatch_tiles<A_IM2COL_V4, B_NK_V4>(p, s);
+      return dispatch_small<A_IM2COL_S, B_NK_S>(p, s);
+    }
+    VLNCE_CHECK_ARG(aligned16(B), "gemm: B must be 16-byte aligned");
+    if (av4) return dispatch_tiles<A_IM2COL_V4, B_KN>(p, s);
+    return dispatch_small<A_IM2COL_S, B_KN>(p, s);
+  }
+  VLNCE_CHECK_ARG(transB, "gemm: transA requires transB (only A^T * B^T-stored form is built)");
+  VLNCE_CHECK_ARG(aligned16(A) && aligned16(B), "gemm: operands must be 16-byte aligned");
+  return dispatch_tiles<A_TRANS, B_KN>(p, s);
+}

@@ -1,0 +1,266 @@
+// Normalisation kernels (HBM-bound): BatchNorm finalize, GroupNorm statistics,
+// and the shared scale/shift/residual/activation apply pass.  float4 accesses,
+// grid-stride, fp64 only in the tiny finalize reductions.
+#include "common.h"
+
+namespace {
+
+// ---------------------------------------------------------------- BatchNorm finalize
+// partial: [tiles_m][C][2] = {sum, M2 about the tile mean}; 16 channels x 16 tile-slices per block.
+__global__ __launch_bounds__(256) void bn_finalize_kernel(
+    const float* __restrict__ partial, int tiles_m, int tile_rows, int M, int C,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
+    float* running_mean, float* running_var, float* scale_out, float* shift_out, float* mean_out,
+    float* rstd_out) {
+  __shared__ double red[16][17];
+  const int cl = threadIdx.x & 15;
+  const int sl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  const bool cok = c < C;
+  // pass 1: total sum
+  double s = 0.0;
+  if (cok)
+    for (int t = sl; t < tiles_m; t += 16) s += (double)partial[((long)t * C + c) * 2];
+  red[sl][cl] = s;
+  __syncthreads();
+  double tot = 0.0;
+  for (int i = 0; i < 16; ++i) tot += red[i][cl];
+  const double mean = tot / (double)M;
+  __syncthreads();
+  // pass 2: M2 = sum_t [ M2_t + n_t (mean_t - mean)^2 ]
+  double m2 = 0.0;
+  if (cok)
+    for (int t = sl; t < tiles_m; t += 16) {
+      const float* q = partial + ((long)t * C + c) * 2;
+      const int nt = min(tile_rows, M - t * tile_rows);
+      const double d = (double)q[0] / (double)nt - mean;
+      m2 += (double)q[1] + (double)nt * d * d;
+    }
+  red[sl][cl] = m2;
+  __syncthreads();
+  if (sl == 0 && cok) {
+    double tm2 = 0.0;
+    for (int i = 0; i < 16; ++i) tm2 += red[i][cl];
+    const double var = tm2 / (double)M;  // biased, used for normalisation
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float g = gamma ? gamma[c] : 1.f;
+    const float b = beta ? beta[c] : 0.f;
+    const float sc = g * rstd;
+    scale_out[c] = sc;
+    shift_out[c] = b - (float)mean * sc;
+    if (mean_out) mean_out[c] = (float)mean;
+    if (rstd_out) rstd_out[c] = rstd;
+    if (running_mean) {
+      const double unbiased = M > 1 ? tm2 / (double)(M - 1) : var;
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+  }
+}
+
+// ---------------------------------------------------------------- scale/shift/act apply
+template <bool VEC>
+__global__ __launch_bounds__(256) void scale_shift_act_kernel(
+    const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
+    int rows_per_sample, const float* __restrict__ residual, float* __restrict__ y, long M, int C,
+    int act) {
+  if constexpr (VEC) {
+    const int C4 = C >> 2;
+    const long total = M * C4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long)gridDim.x * blockDim.x) {
+      const long row = i / C4;
+      const int c = (int)(i - row * C4) * 4;
+      const long so = rows_per_sample > 0 ? (row / rows_per_sample) * C + c : c;
+      f32x4 v = *reinterpret_cast<const f32x4*>(x + i * 4);
+      const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + so);
+      const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + so);
+      v = v * sc + sh;
+      if (residual) v += *reinterpret_cast<const f32x4*>(residual + i * 4);
+      v.x = apply_act(v.x, act);
+      v.y = apply_act(v.y, act);
+      v.z = apply_act(v.z, act);
+      v.w = apply_act(v.w, act);
+      *reinterpret_cast<f32x4*>(y + i * 4) = v;
+    }
+  } else {
+    const long total = M * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long)gridDim.x * blockDim.x) {
+      const long row = i / C;
+      const int c = (int)(i - row * C);
+      const long so = rows_per_sample > 0 ? (row / rows_per_sample) * C + c : c;
+      float v = x[i] * scale[so] + shift[so];
+      if (residual) v += residual[i];
+      y[i] = apply_act(v, act);
+    }
+  }
+}
+
+// ---------------------------------------------------------------- GroupNorm statistics
+constexpr int GN_CHUNK = 128;  // pixels per block
+
+// x: [N, HW, C]; partial: [N, chunks, C, 2] = {sum, sumsq} over the chunk's pixels
+__global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict__ x, int HW, int C,
+                                                         int chunks, float* __restrict__ partial) {
+  __shared__ float red[256 * 8];
+  const int n = blockIdx.x / chunks;
+  const int ch = blockIdx.x - n * chunks;
+  const int p0 = ch * GN_CHUNK;
+  const int p1 = min(HW, p0 + GN_CHUNK);
+  const int C4 = C >> 2;
+  const int tid = threadIdx.x;
+  const float* base = x + (long)n * HW * C;
+  float* out = partial + ((long)n * chunks + ch) * C * 2;
+  if (C4 >= 256) {
+    for (int c4 = tid; c4 < C4; c4 += 256) {
+      f32x4 s = {0, 0, 0, 0}, q = {0, 0, 0, 0};
+      for (int p = p0; p < p1; ++p) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(base + (long)p * C + c4 * 4);
+        s += v;
+        q += v * v;
+      }
+      for (int e = 0; e < 4; ++e) {
+        out[(c4 * 4 + e) * 2 + 0] = s[e];
+        out[(c4 * 4 + e) * 2 + 1] = q[e];
+      }
+    }
+    return;
+  }
+  const int PL = 256 / C4;  // pixel lanes
+  const int pl = tid / C4;
+  const int c4 = tid - pl * C4;
+  f32x4 s = {0, 0, 0, 0}, q = {0, 0, 0, 0};
+  if (pl < PL)
+    for (int p = p0 + pl; p < p1; p += PL) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(base + (long)p * C + c4 * 4);
+      s += v;
+      q += v * v;
+    }
+  for (int e = 0; e < 4; ++e) {
+    red[tid * 8 + e] = s[e];
+    red[tid * 8 + 4 + e] = q[e];
+  }
+  __syncthreads();
+  if (tid < C4) {
+    for (int l = 1; l < PL; ++l)
+      for (int e = 0; e < 4; ++e) {
+        s[e] += red[(l * C4 + tid) * 8 + e];
+        q[e] += red[(l * C4 + tid) * 8 + 4 + e];
+      }
+    for (int e = 0; e < 4; ++e) {
+      out[(tid * 4 + e) * 2 + 0] = s[e];
+      out[(tid * 4 + e) * 2 + 1] = q[e];
+    }
+  }
+}
+
+// one wave per (sample, group)
+__global__ __launch_bounds__(256) void gn_finalize_kernel(
+    const float* __restrict__ partial, int Nimg, int HW, int C, int groups, int chunks,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+    float* __restrict__ scale_out, float* __restrict__ shift_out, float* mean_out,
+    float* rstd_out) {
+  const int lane = threadIdx.x & 63;
+  const int pair = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (pair >= Nimg * groups) return;
+  const int n = pair / groups;
+  const int g = pair - n * groups;
+  const int cpg = C / groups;
+  const int items = chunks * cpg;
+  double s = 0.0, q = 0.0;
+  for (int i = lane; i < items; i += 64) {
+    const int ch = i / cpg;
+    const int c = g * cpg + (i - ch * cpg);
+    const float* src = partial + (((long)n * chunks + ch) * C + c) * 2;
+    s += (double)src[0];
+    q += (double)src[1];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s += __shfl_xor(s, o, 64);
+    q += __shfl_xor(q, o, 64);
+  }
+  const double cnt = (double)HW * (double)cpg;
+  const double mean = s / cnt;
+  double var = q / cnt - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  for (int i = lane; i < cpg; i += 64) {
+    const int c = g * cpg + i;
+    const float sc = (gamma ? gamma[c] : 1.f) * rstd;
+    scale_out[(long)n * C + c] = sc;
+    shift_out[(long)n * C + c] = (beta ? beta[c] : 0.f) - (float)mean * sc;
+  }
+  if (lane == 0) {
+    if (mean_out) mean_out[pair] = (float)mean;
+    if (rstd_out) rstd_out[pair] = rstd;
+  }
+}
+
+}  // namespace
+
+extern "C" int vlnce_bn_finalize(const float* stat_partial, int tiles_m, int tile_rows, int M,
+                                 int C, const float* gamma, const float* beta, float eps,
+                                 float momentum, float* running_mean, float* running_var,
+                                 float* scale_out, float* shift_out, float* mean_out,
+                                 float* rstd_out, vlnce_stream_t stream) {
+  VLNCE_CHECK_ARG(stat_partial && scale_out && shift_out, "bn_finalize: null argument");
+  VLNCE_CHECK_ARG(tiles_m > 0 && tile_rows > 0 && M > 0 && C > 0, "bn_finalize: bad shape");
+  VLNCE_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr),
+                  "bn_finalize: running stats must come together");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 16)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), stat_partial, tiles_m, tile_rows, M, C,
+                     gamma, beta, eps, momentum, running_mean, running_var, scale_out, shift_out,
+                     mean_out, rstd_out);
+  VLNCE_CHECK_LAUNCH("bn_finalize");
+  return 0;
+}
+
+extern "C" int vlnce_scale_shift_act(const float* x, const float* scale, const float* shift,
+                                     int rows_per_sample, const float* residual, float* y, long M,
+                                     int C, int act, vlnce_stream_t stream) {
+  VLNCE_CHECK_ARG(x && scale && shift && y, "scale_shift_act: null argument");
+  VLNCE_CHECK_ARG(M > 0 && C > 0, "scale_shift_act: bad shape");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  const bool vec = (C % 4 == 0) && al(x) && al(y) && al(scale) && al(shift) &&
+                   (!residual || al(residual));
+  const long work = vec ? M * (C / 4) : M * (long)C;
+  const int grid = (int)(work / 256 + 1 < 8192 ? work / 256 + 1 : 8192);
+  if (vec)
+    hipLaunchKernelGGL(scale_shift_act_kernel<true>, dim3(grid), dim3(256), 0, s, x, scale, shift,
+                       rows_per_sample, residual, y, M, C, act);
+  else
+    hipLaunchKernelGGL(scale_shift_act_kernel<false>, dim3(grid), dim3(256), 0, s, x, scale, shift,
+                       rows_per_sample, residual, y, M, C, act);
+  VLNCE_CHECK_LAUNCH("scale_shift_act");
+  return 0;
+}
+
+extern "C" int vlnce_gn_chunks(int HW) { return ceil_div(HW, GN_CHUNK); }
+
+extern "C" int vlnce_gn_partial(const float* x, int Nimg, int HW, int C, float* partial,
+                                vlnce_stream_t stream) {
+  VLNCE_CHECK_ARG(x && partial, "gn_partial: null argument");
+  VLNCE_CHECK_ARG(Nimg > 0 && HW > 0 && C > 0 && C % 4 == 0, "gn_partial: C must be a multiple of 4");
+  const int chunks = ceil_div(HW, GN_CHUNK);
+  hipLaunchKernelGGL(gn_partial_kernel, dim3(Nimg * chunks), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), x, HW, C, chunks, partial);
+  VLNCE_CHECK_LAUNCH("gn_partial");
+  return 0;
+}
+
+extern "C" int vlnce_gn_finalize(const float* partial, int Nimg, int HW, int C, int groups,
+                                 const float* gamma, const float* beta, float eps,
+                                 float* scale_out, float* shift_out, float* mean_out,
+                                 float* rstd_out, vlnce_stream_t stream) {
+  VLNCE_CHECK_ARG(partial && scale_out && shift_out, "gn_finalize: null argument");
+  VLNCE_CHECK_ARG(groups > 0 && C % groups == 0, "gn_finalize: C %% groups != 0");
+  const int chunks = ceil_div(HW, GN_CHUNK);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(ceil_div((long)Nimg * groups, 4)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), partial, Nimg, HW, C, groups, chunks,
+                     gamma, beta, eps, scale_out, shift_out, mean_out, rstd_out);
+  VLNCE_CHECK_LAUNCH("gn_finalize");
+  return 0;
+}

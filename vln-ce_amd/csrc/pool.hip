@@ -1,0 +1,154 @@
+// Pooling kernels, channels-last, one thread per output vector (HBM-bound).
+#include "common.h"
+
+namespace {
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const float* __restrict__ x,
+                                                           float* __restrict__ y, int N, int H,
+                                                           int W, int C, int Ho, int Wo) {
+  constexpr int V = VEC ? 4 : 1;
+  const int Cv = C / V;
+  const long total = (long)N * Ho * Wo * Cv;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const int cv = (int)(i % Cv);
+    long t = i / Cv;
+    const int wo = (int)(t % Wo);
+    t /= Wo;
+    const int ho = (int)(t % Ho);
+    const int n = (int)(t / Ho);
+    float m[V];
+    for (int e = 0; e < V; ++e) m[e] = -INFINITY;
+    for (int r = 0; r < 3; ++r) {
+      const int hi = ho * 2 - 1 + r;
+      if ((unsigned)hi >= (unsigned)H) continue;
+      for (int q = 0; q < 3; ++q) {
+        const int wi = wo * 2 - 1 + q;
+        if ((unsigned)wi >= (unsigned)W) continue;
+        const float* src = x + (((long)n * H + hi) * W + wi) * C + cv * V;
+        if constexpr (VEC) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(src);
+          for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], v[e]);
+        } else {
+          m[0] = fmaxf(m[0], src[0]);
+        }
+      }
+    }
+    float* dst = y + i * V;
+    for (int e = 0; e < V; ++e) dst[e] = m[e];
+  }
+}
+
+__global__ __launch_bounds__(256) void avgpool2x2_kernel(const float* __restrict__ x,
+                                                         float* __restrict__ y, int N, int H, int W,
+                                                         int C) {
+  const int Ho = H / 2, Wo = W / 2;
+  const long total = (long)N * Ho * Wo * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    long t = i / C;
+    const int wo = (int)(t % Wo);
+    t /= Wo;
+    const int ho = (int)(t % Ho);
+    const int n = (int)(t / Ho);
+    const float* p = x + (((long)n * H + ho * 2) * W + wo * 2) * C + c;
+    // same summation order as at::avg_pool2d: row-major over the window
+    float s = p[0];
+    s += p[C];
+    s += p[(long)W * C];
+    s += p[(long)W * C + C];
+    y[i] = s / 4.0f;
+  }
+}
+
+// adaptive average pool: out cell (oh, ow) averages rows [floor(oh*H/OH), ceil((oh+1)*H/OH)) etc.
+__global__ __launch_bounds__(256) void adaptive_avgpool_kernel(const float* __restrict__ x,
+                                                               float* __restrict__ y, int N, int H,
+                                                               int W, int C, int OH, int OW,
+                                                               int ldy) {
+  const long total = (long)N * OH * OW * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    long t = i / C;
+    const int ow = (int)(t % OW);
+    t /= OW;
+    const int oh = (int)(t % OH);
+    const int n = (int)(t / OH);
+    const int hs = (oh * H) / OH, he = ((oh + 1) * H + OH - 1) / OH;
+    const int ws = (ow * W) / OW, we = ((ow + 1) * W + OW - 1) / OW;
+    float s = 0.f;
+    for (int h = hs; h < he; ++h)
+      for (int w = ws; w < we; ++w) s += x[(((long)n * H + h) * W + w) * C + c];
+    y[(((long)n * OH + oh) * OW + ow) * ldy + c] = s / (float)((he - hs) * (we - ws));
+  }
+}
+
+// y[b, c] = mean_p x[b, p, c]
+__global__ __launch_bounds__(256) void mean_rows_kernel(const float* __restrict__ x,
+                                                        float* __restrict__ y, int B, int P,
+                                                        int C) {
+  const long total = (long)B * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const long b = i / C;
+    float s = 0.f;
+    for (int p = 0; p < P; ++p) s += x[(b * P + p) * C + c];
+    y[i] = s / (float)P;
+  }
+}
+
+inline int grid_for(long work) {
+  long g = (work + 255) / 256;
+  if (g < 1) g = 1;
+  if (g > 8192) g = 8192;
+  return (int)g;
+}
+
+}  // namespace
+
+extern "C" int vlnce_maxpool3x3s2(const float* x, float* y, int N, int H, int W, int C, int Ho,
+                                  int Wo, vlnce_stream_t stream) {
+  VLNCE_CHECK_ARG(x && y, "maxpool: null argument");
+  VLNCE_CHECK_ARG(Ho == (H + 2 - 3) / 2 + 1 && Wo == (W + 2 - 3) / 2 + 1, "maxpool: bad Ho/Wo");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const bool vec = (C % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0;
+  if (vec)
+    hipLaunchKernelGGL(maxpool3x3s2_kernel<true>, dim3(grid_for((long)N * Ho * Wo * C / 4)),
+                       dim3(256), 0, s, x, y, N, H, W, C, Ho, Wo);
+  else
+    hipLaunchKernelGGL(maxpool3x3s2_kernel<false>, dim3(grid_for((long)N * Ho * Wo * C)), dim3(256),
+                       0, s, x, y, N, H, W, C, Ho, Wo);
+  VLNCE_CHECK_LAUNCH("maxpool3x3s2");
+  return 0;
+}
+
+extern "C" int vlnce_avgpool2x2(const float* x, float* y, int N, int H, int W, int C,
+                                vlnce_stream_t stream) {
+  VLNCE_CHECK_ARG(x && y && H >= 2 && W >= 2, "avgpool2x2: bad argument");
+  hipLaunchKernelGGL(avgpool2x2_kernel, dim3(grid_for((long)N * (H / 2) * (W / 2) * C)), dim3(256),
+                     0, reinterpret_cast<hipStream_t>(stream), x, y, N, H, W, C);
+  VLNCE_CHECK_LAUNCH("avgpool2x2");
+  return 0;
+}
+
+extern "C" int vlnce_adaptive_avgpool(const float* x, float* y, int N, int H, int W, int C, int OH,
+                                      int OW, int ldy, vlnce_stream_t stream) {
+  VLNCE_CHECK_ARG(x && y && OH > 0 && OW > 0 && ldy >= C, "adaptive_avgpool: bad argument");
+  hipLaunchKernelGGL(adaptive_avgpool_kernel, dim3(grid_for((long)N * OH * OW * C)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), x, y, N, H, W, C, OH, OW, ldy);
+  VLNCE_CHECK_LAUNCH("adaptive_avgpool");
+  return 0;
+}
+
+extern "C" int vlnce_mean_rows(const float* x, float* y, int B, int P, int C,
+                               vlnce_stream_t stream) {
+  VLNCE_CHECK_ARG(x && y && B > 0 && P > 0 && C > 0, "mean_rows: bad argument");
+  hipLaunchKernelGGL(mean_rows_kernel, dim3(grid_for((long)B * C)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), x, y, B, P, C);
+  VLNCE_CHECK_LAUNCH("mean_rows");
+  return 0;
+}

@@ -1,0 +1,112 @@
+"""Instruction encoder (reference: models/encoders/instruction_encoder.py:11-94):
+token embedding (or RxR BERT features) -> packed (bi)directional LSTM/GRU ->
+final state, or the zero-padded output sequence.
+
+nn.LSTM / nn.GRU / nn.Embedding are parameter containers only (state_dict
+keys `encoder_rnn.weight_ih_l0[_reverse]`, `embedding_layer.weight`).  The
+input projection x W_ih^T for ALL steps and both directions is one MFMA GEMM
+in time-major layout; the recurrence runs the fused gate kernels step by step
+with packed-sequence semantics (steps past a sample's length keep its state
+and emit zeros).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+
+
+class InstructionEncoder(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        rnn = nn.GRU if config.rnn_type == "GRU" else nn.LSTM
+        self.encoder_rnn = rnn(input_size=config.embedding_size, hidden_size=config.hidden_size,
+                               bidirectional=config.bidirectional)
+        if config.sensor_uuid == "instruction":
+            if config.use_pretrained_embeddings:
+                self.embedding_layer = nn.Embedding.from_pretrained(
+                    embeddings=self._load_embeddings(), freeze=not config.fine_tune_embeddings)
+            else:
+                self.embedding_layer = nn.Embedding(num_embeddings=config.vocab_size,
+                                                    embedding_dim=config.embedding_size,
+                                                    padding_idx=0)
+
+    @property
+    def output_size(self):
+        return self.config.hidden_size * (1 + int(self.config.bidirectional))
+
+    def _load_embeddings(self):
+        import gzip
+        import json
+
+        with gzip.open(self.config.embedding_file, "rt") as f:
+            return torch.tensor(json.load(f))
+
+    def _direction(self, gi_tm, lengths_ok, active, w_hh, b_hh, reverse):
+        """gi_tm [L, B, G*H] time-major input gates of one direction."""
+        Lmax, B, _ = gi_tm.shape
+        H = self.config.hidden_size
+        lstm = self.config.rnn_type == "LSTM"
+        h = gi_tm.new_zeros((B, H))
+        c = gi_tm.new_zeros((B, H)) if lstm else None
+        outs = [None] * Lmax
+        steps = range(Lmax - 1, -1, -1) if reverse else range(Lmax)
+        for t in steps:
+            if lstm:
+                h_new, c_new = ops.lstm_cell(gi_tm[t], h, c, w_hh, b_hh)
+            else:
+                h_new = ops.gru_cell(gi_tm[t], h, w_hh, b_hh)
+            if lengths_ok:  # every sample is still running at every step
+                h = h_new
+                c = c_new if lstm else None
+                outs[t] = h_new
+            else:
+                m = active[t]
+                outs[t] = ops.select_rows(m, h_new, None)
+                h = ops.select_rows(m, h_new, h)
+                if lstm:
+                    c = ops.select_rows(m, c_new, c)
+        return outs, h
+
+    def forward(self, observations):
+        cfg = self.config
+        if cfg.sensor_uuid == "instruction":
+            tokens = observations["instruction"].long()
+            feats = F.embedding(tokens, self.embedding_layer.weight,
+                                padding_idx=self.embedding_layer.padding_idx)
+        else:
+            feats = observations["rxr_instruction"]
+        # :77-78 a step counts iff its feature vector is not all-zero; pack_padded_sequence
+        # then keeps the first `length` steps of each sample.  One host sync, as upstream (.cpu()).
+        lengths = (feats != 0.0).any(dim=2).sum(dim=1)
+        lmin, lmax = (int(v) for v in torch.stack([lengths.min(), lengths.max()]).tolist())
+        if lmin <= 0:
+            raise RuntimeError("Length of all samples has to be greater than 0, "
+                               "but found an element in 'lengths' that is <= 0")
+        B, E = feats.size(0), feats.size(2)
+        H = cfg.hidden_size
+        rnn = self.encoder_rnn
+        x_tm = feats[:, :lmax].transpose(0, 1).reshape(lmax * B, E)
+        same_len = lmin == lmax
+        active = None
+        if not same_len:
+            active = (torch.arange(lmax, device=feats.device)[:, None] < lengths[None, :]).to(
+                torch.uint8).contiguous()
+        dirs = [("", False)] + ([("_reverse", True)] if cfg.bidirectional else [])
+        seqs, finals = [], []
+        for sfx, rev in dirs:
+            w_ih = getattr(rnn, "weight_ih_l0" + sfx)
+            w_hh = getattr(rnn, "weight_hh_l0" + sfx)
+            b_ih = getattr(rnn, "bias_ih_l0" + sfx)
+            b_hh = getattr(rnn, "bias_hh_l0" + sfx)
+            gi = ops.linear(x_tm, w_ih, b_ih).view(lmax, B, -1)
+            outs, h_last = self._direction(gi, same_len, active, w_hh, b_hh, rev)
+            finals.append(h_last)
+            if not cfg.final_state_only:
+                seqs.append(torch.stack(outs, dim=1))  # [B, L, H]
+        if cfg.final_state_only:
+            # final_state.squeeze(0): [1,B,H] -> [B,H]; a bidirectional [2,B,H] is left as is (App. B-10)
+            return finals[0] if len(finals) == 1 else torch.stack(finals, 0)
+        seq = seqs[0] if len(seqs) == 1 else torch.cat(seqs, dim=2)
+        return seq.permute(0, 2, 1)  # logical [B, H*dirs, Lmax]; memory stays [B, L, C]

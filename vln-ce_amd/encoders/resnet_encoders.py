@@ -1,0 +1,463 @@
+"""RGB / depth visual encoders of the VLN-CE policies on the HIP kernels.
+
+Mirrors vlnce_baselines/models/encoders/resnet_encoders.py:17-229 (module and
+parameter names, constructor arguments, cached-feature bypass, output shapes)
+plus the two third-party trunks it instantiates (torchvision resnet18/50 and
+habitat-lab v0.1.7 ResNetEncoder).  nn.Conv2d / nn.BatchNorm2d
+/ nn.GroupNorm objects are kept ONLY as parameter containers so state_dict keys
+match published checkpoints; their torch forward is never called.  The trunk
+runs channels-last on libvlnce_hip.so: implicit-GEMM fp32-MFMA convolutions
+with the norm / ReLU / residual fused into the epilogue (eval BatchNorm) or a
+statistics epilogue + one apply pass (train BatchNorm, GroupNorm).
+
+Visual feature maps are returned as *logical* NCHW tensors whose memory is
+NHWC (a permuted view), so forward hooks on `.cnn` / `.visual_encoder`
+(dagger_trainer.py:300-314) see the reference's shapes while downstream HIP
+ops get channels-last rows without a copy.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..config import Box, Dict
+
+
+# ------------------------------------------------------------------ helpers
+class _WeightCache:
+    """OIHW nn.Conv2d weights repacked to the kernels' OHWI layout, refreshed
+    when the parameter is updated in place (optimizer step / load_state_dict)
+    or moved to another device."""
+
+    def __init__(self):
+        self._packed = {}
+        self._folded = {}
+
+    @staticmethod
+    def _key(*ts):
+        return tuple((t.data_ptr(), t._version, t.device) for t in ts)
+
+    def conv(self, conv):
+        k = self._key(conv.weight)
+        hit = self._packed.get(id(conv))
+        if hit is None or hit[0] != k:
+            w = conv.weight.detach().permute(0, 2, 3, 1).contiguous()
+            hit = (k, w)
+            self._packed[id(conv)] = hit
+        return hit[1]
+
+    def bn_eval(self, bn):
+        k = self._key(bn.weight, bn.bias, bn.running_mean, bn.running_var)
+        hit = self._folded.get(id(bn))
+        if hit is None or hit[0] != k:
+            scale = bn.weight.detach() / torch.sqrt(bn.running_var + bn.eps)
+            shift = bn.bias.detach() - bn.running_mean * scale
+            hit = (k, scale.contiguous(), shift.contiguous())
+            self._folded[id(bn)] = hit
+        return hit[1], hit[2]
+
+
+def _require_frozen(module, what):
+    if torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters()):
+        raise NotImplementedError(
+            f"{what}: trainable visual encoders need the conv dgrad/wgrad kernels, which this "
+            "build does not have yet; keep MODEL.*_ENCODER.trainable=False (the reference default)"
+        )
+
+
+def _as_nhwc(t_nchw_logical):
+    """logical NCHW tensor -> contiguous NHWC tensor (no copy when already channels-last)."""
+    return t_nchw_logical.permute(0, 2, 3, 1).contiguous()
+
+
+def _grid_embedding_nhwc(emb, b, h, w):
+    # reference: embeddings(arange(n)).view(1, -1, h, w).expand(b, ...) -- a raw
+    # reinterpretation of the [h*w, 64] table as [64, h, w] (resnet_encoders.py:97-111,201-215)
+    e = emb.weight.view(1, emb.embedding_dim, h, w).permute(0, 2, 3, 1)
+    return e.expand(b, h, w, emb.embedding_dim)
+
+
+# ------------------------------------------------------------------ torchvision trunk
+def _c3(cin, cout, stride=1):
+    return nn.Conv2d(cin, cout, 3, stride=stride, padding=1, bias=False)
+
+
+def _c1(cin, cout, stride=1):
+    return nn.Conv2d(cin, cout, 1, stride=stride, bias=False)
+
+
+class BasicBlock(nn.Module):
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = _c3(inplanes, planes, stride)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = _c3(planes, planes)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.downsample = downsample
+        self.stride = stride
+
+    def stages(self):
+        return [(self.conv1, self.bn1), (self.conv2, self.bn2)]
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = _c1(inplanes, planes)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = _c3(planes, planes, stride)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = _c1(planes, planes * 4)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+        self.stride = stride
+
+    def stages(self):
+        return [(self.conv1, self.bn1), (self.conv2, self.bn2), (self.conv3, self.bn3)]
+
+
+class _GlobalAvgPool(nn.Module):
+    out_hw = (1, 1)
+
+
+class SpatialAvgPool(nn.Module):
+    out_hw = (4, 4)
+
+
+class HipResNetTrunk(nn.Sequential):
+    """torchvision ResNet children[:-1] (conv1, bn1, relu, maxpool, layer1..4,
+    [avgpool]) with indices/keys preserved; forward = fused HIP plan."""
+
+    def __init__(self, block, layers):
+        inplanes = 64
+        mods = [nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False), nn.BatchNorm2d(64),
+                nn.ReLU(inplace=True), nn.MaxPool2d(kernel_size=3, stride=2, padding=1)]
+        for planes, n, stride in zip((64, 128, 256, 512), layers, (1, 2, 2, 2)):
+            down = None
+            if stride != 1 or inplanes != planes * block.expansion:
+                down = nn.Sequential(_c1(inplanes, planes * block.expansion, stride),
+                                     nn.BatchNorm2d(planes * block.expansion))
+            blocks = [block(inplanes, planes, stride, down)]
+            inplanes = planes * block.expansion
+            blocks += [block(inplanes, planes) for _ in range(1, n)]
+            mods.append(nn.Sequential(*blocks))
+        mods.append(_GlobalAvgPool())
+        super().__init__(*mods)
+        self.final_channels = inplanes
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+        self._cache = _WeightCache()
+        self.input_scale = None  # set by the owning encoder: per-channel (scale, shift)
+
+    # -- one conv + BatchNorm (+residual) (+ReLU)
+    def _conv_bn(self, x, conv, bn, relu, residual=None, prologue=None, touched=None):
+        w = self._cache.conv(conv)
+        act = ops.ACT_RELU if relu else ops.ACT_NONE
+        pro = {}
+        if prologue is not None:
+            pro = dict(in_scale=prologue[0], in_shift=prologue[1])
+        stride, pad = conv.stride[0], conv.padding[0]
+        if bn.training:
+            y, stats = ops.conv2d_nhwc(x, w, stride, pad, want_stats=True, **pro)
+            M = y.numel() // y.size(-1)
+            assert bn.momentum is not None
+            scale, shift = ops.bn_finalize(stats, M, bn.weight, bn.bias, bn.eps, bn.momentum,
+                                           bn.running_mean, bn.running_var)
+            touched.append(bn.num_batches_tracked)
+            return ops.scale_shift_act(y, scale, shift, residual=residual, act=act, out=y)
+        scale, shift = self._cache.bn_eval(bn)
+        return ops.conv2d_nhwc(x, w, stride, pad, scale=scale, shift=shift, residual=residual,
+                               act=act, **pro)
+
+    def forward(self, x_nhwc_raw):
+        """x: [B,H,W,3] pixel values 0..255 (channels-last as the simulator
+        delivers them); returns logical NCHW features."""
+        _require_frozen(self, "TorchVisionResNet.cnn")
+        with torch.no_grad():
+            kids = list(self.children())
+            touched = []
+            x = ops._f32c(x_nhwc_raw)
+            x = self._conv_bn(x, kids[0], kids[1], True, prologue=self.input_scale, touched=touched)
+            x = ops.maxpool3x3s2(x)
+            for stage in kids[4:8]:
+                for blk in stage:
+                    identity = x
+                    if blk.downsample is not None:
+                        identity = self._conv_bn(x, blk.downsample[0], blk.downsample[1], False,
+                                                 touched=touched)
+                    st = blk.stages()
+                    for conv, bn in st[:-1]:
+                        x = self._conv_bn(x, conv, bn, True, touched=touched)
+                    x = self._conv_bn(x, st[-1][0], st[-1][1], True, residual=identity,
+                                      touched=touched)
+            for pool in kids[8:]:
+                x = ops.adaptive_avgpool(x, *pool.out_hw)
+            if touched:
+                torch._foreach_add_(touched, 1)
+        return x.permute(0, 3, 1, 2)
+
+
+class TorchVisionResNet(nn.Module):
+    """resnet_encoders.py:118-219."""
+
+    def __init__(self, output_size, resnet_version="resnet50", normalize_visual_inputs=False,
+                 trainable=False, spatial_output=False, single_spatial_filter=True):
+        super().__init__()
+        self.normalize_visual_inputs = normalize_visual_inputs
+        self.spatial_output = spatial_output
+        if resnet_version == "resnet50":
+            self.cnn = HipResNetTrunk(Bottleneck, [3, 4, 6, 3])
+        elif resnet_version == "resnet18":
+            self.cnn = HipResNetTrunk(BasicBlock, [2, 2, 2, 2])
+        else:
+            raise ValueError(resnet_version)
+        self.resnet_layer_size = self.cnn.final_channels
+        for p in self.cnn.parameters():
+            p.requires_grad_(trainable)
+        self.cnn.train(trainable)
+        if not spatial_output:
+            self.output_shape = (output_size,)
+            self.fc = nn.Sequential(nn.Flatten(), nn.Linear(self.resnet_layer_size, output_size),
+                                    nn.ReLU())
+        else:
+            if single_spatial_filter:
+                del self.cnn[8]  # drop the global average pool
+            self.cnn.avgpool = SpatialAvgPool()
+            self.spatial_embeddings = nn.Embedding(4 * 4, 64)
+            self.output_shape = (self.resnet_layer_size + 64, 4, 4)
+        self._in_cache = None
+
+    def _input_transform(self, device):
+        # /255 then optional ImageNet mean/std (:171-192), fused into the stem's loader
+        if self._in_cache is None or self._in_cache[0].device != device:
+            if self.normalize_visual_inputs:
+                mean = torch.tensor([0.485, 0.456, 0.406], device=device)
+                std = torch.tensor([0.229, 0.224, 0.225], device=device)
+                sc, sh = 1.0 / (255.0 * std), -mean / std
+            else:
+                sc = torch.full((3,), 1.0 / 255.0, device=device)
+                sh = torch.zeros(3, device=device)
+            self._in_cache = (sc.contiguous(), sh.contiguous())
+        return self._in_cache
+
+    def forward(self, observations):
+        if "rgb_features" in observations:
+            feats = observations["rgb_features"]
+        else:
+            rgb = observations["rgb"]
+            self.cnn.input_scale = self._input_transform(rgb.device)
+            feats = self.cnn(rgb)
+        if not self.spatial_output:
+            return ops.linear(feats.reshape(feats.size(0), -1), self.fc[1].weight, self.fc[1].bias,
+                              ops.ACT_RELU)
+        b, _, h, w = feats.shape
+        x = torch.cat([_as_nhwc(feats), _grid_embedding_nhwc(self.spatial_embeddings, b, h, w)],
+                      dim=3)
+        return x.permute(0, 3, 1, 2)
+
+
+class TorchVisionResNet50(TorchVisionResNet):
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, resnet_version="resnet50", **kwargs)
+
+
+class TorchVisionResNet18(TorchVisionResNet):
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, resnet_version="resnet18", **kwargs)
+
+
+# ------------------------------------------------------------------ habitat GroupNorm trunk
+class GNBasicBlock(nn.Module):
+    expansion = 1
+
+    def __init__(self, inplanes, planes, ngroups, stride=1, downsample=None):
+        super().__init__()
+        self.convs = nn.Sequential(_c3(inplanes, planes, stride), nn.GroupNorm(ngroups, planes),
+                                   nn.ReLU(True), _c3(planes, planes),
+                                   nn.GroupNorm(ngroups, planes))
+        self.downsample = downsample
+        self.relu = nn.ReLU(True)
+
+
+class GNBottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, ngroups, stride=1, downsample=None):
+        super().__init__()
+        self.convs = nn.Sequential(
+            _c1(inplanes, planes), nn.GroupNorm(ngroups, planes), nn.ReLU(True),
+            _c3(planes, planes, stride), nn.GroupNorm(ngroups, planes), nn.ReLU(True),
+            _c1(planes, planes * 4), nn.GroupNorm(ngroups, planes * 4))
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+
+
+class GNResNet(nn.Module):
+    """habitat_baselines.rl.ddppo.policy.resnet.ResNet parameter tree."""
+
+    def __init__(self, in_channels, base_planes, ngroups, block, layers):
+        super().__init__()
+        self.conv1 = nn.Sequential(
+            nn.Conv2d(in_channels, base_planes, 7, stride=2, padding=3, bias=False),
+            nn.GroupNorm(ngroups, base_planes), nn.ReLU(True))
+        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        self.inplanes = base_planes
+        self.layer1 = self._stage(block, ngroups, base_planes, layers[0], 1)
+        self.layer2 = self._stage(block, ngroups, base_planes * 2, layers[1], 2)
+        self.layer3 = self._stage(block, ngroups, base_planes * 4, layers[2], 2)
+        self.layer4 = self._stage(block, ngroups, base_planes * 8, layers[3], 2)
+        self.final_channels = self.inplanes
+        self.final_spatial_compress = 1.0 / (2 ** 5)
+
+    def _stage(self, block, ngroups, planes, n, stride):
+        down = None
+        if stride != 1 or self.inplanes != planes * block.expansion:
+            down = nn.Sequential(_c1(self.inplanes, planes * block.expansion, stride),
+                                 nn.GroupNorm(ngroups, planes * block.expansion))
+        blocks = [block(self.inplanes, planes, ngroups, stride, down)]
+        self.inplanes = planes * block.expansion
+        blocks += [block(self.inplanes, planes, ngroups) for _ in range(1, n)]
+        return nn.Sequential(*blocks)
+
+
+def resnet18(in_channels, base_planes, ngroups):
+    return GNResNet(in_channels, base_planes, ngroups, GNBasicBlock, [2, 2, 2, 2])
+
+
+def resnet50(in_channels, base_planes, ngroups):
+    return GNResNet(in_channels, base_planes, ngroups, GNBottleneck, [3, 4, 6, 3])
+
+
+class HipResNetEncoder(nn.Module):
+    """habitat ResNetEncoder (depth-only use in VLN-CE): avg_pool2d(2) ->
+    GroupNorm ResNet -> 3x3 compression conv + GroupNorm(1, C) + ReLU."""
+
+    def __init__(self, observation_space, baseplanes=32, ngroups=32, spatial_size=128,
+                 make_backbone=None, normalize_visual_inputs=False):
+        super().__init__()
+        sp = observation_space.spaces
+        assert "rgb" not in sp, "VLN-CE builds the habitat encoder for depth only"
+        self._n_input_rgb = 0
+        self._n_input_depth = sp["depth"].shape[2]
+        spatial_size = sp["depth"].shape[0] // 2
+        assert not normalize_visual_inputs
+        self.running_mean_and_var = nn.Sequential()
+        self.backbone = make_backbone(self._n_input_depth, baseplanes, ngroups)
+        final_spatial = int(spatial_size * self.backbone.final_spatial_compress)
+        ncomp = int(round(2048 / (final_spatial ** 2)))
+        self.compression = nn.Sequential(
+            nn.Conv2d(self.backbone.final_channels, ncomp, 3, padding=1, bias=False),
+            nn.GroupNorm(1, ncomp), nn.ReLU(True))
+        self.output_shape = (ncomp, final_spatial, final_spatial)
+        for layer in self.modules():
+            if isinstance(layer, (nn.Conv2d, nn.Linear)):
+                nn.init.kaiming_normal_(layer.weight, nn.init.calculate_gain("relu"))
+        self._cache = _WeightCache()
+
+    @property
+    def is_blind(self):
+        return self._n_input_rgb + self._n_input_depth == 0
+
+    def _conv_gn(self, x, conv, gn, relu, residual=None):
+        y = ops.conv2d_nhwc(x, self._cache.conv(conv), conv.stride[0], conv.padding[0])
+        return ops.group_norm_act(y, gn.num_groups, gn.weight, gn.bias, gn.eps, residual=residual,
+                                  act=ops.ACT_RELU if relu else ops.ACT_NONE)
+
+    def _run_convs(self, x, seq, residual):
+        """block.convs = [conv, GN, ReLU]* + [conv, GN]; the last GroupNorm output gets
+        the skip connection added and then the block's ReLU."""
+        mods, pairs, i = list(seq), [], 0
+        while i < len(mods):
+            relu = i + 2 < len(mods) and isinstance(mods[i + 2], nn.ReLU)
+            pairs.append((mods[i], mods[i + 1], relu))
+            i += 3 if relu else 2
+        for j, (conv, gn, relu) in enumerate(pairs):
+            if j == len(pairs) - 1:
+                x = self._conv_gn(x, conv, gn, True, residual=residual)
+            else:
+                x = self._conv_gn(x, conv, gn, relu)
+        return x
+
+    def forward(self, observations):
+        _require_frozen(self, "VlnResnetDepthEncoder.visual_encoder")
+        with torch.no_grad():
+            x = ops._f32c(observations["depth"])  # [B,H,W,1] is already channels-last
+            x = ops.avgpool2x2(x)
+            bb = self.backbone
+            x = self._conv_gn(x, bb.conv1[0], bb.conv1[1], True)
+            x = ops.maxpool3x3s2(x)
+            for stage in (bb.layer1, bb.layer2, bb.layer3, bb.layer4):
+                for blk in stage:
+                    identity = x
+                    if blk.downsample is not None:
+                        identity = self._conv_gn(x, blk.downsample[0], blk.downsample[1], False)
+                    x = self._run_convs(x, blk.convs, identity)
+            x = self._conv_gn(x, self.compression[0], self.compression[1], True)
+        return x.permute(0, 3, 1, 2)
+
+
+def single_frame_box_shape(box):
+    """vlnce_baselines/common/utils.py:32-42."""
+    if len(box.shape) < 4:
+        return box
+    return Box(float(np.min(box.low)), float(np.max(box.high)), box.shape[1:], box.high.dtype)
+
+
+class VlnResnetDepthEncoder(nn.Module):
+    """resnet_encoders.py:17-115."""
+
+    def __init__(self, observation_space, output_size=128, checkpoint="NONE", backbone="resnet50",
+                 resnet_baseplanes=32, normalize_visual_inputs=False, trainable=False,
+                 spatial_output=False):
+        super().__init__()
+        self.visual_encoder = HipResNetEncoder(
+            Dict({"depth": single_frame_box_shape(observation_space.spaces["depth"])}),
+            baseplanes=resnet_baseplanes, ngroups=resnet_baseplanes // 2,
+            make_backbone={"resnet18": resnet18, "resnet50": resnet50}[backbone],
+            normalize_visual_inputs=normalize_visual_inputs)
+        for p in self.visual_encoder.parameters():
+            p.requires_grad_(trainable)
+        if checkpoint != "NONE":
+            ddppo_weights = torch.load(checkpoint, map_location="cpu")
+            prefix = "actor_critic.net.visual_encoder."
+            sd = {k[len(prefix):]: v for k, v in ddppo_weights["state_dict"].items()
+                  if k.startswith(prefix)}
+            del ddppo_weights
+            self.visual_encoder.load_state_dict(sd, strict=True)
+        self.spatial_output = spatial_output
+        c, fh, fw = self.visual_encoder.output_shape
+        if not spatial_output:
+            self.output_shape = (output_size,)
+            self.visual_fc = nn.Sequential(nn.Flatten(), nn.Linear(c * fh * fw, output_size),
+                                           nn.ReLU(True))
+            self._fc_cache = None
+        else:
+            self.spatial_embeddings = nn.Embedding(fh * fw, 64)
+            self.output_shape = (c + 64, fh, fw)
+
+    def _fc_weight_nhwc(self, c, h, w):
+        """visual_fc consumes the NCHW flattening (index c*h*w + p); the features
+        are stored NHWC (index p*c + ch), so the weight's columns are permuted
+        once (view ops: autograd routes the gradient back to the parameter)."""
+        wt = self.visual_fc[1].weight
+        return wt.view(wt.size(0), c, h * w).permute(0, 2, 1).reshape(wt.size(0), h * w * c)
+
+    def forward(self, observations):
+        if "depth_features" in observations:
+            x = observations["depth_features"]
+        else:
+            x = self.visual_encoder(observations)
+        b, c, h, w = x.shape
+        if self.spatial_output:
+            y = torch.cat([_as_nhwc(x), _grid_embedding_nhwc(self.spatial_embeddings, b, h, w)],
+                          dim=3)
+            return y.permute(0, 3, 1, 2)
+        return ops.linear(_as_nhwc(x).reshape(b, -1), self._fc_weight_nhwc(c, h, w),
+                          self.visual_fc[1].bias, ops.ACT_RELU)

@@ -1,0 +1,365 @@
+"""Tensor-level operators of the policy hot path on top of the C ABI.
+
+Plain functions launch forward-only kernels (the frozen visual trunks);
+torch.autograd.Function subclasses pair each forward kernel with its
+hand-written backward for the trainable tail (linear / 1x1 conv, attention,
+GRU / LSTM cells, masked state reset, packed-sequence selects).
+All tensors are fp32; images are channels-last [N,H,W,C].
+"""
+import torch
+from torch.autograd import Function
+
+from . import _lib
+
+ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3
+
+
+def L():
+    return _lib.get_lib()
+
+
+def _f32c(t):
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _rows2d(t):
+    """view t as [rows, cols] with unit inner stride; returns (tensor, ld)."""
+    if t.dim() != 2 or t.stride(1) != 1 or (t.size(0) > 1 and t.stride(0) < t.size(1)):
+        t = t.reshape(-1, t.size(-1)).contiguous()
+    ld = t.stride(0) if t.size(0) > 1 else t.size(1)
+    return t, ld
+
+
+# ----------------------------------------------------------------- conv (forward only)
+def conv_geometry(x, w, stride, pad, ldx=None):
+    N, H, W, Cin = x.shape
+    Cout, KH, KW, Cin2 = w.shape
+    assert Cin == Cin2, (x.shape, w.shape)
+    Ho = (H + 2 * pad - KH) // stride + 1
+    Wo = (W + 2 * pad - KW) // stride + 1
+    return dict(N=N, H=H, W=W, Cin=Cin, Cout=Cout, KH=KH, KW=KW, stride=stride, pad=pad,
+                Ho=Ho, Wo=Wo, ldx=ldx or Cin, ldy=Cout)
+
+
+def conv2d_nhwc(x, w_ohwi, stride, pad, *, in_scale=None, in_shift=None, in_relu=False,
+                scale=None, shift=None, residual=None, act=ACT_NONE, want_stats=False):
+    """y[N,Ho,Wo,Cout] = act((conv(prologue(x), w)) * scale + shift + residual).
+    want_stats=True additionally returns the BatchNorm partials of the RAW
+    accumulator: (partial[tiles_m, Cout, 2], tiles_m, tile_rows)."""
+    assert x.is_contiguous() and w_ohwi.is_contiguous()
+    g = conv_geometry(x, w_ohwi, stride, pad)
+    y = torch.empty((g["N"], g["Ho"], g["Wo"], g["Cout"]), device=x.device, dtype=torch.float32)
+    stats = None
+    partial = None
+    if want_stats:
+        tiles_m, tile_rows = L().conv2d_tiles(g)
+        partial = torch.empty((tiles_m, g["Cout"], 2), device=x.device, dtype=torch.float32)
+        stats = (partial, tiles_m, tile_rows)
+    if residual is not None:
+        assert residual.is_contiguous() and residual.shape == y.shape
+    L().conv2d_fwd(x, w_ohwi, y, g, in_scale=in_scale, in_shift=in_shift, in_relu=int(in_relu),
+                   scale=scale, shift=shift, residual=residual, ldr=g["Cout"], act=act,
+                   stat_partial=partial)
+    return (y, stats) if want_stats else y
+
+
+def bn_finalize(stats, M, gamma, beta, eps, momentum, running_mean, running_var):
+    partial, tiles_m, tile_rows = stats
+    Cc = partial.size(1)
+    scale = torch.empty(Cc, device=partial.device, dtype=torch.float32)
+    shift = torch.empty_like(scale)
+    L().bn_finalize(partial, tiles_m, tile_rows, M, Cc, gamma, beta, float(eps), float(momentum),
+                    running_mean, running_var, scale, shift)
+    return scale, shift
+
+
+def scale_shift_act(x, scale, shift, *, rows_per_sample=0, residual=None, act=ACT_NONE, out=None):
+    """x: [..., C] contiguous; scale/shift: [C] (rows_per_sample=0) or [S, C]."""
+    assert x.is_contiguous()
+    Cc = x.size(-1)
+    M = x.numel() // Cc
+    y = out if out is not None else torch.empty_like(x)
+    L().scale_shift_act(x, scale, shift, rows_per_sample, residual, y, M, Cc, act)
+    return y
+
+
+def group_norm_act(x, groups, gamma, beta, eps, *, residual=None, act=ACT_NONE):
+    """GroupNorm over channels-last x[N,H,W,C] (+residual)(+act)."""
+    assert x.is_contiguous()
+    N, H, W, Cc = x.shape
+    HW = H * W
+    lib = L()
+    chunks = lib.gn_chunks(HW)
+    partial = torch.empty((N, chunks, Cc, 2), device=x.device, dtype=torch.float32)
+    lib.gn_partial(x, N, HW, Cc, partial)
+    scale = torch.empty((N, Cc), device=x.device, dtype=torch.float32)
+    shift = torch.empty_like(scale)
+    lib.gn_finalize(partial, N, HW, Cc, groups, gamma, beta, float(eps), scale, shift)
+    return scale_shift_act(x, scale, shift, rows_per_sample=HW, residual=residual, act=act)
+
+
+def maxpool3x3s2(x):
+    N, H, W, Cc = x.shape
+    Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+    y = torch.empty((N, Ho, Wo, Cc), device=x.device, dtype=torch.float32)
+    L().maxpool3x3s2(x, y, N, H, W, Cc, Ho, Wo)
+    return y
+
+
+def avgpool2x2(x):
+    N, H, W, Cc = x.shape
+    y = torch.empty((N, H // 2, W // 2, Cc), device=x.device, dtype=torch.float32)
+    L().avgpool2x2(x, y, N, H, W, Cc)
+    return y
+
+
+def adaptive_avgpool(x, OH, OW):
+    N, H, W, Cc = x.shape
+    y = torch.empty((N, OH, OW, Cc), device=x.device, dtype=torch.float32)
+    L().adaptive_avgpool(x, y, N, H, W, Cc, OH, OW, Cc)
+    return y
+
+
+def rowzero_mask(x3):
+    """x3 [B, P, C] contiguous -> uint8 [B, P], 1 where the whole row is zero."""
+    B, P, Cc = x3.shape
+    m = torch.empty((B, P), device=x3.device, dtype=torch.uint8)
+    L().rowzero_mask(x3, Cc, B * P, Cc, m)
+    return m
+
+
+# ----------------------------------------------------------------- linear / 1x1 conv
+class LinearFn(Function):
+    """y = act(x W^T + b).  x [M,K] (row stride >= K), W [N,K], b [N] | None."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, act):
+        x, ldx = _rows2d(x)
+        M, K = x.shape
+        N = weight.size(0)
+        w = weight if weight.is_contiguous() else weight.contiguous()
+        y = torch.empty((M, N), device=x.device, dtype=torch.float32)
+        L().gemm(x, ldx, 0, w, K, 0, y, N, M, N, K, shift=bias, act=act)
+        ctx.act = act
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        lib = L()
+        M, K = x.shape
+        N = w.size(0)
+        ldx = x.stride(0) if M > 1 else K
+        dz = _f32c(dy)
+        if ctx.act != ACT_NONE:
+            dz2 = torch.empty_like(dz)
+            lib.act_bwd(dz, y, dz2, dz.numel(), ctx.act)
+            dz = dz2
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((M, K), device=dz.device, dtype=torch.float32)
+            # dx[M,K] = dz[M,N] * W[N,K]   (B stored [K'=N, N'=K])
+            lib.gemm(dz, N, 0, w, K, 1, dx, K, M, K, N)
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty((N, K), device=dz.device, dtype=torch.float32)
+            # dW[N,K] = dz^T[N,M] * x[M,K]
+            lib.gemm(dz, N, 1, x, ldx, 1, dw, K, N, K, M)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = torch.empty((N,), device=dz.device, dtype=torch.float32)
+            lib.colsum(dz, N, M, N, db, 0)
+        return dx, dw, db, None
+
+
+def linear(x, weight, bias=None, act=ACT_NONE):
+    lead = x.shape[:-1]
+    y = LinearFn.apply(x.reshape(-1, x.size(-1)) if x.dim() != 2 else x, weight, bias, act)
+    return y if x.dim() == 2 else y.view(*lead, weight.size(0))
+
+
+# ----------------------------------------------------------------- attention
+class AttnFn(Function):
+    """out[B,Dv] = softmax(mask(q K^T) * scale) V ; K [B,P,Dk], V [B,P,Dv] (views allowed)."""
+
+    @staticmethod
+    def forward(ctx, q, K, V, mask, mask_mode, scale):
+        q = _f32c(q)
+        B, P, Dk = K.shape
+        Dv = V.size(2)
+
+        def ld_of(t):
+            if t.stride(2) != 1 or t.stride(0) != P * t.stride(1):
+                t = t.contiguous()
+            return t, t.stride(1)
+
+        K, ldk = ld_of(K)
+        V, ldv = ld_of(V)
+        out = torch.empty((B, Dv), device=q.device, dtype=torch.float32)
+        attn = torch.empty((B, P), device=q.device, dtype=torch.float32)
+        mm = 0 if mask is None else int(mask_mode)
+        L().attn_fwd(q, K, ldk, V, ldv, mask, mm, float(scale), out, attn, B, P, Dk, Dv)
+        ctx.save_for_backward(q, K, V, attn, mask)
+        ctx.cfg = (mm, float(scale), ldk, ldv)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, K, V, attn, mask = ctx.saved_tensors
+        mm, scale, ldk, ldv = ctx.cfg
+        B, P, Dk = K.shape
+        Dv = V.size(2)
+        dout = _f32c(dout)
+        dq = torch.empty((B, Dk), device=q.device, dtype=torch.float32)
+        dK = torch.empty((B, P, Dk), device=q.device, dtype=torch.float32)
+        dV = torch.empty((B, P, Dv), device=q.device, dtype=torch.float32)
+        L().attn_bwd(dout, q, K, ldk, V, ldv, mask, mm, scale, attn, dq, dK, Dk, dV, Dv, B, P, Dk, Dv)
+        return dq, dK, dV, None, None, None
+
+
+def attention(q, K, V, mask=None, mask_mode=1, scale=1.0):
+    return AttnFn.apply(q, K, V, mask, mask_mode, scale)
+
+
+# ----------------------------------------------------------------- row utilities
+class MaskRowsFn(Function):
+    @staticmethod
+    def forward(ctx, x, mask_u8):
+        x = _f32c(x)
+        B, H = x.shape
+        out = torch.empty_like(x)
+        L().mask_rows(x, mask_u8, out, B, H)
+        ctx.save_for_backward(mask_u8)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (m,) = ctx.saved_tensors
+        g = _f32c(g)
+        out = torch.empty_like(g)
+        L().mask_rows(g, m, out, g.size(0), g.size(1))
+        return out, None
+
+
+def mask_rows(x, mask_u8):
+    return MaskRowsFn.apply(x, mask_u8)
+
+
+class SelectRowsFn(Function):
+    """out[b] = mask[b] ? a[b] : b_[b]  (either operand may be None = zeros)."""
+
+    @staticmethod
+    def forward(ctx, mask_u8, a, b_):
+        ref = a if a is not None else b_
+        a = _f32c(a) if a is not None else None
+        b_ = _f32c(b_) if b_ is not None else None
+        B, H = ref.shape
+        out = torch.empty((B, H), device=ref.device, dtype=torch.float32)
+        L().select_rows(mask_u8, a, b_, out, B, H)
+        ctx.save_for_backward(mask_u8)
+        ctx.has = (a is not None, b_ is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (m,) = ctx.saved_tensors
+        g = _f32c(g)
+        B, H = g.shape
+        ga = gb = None
+        if ctx.has[0] and ctx.needs_input_grad[1]:
+            ga = torch.empty_like(g)
+            L().select_rows(m, g, None, ga, B, H)
+        if ctx.has[1] and ctx.needs_input_grad[2]:
+            gb = torch.empty_like(g)
+            L().select_rows(m, None, g, gb, B, H)
+        return None, ga, gb
+
+
+def select_rows(mask_u8, a, b_):
+    return SelectRowsFn.apply(mask_u8, a, b_)
+
+
+class MeanRowsFn(Function):
+    """y[b, c] = mean_p x[b, p, c]"""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _f32c(x)
+        B, P, Cc = x.shape
+        y = torch.empty((B, Cc), device=x.device, dtype=torch.float32)
+        L().mean_rows(x, y, B, P, Cc)
+        ctx.P = P
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        return (g / ctx.P).unsqueeze(1).expand(-1, ctx.P, -1)
+
+
+def mean_rows(x):
+    return MeanRowsFn.apply(x)
+
+
+# ----------------------------------------------------------------- recurrent cells
+class GRUGatesFn(Function):
+    """h' = GRU pointwise stage; gi = x W_ih^T + b_ih, gh = h W_hh^T + b_hh  ([B,3H], r|z|n)."""
+
+    @staticmethod
+    def forward(ctx, gi, gh, h_prev):
+        gi, gh, h_prev = _f32c(gi), _f32c(gh), _f32c(h_prev)
+        B, H = h_prev.shape
+        h = torch.empty_like(h_prev)
+        gates = torch.empty((B, 3 * H), device=h.device, dtype=torch.float32)
+        hn = torch.empty_like(h_prev)
+        L().gru_gates_fwd(gi, gh, h_prev, None, h, gates, hn, B, H)
+        ctx.save_for_backward(gates, hn, h_prev)
+        return h
+
+    @staticmethod
+    def backward(ctx, dh):
+        gates, hn, h_prev = ctx.saved_tensors
+        B, H = h_prev.shape
+        dh = _f32c(dh)
+        dgi = torch.empty_like(gates)
+        dgh = torch.empty_like(gates)
+        dhp = torch.empty_like(h_prev)
+        L().gru_gates_bwd(dh, gates, hn, h_prev, None, dgi, dgh, dhp, B, H)
+        return dgi, dgh, dhp
+
+
+class LSTMGatesFn(Function):
+    """(h', c') = LSTM pointwise stage; gates pre-activation = gi + gh ([B,4H], i|f|g|o)."""
+
+    @staticmethod
+    def forward(ctx, gi, gh, c_prev):
+        gi, gh, c_prev = _f32c(gi), _f32c(gh), _f32c(c_prev)
+        B, H = c_prev.shape
+        h = torch.empty_like(c_prev)
+        c = torch.empty_like(c_prev)
+        gates = torch.empty((B, 4 * H), device=h.device, dtype=torch.float32)
+        L().lstm_gates_fwd(gi, gh, c_prev, None, h, c, gates, B, H)
+        ctx.save_for_backward(gates, c_prev, c)
+        return h, c
+
+    @staticmethod
+    def backward(ctx, dh, dc):
+        gates, c_prev, c = ctx.saved_tensors
+        B, H = c_prev.shape
+        dh = _f32c(dh) if dh is not None else None
+        dc = _f32c(dc) if dc is not None else None
+        dg = torch.empty_like(gates)
+        dcp = torch.empty_like(c_prev)
+        L().lstm_gates_bwd(dh, dc, gates, c_prev, c, None, dg, dcp, B, H)
+        return dg, dg, dcp
+
+
+def gru_cell(x_gates, h_prev, w_hh, b_hh):
+    gh = linear(h_prev, w_hh, b_hh)
+    return GRUGatesFn.apply(x_gates, gh, h_prev)
+
+
+def lstm_cell(x_gates, h_prev, c_prev, w_hh, b_hh):
+    gh = linear(h_prev, w_hh, b_hh)
+    return LSTMGatesFn.apply(x_gates, gh, c_prev)
