@@ -1,0 +1,76 @@
+"""CPU tier: the data-parallel gradient exchange (vlnce_amd.distributed) with
+world_size 2 over gloo: averaged shard gradients == single-process gradient of
+the global batch, including a parameter that never receives a gradient."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+from vlnce_amd.distributed import GradientAllReducer, shard_rows
+
+
+class Tiny(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.a = nn.Linear(12, 32)
+        self.b = nn.Linear(32, 4)
+        self.unused = nn.Linear(3, 3)  # WaypointPolicy.action_distribution analogue
+        self.frozen = nn.Linear(5, 5)
+        for p in self.frozen.parameters():
+            p.requires_grad_(False)
+
+    def forward(self, x):
+        return self.b(torch.relu(self.a(x)))
+
+
+def il_loss(model, x, tgt, w):
+    # per-episode normalised, then mean over episodes (base_il_trainer.py:159-165)
+    T, N = tgt.shape
+    logits = model(x).view(T, N, -1)
+    ce = torch.nn.functional.cross_entropy(logits.permute(0, 2, 1), tgt, reduction="none")
+    return ((w * ce).sum(0) / w.sum(0)).mean()
+
+
+def make_data():
+    g = torch.Generator().manual_seed(3)
+    T, N = 3, 8
+    return (torch.randn(T, N, 12, generator=g), torch.randint(0, 4, (T, N), generator=g),
+            torch.rand(T, N, generator=g) + 0.5)
+
+
+def worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    model = Tiny()
+    red = GradientAllReducer(model, bucket_bytes=1024)  # several buckets
+    x, tgt, w = make_data()
+    sl = shard_rows(x.size(1), rank, world)
+    for _ in range(2):  # second pass checks the hooks re-arm
+        model.zero_grad()
+        il_loss(model, x[:, sl].reshape(-1, 12), tgt[:, sl], w[:, sl]).backward()
+        red.finish()
+    if rank == 0:
+        torch.save({n: p.grad for n, p in model.named_parameters() if p.grad is not None}, out)
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradients_equal_single_process(tmp_path):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "grads.pt")
+    mp.spawn(worker, args=(2, port, out), nprocs=2, join=True)
+    got = torch.load(out)
+    torch.manual_seed(0)
+    model = Tiny()
+    x, tgt, w = make_data()
+    il_loss(model, x.reshape(-1, 12), tgt, w).backward()
+    want = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
+    assert set(got) == set(want) and "unused.weight" not in got
+    for n in want:
+        assert torch.allclose(got[n], want[n], atol=1e-6), n

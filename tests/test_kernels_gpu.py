@@ -1,0 +1,320 @@
+"""GPU tier, per-kernel parity: every C-ABI entry point on the MI355X against
+its contract (tests/hostsim.py: plain torch fp32 CPU ops) on the same seeded
+random inputs.  Tolerance: 1e-4 relative to the output scale (fp32; the MFMA
+is an exact-fp32 fmaf chain, differences are summation order only).
+Shapes are the ones the policies issue scaled to a small
+batch, plus ragged edges (rows / channels / K not multiples of the tile)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+import hostsim
+from vlnce_amd import _lib, ops
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+SIM = hostsim.HostSim()
+
+
+@pytest.fixture(scope="module")
+def hip():
+    return _lib.get_lib()
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(hash((shape, seed)) & 0x7FFFFFFF)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def close(a, b, tol=1e-4, what=""):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    scale = max(b.abs().max().item(), 1e-6)
+    err = (a - b).abs().max().item()
+    assert err <= tol * scale + 1e-6, f"{what}: max|d|={err:.3e} scale={scale:.3e}"
+
+
+def both(method, tensors, scalars):
+    """Run lib.<method>(**tensors, **scalars) on the simulator (CPU) and on the HIP
+    library (GPU copies); return ({name: cpu tensor}, {name: gpu tensor})."""
+    cpu = {k: (v.clone() if v is not None else None) for k, v in tensors.items()}
+    gpu = {k: (v.to(DEV) if v is not None else None) for k, v in tensors.items()}
+    getattr(SIM, method)(**cpu, **scalars)
+    getattr(_lib.get_lib(), method)(**gpu, **scalars)
+    torch.cuda.synchronize()
+    return cpu, gpu
+
+
+# ------------------------------------------------------------------ conv
+CONV_CASES = [
+    # name,            N,  H,  W, Cin, Cout, k, s, p, extras
+    ("1x1_64_256",     2, 16, 16,  64, 256, 1, 1, 0, dict(scale=True, relu=True)),
+    ("1x1_256_64_res", 2, 16, 16, 256,  64, 1, 1, 0, dict(scale=True, relu=True, residual=True)),
+    ("3x3_64_64",      2, 16, 16,  64,  64, 3, 1, 1, dict(scale=True, relu=True)),
+    ("3x3s2_128",      2, 16, 16, 128, 128, 3, 2, 1, dict()),
+    ("1x1s2_256_512",  2, 16, 16, 256, 512, 1, 2, 0, dict(scale=True)),
+    ("3x3_512_8x8",    1,  8,  8, 512, 512, 3, 1, 1, dict(stats=True)),
+    ("stem_rgb",       2, 64, 64,   3,  64, 7, 2, 3, dict(prologue=True, scale=True, relu=True)),
+    ("stem_depth",     2, 32, 32,   1,  32, 7, 2, 3, dict()),
+    ("big_128x128",    8, 32, 32,  64, 256, 1, 1, 0, dict(stats=True)),      # 128x128 tiles
+    ("big_128x64",    16, 32, 32,  64,  64, 3, 1, 1, dict(stats=True)),      # 128x64 tiles
+    ("ragged",         3,  7,  9,  36,  48, 3, 1, 1, dict(scale=True, residual=True, relu=True)),
+    ("prologue_v4",    2, 12, 12,  32,  64, 3, 1, 1, dict(prologue=True, in_relu=True)),
+    ("compress_1024",  2,  4,  4, 1024, 128, 3, 1, 1, dict()),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv2d_fwd(hip, case):
+    name, N, H, W, Cin, Cout, k, s, p, ex = case
+    x = rnd(N, H, W, Cin, seed=1)
+    w = rnd(Cout, k, k, Cin, seed=2, scale=(Cin * k * k) ** -0.5)
+    g = ops.conv_geometry(x, w, s, p)
+    M = N * g["Ho"] * g["Wo"]
+    t = dict(x=x, w=w, y=torch.zeros(N, g["Ho"], g["Wo"], Cout))
+    t["in_scale"] = rnd(Cin, seed=3).abs() + 0.5 if ex.get("prologue") else None
+    t["in_shift"] = rnd(Cin, seed=4) * 0.3 if ex.get("prologue") else None
+    t["scale"] = rnd(Cout, seed=5).abs() + 0.5 if ex.get("scale") else None
+    t["shift"] = rnd(Cout, seed=6) if ex.get("scale") else None
+    t["residual"] = rnd(N, g["Ho"], g["Wo"], Cout, seed=7) if ex.get("residual") else None
+    sc = dict(g=g, in_relu=int(bool(ex.get("in_relu"))), ldr=Cout,
+              act=1 if ex.get("relu") else 0, accumulate=0)
+    # statistics use each side's own tiling; compare after finalize
+    cpu, gpu = both("conv2d_fwd", t, sc)
+    close(gpu["y"], cpu["y"], what=name)
+    if ex.get("stats"):
+        x_d, w_d = x.to(DEV), w.to(DEV)
+        y, stats = ops.conv2d_nhwc(x_d, w_d, s, p, want_stats=True)
+        gamma, beta = (rnd(Cout, seed=8).abs() + 0.5).to(DEV), rnd(Cout, seed=9).to(DEV)
+        rm, rv = torch.zeros(Cout, device=DEV), torch.ones(Cout, device=DEV)
+        scale, shift = ops.bn_finalize(stats, M, gamma, beta, 1e-5, 0.1, rm, rv)
+        out = ops.scale_shift_act(y, scale, shift, act=1)
+        raw = cpu["y"].reshape(M, Cout)
+        rm_ref, rv_ref = torch.zeros(Cout), torch.ones(Cout)
+        ref = F.batch_norm(raw.t().reshape(1, Cout, M), rm_ref, rv_ref, gamma.cpu(), beta.cpu(),
+                           True, 0.1, 1e-5)
+        ref = torch.relu(ref).reshape(Cout, M).t()
+        close(out.reshape(M, Cout), ref, what=name + "/bn_train")
+        close(rm, rm_ref, what=name + "/running_mean")
+        close(rv, rv_ref, what=name + "/running_var")
+
+
+def test_conv_identity_weight_is_not_transposed(hip):
+    """A = I style check with an asymmetric operand: a 1x1 conv whose weight is a
+    permutation matrix must permute channels exactly (bit-exact)."""
+    Cc = 64
+    perm = torch.randperm(Cc, generator=torch.Generator().manual_seed(3))
+    w = torch.zeros(Cc, 1, 1, Cc)
+    w[torch.arange(Cc), 0, 0, perm] = 1.0
+    x = rnd(2, 9, 5, Cc, seed=11).to(DEV)
+    y = ops.conv2d_nhwc(x, w.to(DEV), 1, 0)
+    assert torch.equal(y, x[..., perm.to(DEV)])
+
+
+# ------------------------------------------------------------------ gemm
+GEMM_CASES = [
+    # M, N, K, transA, transB, act, bias
+    (64, 256, 2112, 0, 0, 1, True),    # rgb_linear
+    (64, 1536, 416, 0, 0, 0, True),    # GRU input projection
+    (64, 4, 512, 0, 0, 0, True),       # action head
+    (64, 1, 512, 0, 0, 3, True),       # progress monitor (tanh)
+    (640, 512, 50, 0, 0, 0, True),     # instruction x W_ih (K % 4 != 0: scalar loaders)
+    (100, 260, 388, 0, 0, 2, True),    # waypoint sizes (sigmoid)
+    (64, 512, 256, 0, 1, 0, False),    # dX = dY W
+    (70, 50, 36, 0, 1, 0, False),      # dX ragged, scalar A
+    (256, 2112, 64, 1, 1, 0, False),   # dW = dY^T X
+    (4, 512, 64, 1, 1, 0, False),      # dW of the action head
+    (1, 512, 37, 1, 1, 0, False),      # dW of a 1-output head, ragged K
+    (5000, 256, 256, 0, 0, 0, True),   # text_k over B*L rows (128-row tiles)
+    (40000, 64, 64, 0, 0, 0, False),   # M > 32767: row folding
+]
+
+
+@pytest.mark.parametrize("case", GEMM_CASES, ids=[f"{c[0]}x{c[1]}x{c[2]}_{c[3]}{c[4]}" for c in GEMM_CASES])
+def test_gemm(hip, case):
+    M, N, K, ta, tb, act, bias = case
+    A = rnd(K, M, seed=1) if ta else rnd(M, K, seed=1)
+    B = rnd(K, N, seed=2) if tb else rnd(N, K, seed=2)
+    A *= K ** -0.5
+    t = dict(A=A, B=B, Cm=torch.zeros(M, N), shift=rnd(N, seed=3) if bias else None)
+    sc = dict(lda=A.size(1), transA=ta, ldb=B.size(1), transB=tb, ldc=N, M=M, N=N, K=K, act=act)
+    cpu, gpu = both("gemm", t, sc)
+    close(gpu["Cm"], cpu["Cm"], what=str(case))
+
+
+def test_gemm_accumulate_and_strided_views(hip):
+    M, N, K = 48, 96, 128
+    big = rnd(M, 2 * K, seed=1)
+    A = big[:, K:]  # row stride 2K, 16-byte aligned offset
+    B = rnd(N, K, seed=2)
+    C0 = rnd(M, N, seed=3)
+    t = dict(A=A, B=B, Cm=C0.clone())
+    cpu = {k: v.clone() for k, v in t.items()}
+    SIM.gemm(A, 2 * K, 0, B, K, 0, cpu["Cm"], N, M, N, K, accumulate=1)
+    bg = big.to(DEV)
+    Cg = C0.to(DEV)
+    _lib.get_lib().gemm(bg[:, K:], 2 * K, 0, B.to(DEV), K, 0, Cg, N, M, N, K, accumulate=1)
+    close(Cg, cpu["Cm"], what="accumulate")
+
+
+# ------------------------------------------------------------------ norms / pools
+def test_bn_finalize_contract(hip):
+    tiles, rows, Cc = 7, 128, 96
+    M = tiles * rows - 40
+    part = rnd(tiles, Cc, 2, seed=1).abs()
+    t = dict(partial=part, gamma=rnd(Cc, seed=2), beta=rnd(Cc, seed=3),
+             running_mean=rnd(Cc, seed=4), running_var=rnd(Cc, seed=5).abs(),
+             scale_out=torch.zeros(Cc), shift_out=torch.zeros(Cc), mean_out=torch.zeros(Cc),
+             rstd_out=torch.zeros(Cc))
+    sc = dict(tiles_m=tiles, tile_rows=rows, M=M, Cc=Cc, eps=1e-5, momentum=0.1)
+    cpu, gpu = both("bn_finalize", t, sc)
+    for k in ("scale_out", "shift_out", "mean_out", "rstd_out", "running_mean", "running_var"):
+        close(gpu[k], cpu[k], what=k)
+
+
+@pytest.mark.parametrize("shape", [(4, 32, 32, 32, 16), (2, 8, 8, 256, 16), (3, 4, 4, 1024, 16),
+                                   (2, 4, 4, 128, 1), (2, 2, 2, 2048, 1), (5, 16, 16, 64, 16)])
+def test_group_norm(hip, shape):
+    N, H, W, Cc, G = shape
+    x = rnd(N, H, W, Cc, seed=1) + 0.5
+    gamma, beta = rnd(Cc, seed=2), rnd(Cc, seed=3)
+    res = rnd(N, H, W, Cc, seed=4)
+    ref = F.group_norm(x.permute(0, 3, 1, 2), G, gamma, beta, 1e-5) + res.permute(0, 3, 1, 2)
+    ref = torch.relu(ref).permute(0, 2, 3, 1)
+    out = ops.group_norm_act(x.to(DEV), G, gamma.to(DEV), beta.to(DEV), 1e-5,
+                             residual=res.to(DEV), act=1)
+    close(out, ref, what=str(shape))
+
+
+def test_scale_shift_act_scalar_path(hip):
+    x = rnd(33, 7, seed=1)
+    s, b = rnd(7, seed=2), rnd(7, seed=3)
+    out = ops.scale_shift_act(x.to(DEV), s.to(DEV), b.to(DEV), act=3)
+    close(out, torch.tanh(x * s + b))
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 32, 64), (3, 17, 13, 32), (2, 9, 9, 3)])
+def test_maxpool(hip, shape):
+    x = rnd(*shape, seed=1)
+    ref = F.max_pool2d(x.permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1)
+    assert torch.equal(ops.maxpool3x3s2(x.to(DEV)).cpu(), ref)
+
+
+def test_avgpool_and_adaptive(hip):
+    x = rnd(3, 64, 64, 1, seed=1)
+    close(ops.avgpool2x2(x.to(DEV)), F.avg_pool2d(x.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1), 1e-6)
+    for (h, w, oh, ow) in [(8, 8, 4, 4), (2, 2, 4, 4), (1, 1, 4, 4), (8, 8, 1, 1), (7, 5, 4, 4)]:
+        y = rnd(2, h, w, 96, seed=h * 10 + w)
+        ref = F.adaptive_avg_pool2d(y.permute(0, 3, 1, 2), (oh, ow)).permute(0, 2, 3, 1)
+        close(ops.adaptive_avgpool(y.to(DEV), oh, ow), ref, 1e-6, what=f"{h}x{w}->{oh}x{ow}")
+    z = rnd(5, 16, 2112, seed=2)
+    close(ops.mean_rows(z.to(DEV)), z.mean(1), 1e-6)
+
+
+# ------------------------------------------------------------------ attention
+@pytest.mark.parametrize("cfg", [(3, 80, 256, 256, 1), (2, 200, 256, 256, 1), (4, 16, 256, 128, 0),
+                                 (5, 12, 128, 128, 0), (2, 37, 256, 256, 2), (2, 1, 64, 32, 0)])
+def test_attention_fwd_bwd(hip, cfg):
+    B, P, Dk, Dv, mode = cfg
+    q, K, V = rnd(B, Dk, seed=1), rnd(B, P, Dk, seed=2), rnd(B, P, Dv, seed=3)
+    mask = None
+    if mode:
+        mask = torch.zeros(B, P, dtype=torch.uint8)
+        for b in range(B):
+            mask[b, max(1, P - 3 - b):] = 1
+    dout = rnd(B, Dv, seed=4)
+    scale = Dk ** -0.5
+    t = dict(q=q, K=K, V=V, mask=mask, out=torch.zeros(B, Dv), attn_out=torch.zeros(B, P))
+    sc = dict(ldk=Dk, ldv=Dv, mask_mode=mode, scale=scale, B=B, P=P, Dk=Dk, Dv=Dv)
+    cpu, gpu = both("attn_fwd", t, sc)
+    close(gpu["out"], cpu["out"], what="attn out")
+    close(gpu["attn_out"], cpu["attn_out"], what="attn probs")
+    t = dict(dout=dout, q=q, K=K, V=V, mask=mask, attn=cpu["attn_out"], dq=torch.zeros(B, Dk),
+             dK=torch.zeros(B, P, Dk), dV=torch.zeros(B, P, Dv))
+    sc = dict(ldk=Dk, ldv=Dv, mask_mode=mode, scale=scale, lddk=Dk, lddv=Dv, B=B, P=P, Dk=Dk, Dv=Dv)
+    cpu, gpu = both("attn_bwd", t, sc)
+    for k in ("dq", "dK", "dV"):
+        close(gpu[k], cpu[k], what=k)
+
+
+def test_attention_autograd_matches_torch(hip):
+    B, P, D = 3, 16, 256
+    kv = rnd(B, P, 2 * D, seed=1).to(DEV).requires_grad_()
+    q = rnd(B, D, seed=2).to(DEV).requires_grad_()
+    out = ops.attention(q, kv[..., :D], kv[..., D:], None, 1, D ** -0.5)
+    out.square().sum().backward()
+    kv2, q2 = kv.detach().cpu().requires_grad_(), q.detach().cpu().requires_grad_()
+    a = torch.softmax(torch.einsum("bd,bpd->bp", q2, kv2[..., :D]) * D ** -0.5, 1)
+    torch.einsum("bp,bpd->bd", a, kv2[..., D:]).square().sum().backward()
+    close(kv.grad, kv2.grad, what="d kv (strided K/V views)")
+    close(q.grad, q2.grad, what="d q")
+
+
+def test_rowzero_mask(hip):
+    x = rnd(4, 30, 256, seed=1)
+    x[1, 20:] = 0
+    x[3, 5:] = 0
+    x[2, 7, :255] = 0  # one non-zero element left: NOT masked
+    assert torch.equal(ops.rowzero_mask(x.to(DEV)).cpu(), (x == 0).all(2).to(torch.uint8))
+
+
+# ------------------------------------------------------------------ recurrent cells
+def test_gru_lstm_cells_match_torch(hip):
+    B, D, H = 7, 96, 128
+    for kind in ("GRU", "LSTM"):
+        cell = (torch.nn.GRUCell if kind == "GRU" else torch.nn.LSTMCell)(D, H)
+        x, h0, c0 = rnd(B, D, seed=1), rnd(B, H, seed=2), rnd(B, H, seed=3)
+        pd = {k: v.detach().to(DEV).requires_grad_() for k, v in cell.named_parameters()}
+        xd, hd, cd = (t.to(DEV).requires_grad_() for t in (x, h0, c0))
+        gi = ops.linear(xd, pd["weight_ih"], pd["bias_ih"])
+        xr, hr, cr = (t.clone().requires_grad_() for t in (x, h0, c0))
+        if kind == "GRU":
+            out = ops.gru_cell(gi, hd, pd["weight_hh"], pd["bias_hh"])
+            ref = cell(xr, hr)
+            (out * out).sum().backward()
+            (ref * ref).sum().backward()
+        else:
+            out, cn = ops.lstm_cell(gi, hd, cd, pd["weight_hh"], pd["bias_hh"])
+            ref, cref = cell(xr, (hr, cr))
+            ((out * out).sum() + (cn * 0.5).sum()).backward()
+            ((ref * ref).sum() + (cref * 0.5).sum()).backward()
+            close(cn, cref, what="c'")
+            close(cd.grad, cr.grad, what="dc")
+        close(out, ref, what=kind + " h'")
+        close(xd.grad, xr.grad, what=kind + " dx")
+        close(hd.grad, hr.grad, what=kind + " dh")
+        for k, v in cell.named_parameters():
+            close(pd[k].grad, v.grad, what=f"{kind} d{k}")
+
+
+def test_row_utilities(hip):
+    x, y = rnd(9, 40, seed=1), rnd(9, 40, seed=2)
+    m = torch.tensor([1, 0, 1, 1, 0, 0, 1, 0, 1], dtype=torch.uint8)
+    close(ops.mask_rows(x.to(DEV), m.to(DEV)), x * m[:, None].float(), 0)
+    close(ops.select_rows(m.to(DEV), x.to(DEV), y.to(DEV)), torch.where(m[:, None] != 0, x, y), 0)
+    close(ops.select_rows(m.to(DEV), x.to(DEV), None), torch.where(m[:, None] != 0, x, 0 * x), 0)
+    t = dict(x=rnd(301, 77, seed=3), out=torch.zeros(77))
+    cpu, gpu = both("colsum", t, dict(ldx=77, M=301, N=77, accumulate=0))
+    close(gpu["out"], cpu["out"], what="colsum")
+    for act in (1, 2, 3):
+        yv = torch.sigmoid(rnd(50, 12, seed=4)) if act == 2 else torch.tanh(rnd(50, 12, seed=4))
+        t = dict(dy=rnd(50, 12, seed=5), y=yv, dz=torch.zeros(50, 12))
+        cpu, gpu = both("act_bwd", t, dict(n=600, act=act))
+        close(gpu["dz"], cpu["dz"], what=f"act_bwd {act}")
+
+
+def test_linear_autograd_matches_torch(hip):
+    for (M, K, N, act) in [(64, 1184, 512, 1), (33, 50, 20, 0), (16, 512, 1, 3)]:
+        lin = torch.nn.Linear(K, N)
+        x = rnd(M, K, seed=1)
+        xd = x.to(DEV).requires_grad_()
+        w, b = (p.detach().to(DEV).requires_grad_() for p in lin.parameters())
+        y = ops.linear(xd, w, b, act)
+        (y * y).sum().backward()
+        xr = x.clone().requires_grad_()
+        yr = hostsim._act(lin(xr), act)
+        (yr * yr).sum().backward()
+        close(y, yr, what="linear fwd")
+        close(xd.grad, xr.grad, what="linear dx")
+        close(w.grad, lin.weight.grad, what="linear dW")
+        close(b.grad, lin.bias.grad, what="linear db")

@@ -1,0 +1,109 @@
+"""Data-parallel gradient exchange for the policy update.
+
+One process per GPU (torch.distributed; backend "nccl" is RCCL over xGMI on
+ROCm, "gloo" on CPU for tests).  The env / episode dimension N is sharded
+across ranks, weights are replicated, the forward needs no communication and
+the only exchange step is a sum-all-reduce (then / world) of the gradients of
+the TRAINABLE tensors (25.1 MB for CMA with frozen encoders).
+
+Buckets are filled in reverse parameter order -- the order backward produces
+gradients -- and each bucket's all-reduce is launched asynchronously from a
+post-accumulate-grad hook the moment its last gradient lands, so it overlaps
+with the rest of backward.  xGMI is point-to-point (7 links x ~153 GB/s per
+GPU): few, large collectives beat many small ones, hence 8 MiB buckets rather
+than DDP's NVSwitch-era 25 MB first/1 MB rest heuristics being copied.
+Parameters that never receive a gradient (WaypointPolicy's unused
+action_distribution, ddppo_waypoint_trainer.py:370 `find_unused_params=True`)
+contribute zeros on every rank, so ranks stay in lock-step.
+
+Semantics preserved (base_il_trainer.py:159-165): the IL loss is normalised
+per episode and then .mean()'d over episodes, so equal-sized shards + gradient
+averaging reproduce the single-process gradient exactly.
+"""
+import torch
+import torch.distributed as dist
+
+
+class _Bucket:
+    __slots__ = ("params", "flat", "views", "pending", "work")
+
+
+class GradientAllReducer:
+    def __init__(self, module, bucket_bytes=8 << 20, process_group=None):
+        self.group = process_group
+        self.world = dist.get_world_size(process_group)
+        params = [p for p in module.parameters() if p.requires_grad]
+        params.reverse()
+        self.buckets = []
+        cur, cur_bytes = [], 0
+        for p in params:
+            cur.append(p)
+            cur_bytes += p.numel() * 4
+            if cur_bytes >= bucket_bytes:
+                self.buckets.append(self._make_bucket(cur))
+                cur, cur_bytes = [], 0
+        if cur:
+            self.buckets.append(self._make_bucket(cur))
+        self._bucket_of = {}
+        self._handles = []
+        for b in self.buckets:
+            for p in b.params:
+                self._bucket_of[p] = b
+                self._handles.append(p.register_post_accumulate_grad_hook(self._on_grad))
+
+    @staticmethod
+    def _make_bucket(params):
+        b = _Bucket()
+        b.params = list(params)
+        n = sum(p.numel() for p in params)
+        b.flat = torch.zeros(n, device=params[0].device, dtype=torch.float32)
+        b.views, off = [], 0
+        for p in params:
+            b.views.append(b.flat[off:off + p.numel()].view_as(p))
+            off += p.numel()
+        b.pending = len(params)
+        b.work = None
+        return b
+
+    def _launch(self, b):
+        have = [(v, p.grad) for v, p in zip(b.views, b.params) if p.grad is not None]
+        if len(have) != len(b.params):
+            b.flat.zero_()
+        if have:
+            torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+        b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def _on_grad(self, p):
+        b = self._bucket_of[p]
+        b.pending -= 1
+        if b.pending == 0:
+            self._launch(b)
+
+    def finish(self):
+        """Call after loss.backward(): waits for every bucket, writes the averaged
+        gradients back into .grad and re-arms the hooks for the next step."""
+        for b in self.buckets:
+            if b.work is None:  # some parameter never produced a gradient this step
+                self._launch(b)
+        inv = 1.0 / self.world
+        for b in self.buckets:
+            b.work.wait()
+            b.flat.mul_(inv)
+            have = [(p.grad, v) for v, p in zip(b.views, b.params) if p.grad is not None]
+            if have:
+                torch._foreach_copy_([g for g, _ in have], [v for _, v in have])
+            b.pending = len(b.params)
+            b.work = None
+
+    def remove(self):
+        for h in self._handles:
+            h.remove()
+        self._handles = []
+
+
+def shard_rows(n_total, rank, world):
+    """Contiguous, equal-sized env shard of rank `rank` (N must divide evenly so the
+    per-episode-normalised IL loss averages exactly; see module docstring)."""
+    assert n_total % world == 0, "num_envs must be divisible by the number of ranks"
+    per = n_total // world
+    return slice(rank * per, (rank + 1) * per)
