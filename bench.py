@@ -36,6 +36,10 @@ CMA_FWD_BWD_FROZEN_GFLOP = 11.630
 CONV_GFLOP_PER_ENV = 10.677 + 0.699  # RGB ResNet-50 + depth ResNet-50 trunks (conv MACs x2)
 
 
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
 def synth_batch(N, hw, L, device, seed=1):
     g = torch.Generator().manual_seed(seed)
     obs = {"rgb": torch.randint(0, 256, (N, hw, hw, 3), generator=g).float(),
@@ -50,34 +54,55 @@ def synth_batch(N, hw, L, device, seed=1):
     return ({k: mv(v) for k, v in obs.items()}, mv(prev), mv(masks), mv(targets), mv(weights))
 
 
-def cpu_baseline(num_envs, hw, L, budget_s=20.0):
-    """CPU oracle (port of the reference policy) on the host cores: bounded sample."""
+def cpu_baseline_worker(num_envs, hw, L, threads):
+    """Runs in a child process: CPU oracle (port of the reference policy) timed on
+    `threads` host threads on a bounded sample of the bench workload."""
     from oracle import policy_cpu as oc
     from oracle import thirdparty as tp
 
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    torch.set_num_threads(threads)
     pol = oc.CMAPolicy.from_config(tp.make_config("CMAPolicy"), *tp.make_spaces(hw, hw))
     opt = torch.optim.Adam(pol.parameters(), lr=2.5e-4)
     n = min(num_envs, 8)
     obs, prev, masks, tgt, w = synth_batch(n, hw, L, "cpu")
     oc.AuxLosses.activate()
     times = []
-    t_start = time.time()
     for i in range(4):
         t0 = time.time()
         oc.il_update(pol, opt, obs, prev, masks, tgt, w, 512)
         dt = time.time() - t0
+        log(f"cpu_baseline iter {i}: {dt:.2f}s")
         if i > 0:
             times.append(dt)
-        if time.time() - t_start > budget_s and times:
-            break
-    oc.AuxLosses.deactivate()
     best = min(times)
-    return {"value": round(n / best, 2), "unit": "policy-steps/sec", "cores": cores,
-            "kind": "port",
-            "sample": f"CMA fwd+bwd+Adam, {n} envs x {hw}x{hw} RGB-D, L={L}, "
-                      f"min of {len(times)} iters after 1 warm-up, torch CPU fp32 {cores} threads"}
+    print(json.dumps({
+        "value": round(n / best, 2), "unit": "policy-steps/sec", "cores": threads, "kind": "port",
+        "sample": f"CMA fwd+bwd+Adam (oracle/policy_cpu.py), {n} envs x {hw}x{hw} RGB-D, L={L}, "
+                  f"min of {len(times)} iters after 1 warm-up, torch CPU fp32, {threads} threads"}))
+
+
+def cpu_baseline(num_envs, hw, L, timeout_s=100):
+    """Bounded: the child is killed after `timeout_s` (the default bench run must
+    finish within minutes).  Thread count: MKL-DNN/OpenMP degrade badly when
+    oversubscribed on a many-core shared host, so at most 32 threads are used and
+    that number is what `cores` reports."""
+    import subprocess
+
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count() or 1
+    threads = min(usable, 32)
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--num-envs",
+           str(num_envs), "--hw", str(hw), "--tokens", str(L), "--threads", str(threads)]
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads))
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, env=env)
+        sys.stderr.write(r.stderr[-2000:])
+        return json.loads(r.stdout.strip().splitlines()[-1])
+    except Exception as e:  # timeout / parse error: report, never block the GPU line
+        return {"value": None, "unit": "policy-steps/sec", "cores": threads, "kind": "port",
+                "sample": f"cpu baseline did not finish within {timeout_s}s ({type(e).__name__})"}
 
 
 def main():
@@ -91,7 +116,12 @@ def main():
     ap.add_argument("--bn", choices=["train", "eval"], default="train",
                     help="train = as constructed by the reference (batch statistics)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--threads", type=int, default=8, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpu_baseline_only:
+        cpu_baseline_worker(args.num_envs, args.hw, args.tokens, args.threads)
+        return
 
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -126,8 +156,12 @@ def main():
         obs, prev, masks, tgt, w = batch
         update_agent(policy, opt, obs, prev, masks, tgt, w, 512, grad_hook=grad_hook)
 
-    for _ in range(args.warmup):
+    log("policy built, starting warm-up")
+    for i in range(args.warmup):
+        t0 = time.perf_counter()
         step()
+        torch.cuda.synchronize()
+        log(f"warm-up step {i}: {1e3 * (time.perf_counter() - t0):.1f} ms")
 
     # conv-kernel time: HIP events around every conv launch on the launch stream
     conv_events = []
@@ -152,6 +186,7 @@ def main():
         step()
     sync()
     elapsed = time.perf_counter() - t0
+    log(f"timed region: {args.steps} steps in {elapsed:.3f}s")
     if world > 1:
         tmax = torch.tensor([elapsed], device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
