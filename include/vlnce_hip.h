@@ -179,6 +179,32 @@ int vlnce_lstm_gates_bwd(const float* dh_out, const float* dc_out, const float* 
                          float* dgates /* [B,4H] */, float* dc_prev, int B, int H,
                          vlnce_stream_t stream);
 
+/* Packed-sequence instruction RNN (instruction_encoder.py:27-32,80-94): the whole
+ * time loop (and its BPTT) in ONE launch, one workgroup per (direction, 16-sample
+ * tile), recurrent weights resident in registers, h W_hh^T on v_mfma_f32_16x16x4_f32.
+ * kind 0 = LSTM (gates i|f|g|o), 1 = GRU (r|z|n); dirs 1 or 2 (index 1 = reverse).
+ * All per-direction arguments are HOST arrays of `dirs` device pointers.
+ *   gi[d]      [L,B,G*H]  x W_ih^T + b_ih, time-major
+ *   w_hh[d]    [G*H,H], b_hh[d] [G*H]
+ *   out[d]     [L,B,H]    must be pre-zeroed: steps t >= lengths[b] emit zeros
+ *   h_final[d] [B,H]      state after each sample's last step
+ *   gates_save[d] [L,B,G*H], aux_save[d] [L,B,H] (LSTM: c_t; GRU: W_hn h + b_hn) or NULL arrays
+ * Steps t >= lengths[b] leave the state untouched; the reverse direction walks
+ * t = lengths[b]-1 .. 0 (pack_padded_sequence / pad_packed_sequence semantics). */
+int vlnce_rnn_seq_supported(int kind, int H);
+int vlnce_rnn_seq_fwd(int kind, int dirs, const float* const* gi, const float* const* w_hh,
+                      const float* const* b_hh, const int* lengths, float* const* out,
+                      float* const* h_final, float* const* gates_save, float* const* aux_save,
+                      int B, int L, int H, vlnce_stream_t stream);
+/* BPTT: w_hh_t[d] = W_hh^T [H,G*H]; dout[d] [L,B,H] / dh_final[d] [B,H] may be NULL;
+ * dgi[d] [L,B,G*H] (pre-zeroed) receives d/d gi; GRU additionally fills dgh[d]
+ * (gradient wrt h W_hh^T + b_hh; its n-gate differs by the factor r). */
+int vlnce_rnn_seq_bwd(int kind, int dirs, const float* const* w_hh_t, const int* lengths,
+                      const float* const* out, const float* const* gates_save,
+                      const float* const* aux_save, const float* const* dout,
+                      const float* const* dh_final, float* const* dgi, float* const* dgh,
+                      int B, int L, int H, vlnce_stream_t stream);
+
 /* ---------------------------------------------------------------- utilities */
 /* y[b, c] = mean_p x[b, p, c]   (AdaptiveAvgPool1d(1) of rgb_linear, cma_policy.py:104) */
 int vlnce_mean_rows(const float* x, float* y, int B, int P, int C, vlnce_stream_t stream);

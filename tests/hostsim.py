@@ -251,6 +251,97 @@ class HostSim:
                                 dh * tc * o * (1 - o)], 1))
         dc_prev.copy_(dc * f * mk)
 
+    # ---- packed-sequence RNN (contract of csrc/rnn_seq.hip)
+    def rnn_seq_supported(self, kind, H):
+        return kind in (0, 1) and H in (64, 128)
+
+    @staticmethod
+    def _time_index(lengths, s, reverse):
+        active = s < lengths
+        tt = (lengths - 1 - s) if reverse else torch.full_like(lengths, s)
+        return active, tt.clamp_min(0)
+
+    def rnn_seq_fwd(self, kind, dirs, gi, w_hh, b_hh, lengths, out, h_final, gates_save, aux_save,
+                    B, Lm, H):
+        G = 4 if kind == 0 else 3
+        ar = torch.arange(B)
+        ln = lengths.long()
+        for d in range(dirs):
+            h = torch.zeros(B, H)
+            c = torch.zeros(B, H)
+            for s in range(Lm):
+                active, tt = self._time_index(ln, s, d == 1)
+                x = gi[d][tt, ar]  # [B, G*H]
+                gh = h @ w_hh[d].t() + b_hh[d]
+                if kind == 0:
+                    i, f, g, o = (x + gh).split(H, 1)
+                    i, f, g, o = torch.sigmoid(i), torch.sigmoid(f), torch.tanh(g), torch.sigmoid(o)
+                    cn = f * c + i * g
+                    hn_ = o * torch.tanh(cn)
+                    gs, ax = torch.cat([i, f, g, o], 1), cn
+                else:
+                    xr, xz, xn = x.split(H, 1)
+                    hr, hz, hn = gh.split(H, 1)
+                    r, z = torch.sigmoid(xr + hr), torch.sigmoid(xz + hz)
+                    n = torch.tanh(xn + r * hn)
+                    hn_ = (1 - z) * n + z * h
+                    cn = c
+                    gs, ax = torch.cat([r, z, n], 1), hn
+                a = active.view(B, 1)
+                idx = (tt[active], ar[active])
+                out[d][idx] = hn_[active]
+                if gates_save is not None:
+                    gates_save[d][idx] = gs[active]
+                    aux_save[d][idx] = ax[active]
+                h = torch.where(a, hn_, h)
+                c = torch.where(a, cn, c)
+            h_final[d].copy_(h)
+
+    def rnn_seq_bwd(self, kind, dirs, w_hh_t, lengths, out, gates_save, aux_save, dout, dh_final,
+                    dgi, dgh, B, Lm, H):
+        ar = torch.arange(B)
+        ln = lengths.long()
+        for d in range(dirs):
+            rev = d == 1
+            dh = dh_final[d].clone() if dh_final is not None and dh_final[d] is not None \
+                else torch.zeros(B, H)
+            dc = torch.zeros(B, H)
+            W = w_hh_t[d].t()  # [G*H, H]
+            for s in range(Lm - 1, -1, -1):
+                active, tt = self._time_index(ln, s, rev)
+                tp = (tt + 1) if rev else (tt - 1)
+                tp = tp.clamp(0, Lm - 1)
+                a = active.view(B, 1)
+                gs = gates_save[d][tt, ar]
+                ax = aux_save[d][tt, ar]
+                dht = dh + (dout[d][tt, ar] if dout is not None and dout[d] is not None else 0)
+                if kind == 0:
+                    i, f, g, o = gs.split(H, 1)
+                    cp = aux_save[d][tp, ar] if s > 0 else torch.zeros(B, H)
+                    tc = torch.tanh(ax)
+                    dct = dc + dht * o * (1 - tc * tc)
+                    dpre = torch.cat([dct * g * i * (1 - i), dct * cp * f * (1 - f),
+                                      dct * i * (1 - g * g), dht * tc * o * (1 - o)], 1)
+                    dpre_h = dpre
+                    dc = torch.where(a, dct * f, dc)
+                    keep = 0
+                else:
+                    r, z, n = gs.split(H, 1)
+                    hp = out[d][tp, ar] if s > 0 else torch.zeros(B, H)
+                    dn = dht * (1 - z)
+                    dz = dht * (hp - n)
+                    dnp = dn * (1 - n * n)
+                    drp = dnp * ax * r * (1 - r)
+                    dzp = dz * z * (1 - z)
+                    dpre = torch.cat([drp, dzp, dnp], 1)
+                    dpre_h = torch.cat([drp, dzp, dnp * r], 1)
+                    keep = dht * z
+                idx = (tt[active], ar[active])
+                dgi[d][idx] = dpre[active]
+                if kind == 1:
+                    dgh[d][idx] = dpre_h[active]
+                dh = torch.where(a, dpre_h @ W + keep, dh)
+
     def mask_rows(self, x, mask, out, B, H):
         out.copy_(x.view(B, H) * mask.view(B, 1).float())
 

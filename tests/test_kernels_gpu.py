@@ -318,3 +318,73 @@ def test_linear_autograd_matches_torch(hip):
         close(xd.grad, xr.grad, what="linear dx")
         close(w.grad, lin.weight.grad, what="linear dW")
         close(b.grad, lin.bias.grad, what="linear db")
+
+
+# ------------------------------------------------------------------ persistent packed-sequence RNN
+@pytest.mark.parametrize("cfg", [(0, 2, 128, 19, 23), (1, 2, 128, 5, 9), (0, 1, 64, 33, 7),
+                                 (1, 1, 64, 16, 12), (0, 2, 128, 64, 80)])
+def test_rnn_seq_kernels_match_contract(hip, cfg):
+    kind, dirs, H, B, Lm = cfg
+    G = 4 if kind == 0 else 3
+    gen = torch.Generator().manual_seed(7)
+    lengths = torch.randint(1, Lm + 1, (B,), generator=gen).to(torch.int32)
+    lengths[0] = Lm
+    gi = [rnd(Lm, B, G * H, seed=10 + d) for d in range(dirs)]
+    w = [rnd(G * H, H, seed=20 + d, scale=H ** -0.5) for d in range(dirs)]
+    bh = [rnd(G * H, seed=30 + d, scale=0.1) for d in range(dirs)]
+
+    def run(lib, dev):
+        mv = lambda ts: [t.to(dev) for t in ts]  # noqa: E731
+        out = [torch.zeros(Lm, B, H, device=dev) for _ in range(dirs)]
+        hf = [torch.zeros(B, H, device=dev) for _ in range(dirs)]
+        gs = [torch.zeros(Lm, B, G * H, device=dev) for _ in range(dirs)]
+        ax = [torch.zeros(Lm, B, H, device=dev) for _ in range(dirs)]
+        lib.rnn_seq_fwd(kind, dirs, mv(gi), mv(w), mv(bh), lengths.to(dev), out, hf, gs, ax, B, Lm, H)
+        dout = mv([rnd(Lm, B, H, seed=40 + d) for d in range(dirs)])
+        dhf = mv([rnd(B, H, seed=50 + d) for d in range(dirs)])
+        dgi = [torch.zeros(Lm, B, G * H, device=dev) for _ in range(dirs)]
+        dgh = [torch.zeros(Lm, B, G * H, device=dev) for _ in range(dirs)] if kind == 1 else None
+        wt = [x.t().contiguous().to(dev) for x in w]
+        lib.rnn_seq_bwd(kind, dirs, wt, lengths.to(dev), out, gs, ax, dout, dhf, dgi, dgh, B, Lm, H)
+        return out, hf, dgi, dgh
+
+    ref = run(SIM, "cpu")
+    got = run(_lib.get_lib(), DEV)
+    torch.cuda.synchronize()
+    names = ["out", "h_final", "dgi", "dgh"]
+    for name, r, g in zip(names, ref, got):
+        if r is None:
+            continue
+        for d in range(dirs):
+            close(g[d], r[d], 2e-4, what=f"{name}[{d}] {cfg}")
+
+
+@pytest.mark.parametrize("rnn_type,bidir,final_only", [("LSTM", True, False), ("LSTM", False, True),
+                                                       ("GRU", True, False), ("GRU", False, True)])
+def test_instruction_encoder_matches_torch_packed_rnn(hip, rnn_type, bidir, final_only):
+    """Whole InstructionEncoder (embedding -> packed (bi)RNN) on HIP vs the CPU oracle's
+    nn.LSTM/GRU + pack_padded_sequence, forward AND all parameter gradients."""
+    from oracle import policy_cpu as oc
+    from oracle import thirdparty as tp
+    from vlnce_amd.encoders.instruction_encoder import InstructionEncoder
+
+    cfg = tp.default_model_config().INSTRUCTION_ENCODER
+    cfg.rnn_type, cfg.bidirectional, cfg.final_state_only = rnn_type, bidir, final_only
+    ref = oc.InstructionEncoder(cfg)
+    hipm = InstructionEncoder(cfg)
+    hipm.load_state_dict(ref.state_dict())
+    hipm.to(DEV)
+    B = 21
+    gen = torch.Generator().manual_seed(3)
+    tok = torch.zeros(B, 200, dtype=torch.long)
+    for i in range(B):
+        n = int(torch.randint(1, 60, (1,), generator=gen))
+        tok[i, :n] = torch.randint(1, 2504, (n,), generator=gen)
+    yr = ref({"instruction": tok})
+    yh = hipm({"instruction": tok.to(DEV)})
+    close(yh, yr, 2e-4, what="instruction encoder output")
+    wgt = rnd(*yr.shape, seed=9)
+    (yr * wgt).sum().backward()
+    (yh * wgt.to(DEV)).sum().backward()
+    for (n, pr), (_, ph) in zip(ref.named_parameters(), hipm.named_parameters()):
+        close(ph.grad, pr.grad, 5e-4, what=f"d {n}")

@@ -62,6 +62,9 @@ _SIGNATURES = {
     "vlnce_lstm_gates_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "vlnce_mean_rows": (_I, [_P, _P, _I, _I, _I, _P]),
     "vlnce_mask_rows": (_I, [_P, _P, _P, _I, _I, _P]),
+    "vlnce_rnn_seq_supported": (_I, [_I, _I]),
+    "vlnce_rnn_seq_fwd": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "vlnce_rnn_seq_bwd": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "vlnce_select_rows": (_I, [_P, _P, _P, _P, _I, _I, _P]),
     "vlnce_act_bwd": (_I, [_P, _P, _P, _L, _I, _P]),
 }
@@ -223,6 +226,35 @@ class HipLib:
     def mask_rows(self, x, mask, out, B, H):
         self._check(self.dll.vlnce_mask_rows(_ptr(x), _ptr(mask), _ptr(out), B, H, _stream()),
                     "vlnce_mask_rows")
+
+    @staticmethod
+    def _parr(ts, n):
+        """host array of `n` device pointers (NULL array when ts is None)."""
+        if ts is None:
+            return None
+        arr = (C.c_void_p * 2)()
+        for i in range(n):
+            arr[i] = _ptr(ts[i])
+        return arr
+
+    def rnn_seq_supported(self, kind, H):
+        return bool(self.dll.vlnce_rnn_seq_supported(kind, H))
+
+    def rnn_seq_fwd(self, kind, dirs, gi, w_hh, b_hh, lengths, out, h_final, gates_save, aux_save,
+                    B, Lm, H):
+        pa = self._parr
+        self._check(self.dll.vlnce_rnn_seq_fwd(
+            kind, dirs, pa(gi, dirs), pa(w_hh, dirs), pa(b_hh, dirs), _ptr(lengths), pa(out, dirs),
+            pa(h_final, dirs), pa(gates_save, dirs), pa(aux_save, dirs), B, Lm, H, _stream()),
+            "vlnce_rnn_seq_fwd")
+
+    def rnn_seq_bwd(self, kind, dirs, w_hh_t, lengths, out, gates_save, aux_save, dout, dh_final,
+                    dgi, dgh, B, Lm, H):
+        pa = self._parr
+        self._check(self.dll.vlnce_rnn_seq_bwd(
+            kind, dirs, pa(w_hh_t, dirs), _ptr(lengths), pa(out, dirs), pa(gates_save, dirs),
+            pa(aux_save, dirs), pa(dout, dirs), pa(dh_final, dirs), pa(dgi, dirs), pa(dgh, dirs),
+            B, Lm, H, _stream()), "vlnce_rnn_seq_bwd")
 
     def select_rows(self, mask, a, b, out, B, H):
         self._check(self.dll.vlnce_select_rows(_ptr(mask), _ptr(a), _ptr(b), _ptr(out), B, H,

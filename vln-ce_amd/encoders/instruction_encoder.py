@@ -94,17 +94,29 @@ class InstructionEncoder(nn.Module):
             active = (torch.arange(lmax, device=feats.device)[:, None] < lengths[None, :]).to(
                 torch.uint8).contiguous()
         dirs = [("", False)] + ([("_reverse", True)] if cfg.bidirectional else [])
+        kind = 0 if cfg.rnn_type == "LSTM" else 1
+        gis = []
+        for sfx, _ in dirs:
+            gis.append(ops.linear(x_tm, getattr(rnn, "weight_ih_l0" + sfx),
+                                  getattr(rnn, "bias_ih_l0" + sfx)).view(lmax, B, -1))
         seqs, finals = [], []
-        for sfx, rev in dirs:
-            w_ih = getattr(rnn, "weight_ih_l0" + sfx)
-            w_hh = getattr(rnn, "weight_hh_l0" + sfx)
-            b_ih = getattr(rnn, "bias_ih_l0" + sfx)
-            b_hh = getattr(rnn, "bias_hh_l0" + sfx)
-            gi = ops.linear(x_tm, w_ih, b_ih).view(lmax, B, -1)
-            outs, h_last = self._direction(gi, same_len, active, w_hh, b_hh, rev)
-            finals.append(h_last)
-            if not cfg.final_state_only:
-                seqs.append(torch.stack(outs, dim=1))  # [B, L, H]
+        if ops.L().rnn_seq_supported(kind, H):
+            # whole recurrence (both directions) in one persistent launch
+            need_grad = torch.is_grad_enabled() and (
+                gis[0].requires_grad or rnn.weight_hh_l0.requires_grad)
+            trips = [(gis[i], getattr(rnn, "weight_hh_l0" + sfx), getattr(rnn, "bias_hh_l0" + sfx))
+                     for i, (sfx, _) in enumerate(dirs)]
+            outs_tm, finals = ops.rnn_seq(kind, lengths.to(torch.int32).contiguous(), trips,
+                                          need_grad)
+            seqs = [o.transpose(0, 1) for o in outs_tm]  # [B, L, H] views
+        else:
+            for i, (sfx, rev) in enumerate(dirs):
+                outs, h_last = self._direction(gis[i], same_len, active,
+                                               getattr(rnn, "weight_hh_l0" + sfx),
+                                               getattr(rnn, "bias_hh_l0" + sfx), rev)
+                finals.append(h_last)
+                if not cfg.final_state_only:
+                    seqs.append(torch.stack(outs, dim=1))  # [B, L, H]
         if cfg.final_state_only:
             # final_state.squeeze(0): [1,B,H] -> [B,H]; a bidirectional [2,B,H] is left as is (App. B-10)
             return finals[0] if len(finals) == 1 else torch.stack(finals, 0)

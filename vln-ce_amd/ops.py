@@ -363,3 +363,74 @@ def gru_cell(x_gates, h_prev, w_hh, b_hh):
 def lstm_cell(x_gates, h_prev, c_prev, w_hh, b_hh):
     gh = linear(h_prev, w_hh, b_hh)
     return LSTMGatesFn.apply(x_gates, gh, c_prev)
+
+
+# ----------------------------------------------------------------- packed-sequence RNN
+class RNNSeqFn(Function):
+    """Whole packed (bi)directional LSTM/GRU recurrence in one launch (+ one for BPTT).
+
+    forward(kind, save, lengths_i32, dirs, gi_0, w_hh_0, b_hh_0[, gi_1, w_hh_1, b_hh_1])
+      gi_d [L,B,G*H] time-major input projections (x W_ih^T + b_ih)
+    returns out_0[, out_1] ([L,B,H], zeros past each length) then hfin_0[, hfin_1] ([B,H]).
+    """
+
+    @staticmethod
+    def forward(ctx, kind, save, lengths, dirs, *t):
+        gis = [_f32c(t[3 * d]) for d in range(dirs)]
+        whh = [_f32c(t[3 * d + 1]) for d in range(dirs)]
+        bhh = [_f32c(t[3 * d + 2]) for d in range(dirs)]
+        Lm, B, GH = gis[0].shape
+        H = whh[0].size(1)
+        dev = gis[0].device
+        outs = [torch.zeros((Lm, B, H), device=dev, dtype=torch.float32) for _ in range(dirs)]
+        hfin = [torch.empty((B, H), device=dev, dtype=torch.float32) for _ in range(dirs)]
+        gates = aux = None
+        if save:
+            gates = [torch.empty((Lm, B, GH), device=dev, dtype=torch.float32) for _ in range(dirs)]
+            aux = [torch.empty((Lm, B, H), device=dev, dtype=torch.float32) for _ in range(dirs)]
+        L().rnn_seq_fwd(kind, dirs, gis, whh, bhh, lengths, outs, hfin, gates, aux, B, Lm, H)
+        ctx.cfg = (kind, dirs, Lm, B, H, GH)
+        if save:
+            ctx.save_for_backward(lengths, *whh, *outs, *gates, *aux)
+        return (*outs, *hfin)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        kind, dirs, Lm, B, H, GH = ctx.cfg
+        sv = ctx.saved_tensors
+        lengths = sv[0]
+        whh = sv[1:1 + dirs]
+        outs = sv[1 + dirs:1 + 2 * dirs]
+        gates = sv[1 + 2 * dirs:1 + 3 * dirs]
+        aux = sv[1 + 3 * dirs:1 + 4 * dirs]
+        dev = outs[0].device
+        douts = [(_f32c(g) if g is not None else None) for g in grads[:dirs]]
+        dhf = [(_f32c(g) if g is not None else None) for g in grads[dirs:2 * dirs]]
+        whh_t = [w.t().contiguous() for w in whh]
+        dgi = [torch.zeros((Lm, B, GH), device=dev, dtype=torch.float32) for _ in range(dirs)]
+        dgh = None
+        if kind == 1:
+            dgh = [torch.zeros((Lm, B, GH), device=dev, dtype=torch.float32) for _ in range(dirs)]
+        lib = L()
+        lib.rnn_seq_bwd(kind, dirs, whh_t, lengths, list(outs), list(gates), list(aux), douts, dhf,
+                        dgi, dgh, B, Lm, H)
+        res = [None, None, None, None]
+        for d in range(dirs):
+            dG = dgh[d] if kind == 1 else dgi[d]
+            zero = torch.zeros((1, B, H), device=dev, dtype=torch.float32)
+            # state entering step t: previous output in processing order (zeros at the start)
+            hprev = torch.cat([outs[d][1:], zero] if d == 1 else [zero, outs[d][:-1]], dim=0)
+            dw = torch.empty((GH, H), device=dev, dtype=torch.float32)
+            lib.gemm(dG, GH, 1, hprev, H, 1, dw, H, GH, H, Lm * B)  # dW_hh = dG^T H_prev
+            db = torch.empty((GH,), device=dev, dtype=torch.float32)
+            lib.colsum(dG, GH, Lm * B, GH, db, 0)
+            res += [dgi[d], dw, db]
+        return tuple(res)
+
+
+def rnn_seq(kind, lengths_i32, per_direction, need_grad):
+    """per_direction: list of (gi [L,B,G*H], w_hh, b_hh).  Returns ([out_d], [hfin_d])."""
+    dirs = len(per_direction)
+    flat = [t for trip in per_direction for t in trip]
+    res = RNNSeqFn.apply(kind, bool(need_grad), lengths_i32, dirs, *flat)
+    return list(res[:dirs]), list(res[dirs:])
