@@ -98,11 +98,13 @@ int vlnce_colsum(const float* x, int ldx, int M, int N, float* out, int accumula
  * vlnce_bn_finalize reduces the conv epilogue's partials (Chan's parallel
  * variance, fp64 combine) into per-channel scale/shift and updates the running
  * statistics exactly like torch (unbiased running_var). */
+size_t vlnce_bn_finalize_workspace_bytes(int tiles_m, int C); /* 0 when no workspace is needed */
 int vlnce_bn_finalize(const float* stat_partial, int tiles_m, int tile_rows, int M, int C,
                       const float* gamma, const float* beta, float eps, float momentum,
                       float* running_mean, float* running_var, /* may be NULL */
                       float* scale_out, float* shift_out,
                       float* mean_out, float* rstd_out, /* may be NULL; saved for backward */
+                      void* workspace, size_t workspace_bytes, /* caller-allocated scratch */
                       vlnce_stream_t stream);
 
 /* y = act(x * scale[s, c] + shift[s, c] + residual)   with s = row / rows_per_sample

@@ -94,8 +94,12 @@ class HostSim:
             out.copy_(s)
 
     # ---- norms
+    def bn_finalize_workspace_bytes(self, tiles_m, Cc):
+        return 0
+
     def bn_finalize(self, partial, tiles_m, tile_rows, M, Cc, gamma, beta, eps, momentum,
-                    running_mean, running_var, scale_out, shift_out, mean_out=None, rstd_out=None):
+                    running_mean, running_var, scale_out, shift_out, mean_out=None, rstd_out=None,
+                    workspace=None):
         p = partial.double()
         n_t = torch.full((tiles_m,), float(tile_rows), dtype=torch.float64)
         n_t[-1] = M - tile_rows * (tiles_m - 1)

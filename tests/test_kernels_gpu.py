@@ -127,6 +127,9 @@ GEMM_CASES = [
     (1, 512, 37, 1, 1, 0, False),      # dW of a 1-output head, ragged K
     (5000, 256, 256, 0, 0, 0, True),   # text_k over B*L rows (128-row tiles)
     (40000, 64, 64, 0, 0, 0, False),   # M > 32767: row folding
+    (512, 50, 5120, 1, 1, 0, False),   # dW_ih of the instruction RNN: split-K over L*B rows
+    (64, 128, 3072, 0, 0, 1, True),    # depth_linear: split-K + bias/ReLU second pass
+    (64, 416, 1536, 0, 1, 0, False),   # dX of the GRU input projection: split-K
 ]
 
 
@@ -158,14 +161,18 @@ def test_gemm_accumulate_and_strided_views(hip):
 
 
 # ------------------------------------------------------------------ norms / pools
-def test_bn_finalize_contract(hip):
-    tiles, rows, Cc = 7, 128, 96
+@pytest.mark.parametrize("tiles,Cc", [(7, 96), (256, 64), (700, 64), (8192, 64), (300, 200)])
+def test_bn_finalize_contract(hip, tiles, Cc):
+    rows = 128
     M = tiles * rows - 40
     part = rnd(tiles, Cc, 2, seed=1).abs()
     t = dict(partial=part, gamma=rnd(Cc, seed=2), beta=rnd(Cc, seed=3),
              running_mean=rnd(Cc, seed=4), running_var=rnd(Cc, seed=5).abs(),
              scale_out=torch.zeros(Cc), shift_out=torch.zeros(Cc), mean_out=torch.zeros(Cc),
              rstd_out=torch.zeros(Cc))
+    wb = _lib.get_lib().bn_finalize_workspace_bytes(tiles, Cc)
+    assert (wb > 0) == (tiles > 256)
+    t["workspace"] = torch.zeros(max(wb // 8, 1), dtype=torch.float64)
     sc = dict(tiles_m=tiles, tile_rows=rows, M=M, Cc=Cc, eps=1e-5, momentum=0.1)
     cpu, gpu = both("bn_finalize", t, sc)
     for k in ("scale_out", "shift_out", "mean_out", "rstd_out", "running_mean", "running_var"):

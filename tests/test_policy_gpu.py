@@ -112,3 +112,37 @@ def test_full_batch_properties_num_envs_64():
     assert torch.equal(act.view(-1), full.argmax(1))
     # rows with a shorter Lmax see fewer (masked) keys: still identical up to fp32 rounding
     assert (full[idx] - sub).abs().max().item() < 2e-5
+
+
+def test_graph_replay_equals_eager(monkeypatch):
+    """The frozen trunks replay as captured HIP graphs from the 2nd call on; eager, the
+    capturing call and pure replays must agree bit-for-bit, in eval AND train BatchNorm
+    (running statistics advance exactly once per call)."""
+    N = 4
+    obs, prev, masks = synth_batch(N, 128, 20)
+    obs, prev, masks = to_dev(obs), prev.to(DEV), masks.to(DEV)
+    sd = None
+    results = {}
+    for graphs in ("0", "1"):
+        monkeypatch.setenv("VLNCE_HIP_GRAPHS", graphs)
+        pol = vlnce_amd.build_model(vlnce_amd.make_config("CMAPolicy"), *vlnce_amd.make_spaces(128, 128))
+        if sd is None:
+            sd = tp.synth_state_dict(pol)
+        pol.load_state_dict(sd)
+        pol.to(DEV)
+        h0 = torch.zeros(N, 2, 512, device=DEV)
+        outs = []
+        with torch.no_grad():
+            for _ in range(4):  # train-mode BatchNorm (as constructed)
+                outs.append(pol.build_distribution(obs, h0, prev, masks).logits.clone())
+            pol.eval()
+            for _ in range(3):
+                outs.append(pol.build_distribution(obs, h0, prev, masks).logits.clone())
+        results[graphs] = (outs, pol.state_dict()["net.rgb_encoder.cnn.1.running_mean"].clone(),
+                           int(pol.state_dict()["net.rgb_encoder.cnn.1.num_batches_tracked"]))
+    for a, b in zip(results["0"][0], results["1"][0]):
+        assert torch.equal(a, b)
+    assert torch.equal(results["0"][1], results["1"][1])
+    assert results["0"][2] == results["1"][2] == 4
+    # eval calls are idempotent
+    assert torch.equal(results["1"][0][4], results["1"][0][5])

@@ -44,7 +44,9 @@ _SIGNATURES = {
                               C.POINTER(Epilogue), _P]),
     "vlnce_gemm": (_I, [_P, _I, _I, _P, _I, _I, _P, _I, _I, _I, _I, C.POINTER(Epilogue), _P]),
     "vlnce_colsum": (_I, [_P, _I, _I, _I, _P, _I, _P]),
-    "vlnce_bn_finalize": (_I, [_P, _I, _I, _I, _I, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P]),
+    "vlnce_bn_finalize_workspace_bytes": (C.c_size_t, [_I, _I]),
+    "vlnce_bn_finalize": (_I, [_P, _I, _I, _I, _I, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P,
+                               C.c_size_t, _P]),
     "vlnce_scale_shift_act": (_I, [_P, _P, _P, _I, _P, _P, _L, _I, _I, _P]),
     "vlnce_gn_chunks": (_I, [_I]),
     "vlnce_gn_partial": (_I, [_P, _I, _I, _I, _P, _P]),
@@ -142,12 +144,17 @@ class HipLib:
                     "vlnce_colsum")
 
     # ---- norms
+    def bn_finalize_workspace_bytes(self, tiles_m, Cc):
+        return int(self.dll.vlnce_bn_finalize_workspace_bytes(tiles_m, Cc))
+
     def bn_finalize(self, partial, tiles_m, tile_rows, M, Cc, gamma, beta, eps, momentum,
-                    running_mean, running_var, scale_out, shift_out, mean_out=None, rstd_out=None):
+                    running_mean, running_var, scale_out, shift_out, mean_out=None, rstd_out=None,
+                    workspace=None):
+        wb = workspace.numel() * workspace.element_size() if workspace is not None else 0
         self._check(self.dll.vlnce_bn_finalize(
             _ptr(partial), tiles_m, tile_rows, M, Cc, _ptr(gamma), _ptr(beta), eps, momentum,
             _ptr(running_mean), _ptr(running_var), _ptr(scale_out), _ptr(shift_out),
-            _ptr(mean_out), _ptr(rstd_out), _stream()), "vlnce_bn_finalize")
+            _ptr(mean_out), _ptr(rstd_out), _ptr(workspace), wb, _stream()), "vlnce_bn_finalize")
 
     def scale_shift_act(self, x, scale, shift, rows_per_sample, residual, y, M, Cc, act):
         self._check(self.dll.vlnce_scale_shift_act(

@@ -48,11 +48,14 @@ struct IgemmParams {
   int accumulate;
   float* stat_partial;
   int tiles_m, tiles_n;
+  int splitk;  // > 1: blockIdx.y owns a K range and atomically adds into a pre-zeroed C
 };
 
 __device__ __forceinline__ f32x4 ldg4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
-template <int BM, int BN, int WM, int WN, int AMODE, int BMODE>
+// CIN_C / KW_C: compile-time Cin and KW for the scalar im2col loader (0 = runtime values);
+// the 7x7 stems (Cin 3 / 1) use them so k -> (r, q, ci) is multiply-shift, not a division.
+template <int BM, int BN, int WM, int WN, int AMODE, int BMODE, int CIN_C = 0, int KW_C = 0>
 __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
   constexpr int WTM = BM / WM;  // rows per wave
   constexpr int WTN = BN / WN;
@@ -86,6 +89,13 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
   const int half = lane >> 5;
   const int l31 = lane & 31;
 
+  // K-tile range of this workgroup (split-K along blockIdx.y)
+  const int KT_all = (p.K + BK - 1) / BK;
+  const int kt_per = (KT_all + p.splitk - 1) / p.splitk;
+  const int kt0 = blockIdx.y * kt_per;
+  const int kt1 = min(KT_all, kt0 + kt_per);
+  if (kt0 >= kt1) return;
+
   // ------------------------------------------------------------------ A loader state
   constexpr int A_ROWS = BM / 32;  // row-major modes: 32 rows x 8 float4 per pass
   const int lrow = tid >> 3;
@@ -114,8 +124,9 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
       }
     }
     if constexpr (AMODE == A_IM2COL_V4) {
-      const int tap = lk4 / p.Cin;
-      k_ci = lk4 - tap * p.Cin;
+      const int kfirst = kt0 * BK + lk4;
+      const int tap = kfirst / p.Cin;
+      k_ci = kfirst - tap * p.Cin;
       k_r = tap / p.KW;
       k_q = tap - k_r * p.KW;
     }
@@ -166,13 +177,15 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
     } else if constexpr (AMODE == A_IM2COL_S) {
       int er[4], eq[4], eci[4];
       float es[4], et[4];
+      const int cin = CIN_C > 0 ? CIN_C : p.Cin;
+      const int kw = KW_C > 0 ? KW_C : p.KW;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int k = k0 + lk4 + e;
-        const int tap = k / p.Cin;
-        eci[e] = k - tap * p.Cin;
-        er[e] = tap / p.KW;
-        eq[e] = tap - er[e] * p.KW;
+        const int tap = k / cin;
+        eci[e] = k - tap * cin;
+        er[e] = tap / kw;
+        eq[e] = tap - er[e] * kw;
         es[e] = 1.f;
         et[e] = 0.f;
         if (p.in_scale != nullptr && k < p.K) {
@@ -330,9 +343,9 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int KT = (p.K + BK - 1) / BK;
-  load_a(0);
-  load_b(0);
+  const int KT = kt1 - kt0;
+  load_a(kt0 * BK);
+  load_b(kt0 * BK);
   store_ab(smem);
   __syncthreads();
 
@@ -340,8 +353,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
     float* cur = smem + (t & 1) * STAGE;
     const bool more = (t + 1) < KT;
     if (more) {
-      load_a((t + 1) * BK);
-      load_b((t + 1) * BK);
+      load_a((kt0 + t + 1) * BK);
+      load_b((kt0 + t + 1) * BK);
     }
     const float* Aw = cur + (wm * WTM + l31) * LDP + 4 * half;
     const float* Bw = cur + A_TILE + (wn * WTN + l31) * LDP + 4 * half;
@@ -426,6 +439,68 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
   }
 
   // ------------------------------------------------------------------ epilogue
+  if (p.splitk > 1) {
+    // partial sums of this K range: plain atomic accumulation (C was zeroed by the host entry)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int col = n0 + wn * WTN + j * 32 + l31;
+      if (col >= p.N) continue;
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          if (row < p.M) atomicAdd(p.C + (long)row * p.ldc + col, acc[i][j][r]);
+        }
+    }
+    return;
+  }
+  const bool vec_out = ((p.N & 3) == 0) && ((p.ldc & 3) == 0) &&
+                       ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0) &&
+                       (!p.residual || (((p.ldr & 3) == 0) &&
+                                        (reinterpret_cast<uintptr_t>(p.residual) & 15) == 0));
+  if (vec_out) {
+    // stage the accumulator tile through LDS so every lane stores 16 contiguous bytes of a row
+    // (the MFMA layout would give 4-byte stores: store-issue bound on the wide layers)
+    constexpr int LDC = BN + 4;
+    float* Ct = smem;
+    __syncthreads();  // all waves are done with the K-loop / statistics scratch
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          Ct[row * LDC + wn * WTN + j * 32 + l31] = acc[i][j][r];
+        }
+    __syncthreads();
+    constexpr int TPR = BN / 4;        // threads per output row
+    constexpr int RPP = 256 / TPR;     // rows per pass
+    const int c4 = (tid % TPR) * 4;
+    const int col = n0 + c4;
+    if (col < p.N) {
+      f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+      if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + col);
+      if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + col);
+#pragma unroll 4
+      for (int rr = tid / TPR; rr < BM; rr += RPP) {
+        const int row = m0 + rr;
+        if (row >= p.M) break;
+        f32x4 v = *reinterpret_cast<const f32x4*>(Ct + rr * LDC + c4);
+        v = v * sc + sh;
+        if (p.residual) v += *reinterpret_cast<const f32x4*>(p.residual + (long)row * p.ldr + col);
+        v.x = apply_act(v.x, p.act);
+        v.y = apply_act(v.y, p.act);
+        v.z = apply_act(v.z, p.act);
+        v.w = apply_act(v.w, p.act);
+        float* dst = p.C + (long)row * p.ldc + col;
+        if (p.accumulate) v += *reinterpret_cast<const f32x4*>(dst);
+        *reinterpret_cast<f32x4*>(dst) = v;
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int col = n0 + wn * WTN + j * 32 + l31;
@@ -450,10 +525,24 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
   }
 }
 
-template <int BM, int BN, int WM, int WN, int AMODE, int BMODE>
+// y = act(y + shift): second pass of a split-K GEMM that has a bias / activation
+__global__ __launch_bounds__(256) void bias_act_kernel(float* __restrict__ c, int ldc, int M, int N,
+                                                       const float* __restrict__ shift, int act) {
+  const long total = (long)M * N;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const long row = i / N;
+    const int col = (int)(i - row * N);
+    float* q = c + row * ldc + col;
+    *q = apply_act(*q + (shift ? shift[col] : 0.f), act);
+  }
+}
+
+template <int BM, int BN, int WM, int WN, int AMODE, int BMODE, int CIN_C = 0, int KW_C = 0>
 int launch(const IgemmParams& p, hipStream_t stream) {
   constexpr int smem_bytes = 2 * (BM + BN) * LDP * (int)sizeof(float);
-  auto kern = igemm_kernel<BM, BN, WM, WN, AMODE, BMODE>;
+  static_assert(BM * (BN + 4) * (int)sizeof(float) <= smem_bytes, "epilogue tile must fit");
+  auto kern = igemm_kernel<BM, BN, WM, WN, AMODE, BMODE, CIN_C, KW_C>;
   static bool attr_set = false;  // per instantiation
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -467,12 +556,14 @@ int launch(const IgemmParams& p, hipStream_t stream) {
   IgemmParams q = p;
   q.tiles_m = ceil_div(p.M, BM);
   q.tiles_n = ceil_div(p.N, BN);
+  if (q.splitk < 1) q.splitk = 1;
   const long nwg = (long)q.tiles_m * q.tiles_n;
   if (nwg <= 0 || nwg > 0x7fffffffL) {
     vlnce_set_error("igemm: bad grid %ld", nwg);
     return 1;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), smem_bytes, stream, q);
+  hipLaunchKernelGGL(kern, dim3((unsigned)nwg, (unsigned)q.splitk), dim3(256), smem_bytes, stream,
+                     q);
   VLNCE_CHECK_LAUNCH("igemm");
   return 0;
 }
@@ -499,6 +590,24 @@ int dispatch_tiles(const IgemmParams& p, hipStream_t s) {
 template <int AMODE, int BMODE>
 int dispatch_small(const IgemmParams& p, hipStream_t s) {
   return launch<64, 64, 2, 2, AMODE, BMODE>(p, s);
+}
+// 7x7 stems: scalar loaders with compile-time Cin / KW
+template <int CIN_C>
+int dispatch_stem(const IgemmParams& p, hipStream_t s) {
+  const TileChoice t = choose_tile(p.M, p.N);
+  if (t.bm == 128) return launch<128, 64, 2, 2, A_IM2COL_S, B_NK_S, CIN_C, 7>(p, s);
+  return launch<64, 64, 2, 2, A_IM2COL_S, B_NK_S, CIN_C, 7>(p, s);
+}
+
+// split-K factor for a plain GEMM with few output tiles and a long reduction
+int choose_splitk(const IgemmParams& p) {
+  const long tiles = (long)ceil_div(p.M, 64) * ceil_div(p.N, 64);
+  const int KT = ceil_div(p.K, BK);
+  if (tiles >= 128 || KT < 8) return 1;
+  long s = (256 + tiles - 1) / tiles;
+  if (s > KT / 2) s = KT / 2;
+  if (s > 64) s = 64;
+  return s < 2 ? 1 : (int)s;
 }
 
 void fill_epilogue(IgemmParams& p, const vlnce_epilogue* e) {
@@ -566,8 +675,11 @@ extern "C" int vlnce_conv2d_fwd(const float* x, const float* w, float* y, const 
   fill_epilogue(p, epi);
   const bool v4 = (d->Cin % 4 == 0) && (p.lda % 4 == 0) && aligned16(x) && aligned16(w) &&
                   (!p.in_scale || (aligned16(p.in_scale) && aligned16(p.in_shift)));
+  p.splitk = 1;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (v4) return dispatch_tiles<A_IM2COL_V4, B_NK_V4>(p, s);
+  if (d->KW == 7 && d->Cin == 3) return dispatch_stem<3>(p, s);
+  if (d->KW == 7 && d->Cin == 1) return dispatch_stem<1>(p, s);
   return dispatch_tiles<A_IM2COL_S, B_NK_S>(p, s);
 }
 
@@ -600,18 +712,51 @@ extern "C" int vlnce_gemm(const float* A, int lda, int transA, const float* B, i
   p.ldc = ldc;
   fill_epilogue(p, epi);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  // split-K: few output tiles + long reduction (tail GEMMs at num_envs rows, dW GEMMs).
+  // The K ranges add atomically into a zeroed C; bias / activation run as a second pass.
+  p.splitk = 1;
+  const bool plain = !p.scale && !p.residual && !p.accumulate;
+  if (plain) p.splitk = choose_splitk(p);
+  const float* bias2 = nullptr;
+  int act2 = 0;
+  if (p.splitk > 1) {
+    bias2 = p.shift;
+    act2 = p.act;
+    p.shift = nullptr;
+    p.act = 0;
+    hipError_t e = hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float),
+                                    (size_t)M, s);
+    VLNCE_CHECK_ARG(e == hipSuccess, "gemm: memset failed: %s", hipGetErrorString(e));
+  }
+  int rc;
   if (!transA) {
     const bool av4 = (K % 4 == 0) && (lda % 4 == 0) && aligned16(A);
     if (!transB) {
       const bool bv4 = (K % 4 == 0) && (ldb % 4 == 0) && aligned16(B);
-      if (av4 && bv4) return dispatch_tiles<A_IM2COL_V4, B_NK_V4>(p, s);
-      return dispatch_small<A_IM2COL_S, B_NK_S>(p, s);
+      if (av4 && bv4)
+        rc = p.splitk > 1 ? dispatch_small<A_IM2COL_V4, B_NK_V4>(p, s)
+                          : dispatch_tiles<A_IM2COL_V4, B_NK_V4>(p, s);
+      else
+        rc = dispatch_small<A_IM2COL_S, B_NK_S>(p, s);
+    } else {
+      VLNCE_CHECK_ARG(aligned16(B), "gemm: B must be 16-byte aligned");
+      if (av4)
+        rc = p.splitk > 1 ? dispatch_small<A_IM2COL_V4, B_KN>(p, s)
+                          : dispatch_tiles<A_IM2COL_V4, B_KN>(p, s);
+      else
+        rc = dispatch_small<A_IM2COL_S, B_KN>(p, s);
     }
-    VLNCE_CHECK_ARG(aligned16(B), "gemm: B must be 16-byte aligned");
-    if (av4) return dispatch_tiles<A_IM2COL_V4, B_KN>(p, s);
-    return dispatch_small<A_IM2COL_S, B_KN>(p, s);
+  } else {
+    VLNCE_CHECK_ARG(transB, "gemm: transA requires transB (only A^T * B^T-stored form is built)");
+    VLNCE_CHECK_ARG(aligned16(A) && aligned16(B), "gemm: operands must be 16-byte aligned");
+    rc = p.splitk > 1 ? dispatch_small<A_TRANS, B_KN>(p, s) : dispatch_tiles<A_TRANS, B_KN>(p, s);
   }
-  VLNCE_CHECK_ARG(transB, "gemm: transA requires transB (only A^T * B^T-stored form is built)");
-  VLNCE_CHECK_ARG(aligned16(A) && aligned16(B), "gemm: operands must be 16-byte aligned");
-  return dispatch_tiles<A_TRANS, B_KN>(p, s);
+  if (rc != 0) return rc;
+  if (p.splitk > 1 && (bias2 || act2)) {
+    const long work = (long)M * N;
+    const int grid = (int)((work + 255) / 256 > 2048 ? 2048 : (work + 255) / 256);
+    hipLaunchKernelGGL(bias_act_kernel, dim3(grid), dim3(256), 0, s, C, ldc, M, N, bias2, act2);
+    VLNCE_CHECK_LAUNCH("gemm bias/act");
+  }
+  return 0;
 }

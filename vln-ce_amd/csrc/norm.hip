@@ -6,53 +6,91 @@
 namespace {
 
 // ---------------------------------------------------------------- BatchNorm finalize
-// partial: [tiles_m][C][2] = {sum, M2 about the tile mean}; 16 channels x 16 tile-slices per block.
-__global__ __launch_bounds__(256) void bn_finalize_kernel(
-    const float* __restrict__ partial, int tiles_m, int tile_rows, int M, int C,
-    const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
-    float* running_mean, float* running_var, float* scale_out, float* shift_out, float* mean_out,
-    float* rstd_out) {
-  __shared__ double red[16][17];
-  const int cl = threadIdx.x & 15;
-  const int sl = threadIdx.x >> 4;
-  const int c = blockIdx.x * 16 + cl;
-  const bool cok = c < C;
-  // pass 1: total sum
-  double s = 0.0;
-  if (cok)
-    for (int t = sl; t < tiles_m; t += 16) s += (double)partial[((long)t * C + c) * 2];
-  red[sl][cl] = s;
+// partial: [tiles_m][C][2] = {sum, M2 about the tile mean}.  Tiles are merged with Chan's
+// parallel-variance update in fp64.  Up to 256 tiles: one launch; beyond that a first
+// launch reduces runs of 64 tiles into a workspace [slices][C][3] (n, mean, M2) so the
+// reduction is spread over (C/64) x slices workgroups instead of C/64.
+struct Moments {
+  double n, mean, m2;
+};
+__device__ __forceinline__ void merge(Moments& a, double n, double mean, double m2) {
+  if (n <= 0.0) return;
+  const double tot = a.n + n;
+  const double d = mean - a.mean;
+  a.mean += d * (n / tot);
+  a.m2 += m2 + d * d * (a.n * n / tot);
+  a.n = tot;
+}
+__device__ __forceinline__ Moments block_merge4(Moments m, Moments (*red)[64], int cl, int sl) {
+  red[sl][cl] = m;
   __syncthreads();
-  double tot = 0.0;
-  for (int i = 0; i < 16; ++i) tot += red[i][cl];
-  const double mean = tot / (double)M;
-  __syncthreads();
-  // pass 2: M2 = sum_t [ M2_t + n_t (mean_t - mean)^2 ]
-  double m2 = 0.0;
-  if (cok)
-    for (int t = sl; t < tiles_m; t += 16) {
+  Moments r = red[0][cl];
+#pragma unroll
+  for (int i = 1; i < 4; ++i) merge(r, red[i][cl].n, red[i][cl].mean, red[i][cl].m2);
+  return r;
+}
+
+constexpr int BN_RUN = 64;  // tiles per first-stage workgroup
+
+__global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict__ partial,
+                                                        int tiles_m, int tile_rows, int M, int C,
+                                                        double* __restrict__ ws) {
+  __shared__ Moments red[4][64];
+  const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  const int t0 = blockIdx.y * BN_RUN;
+  const int t1 = min(tiles_m, t0 + BN_RUN);
+  Moments m{0.0, 0.0, 0.0};
+  if (c < C)
+    for (int t = t0 + sl; t < t1; t += 4) {
       const float* q = partial + ((long)t * C + c) * 2;
-      const int nt = min(tile_rows, M - t * tile_rows);
-      const double d = (double)q[0] / (double)nt - mean;
-      m2 += (double)q[1] + (double)nt * d * d;
+      const double nt = (double)min(tile_rows, M - t * tile_rows);
+      merge(m, nt, (double)q[0] / nt, (double)q[1]);
     }
-  red[sl][cl] = m2;
-  __syncthreads();
-  if (sl == 0 && cok) {
-    double tm2 = 0.0;
-    for (int i = 0; i < 16; ++i) tm2 += red[i][cl];
-    const double var = tm2 / (double)M;  // biased, used for normalisation
+  m = block_merge4(m, red, cl, sl);
+  if (sl == 0 && c < C) {
+    double* dst = ws + ((long)blockIdx.y * C + c) * 3;
+    dst[0] = m.n;
+    dst[1] = m.mean;
+    dst[2] = m.m2;
+  }
+}
+
+template <bool FROM_WS>
+__global__ __launch_bounds__(256) void bn_finalize_kernel(
+    const float* __restrict__ partial, const double* __restrict__ ws, int items, int tile_rows,
+    int M, int C, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+    float momentum, float* running_mean, float* running_var, float* scale_out, float* shift_out,
+    float* mean_out, float* rstd_out) {
+  __shared__ Moments red[4][64];
+  const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  Moments m{0.0, 0.0, 0.0};
+  if (c < C)
+    for (int t = sl; t < items; t += 4) {
+      if (FROM_WS) {
+        const double* q = ws + ((long)t * C + c) * 3;
+        merge(m, q[0], q[1], q[2]);
+      } else {
+        const float* q = partial + ((long)t * C + c) * 2;
+        const double nt = (double)min(tile_rows, M - t * tile_rows);
+        merge(m, nt, (double)q[0] / nt, (double)q[1]);
+      }
+    }
+  m = block_merge4(m, red, cl, sl);
+  if (sl == 0 && c < C) {
+    const double var = m.m2 / (double)M;  // biased, used for normalisation
     const float rstd = (float)(1.0 / sqrt(var + (double)eps));
     const float g = gamma ? gamma[c] : 1.f;
     const float b = beta ? beta[c] : 0.f;
     const float sc = g * rstd;
     scale_out[c] = sc;
-    shift_out[c] = b - (float)mean * sc;
-    if (mean_out) mean_out[c] = (float)mean;
+    shift_out[c] = b - (float)m.mean * sc;
+    if (mean_out) mean_out[c] = (float)m.mean;
     if (rstd_out) rstd_out[c] = rstd;
     if (running_mean) {
-      const double unbiased = M > 1 ? tm2 / (double)(M - 1) : var;
-      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+      const double unbiased = M > 1 ? m.m2 / (double)(M - 1) : var;
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m.mean;
       running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
     }
   }
@@ -200,19 +238,40 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(
 
 }  // namespace
 
+extern "C" size_t vlnce_bn_finalize_workspace_bytes(int tiles_m, int C) {
+  if (tiles_m <= 256) return 0;
+  return (size_t)ceil_div(tiles_m, BN_RUN) * (size_t)C * 3 * sizeof(double);
+}
+
 extern "C" int vlnce_bn_finalize(const float* stat_partial, int tiles_m, int tile_rows, int M,
                                  int C, const float* gamma, const float* beta, float eps,
                                  float momentum, float* running_mean, float* running_var,
                                  float* scale_out, float* shift_out, float* mean_out,
-                                 float* rstd_out, vlnce_stream_t stream) {
+                                 float* rstd_out, void* workspace, size_t workspace_bytes,
+                                 vlnce_stream_t stream) {
   VLNCE_CHECK_ARG(stat_partial && scale_out && shift_out, "bn_finalize: null argument");
   VLNCE_CHECK_ARG(tiles_m > 0 && tile_rows > 0 && M > 0 && C > 0, "bn_finalize: bad shape");
   VLNCE_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr),
                   "bn_finalize: running stats must come together");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 16)), dim3(256), 0,
-                     reinterpret_cast<hipStream_t>(stream), stat_partial, tiles_m, tile_rows, M, C,
-                     gamma, beta, eps, momentum, running_mean, running_var, scale_out, shift_out,
-                     mean_out, rstd_out);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const size_t need = vlnce_bn_finalize_workspace_bytes(tiles_m, C);
+  if (need == 0) {
+    hipLaunchKernelGGL(bn_finalize_kernel<false>, dim3(ceil_div(C, 64)), dim3(256), 0, s,
+                       stat_partial, (const double*)nullptr, tiles_m, tile_rows, M, C, gamma, beta,
+                       eps, momentum, running_mean, running_var, scale_out, shift_out, mean_out,
+                       rstd_out);
+  } else {
+    VLNCE_CHECK_ARG(workspace && workspace_bytes >= need,
+                    "bn_finalize: workspace of %zu bytes required", need);
+    const int slices = ceil_div(tiles_m, BN_RUN);
+    double* ws = reinterpret_cast<double*>(workspace);
+    hipLaunchKernelGGL(bn_reduce_kernel, dim3(ceil_div(C, 64), slices), dim3(256), 0, s,
+                       stat_partial, tiles_m, tile_rows, M, C, ws);
+    hipLaunchKernelGGL(bn_finalize_kernel<true>, dim3(ceil_div(C, 64)), dim3(256), 0, s,
+                       stat_partial, (const double*)ws, slices, tile_rows, M, C, gamma, beta, eps,
+                       momentum, running_mean, running_var, scale_out, shift_out, mean_out,
+                       rstd_out);
+  }
   VLNCE_CHECK_LAUNCH("bn_finalize");
   return 0;
 }

@@ -159,22 +159,22 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
   }
 }
 
-// out[n] (+)= sum_m x[m, n]: 64 columns per block, 4 row-slices, LDS combine
+// out[n] += sum_m x[m, n]: 64 columns x a slice of rows per block; slices combine with
+// atomics into an output the host entry has zeroed (unless accumulating).
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int ldx, int M,
                                                      int N, float* __restrict__ out,
-                                                     int accumulate) {
+                                                     int rows_per_block) {
   __shared__ float red[4][64];
   const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
   const int n = blockIdx.x * 64 + cl;
+  const int m0 = blockIdx.y * rows_per_block;
+  const int m1 = min(M, m0 + rows_per_block);
   float s = 0.f;
   if (n < N)
-    for (int m = sl; m < M; m += 4) s += x[(long)m * ldx + n];
+    for (int m = m0 + sl; m < m1; m += 4) s += x[(long)m * ldx + n];
   red[sl][cl] = s;
   __syncthreads();
-  if (sl == 0 && n < N) {
-    const float t = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
-    out[n] = accumulate ? out[n] + t : t;
-  }
+  if (sl == 0 && n < N) atomicAdd(out + n, red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]);
 }
 
 inline int grid_for(long work) {
@@ -244,8 +244,17 @@ extern "C" int vlnce_mask_rows(const float* x, const uint8_t* mask, float* out, 
 extern "C" int vlnce_colsum(const float* x, int ldx, int M, int N, float* out, int accumulate,
                             vlnce_stream_t stream) {
   VLNCE_CHECK_ARG(x && out && M > 0 && N > 0, "colsum: bad argument");
-  hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(N, 64)), dim3(256), 0,
-                     reinterpret_cast<hipStream_t>(stream), x, ldx, M, N, out, accumulate);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (!accumulate) {
+    hipError_t e = hipMemsetAsync(out, 0, (size_t)N * sizeof(float), s);
+    VLNCE_CHECK_ARG(e == hipSuccess, "colsum: memset failed: %s", hipGetErrorString(e));
+  }
+  const int col_blocks = ceil_div(N, 64);
+  int slices = ceil_div(256, col_blocks);
+  if (slices > ceil_div(M, 32)) slices = ceil_div(M, 32);
+  const int rows_per_block = ceil_div(M, slices);
+  hipLaunchKernelGGL(colsum_kernel, dim3(col_blocks, ceil_div(M, rows_per_block)), dim3(256), 0, s,
+                     x, ldx, M, N, out, rows_per_block);
   VLNCE_CHECK_LAUNCH("colsum");
   return 0;
 }

@@ -15,6 +15,9 @@ NHWC (a permuted view), so forward hooks on `.cnn` / `.visual_encoder`
 (dagger_trainer.py:300-314) see the reference's shapes while downstream HIP
 ops get channels-last rows without a copy.
 """
+import os
+from collections import OrderedDict
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -46,8 +49,10 @@ class _WeightCache:
             self._packed[id(conv)] = hit
         return hit[1]
 
-    def bn_eval(self, bn):
-        k = self._key(bn.weight, bn.bias, bn.running_mean, bn.running_var)
+    def bn_eval(self, bn, gen=0):
+        # `gen` counts train-mode forwards: the HIP kernels update the running statistics
+        # through raw pointers, which torch's version counters do not see
+        k = self._key(bn.weight, bn.bias, bn.running_mean, bn.running_var) + (gen,)
         hit = self._folded.get(id(bn))
         if hit is None or hit[0] != k:
             scale = bn.weight.detach() / torch.sqrt(bn.running_var + bn.eps)
@@ -55,6 +60,49 @@ class _WeightCache:
             hit = (k, scale.contiguous(), shift.contiguous())
             self._folded[id(bn)] = hit
         return hit[1], hit[2]
+
+
+class _GraphRunner:
+    """Replays a frozen trunk forward as a captured HIP graph (hipGraph through
+    torch.cuda.CUDAGraph).  A trunk is ~110-210 short kernel launches whose
+    host-side issue cost exceeds the GPU time of the small layers; the graph
+    removes it.  Protocol per key (input shape + norm modes + parameter
+    versions): 1st call runs eagerly (real forward, warms kernel attributes and
+    the weight caches), 2nd call captures and replays, later calls replay.
+    BatchNorm running-stat side effects happen exactly once per call either way.
+    Set VLNCE_HIP_GRAPHS=0 to disable."""
+
+    MAX_GRAPHS = 6
+
+    def __init__(self, fn):
+        self.fn = fn
+        self.entries = OrderedDict()
+
+    @staticmethod
+    def enabled():
+        return os.environ.get("VLNCE_HIP_GRAPHS", "1") != "0"
+
+    def __call__(self, x, key):
+        if (not self.enabled() or not x.is_cuda or torch.cuda.is_current_stream_capturing()):
+            return self.fn(x)
+        ent = self.entries.get(key)
+        if ent is None:
+            while len(self.entries) >= self.MAX_GRAPHS:
+                self.entries.popitem(last=False)
+            self.entries[key] = "seen"
+            return self.fn(x)
+        self.entries.move_to_end(key)
+        if ent == "seen":
+            static_in = x.clone()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                static_out = self.fn(static_in)
+            ent = (graph, static_in, static_out)
+            self.entries[key] = ent
+        else:
+            ent[1].copy_(x)
+        ent[0].replay()
+        return ent[2].clone()
 
 
 def _require_frozen(module, what):
@@ -155,6 +203,9 @@ class HipResNetTrunk(nn.Sequential):
                 nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
         self._cache = _WeightCache()
         self.input_scale = None  # set by the owning encoder: per-channel (scale, shift)
+        self._bn_gen = 0
+        self._graphs = _GraphRunner(self._forward_impl)
+        self._norms = [m for m in self.modules() if isinstance(m, nn.BatchNorm2d)]
 
     # -- one conv + BatchNorm (+residual) (+ReLU)
     def _conv_bn(self, x, conv, bn, relu, residual=None, prologue=None, touched=None):
@@ -172,7 +223,7 @@ class HipResNetTrunk(nn.Sequential):
                                            bn.running_mean, bn.running_var)
             touched.append(bn.num_batches_tracked)
             return ops.scale_shift_act(y, scale, shift, residual=residual, act=act, out=y)
-        scale, shift = self._cache.bn_eval(bn)
+        scale, shift = self._cache.bn_eval(bn, self._bn_gen)
         return ops.conv2d_nhwc(x, w, stride, pad, scale=scale, shift=shift, residual=residual,
                                act=act, **pro)
 
@@ -180,10 +231,20 @@ class HipResNetTrunk(nn.Sequential):
         """x: [B,H,W,3] pixel values 0..255 (channels-last as the simulator
         delivers them); returns logical NCHW features."""
         _require_frozen(self, "TorchVisionResNet.cnn")
+        x = ops._f32c(x_nhwc_raw)
+        modes = tuple(m.training for m in self._norms)
+        key = (tuple(x.shape), modes, tuple(p._version for p in self.parameters()),
+               id(self.input_scale[0]), len(list(self.children())),
+               0 if any(modes) else self._bn_gen)
+        y = self._graphs(x, key)
+        if any(modes):
+            self._bn_gen += 1
+        return y.permute(0, 3, 1, 2)
+
+    def _forward_impl(self, x):
         with torch.no_grad():
             kids = list(self.children())
             touched = []
-            x = ops._f32c(x_nhwc_raw)
             x = self._conv_bn(x, kids[0], kids[1], True, prologue=self.input_scale, touched=touched)
             x = ops.maxpool3x3s2(x)
             for stage in kids[4:8]:
@@ -201,7 +262,7 @@ class HipResNetTrunk(nn.Sequential):
                 x = ops.adaptive_avgpool(x, *pool.out_hw)
             if touched:
                 torch._foreach_add_(touched, 1)
-        return x.permute(0, 3, 1, 2)
+        return x
 
 
 class TorchVisionResNet(nn.Module):
@@ -360,6 +421,7 @@ class HipResNetEncoder(nn.Module):
             if isinstance(layer, (nn.Conv2d, nn.Linear)):
                 nn.init.kaiming_normal_(layer.weight, nn.init.calculate_gain("relu"))
         self._cache = _WeightCache()
+        self._graphs = _GraphRunner(self._forward_impl)
 
     @property
     def is_blind(self):
@@ -387,8 +449,12 @@ class HipResNetEncoder(nn.Module):
 
     def forward(self, observations):
         _require_frozen(self, "VlnResnetDepthEncoder.visual_encoder")
+        x = ops._f32c(observations["depth"])  # [B,H,W,1] is already channels-last
+        key = (tuple(x.shape), tuple(p._version for p in self.parameters()))
+        return self._graphs(x, key).permute(0, 3, 1, 2)
+
+    def _forward_impl(self, x):
         with torch.no_grad():
-            x = ops._f32c(observations["depth"])  # [B,H,W,1] is already channels-last
             x = ops.avgpool2x2(x)
             bb = self.backbone
             x = self._conv_gn(x, bb.conv1[0], bb.conv1[1], True)
@@ -400,7 +466,7 @@ class HipResNetEncoder(nn.Module):
                         identity = self._conv_gn(x, blk.downsample[0], blk.downsample[1], False)
                     x = self._run_convs(x, blk.convs, identity)
             x = self._conv_gn(x, self.compression[0], self.compression[1], True)
-        return x.permute(0, 3, 1, 2)
+        return x
 
 
 def single_frame_box_shape(box):

@@ -70,8 +70,11 @@ def bn_finalize(stats, M, gamma, beta, eps, momentum, running_mean, running_var)
     Cc = partial.size(1)
     scale = torch.empty(Cc, device=partial.device, dtype=torch.float32)
     shift = torch.empty_like(scale)
-    L().bn_finalize(partial, tiles_m, tile_rows, M, Cc, gamma, beta, float(eps), float(momentum),
-                    running_mean, running_var, scale, shift)
+    lib = L()
+    wb = lib.bn_finalize_workspace_bytes(tiles_m, Cc)
+    ws = torch.empty(wb // 8, device=partial.device, dtype=torch.float64) if wb else None
+    lib.bn_finalize(partial, tiles_m, tile_rows, M, Cc, gamma, beta, float(eps), float(momentum),
+                    running_mean, running_var, scale, shift, workspace=ws)
     return scale, shift
 
 
