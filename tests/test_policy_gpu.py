@@ -140,9 +140,11 @@ def test_graph_replay_equals_eager(monkeypatch):
                 outs.append(pol.build_distribution(obs, h0, prev, masks).logits.clone())
         results[graphs] = (outs, pol.state_dict()["net.rgb_encoder.cnn.1.running_mean"].clone(),
                            int(pol.state_dict()["net.rgb_encoder.cnn.1.num_batches_tracked"]))
+    # the trunks are deterministic; the tail's split-K GEMMs combine with fp32 atomics, so
+    # logits agree to rounding (not bit-for-bit) between any two runs
     for a, b in zip(results["0"][0], results["1"][0]):
-        assert torch.equal(a, b)
+        assert (a - b).abs().max().item() < 1e-5
     assert torch.equal(results["0"][1], results["1"][1])
     assert results["0"][2] == results["1"][2] == 4
     # eval calls are idempotent
-    assert torch.equal(results["1"][0][4], results["1"][0][5])
+    assert (results["1"][0][4] - results["1"][0][5]).abs().max().item() < 1e-5

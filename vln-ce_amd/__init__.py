@@ -7,3 +7,4 @@ from .config import make_config, make_spaces  # noqa: F401
 from .registry import baseline_registry, build_model  # noqa: F401
 from .seq2seq_policy import Seq2SeqPolicy  # noqa: F401
 from .cma_policy import CMAPolicy  # noqa: F401
+from .waypoint_policy import WaypointPolicy  # noqa: F401

@@ -1,0 +1,250 @@
+"""Waypoint prediction network (reference: vlnce_baselines/models/
+waypoint_predictors.py:29-625): 12 panorama frames + 1 history frame through
+the RGB (ResNet-18) / depth encoders, visual-history GRU, instruction
+attention, per-frame spatial attention, panorama multi-head attention, main
+GRU and the pano / offset / distance heads.  Module and parameter names match
+the reference; all dense math runs on the HIP kernels with features kept as
+[batch, positions, channels] rows."""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from .cma_policy import nchw_flat_weight, rows_of
+from .encoders import resnet_encoders
+from .encoders.instruction_encoder import InstructionEncoder
+from .policy import Net
+from .rnn_state_encoder import build_rnn_state_encoder
+from .utils import (CustomFixedCategorical, DotProductAttention, MultiHeadDotProductAttention,
+                    TemperatureTanh)
+
+PREV_ACTION_DIM = 4
+PANO_ATTN_KEY_DIM = 128
+ANGLE_FEATURE_SIZE = 4
+
+
+def _lin(module, x, act=ops.ACT_NONE):
+    return ops.linear(x, module.weight, module.bias, act)
+
+
+class WaypointPredictionNet(Net):
+    def __init__(self, observation_space, model_config):
+        super().__init__()
+        self.model_config = model_config
+        self.wypt_cfg = model_config.WAYPOINT
+        self._hidden_size = model_config.STATE_ENCODER.hidden_size
+        self._num_panos = model_config.num_panos
+        hs = self._hidden_size
+        r_out = model_config.RGB_ENCODER.output_size
+        d_out = model_config.DEPTH_ENCODER.output_size
+
+        self.instruction_encoder = InstructionEncoder(model_config.INSTRUCTION_ENCODER)
+        ins = self.instruction_encoder.output_size
+        cnn_type = model_config.DEPTH_ENCODER.cnn_type
+        assert cnn_type in ["VlnResnetDepthEncoder"]
+        self.depth_encoder = getattr(resnet_encoders, cnn_type)(
+            observation_space,
+            output_size=d_out,
+            checkpoint=model_config.DEPTH_ENCODER.ddppo_checkpoint,
+            backbone=model_config.DEPTH_ENCODER.backbone,
+            spatial_output=True,
+        )
+        cnn_type = model_config.RGB_ENCODER.cnn_type
+        assert cnn_type in ["TorchVisionResNet18", "TorchVisionResNet50"]
+        self.rgb_encoder = getattr(resnet_encoders, cnn_type)(
+            r_out,
+            normalize_visual_inputs=model_config.normalize_rgb,
+            spatial_output=True,
+            single_spatial_filter=False,
+        )
+        self.visual_rnn = build_rnn_state_encoder(
+            input_size=r_out + PREV_ACTION_DIM + d_out + r_out, hidden_size=hs,
+            rnn_type=model_config.STATE_ENCODER.rnn_type, num_layers=1)
+        self.rgb_pool_linear = nn.Linear(self.rgb_encoder.resnet_layer_size, r_out)
+        self.rgb_hist_linear = nn.Sequential(
+            nn.AdaptiveAvgPool1d(1), nn.Flatten(),
+            nn.Linear(self.rgb_encoder.output_shape[0], r_out), nn.ReLU(True))
+        self.depth_hist_linear = nn.Sequential(
+            nn.Flatten(), nn.Linear(int(np.prod(self.depth_encoder.output_shape)), d_out),
+            nn.ReLU(True))
+        dk_inst = hs // 2
+        self.inst_attn_q = nn.Sequential(nn.Linear(hs, dk_inst), nn.ReLU(True))
+        self.inst_attn_k = nn.Conv1d(ins, dk_inst, 1)
+        self.inst_attn = DotProductAttention(dk_inst)
+        self.text_q_linear = nn.Linear(ins, hs // 2)
+        self.rgb_kv_spatial = nn.Conv1d(self.rgb_encoder.output_shape[0], hs // 2 + r_out, 1)
+        self.rgb_spatial_attn = DotProductAttention(hs // 2)
+        self.depth_kv_spatial = nn.Conv1d(self.depth_encoder.output_shape[0], hs // 2 + d_out, 1)
+        self.depth_spatial_attn = DotProductAttention(hs // 2)
+        d_kv_in = r_out + d_out + ANGLE_FEATURE_SIZE
+        self.pano_attn = MultiHeadDotProductAttention(
+            d_q_in=ins, d_k_in=d_kv_in, d_v_in=d_kv_in, d_qk=PANO_ATTN_KEY_DIM,
+            d_v=PANO_ATTN_KEY_DIM, num_heads=1, d_out=d_kv_in)
+        self.main_state_compress = nn.Sequential(
+            nn.Linear(ins + d_kv_in + hs + PREV_ACTION_DIM, hs), nn.ReLU(True))
+        self.main_state_encoder = build_rnn_state_encoder(
+            input_size=hs, hidden_size=hs, rnn_type=model_config.STATE_ENCODER.rnn_type,
+            num_layers=1)
+        final_feature_size = d_kv_in
+        self.stop_linear = nn.Linear(hs, 1)
+        nn.init.constant_(self.stop_linear.bias, 0)
+        self.compress_x_linear = nn.Sequential(nn.Linear(hs, final_feature_size), nn.ReLU(True))
+        in_dim = hs + final_feature_size
+        self._init_distance_linear(in_dim, final_feature_size)
+        self._init_offset_linear(in_dim, final_feature_size)
+        self.train()
+
+    # ---- reference helpers (waypoint_predictors.py:184-264)
+    def distance_to_continuous(self, distance):
+        if self.wypt_cfg.continuous_distance:
+            return distance
+        rng = self.wypt_cfg.max_distance_prediction - self.wypt_cfg.min_distance_prediction
+        return self.wypt_cfg.min_distance_prediction + distance * (
+            rng / (self.wypt_cfg.discrete_distances - 1))
+
+    def offset_to_continuous(self, offset):
+        if self.wypt_cfg.continuous_offset:
+            return offset
+        per_pano = 2 * np.pi / self._num_panos
+        return (-per_pano / 2) + offset * (per_pano / (self.wypt_cfg.discrete_offsets - 1))
+
+    @property
+    def num_recurrent_layers(self):
+        return (self.main_state_encoder.num_recurrent_layers
+                + self.visual_rnn.num_recurrent_layers)
+
+    @property
+    def is_blind(self):
+        return self.rgb_encoder.is_blind and self.depth_encoder.is_blind
+
+    @property
+    def output_size(self):
+        return self._hidden_size
+
+    def _init_distance_linear(self, in_dim, final_feature_size):
+        if self.wypt_cfg.continuous_distance:
+            self.distance_linear = nn.Sequential(nn.Linear(in_dim, 1), nn.Sigmoid())
+            self.distance_var_linear = nn.Sequential(
+                nn.Linear(self._hidden_size + final_feature_size, 1), nn.Sigmoid())
+        else:
+            self.distance_linear = nn.Linear(in_dim, self.wypt_cfg.discrete_distances)
+
+    def _init_offset_linear(self, in_dim, final_feature_size):
+        if self.wypt_cfg.continuous_offset:
+            self.offset_linear = nn.Sequential(
+                nn.Linear(in_dim, 1), TemperatureTanh(temperature=self.wypt_cfg.offset_temperature))
+            self.offset_scale = np.pi / self._num_panos
+            self.offset_var_linear = nn.Sequential(
+                nn.Linear(self._hidden_size + final_feature_size, 1), nn.Sigmoid())
+        else:
+            self.offset_linear = nn.Linear(in_dim, self.wypt_cfg.discrete_offsets)
+
+    def _encode_frames(self, encoder, key, frames, history, masks):
+        """12 pano frames + the (done-masked) history frame as one batch of B*13 images
+        (:330-375).  Returns rows [B, 12, P, C] and [B, P, C]."""
+        hist = history * masks.view(-1, 1, 1, 1).to(history.dtype)
+        allf = torch.cat([frames, hist.unsqueeze(1)], dim=1)
+        b, n = allf.shape[:2]
+        emb = rows_of(encoder({key: allf.reshape(b * n, *allf.shape[2:])}))  # [B*13, P, C]
+        emb = emb.reshape(b, n, *emb.shape[1:])
+        return emb[:, : self._num_panos], emb[:, self._num_panos]
+
+    def forward(self, observations, rnn_states, prev_actions, masks):
+        for k in ("rgb", "depth", "instruction", "rgb_history", "depth_history", "angle_features"):
+            assert k in observations
+        P = self._num_panos
+        assert observations["rgb"].shape[1] == P
+        assert observations["depth"].shape[1] == P
+        mc, wc = self.model_config, self.wypt_cfg
+        hs = self._hidden_size
+        half = hs // 2
+
+        ins = self.instruction_encoder(observations).permute(0, 2, 1)  # [B, L, C]
+        rgb, rgb_hist = self._encode_frames(self.rgb_encoder, "rgb", observations["rgb"],
+                                            observations["rgb_history"], masks)
+        dep, dep_hist = self._encode_frames(self.depth_encoder, "depth", observations["depth"],
+                                            observations["depth_history"], masks)
+        B = rgb.shape[0]
+
+        if len(prev_actions["pano"].shape) == 1:  # :380-382, mutates the caller's dict
+            for k in prev_actions:
+                prev_actions[k] = prev_actions[k].unsqueeze(1)
+        heading = prev_actions["pano"] * ((np.pi * 2) / P)
+        pa = torch.cat([torch.sin(heading), torch.cos(heading),
+                        self.offset_to_continuous(prev_actions["offset"]),
+                        self.distance_to_continuous(prev_actions["distance"])],
+                       dim=1).float() * masks
+
+        if mc.ablate_instruction:
+            ins = ins * 0
+        if mc.ablate_rgb:
+            rgb, rgb_hist = rgb * 0, rgb_hist * 0
+        if mc.ablate_depth:
+            dep, dep_hist = dep * 0, dep_hist * 0
+        ins = ins.contiguous()
+        Pr, Cr = rgb.shape[2:]
+        Pd, Cd = dep.shape[2:]
+
+        # visual history GRU (:275-284, 400-427)
+        rl = self.rgb_encoder.resnet_layer_size
+        pooled = ops.mean_rows(rgb.reshape(B * P, Pr, Cr))[:, :rl]  # mean over positions
+        pooled = ops.mean_rows(_lin(self.rgb_pool_linear, pooled).view(B, P, -1))
+        rgb_h = _lin(self.rgb_hist_linear[2], ops.mean_rows(rgb_hist.contiguous()), ops.ACT_RELU)
+        dep_h = ops.linear(dep_hist.reshape(B, Pd * Cd),
+                           nchw_flat_weight(self.depth_hist_linear[1], Cd, Pd),
+                           self.depth_hist_linear[1].bias, ops.ACT_RELU)
+        nv = self.visual_rnn.num_recurrent_layers
+        vis, h1 = self.visual_rnn(torch.cat([pooled, pa, rgb_h, dep_h], dim=1),
+                                  rnn_states[:, 0:nv], masks)
+
+        # instruction attention -- multiplicative mask on PAD (:433-438, App. B-3)
+        q = _lin(self.inst_attn_q[0], vis, ops.ACT_RELU)
+        k = ops.linear(ins, self.inst_attn_k.weight.view(half, -1), self.inst_attn_k.bias)
+        text = ops.attention(q, k, ins, ops.rowzero_mask(ins.detach()), 2,
+                             self.inst_attn._scale_f)
+
+        # spatial attention per pano frame; repeat_interleave WITHOUT dim repeats elements
+        # (:456-462, App. B-4) -- reproduced verbatim
+        tq = _lin(self.text_q_linear, text)
+        tq = tq.repeat_interleave(P).view(B * P, tq.shape[1])
+        rgb_kv = ops.linear(rgb.reshape(B * P, Pr, Cr), self.rgb_kv_spatial.weight.view(-1, Cr),
+                            self.rgb_kv_spatial.bias)
+        dep_kv = ops.linear(dep.reshape(B * P, Pd, Cd), self.depth_kv_spatial.weight.view(-1, Cd),
+                            self.depth_kv_spatial.bias)
+        att_rgb = ops.attention(tq, rgb_kv[..., :half], rgb_kv[..., half:], None, 0,
+                                self.rgb_spatial_attn._scale_f).view(B, P, -1)
+        att_dep = ops.attention(tq, dep_kv[..., :half], dep_kv[..., half:], None, 0,
+                                self.depth_spatial_attn._scale_f).view(B, P, -1)
+
+        vis_feats = torch.cat([att_rgb, att_dep, observations["angle_features"]], dim=2)  # [B,12,d]
+        shared = vis_feats.permute(0, 2, 1)  # logical [B, d, 12]
+        pano = self.pano_attn(Q=text, K=shared, V=shared)
+
+        x = _lin(self.main_state_compress[0], torch.cat([text, pano, vis, pa], dim=1), ops.ACT_RELU)
+        x, h2 = self.main_state_encoder(x, rnn_states[:, nv:], masks)
+        rnn_states_out = torch.cat([h1, h2], dim=1)
+
+        # heads (:549-625)
+        x_small = _lin(self.compress_x_linear[0], x, ops.ACT_RELU).unsqueeze(1)
+        dotted = (vis_feats * x_small).sum(2)
+        pano_stop = CustomFixedCategorical(
+            logits=torch.cat([dotted, _lin(self.stop_linear, x)], dim=1))
+        catted = torch.cat([vis_feats, x.unsqueeze(1).expand(-1, P, -1)], dim=2)
+
+        if wc.continuous_distance:
+            d1 = _lin(self.distance_linear[0], catted, ops.ACT_SIGMOID).squeeze(2)
+            d1 = (wc.max_distance_prediction - wc.min_distance_prediction) * d1 \
+                + wc.min_distance_prediction
+            d2 = (wc.max_distance_var - wc.min_distance_var) * _lin(
+                self.distance_var_linear[0], catted, ops.ACT_SIGMOID).squeeze(2) \
+                + wc.min_distance_var
+        else:
+            d1, d2 = _lin(self.distance_linear, catted).squeeze(2), None
+        if wc.continuous_offset:
+            o1 = self.offset_scale * self.offset_linear[1](
+                _lin(self.offset_linear[0], catted)).squeeze(2)
+            o2 = (wc.max_offset_var - wc.min_offset_var) * _lin(
+                self.offset_var_linear[0], catted, ops.ACT_SIGMOID).squeeze(2) + wc.min_offset_var
+        else:
+            o1, o2 = _lin(self.offset_linear, catted).squeeze(2), None
+        return pano_stop, o1, o2, d1, d2, x, rnn_states_out
