@@ -14,6 +14,7 @@ from .policy import ILPolicy, Net
 from .registry import baseline_registry
 from .rnn_state_encoder import build_rnn_state_encoder
 from .seq2seq_policy import prev_action_index, register_progress_loss
+from .streams import BranchStreams
 
 
 @baseline_registry.register_policy
@@ -97,6 +98,7 @@ class CMANet(Net):
             input_size=hidden_size, hidden_size=hidden_size,
             rnn_type=model_config.STATE_ENCODER.rnn_type, num_layers=1)
         self._output_size = hidden_size
+        self._branches = BranchStreams()
         self.progress_monitor = nn.Linear(self.output_size, 1)
         if model_config.PROGRESS_MONITOR.use:
             nn.init.kaiming_normal_(self.progress_monitor.weight, nonlinearity="tanh")
@@ -122,9 +124,16 @@ class CMANet(Net):
 
     def forward(self, observations, rnn_states, prev_actions, masks):
         mc = self.model_config
-        ins = self.instruction_encoder(observations).permute(0, 2, 1)  # [B, L, 2H]
-        dep = rows_of(self.depth_encoder(observations))  # [B, P, 192]
+        # the three encoders are independent: RGB trunk on the current stream, depth trunk
+        # and instruction RNN overlapped on side streams
+        dev = rnn_states.device
+        dep, join_d = self._branches.run(1, dev, lambda: self.depth_encoder(observations))
+        ins, join_i = self._branches.run(0, dev, lambda: self.instruction_encoder(observations))
         rgb = rows_of(self.rgb_encoder(observations))  # [B, 16, 2112]
+        join_d()
+        join_i()
+        ins = ins.permute(0, 2, 1)  # [B, L, 2H]
+        dep = rows_of(dep)  # [B, P, 192]
         act = F.embedding(prev_action_index(prev_actions, masks),
                           self.prev_action_embedding.weight)
         if mc.ablate_instruction:

@@ -10,6 +10,7 @@ from .encoders.instruction_encoder import InstructionEncoder
 from .policy import ILPolicy, Net
 from .registry import baseline_registry
 from .rnn_state_encoder import build_rnn_state_encoder
+from .streams import BranchStreams
 
 
 def prev_action_index(prev_actions, masks):
@@ -78,6 +79,7 @@ class Seq2SeqNet(Net):
         self.state_encoder = build_rnn_state_encoder(
             input_size=rnn_input_size, hidden_size=model_config.STATE_ENCODER.hidden_size,
             rnn_type=model_config.STATE_ENCODER.rnn_type, num_layers=1)
+        self._branches = BranchStreams()
         self.progress_monitor = nn.Linear(model_config.STATE_ENCODER.hidden_size, 1)
         nn.init.kaiming_normal_(self.progress_monitor.weight, nonlinearity="tanh")
         nn.init.constant_(self.progress_monitor.bias, 0)
@@ -97,9 +99,14 @@ class Seq2SeqNet(Net):
 
     def forward(self, observations, rnn_states, prev_actions, masks):
         mc = self.model_config
-        instruction_embedding = self.instruction_encoder(observations)
-        depth_embedding = self.depth_encoder(observations)
+        dev = rnn_states.device
+        depth_embedding, join_d = self._branches.run(
+            1, dev, lambda: self.depth_encoder(observations))
+        instruction_embedding, join_i = self._branches.run(
+            0, dev, lambda: self.instruction_encoder(observations))
         rgb_embedding = self.rgb_encoder(observations)
+        join_d()
+        join_i()
         if mc.ablate_instruction:
             instruction_embedding = instruction_embedding * 0
         if mc.ablate_depth:

@@ -1,0 +1,48 @@
+"""Side HIP streams for the independent branches of a policy step.
+
+The three encoders of a policy (RGB trunk, depth trunk, instruction RNN) do
+not depend on each other.  The RGB trunk is a train of large MFMA kernels;
+the depth trunk is ~200 small launches and the packed instruction RNN occupies
+only (directions x batch/16) workgroups for ~1 ms -- both leave most of the 256
+CUs idle when run alone.  Running them on side streams overlaps them with the
+RGB trunk; autograd replays each branch's backward on the stream its forward
+used, so the BPTT kernel overlaps the tail's backward as well.
+Set VLNCE_SIDE_STREAMS=0 to serialise everything on the current stream."""
+import os
+
+import torch
+
+
+class BranchStreams:
+    def __init__(self):
+        self._streams = {}
+
+    @staticmethod
+    def enabled(device):
+        return (device.type == "cuda" and os.environ.get("VLNCE_SIDE_STREAMS", "1") != "0"
+                and not torch.cuda.is_current_stream_capturing())
+
+    def _stream(self, idx, device):
+        key = (idx, device.index)
+        if key not in self._streams:
+            self._streams[key] = torch.cuda.Stream(device=device)
+        return self._streams[key]
+
+    def run(self, idx, device, fn):
+        """fn() on side stream `idx` (after everything already queued on the current
+        stream).  Returns (result, join) -- call join() before consuming the result."""
+        if not self.enabled(device):
+            return fn(), (lambda: None)
+        cur = torch.cuda.current_stream(device)
+        side = self._stream(idx, device)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            out = fn()
+
+        def join():
+            cur.wait_stream(side)
+            for t in (out if isinstance(out, (tuple, list)) else (out,)):
+                if isinstance(t, torch.Tensor) and t.is_cuda:
+                    t.record_stream(cur)
+
+        return out, join
