@@ -114,6 +114,12 @@ int vlnce_scale_shift_act(const float* x, const float* scale, const float* shift
                           int rows_per_sample, const float* residual, float* y,
                           long M, int C, int act, vlnce_stream_t stream);
 
+/* y = act(x1*scale1[c]+shift1[c] + x2*scale2[c]+shift2[c]); y may alias x1.  End of a residual
+ * block with a conv+BatchNorm downsample: both raw conv outputs normalised in one pass. */
+int vlnce_scale_shift_add_act(const float* x1, const float* scale1, const float* shift1,
+                              const float* x2, const float* scale2, const float* shift2,
+                              float* y, long M, int C, int act, vlnce_stream_t stream);
+
 /* GroupNorm (habitat depth trunk: ngroups 16, and GroupNorm(1,C) in the
  * compression block; eps 1e-5).  Two launches: partial sums per
  * (sample, pixel-chunk, channel) then a finalize that emits per-(sample,channel)
@@ -131,7 +137,10 @@ int vlnce_gn_finalize(const float* partial, int Nimg, int HW, int C, int groups,
  * NHWC. maxpool 3x3/s2/p1 (torchvision + habitat stems), avg_pool2d(2)
  * (ResNetEncoder.forward), adaptive_avg_pool2d -> (OH,OW)
  * (resnet_encoders.py:154-162; also the global 1x1 pool). */
+/* maxpool over act(x*in_scale[c]+in_shift[c]) when in_scale != NULL: the stem's BatchNorm+ReLU
+ * is applied on the fly to the raw conv output (train mode), saving one HBM round trip. */
 int vlnce_maxpool3x3s2(const float* x, float* y, int N, int H, int W, int C, int Ho, int Wo,
+                       const float* in_scale, const float* in_shift, int in_relu,
                        vlnce_stream_t stream);
 int vlnce_avgpool2x2(const float* x, float* y, int N, int H, int W, int C, vlnce_stream_t stream);
 int vlnce_adaptive_avgpool(const float* x, float* y, int N, int H, int W, int C, int OH, int OW,

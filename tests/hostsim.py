@@ -159,8 +159,16 @@ class HostSim:
             rstd_out.copy_(rstd)
 
     # ---- pools
-    def maxpool3x3s2(self, x, y, N, H, W, Cc, Ho, Wo):
+    def maxpool3x3s2(self, x, y, N, H, W, Cc, Ho, Wo, in_scale=None, in_shift=None, in_relu=0):
+        if in_scale is not None:
+            x = x * in_scale + in_shift
+            if in_relu:
+                x = torch.relu(x)
         y.copy_(F.max_pool2d(x.permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1))
+
+    def scale_shift_add_act(self, x1, s1, t1, x2, s2, t2, y, M, Cc, act):
+        v = x1.reshape(M, Cc) * s1 + t1 + x2.reshape(M, Cc) * s2 + t2
+        y.view(M, Cc).copy_(_act(v, act))
 
     def avgpool2x2(self, x, y, N, H, W, Cc):
         y.copy_(F.avg_pool2d(x.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1))

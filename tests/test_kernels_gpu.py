@@ -395,3 +395,19 @@ def test_instruction_encoder_matches_torch_packed_rnn(hip, rnn_type, bidir, fina
     (yh * wgt.to(DEV)).sum().backward()
     for (n, pr), (_, ph) in zip(ref.named_parameters(), hipm.named_parameters()):
         close(ph.grad, pr.grad, 5e-4, what=f"d {n}")
+
+
+def test_fused_bn_consumers(hip):
+    """max-pool with the stem's BatchNorm+ReLU applied on the fly, and the dual-input block-end pass."""
+    x = rnd(2, 18, 22, 64, seed=1)
+    sc, sh = rnd(64, seed=2), rnd(64, seed=3)
+    ref = F.max_pool2d(torch.relu(x * sc + sh).permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1)
+    got = ops.maxpool3x3s2(x.to(DEV), sc.to(DEV), sh.to(DEV), in_relu=True)
+    close(got, ref, 1e-6, what="maxpool(bn+relu)")
+    a, b = rnd(3, 5, 7, 128, seed=4), rnd(3, 5, 7, 128, seed=5)
+    s1, t1, s2, t2 = (rnd(128, seed=6 + i) for i in range(4))
+    ref = torch.relu(a * s1 + t1 + b * s2 + t2)
+    ad = a.to(DEV)
+    got = ops.scale_shift_add_act(ad, s1.to(DEV), t1.to(DEV), b.to(DEV), s2.to(DEV), t2.to(DEV),
+                                  act=1, out=ad)
+    close(got, ref, 1e-6, what="dual-input block end")

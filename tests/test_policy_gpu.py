@@ -148,3 +148,39 @@ def test_graph_replay_equals_eager(monkeypatch):
     assert results["0"][2] == results["1"][2] == 4
     # eval calls are idempotent
     assert (results["1"][0][4] - results["1"][0][5]).abs().max().item() < 1e-5
+
+
+@pytest.mark.parametrize("version,spatial", [("resnet18", True), ("resnet50", False)])
+def test_rgb_encoder_train_then_eval_vs_oracle(version, spatial):
+    """TorchVisionResNet on HIP vs the CPU oracle: two train-mode forwards (batch statistics,
+    running-stat updates, fused BN consumers) followed by an eval-mode forward that must use the
+    UPDATED running statistics."""
+    from vlnce_amd.encoders import resnet_encoders as enc
+
+    ref = oc.TorchVisionResNet(128, resnet_version=version, spatial_output=spatial,
+                               single_spatial_filter=False)
+    hip = enc.TorchVisionResNet(128, resnet_version=version, spatial_output=spatial,
+                                single_spatial_filter=False)
+    sd = tp.synth_state_dict(ref)
+    ref.load_state_dict(sd)
+    hip.load_state_dict(sd)
+    hip.to(DEV)
+    ref.train()
+    hip.train()
+    g = torch.Generator().manual_seed(2)
+    with torch.no_grad():
+        for i in range(2):
+            rgb = torch.randint(0, 256, (5, 96, 96, 3), generator=g).float()
+            yr = ref({"rgb": rgb})
+            yh = hip({"rgb": rgb.to(DEV)})
+            err = (yh.cpu() - yr).abs().max().item()
+            assert err < 2e-4 * max(1.0, yr.abs().max().item()), (version, "train", i, err)
+        ref.eval()
+        hip.eval()
+        yr = ref({"rgb": rgb})
+        yh = hip({"rgb": rgb.to(DEV)})
+        err = (yh.cpu() - yr).abs().max().item()
+        assert err < 2e-4 * max(1.0, yr.abs().max().item()), (version, "eval", err)
+    for k in ("cnn.1.running_var", "cnn.7.1.bn2.running_mean", "cnn.1.num_batches_tracked"):
+        a, b = hip.state_dict()[k].cpu().double(), ref.state_dict()[k].double()
+        assert (a - b).abs().max().item() < 1e-4 * max(1.0, b.abs().max().item()), k

@@ -51,7 +51,8 @@ _SIGNATURES = {
     "vlnce_gn_chunks": (_I, [_I]),
     "vlnce_gn_partial": (_I, [_P, _I, _I, _I, _P, _P]),
     "vlnce_gn_finalize": (_I, [_P, _I, _I, _I, _I, _P, _P, _F, _P, _P, _P, _P, _P]),
-    "vlnce_maxpool3x3s2": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "vlnce_maxpool3x3s2": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P]),
+    "vlnce_scale_shift_add_act": (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P]),
     "vlnce_avgpool2x2": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "vlnce_adaptive_avgpool": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "vlnce_attn_fwd": (_I, [_P, _P, _I, _P, _I, _P, _I, _F, _P, _P, _I, _I, _I, _I, _P]),
@@ -175,9 +176,15 @@ class HipLib:
             _ptr(shift_out), _ptr(mean_out), _ptr(rstd_out), _stream()), "vlnce_gn_finalize")
 
     # ---- pools
-    def maxpool3x3s2(self, x, y, N, H, W, Cc, Ho, Wo):
-        self._check(self.dll.vlnce_maxpool3x3s2(_ptr(x), _ptr(y), N, H, W, Cc, Ho, Wo, _stream()),
-                    "vlnce_maxpool3x3s2")
+    def maxpool3x3s2(self, x, y, N, H, W, Cc, Ho, Wo, in_scale=None, in_shift=None, in_relu=0):
+        self._check(self.dll.vlnce_maxpool3x3s2(_ptr(x), _ptr(y), N, H, W, Cc, Ho, Wo,
+                                                _ptr(in_scale), _ptr(in_shift), int(in_relu),
+                                                _stream()), "vlnce_maxpool3x3s2")
+
+    def scale_shift_add_act(self, x1, s1, t1, x2, s2, t2, y, M, Cc, act):
+        self._check(self.dll.vlnce_scale_shift_add_act(
+            _ptr(x1), _ptr(s1), _ptr(t1), _ptr(x2), _ptr(s2), _ptr(t2), _ptr(y), M, Cc, act,
+            _stream()), "vlnce_scale_shift_add_act")
 
     def avgpool2x2(self, x, y, N, H, W, Cc):
         self._check(self.dll.vlnce_avgpool2x2(_ptr(x), _ptr(y), N, H, W, Cc, _stream()),

@@ -135,6 +135,30 @@ __global__ __launch_bounds__(256) void scale_shift_act_kernel(
   }
 }
 
+// y = act(x1*s1[c]+t1[c] + x2*s2[c]+t2[c]): end of a residual block whose skip path is a
+// (conv + BatchNorm) downsample -- both raw conv outputs are normalised in one pass
+__global__ __launch_bounds__(256) void scale_shift_add_act_kernel(
+    const float* __restrict__ x1, const float* __restrict__ s1, const float* __restrict__ t1,
+    const float* __restrict__ x2, const float* __restrict__ s2, const float* __restrict__ t2,
+    float* __restrict__ y, long M, int C, int act) {
+  const int C4 = C >> 2;
+  const long total = M * C4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4) * 4;
+    f32x4 v = *reinterpret_cast<const f32x4*>(x1 + i * 4) *
+                  *reinterpret_cast<const f32x4*>(s1 + c) +
+              *reinterpret_cast<const f32x4*>(t1 + c);
+    v += *reinterpret_cast<const f32x4*>(x2 + i * 4) * *reinterpret_cast<const f32x4*>(s2 + c) +
+         *reinterpret_cast<const f32x4*>(t2 + c);
+    v.x = apply_act(v.x, act);
+    v.y = apply_act(v.y, act);
+    v.z = apply_act(v.z, act);
+    v.w = apply_act(v.w, act);
+    *reinterpret_cast<f32x4*>(y + i * 4) = v;
+  }
+}
+
 // ---------------------------------------------------------------- GroupNorm statistics
 constexpr int GN_CHUNK = 128;  // pixels per block
 
@@ -294,6 +318,21 @@ extern "C" int vlnce_scale_shift_act(const float* x, const float* scale, const f
     hipLaunchKernelGGL(scale_shift_act_kernel<false>, dim3(grid), dim3(256), 0, s, x, scale, shift,
                        rows_per_sample, residual, y, M, C, act);
   VLNCE_CHECK_LAUNCH("scale_shift_act");
+  return 0;
+}
+
+extern "C" int vlnce_scale_shift_add_act(const float* x1, const float* scale1, const float* shift1,
+                                         const float* x2, const float* scale2, const float* shift2,
+                                         float* y, long M, int C, int act, vlnce_stream_t stream) {
+  VLNCE_CHECK_ARG(x1 && scale1 && shift1 && x2 && scale2 && shift2 && y,
+                  "scale_shift_add_act: null argument");
+  VLNCE_CHECK_ARG(M > 0 && C > 0 && C % 4 == 0, "scale_shift_add_act: C must be a multiple of 4");
+  const long work = M * (C / 4);
+  const int grid = (int)(work / 256 + 1 < 8192 ? work / 256 + 1 : 8192);
+  hipLaunchKernelGGL(scale_shift_add_act_kernel, dim3(grid), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), x1, scale1, shift1, x2, scale2, shift2,
+                     y, M, C, act);
+  VLNCE_CHECK_LAUNCH("scale_shift_add_act");
   return 0;
 }
 

@@ -207,25 +207,49 @@ class HipResNetTrunk(nn.Sequential):
         self._graphs = _GraphRunner(self._forward_impl)
         self._norms = [m for m in self.modules() if isinstance(m, nn.BatchNorm2d)]
 
-    # -- one conv + BatchNorm (+residual) (+ReLU)
-    def _conv_bn(self, x, conv, bn, relu, residual=None, prologue=None, touched=None):
-        w = self._cache.conv(conv)
-        act = ops.ACT_RELU if relu else ops.ACT_NONE
+    # ---- eval mode: BatchNorm folded to a per-channel scale/shift in the conv epilogue
+    def _conv_bn_eval(self, x, conv, bn, relu, residual=None, prologue=None):
+        pro = {} if prologue is None else dict(in_scale=prologue[0], in_shift=prologue[1])
+        scale, shift = self._cache.bn_eval(bn, self._bn_gen)
+        return ops.conv2d_nhwc(x, self._cache.conv(conv), conv.stride[0], conv.padding[0],
+                               scale=scale, shift=shift, residual=residual,
+                               act=ops.ACT_RELU if relu else ops.ACT_NONE, **pro)
+
+    # ---- train mode: conv writes the RAW output + per-tile moments; the finalize kernel
+    # turns them into (scale, shift) and updates the running statistics.  The pending
+    # normalisation (+ReLU) is then applied by whoever consumes the raw tensor: the next
+    # conv's operand loader, the max-pool, or the block-end add pass.
+    def _conv_stats(self, x, conv, bn, touched, prologue=None, in_relu=False):
         pro = {}
         if prologue is not None:
-            pro = dict(in_scale=prologue[0], in_shift=prologue[1])
-        stride, pad = conv.stride[0], conv.padding[0]
-        if bn.training:
-            y, stats = ops.conv2d_nhwc(x, w, stride, pad, want_stats=True, **pro)
-            M = y.numel() // y.size(-1)
-            assert bn.momentum is not None
-            scale, shift = ops.bn_finalize(stats, M, bn.weight, bn.bias, bn.eps, bn.momentum,
-                                           bn.running_mean, bn.running_var)
-            touched.append(bn.num_batches_tracked)
-            return ops.scale_shift_act(y, scale, shift, residual=residual, act=act, out=y)
-        scale, shift = self._cache.bn_eval(bn, self._bn_gen)
-        return ops.conv2d_nhwc(x, w, stride, pad, scale=scale, shift=shift, residual=residual,
-                               act=act, **pro)
+            pro = dict(in_scale=prologue[0], in_shift=prologue[1], in_relu=in_relu)
+        y, stats = ops.conv2d_nhwc(x, self._cache.conv(conv), conv.stride[0], conv.padding[0],
+                                   want_stats=True, **pro)
+        assert bn.momentum is not None
+        scale, shift = ops.bn_finalize(stats, y.numel() // y.size(-1), bn.weight, bn.bias, bn.eps,
+                                       bn.momentum, bn.running_mean, bn.running_var)
+        touched.append(bn.num_batches_tracked)
+        return y, (scale, shift)
+
+    def _block_train(self, x, blk, touched):
+        st = blk.stages()
+        raw, pend = self._conv_stats(x, st[0][0], st[0][1], touched)
+        for conv, bn in st[1:]:
+            raw, pend = self._conv_stats(raw, conv, bn, touched, prologue=pend, in_relu=True)
+        if blk.downsample is not None:
+            rd, pd = self._conv_stats(x, blk.downsample[0], blk.downsample[1], touched)
+            return ops.scale_shift_add_act(raw, pend[0], pend[1], rd, pd[0], pd[1],
+                                           act=ops.ACT_RELU, out=raw)
+        return ops.scale_shift_act(raw, pend[0], pend[1], residual=x, act=ops.ACT_RELU, out=raw)
+
+    def _block_eval(self, x, blk):
+        identity = x
+        if blk.downsample is not None:
+            identity = self._conv_bn_eval(x, blk.downsample[0], blk.downsample[1], False)
+        st = blk.stages()
+        for conv, bn in st[:-1]:
+            x = self._conv_bn_eval(x, conv, bn, True)
+        return self._conv_bn_eval(x, st[-1][0], st[-1][1], True, residual=identity)
 
     def forward(self, x_nhwc_raw):
         """x: [B,H,W,3] pixel values 0..255 (channels-last as the simulator
@@ -233,31 +257,31 @@ class HipResNetTrunk(nn.Sequential):
         _require_frozen(self, "TorchVisionResNet.cnn")
         x = ops._f32c(x_nhwc_raw)
         modes = tuple(m.training for m in self._norms)
-        key = (tuple(x.shape), modes, tuple(p._version for p in self.parameters()),
+        if any(modes) and not all(modes):
+            raise NotImplementedError("mixed train/eval BatchNorm modes inside one trunk")
+        key = (tuple(x.shape), modes[0], tuple(p._version for p in self.parameters()),
                id(self.input_scale[0]), len(list(self.children())),
-               0 if any(modes) else self._bn_gen)
+               0 if modes[0] else self._bn_gen)
         y = self._graphs(x, key)
-        if any(modes):
+        if modes[0]:
             self._bn_gen += 1
         return y.permute(0, 3, 1, 2)
 
     def _forward_impl(self, x):
         with torch.no_grad():
             kids = list(self.children())
+            train = kids[1].training
             touched = []
-            x = self._conv_bn(x, kids[0], kids[1], True, prologue=self.input_scale, touched=touched)
-            x = ops.maxpool3x3s2(x)
+            if train:
+                raw, pend = self._conv_stats(x, kids[0], kids[1], touched,
+                                             prologue=self.input_scale)
+                x = ops.maxpool3x3s2(raw, pend[0], pend[1], in_relu=True)
+            else:
+                x = self._conv_bn_eval(x, kids[0], kids[1], True, prologue=self.input_scale)
+                x = ops.maxpool3x3s2(x)
             for stage in kids[4:8]:
                 for blk in stage:
-                    identity = x
-                    if blk.downsample is not None:
-                        identity = self._conv_bn(x, blk.downsample[0], blk.downsample[1], False,
-                                                 touched=touched)
-                    st = blk.stages()
-                    for conv, bn in st[:-1]:
-                        x = self._conv_bn(x, conv, bn, True, touched=touched)
-                    x = self._conv_bn(x, st[-1][0], st[-1][1], True, residual=identity,
-                                      touched=touched)
+                    x = self._block_train(x, blk, touched) if train else self._block_eval(x, blk)
             for pool in kids[8:]:
                 x = ops.adaptive_avgpool(x, *pool.out_hw)
             if touched:

@@ -103,11 +103,21 @@ def group_norm_act(x, groups, gamma, beta, eps, *, residual=None, act=ACT_NONE):
     return scale_shift_act(x, scale, shift, rows_per_sample=HW, residual=residual, act=act)
 
 
-def maxpool3x3s2(x):
+def maxpool3x3s2(x, in_scale=None, in_shift=None, in_relu=False):
+    """3x3/s2/p1 max pool of act(x*in_scale+in_shift) (transform optional)."""
     N, H, W, Cc = x.shape
     Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
     y = torch.empty((N, Ho, Wo, Cc), device=x.device, dtype=torch.float32)
-    L().maxpool3x3s2(x, y, N, H, W, Cc, Ho, Wo)
+    L().maxpool3x3s2(x, y, N, H, W, Cc, Ho, Wo, in_scale, in_shift, int(in_relu))
+    return y
+
+
+def scale_shift_add_act(x1, s1, t1, x2, s2, t2, act=ACT_NONE, out=None):
+    """act(x1*s1+t1 + x2*s2+t2), per-channel vectors; `out` may alias x1."""
+    assert x1.is_contiguous() and x2.is_contiguous() and x1.shape == x2.shape
+    Cc = x1.size(-1)
+    y = out if out is not None else torch.empty_like(x1)
+    L().scale_shift_add_act(x1, s1, t1, x2, s2, t2, y, x1.numel() // Cc, Cc, act)
     return y
 
 
