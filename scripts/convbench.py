@@ -1,0 +1,85 @@
+"""Per-layer timing of the implicit-GEMM convolution on the conv shapes the policies issue
+ at num_envs frames.  HIP-event timed, eval-style epilogue
+(scale/shift/ReLU) or train-style (raw + BatchNorm partial statistics).
+
+    python scripts/convbench.py [--n 64] [--iters 20] [--mode eval|train] [--only substr]
+"""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from vlnce_amd import ops  # noqa: E402
+
+# name, H(=W) in, Cin, Cout, k, stride, count in the trunk
+R50 = [
+    ("stem7x7s2_3_64", 256, 3, 64, 7, 2, 1),
+    ("l1_1x1_64_64", 64, 64, 64, 1, 1, 1),
+    ("l1_3x3_64_64", 64, 64, 64, 3, 1, 3),
+    ("l1_1x1_64_256", 64, 64, 256, 1, 1, 4),
+    ("l1_1x1_256_64", 64, 256, 64, 1, 1, 2),
+    ("l2_1x1_256_128", 64, 256, 128, 1, 1, 1),
+    ("l2_3x3s2_128_128", 64, 128, 128, 3, 2, 1),
+    ("l2_1x1s2_256_512", 64, 256, 512, 1, 2, 1),
+    ("l2_1x1_128_512", 32, 128, 512, 1, 1, 4),
+    ("l2_1x1_512_128", 32, 512, 128, 1, 1, 3),
+    ("l2_3x3_128_128", 32, 128, 128, 3, 1, 3),
+    ("l3_1x1_512_256", 32, 512, 256, 1, 1, 1),
+    ("l3_3x3s2_256_256", 32, 256, 256, 3, 2, 1),
+    ("l3_1x1s2_512_1024", 32, 512, 1024, 1, 2, 1),
+    ("l3_1x1_256_1024", 16, 256, 1024, 1, 1, 6),
+    ("l3_1x1_1024_256", 16, 1024, 256, 1, 1, 5),
+    ("l3_3x3_256_256", 16, 256, 256, 3, 1, 5),
+    ("l4_1x1_1024_512", 16, 1024, 512, 1, 1, 1),
+    ("l4_3x3s2_512_512", 16, 512, 512, 3, 2, 1),
+    ("l4_1x1s2_1024_2048", 16, 1024, 2048, 1, 2, 1),
+    ("l4_1x1_512_2048", 8, 512, 2048, 1, 1, 3),
+    ("l4_1x1_2048_512", 8, 2048, 512, 1, 1, 2),
+    ("l4_3x3_512_512", 8, 512, 512, 3, 1, 2),
+]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=64)
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--mode", default="eval")
+    ap.add_argument("--only", default="")
+    args = ap.parse_args()
+    dev = "cuda:0"
+    tot_t = tot_f = 0.0
+    print(f"{'layer':22s} {'M':>8s} {'K':>6s} {'N':>5s} {'us':>9s} {'TF/s':>7s} x cnt")
+    for name, hw, cin, cout, k, s, cnt in R50:
+        if args.only and args.only not in name:
+            continue
+        x = torch.randn(args.n, hw, hw, cin, device=dev)
+        w = torch.randn(cout, k, k, cin, device=dev) * (cin * k * k) ** -0.5
+        sc = torch.rand(cout, device=dev) + 0.5
+        sh = torch.randn(cout, device=dev)
+        pad = k // 2
+        kw = dict(want_stats=True) if args.mode == "train" else dict(scale=sc, shift=sh, act=1)
+        if cin == 3:
+            kw.update(in_scale=torch.full((3,), 1 / 255.0, device=dev),
+                      in_shift=torch.zeros(3, device=dev))
+        for _ in range(3):
+            ops.conv2d_nhwc(x, w, s, pad, **kw)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.iters):
+            ops.conv2d_nhwc(x, w, s, pad, **kw)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / args.iters
+        ho = (hw + 2 * pad - k) // s + 1
+        M = args.n * ho * ho
+        fl = 2.0 * M * cin * k * k * cout
+        print(f"{name:22s} {M:8d} {cin*k*k:6d} {cout:5d} {us:9.1f} {fl/us/1e6:7.1f} x{cnt}")
+        tot_t += us * cnt
+        tot_f += fl * cnt
+    print(f"trunk total {tot_t/1e3:.3f} ms  ->  {tot_f/tot_t/1e6:.1f} TF/s  ({args.mode})")
+
+
+if __name__ == "__main__":
+    main()

@@ -136,14 +136,21 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
   constexpr int B_ROWS = BN / 32;
   f32x4 b_reg[B_ROWS];
 
+  // The operand transform (x*s+t, ReLU) is applied when the staged registers are written to
+  // LDS, i.e. AFTER the MFMAs of the current tile: applying it right after the loads would
+  // put the global-load latency in front of the MFMAs instead of behind them.
+  f32x4 pro_s, pro_t;       // V4 mode: scale/shift of this thread's 4 channels (current stage)
+  unsigned a_okmask = 0;    // bit i (V4) / bit 4*i+e (scalar): element is inside the image
+  float pro_es[4], pro_et[4];
+
   auto load_a = [&](int k0) {
     if constexpr (AMODE == A_IM2COL_V4) {
-      f32x4 s4, t4;
       const bool tap_ok = k_r < p.KH;
       if (p.in_scale != nullptr && tap_ok) {
-        s4 = ldg4(p.in_scale + k_ci);
-        t4 = ldg4(p.in_shift + k_ci);
+        pro_s = ldg4(p.in_scale + k_ci);
+        pro_t = ldg4(p.in_shift + k_ci);
       }
+      a_okmask = 0;
 #pragma unroll
       for (int i = 0; i < A_ROWS; ++i) {
         const int hi = (a_hw[i] >> 16) + k_r;
@@ -153,15 +160,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
         if (ok) {
           const long pix = (long)a_off[i] + k_r * p.W + k_q;
           v = ldg4(p.A + pix * p.lda + k_ci);
-          if (p.in_scale != nullptr) {
-            v = v * s4 + t4;
-            if (p.in_relu) {
-              v.x = fmaxf(v.x, 0.f);
-              v.y = fmaxf(v.y, 0.f);
-              v.z = fmaxf(v.z, 0.f);
-              v.w = fmaxf(v.w, 0.f);
-            }
-          }
+          a_okmask |= 1u << i;
         }
         a_reg[i] = v;
       }
@@ -176,7 +175,6 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
       }
     } else if constexpr (AMODE == A_IM2COL_S) {
       int er[4], eq[4], eci[4];
-      float es[4], et[4];
       const int cin = CIN_C > 0 ? CIN_C : p.Cin;
       const int kw = KW_C > 0 ? KW_C : p.KW;
 #pragma unroll
@@ -186,13 +184,14 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
         eci[e] = k - tap * cin;
         er[e] = tap / kw;
         eq[e] = tap - er[e] * kw;
-        es[e] = 1.f;
-        et[e] = 0.f;
+        pro_es[e] = 1.f;
+        pro_et[e] = 0.f;
         if (p.in_scale != nullptr && k < p.K) {
-          es[e] = p.in_scale[eci[e]];
-          et[e] = p.in_shift[eci[e]];
+          pro_es[e] = p.in_scale[eci[e]];
+          pro_et[e] = p.in_shift[eci[e]];
         }
       }
+      a_okmask = 0;
 #pragma unroll
       for (int i = 0; i < A_ROWS; ++i) {
         float v[4];
@@ -206,10 +205,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
           if (ok) {
             const long pix = (long)a_off[i] + er[e] * p.W + eq[e];
             x = p.A[pix * p.lda + eci[e]];
-            if (p.in_scale != nullptr) {
-              x = x * es[e] + et[e];
-              if (p.in_relu) x = fmaxf(x, 0.f);
-            }
+            a_okmask |= 1u << (4 * i + e);
           }
           v[e] = x;
         }
@@ -311,6 +307,30 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
         As[(m4 + 3) * LDP + kk] = a_reg[i].w;
       }
     } else {
+      if (p.in_scale != nullptr) {
+#pragma unroll
+        for (int i = 0; i < A_ROWS; ++i) {
+          f32x4 v = a_reg[i];
+          if constexpr (AMODE == A_IM2COL_V4) {
+            v = v * pro_s + pro_t;
+            if (p.in_relu) {
+              v.x = fmaxf(v.x, 0.f);
+              v.y = fmaxf(v.y, 0.f);
+              v.z = fmaxf(v.z, 0.f);
+              v.w = fmaxf(v.w, 0.f);
+            }
+            if (!((a_okmask >> i) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float x = v[e] * pro_es[e] + pro_et[e];
+              if (p.in_relu) x = fmaxf(x, 0.f);
+              v[e] = ((a_okmask >> (4 * i + e)) & 1u) ? x : 0.f;
+            }
+          }
+          a_reg[i] = v;
+        }
+      }
 #pragma unroll
       for (int i = 0; i < A_ROWS; ++i)
         *reinterpret_cast<f32x4*>(As + (i * 32 + lrow) * LDP + lk4) = a_reg[i];
