@@ -124,14 +124,19 @@ class CMANet(Net):
 
     def forward(self, observations, rnn_states, prev_actions, masks):
         mc = self.model_config
-        # the three encoders are independent: RGB trunk on the current stream, depth trunk
-        # and instruction RNN overlapped on side streams
+        # the three encoders are independent.  The RGB trunk (long MFMA kernels) is enqueued
+        # first on the current stream; the instruction RNN (whose length computation needs
+        # one host sync, as upstream) and the depth trunk (~200 small launches) follow on a
+        # side stream and overlap with it.  The host sync therefore happens while the GPU
+        # already has the RGB trunk queued.
         dev = rnn_states.device
-        dep, join_d = self._branches.run(1, dev, lambda: self.depth_encoder(observations))
-        ins, join_i = self._branches.run(0, dev, lambda: self.instruction_encoder(observations))
+        fork = self._branches.fork(dev)
         rgb = rows_of(self.rgb_encoder(observations))  # [B, 16, 2112]
-        join_d()
+        ins, join_i = self._branches.run(fork, 0, dev,
+                                         lambda: self.instruction_encoder(observations))
+        dep, join_d = self._branches.run(fork, 0, dev, lambda: self.depth_encoder(observations))
         join_i()
+        join_d()
         ins = ins.permute(0, 2, 1)  # [B, L, 2H]
         dep = rows_of(dep)  # [B, P, 192]
         act = F.embedding(prev_action_index(prev_actions, masks),

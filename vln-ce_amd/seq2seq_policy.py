@@ -100,13 +100,14 @@ class Seq2SeqNet(Net):
     def forward(self, observations, rnn_states, prev_actions, masks):
         mc = self.model_config
         dev = rnn_states.device
-        depth_embedding, join_d = self._branches.run(
-            1, dev, lambda: self.depth_encoder(observations))
-        instruction_embedding, join_i = self._branches.run(
-            0, dev, lambda: self.instruction_encoder(observations))
+        fork = self._branches.fork(dev)
         rgb_embedding = self.rgb_encoder(observations)
-        join_d()
+        instruction_embedding, join_i = self._branches.run(
+            fork, 0, dev, lambda: self.instruction_encoder(observations))
+        depth_embedding, join_d = self._branches.run(
+            fork, 0, dev, lambda: self.depth_encoder(observations))
         join_i()
+        join_d()
         if mc.ablate_instruction:
             instruction_embedding = instruction_embedding * 0
         if mc.ablate_depth:

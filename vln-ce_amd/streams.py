@@ -28,14 +28,23 @@ class BranchStreams:
             self._streams[key] = torch.cuda.Stream(device=device)
         return self._streams[key]
 
-    def run(self, idx, device, fn):
-        """fn() on side stream `idx` (after everything already queued on the current
-        stream).  Returns (result, join) -- call join() before consuming the result."""
+    def fork(self, device):
+        """Marks the current point of the current stream; branches started with this
+        token wait for it (and NOT for work enqueued on the current stream afterwards)."""
         if not self.enabled(device):
+            return None
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(device))
+        return ev
+
+    def run(self, token, idx, device, fn):
+        """fn() on side stream `idx`, ordered after the fork point.  Returns
+        (result, join) -- call join() before consuming the result on the current stream."""
+        if token is None:
             return fn(), (lambda: None)
         cur = torch.cuda.current_stream(device)
         side = self._stream(idx, device)
-        side.wait_stream(cur)
+        side.wait_event(token)
         with torch.cuda.stream(side):
             out = fn()
 
