@@ -14,7 +14,7 @@ from .policy import ILPolicy, Net
 from .registry import baseline_registry
 from .rnn_state_encoder import build_rnn_state_encoder
 from .seq2seq_policy import prev_action_index, register_progress_loss
-from .streams import BranchStreams
+from .streams import BranchStreams, GraphedTail
 
 
 @baseline_registry.register_policy
@@ -43,6 +43,54 @@ def nchw_flat_weight(linear, c, p):
     for [B, P, C] rows (column p*C + c)."""
     w = linear.weight
     return w.view(w.size(0), c, p).permute(0, 2, 1).reshape(w.size(0), p * c)
+
+
+class _CMATail(nn.Module):
+    """The part of CMANet.forward downstream of the encoders, as a tensor-only callable
+    (no host syncs, static shapes) so that it can be captured as a HIP graph.  It shares
+    the parent's sub-modules; it is NOT registered as a child of the parent."""
+
+    def __init__(self, net):
+        super().__init__()
+        for name in ("rgb_linear", "depth_linear", "state_encoder", "rgb_kv", "depth_kv", "state_q",
+                     "text_k", "text_q", "second_state_compress", "second_state_encoder"):
+            setattr(self, name, getattr(net, name))
+        self._hidden_size = net._hidden_size
+        self._scale_f = net._scale_f
+
+    def forward(self, ins, dep, rgb, act, rnn_states, masks):
+        B, L, Ci = ins.shape
+        P_d, C_d = dep.shape[1:]
+        C_r = rgb.shape[2]
+        half = self._hidden_size // 2
+        scale = self._scale_f
+        rgb_in = ops.linear(ops.mean_rows(rgb), self.rgb_linear[2].weight,
+                            self.rgb_linear[2].bias, ops.ACT_RELU)
+        depth_in = ops.linear(dep.reshape(B, P_d * C_d),
+                              nchw_flat_weight(self.depth_linear[1], C_d, P_d),
+                              self.depth_linear[1].bias, ops.ACT_RELU)
+        state_in = torch.cat([rgb_in, depth_in, act], dim=1)
+        n1 = self.state_encoder.num_recurrent_layers
+        state, h1 = self.state_encoder(state_in, rnn_states[:, 0:n1], masks)
+
+        text_state_q = ops.linear(state, self.state_q.weight, self.state_q.bias)
+        text_state_k = ops.linear(ins, self.text_k.weight.view(half, Ci), self.text_k.bias)
+        text_mask = ops.rowzero_mask(ins.detach())  # (instruction_embedding == 0).all(dim=1)
+        # softmax((q.k - 1e8 mask) * scale) . v over [B, P, C] rows (cma_policy.py:207-217)
+        text_embedding = ops.attention(text_state_q, text_state_k, ins, text_mask, 1, scale)
+
+        rgb_kv = ops.linear(rgb, self.rgb_kv.weight.view(-1, C_r), self.rgb_kv.bias)
+        depth_kv = ops.linear(dep, self.depth_kv.weight.view(-1, C_d), self.depth_kv.bias)
+        text_q = ops.linear(text_embedding, self.text_q.weight, self.text_q.bias)
+        rgb_embedding = ops.attention(text_q, rgb_kv[..., :half], rgb_kv[..., half:], None, 1, scale)
+        depth_embedding = ops.attention(text_q, depth_kv[..., :half], depth_kv[..., half:], None, 1,
+                                        scale)
+
+        x = torch.cat([state, text_embedding, rgb_embedding, depth_embedding, act], dim=1)
+        x = ops.linear(x, self.second_state_compress[0].weight,
+                       self.second_state_compress[0].bias, ops.ACT_RELU)
+        x, h2 = self.second_state_encoder(x, rnn_states[:, n1:], masks)
+        return x, torch.cat([h1, h2], dim=1)
 
 
 class CMANet(Net):
@@ -99,6 +147,8 @@ class CMANet(Net):
             rnn_type=model_config.STATE_ENCODER.rnn_type, num_layers=1)
         self._output_size = hidden_size
         self._branches = BranchStreams()
+        # kept out of the module tree (shares our sub-modules): see _CMATail
+        object.__setattr__(self, "_tail", GraphedTail(_CMATail(self)))
         self.progress_monitor = nn.Linear(self.output_size, 1)
         if model_config.PROGRESS_MONITOR.use:
             nn.init.kaiming_normal_(self.progress_monitor.weight, nonlinearity="tanh")
@@ -147,36 +197,8 @@ class CMANet(Net):
             dep = dep * 0
         if mc.ablate_rgb:
             rgb = rgb * 0
-        B, L, Ci = ins.shape
-        P_r, C_r = rgb.shape[1:]
-        P_d, C_d = dep.shape[1:]
-        half = self._hidden_size // 2
-
-        rgb_in = ops.linear(ops.mean_rows(rgb), self.rgb_linear[2].weight,
-                            self.rgb_linear[2].bias, ops.ACT_RELU)
-        depth_in = ops.linear(dep.reshape(B, P_d * C_d),
-                              nchw_flat_weight(self.depth_linear[1], C_d, P_d),
-                              self.depth_linear[1].bias, ops.ACT_RELU)
-        state_in = torch.cat([rgb_in, depth_in, act], dim=1)
-        n1 = self.state_encoder.num_recurrent_layers
-        state, h1 = self.state_encoder(state_in, rnn_states[:, 0:n1], masks)
-
-        text_state_q = ops.linear(state, self.state_q.weight, self.state_q.bias)
-        text_state_k = ops.linear(ins, self.text_k.weight.view(half, Ci), self.text_k.bias)
-        ins_c = ins.contiguous()
-        text_mask = ops.rowzero_mask(ins_c.detach())  # (instruction_embedding == 0).all(dim=1)
-        text_embedding = self._attn(text_state_q, text_state_k, ins_c, text_mask)
-
-        rgb_kv = ops.linear(rgb, self.rgb_kv.weight.view(-1, C_r), self.rgb_kv.bias)
-        depth_kv = ops.linear(dep, self.depth_kv.weight.view(-1, C_d), self.depth_kv.bias)
-        text_q = ops.linear(text_embedding, self.text_q.weight, self.text_q.bias)
-        rgb_embedding = self._attn(text_q, rgb_kv[..., :half], rgb_kv[..., half:])
-        depth_embedding = self._attn(text_q, depth_kv[..., :half], depth_kv[..., half:])
-
-        x = torch.cat([state, text_embedding, rgb_embedding, depth_embedding, act], dim=1)
-        x = ops.linear(x, self.second_state_compress[0].weight,
-                       self.second_state_compress[0].bias, ops.ACT_RELU)
-        x, h2 = self.second_state_encoder(x, rnn_states[:, n1:], masks)
-        rnn_states_out = torch.cat([h1, h2], dim=1)
+        masks_u8 = masks.reshape(-1).to(torch.uint8)
+        x, rnn_states_out = self._tail(ins.contiguous(), dep.contiguous(), rgb.contiguous(), act,
+                                       rnn_states.contiguous(), masks_u8)
         register_progress_loss(self, x, observations)
         return x, rnn_states_out

@@ -25,7 +25,10 @@ class BranchStreams:
     def _stream(self, idx, device):
         key = (idx, device.index)
         if key not in self._streams:
-            self._streams[key] = torch.cuda.Stream(device=device)
+            # high priority: the branch kernels are small; without it the hardware only
+            # admits them at the boundaries of the saturating RGB-trunk kernels
+            prio = int(os.environ.get("VLNCE_SIDE_PRIORITY", "-1"))
+            self._streams[key] = torch.cuda.Stream(device=device, priority=prio)
         return self._streams[key]
 
     def fork(self, device):
@@ -55,3 +58,37 @@ class BranchStreams:
                     t.record_stream(cur)
 
         return out, join
+
+
+class GraphedTail:
+    """HIP-graph replay of a policy's trainable tail (everything downstream of the three
+    encoders): ~100 small launches forward and ~200 backward whose host-side issue cost
+    is on the critical path of a step.  Uses torch.cuda.make_graphed_callables, i.e. the
+    forward AND the backward of the tail are captured (autograd-aware) per input-shape
+    signature; the 1st call with a signature runs eagerly, the 2nd captures.
+    Set VLNCE_HIP_GRAPHS=0 to disable."""
+
+    MAX_GRAPHS = 8
+
+    def __init__(self, module):
+        self.module = module
+        self.entries = {}
+
+    def __call__(self, *tensors):
+        t0 = tensors[0]
+        if (not t0.is_cuda or os.environ.get("VLNCE_HIP_GRAPHS", "1") == "0"
+                or torch.cuda.is_current_stream_capturing()):
+            return self.module(*tensors)
+        key = tuple((tuple(t.shape), t.dtype, t.requires_grad) for t in tensors) + (
+            torch.is_grad_enabled(),)
+        ent = self.entries.get(key)
+        if ent is None:
+            if len(self.entries) >= self.MAX_GRAPHS:
+                self.entries.pop(next(iter(self.entries)))
+            self.entries[key] = "seen"
+            return self.module(*tensors)
+        if ent == "seen":
+            sample = tuple(t.detach().clone().requires_grad_(t.requires_grad) for t in tensors)
+            ent = torch.cuda.make_graphed_callables(self.module, sample, allow_unused_input=True)
+            self.entries[key] = ent
+        return ent(*tensors)
