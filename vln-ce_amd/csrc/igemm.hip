@@ -21,14 +21,18 @@
 //     contiguous run of tiles with the N-tile index fastest, so blocks that
 //     share an A row-panel hit the same L2.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
 constexpr int BK = 32;
 constexpr int LDP = 36;  // LDS row pitch in floats (32 + 4 pad)
 
-enum { A_IM2COL_V4 = 0, A_IM2COL_S = 1, A_TRANS = 2 };
-enum { B_NK_V4 = 0, B_NK_S = 1, B_KN = 2 };
+enum { A_IM2COL_V4 = 0, A_IM2COL_S = 1, A_TRANS = 2, A_BUF = 3 };
+enum { B_NK_V4 = 0, B_NK_S = 1, B_KN = 2, B_BUF = 3 };
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr int BUF_OOB = (int)0x80000000;  // voffset beyond any buffer: the load returns zeros
 
 struct IgemmParams {
   const float* A;
@@ -49,6 +53,7 @@ struct IgemmParams {
   float* stat_partial;
   int tiles_m, tiles_n;
   int splitk;  // > 1: blockIdx.y owns a K range and atomically adds into a pre-zeroed C
+  long a_bytes, b_bytes;  // extents of A / B for the buffer-descriptor loaders
 };
 
 __device__ __forceinline__ f32x4 ldg4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
@@ -136,6 +141,57 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
   constexpr int B_ROWS = BN / 32;
   f32x4 b_reg[B_ROWS];
 
+  // ---- buffer-descriptor loaders (A_BUF / B_BUF): the hot path.  Per K-tile the only
+  // per-lane work is one bit test + select per row: the tap offset is a wave-uniform SGPR
+  // (soffset), rows outside the image / matrix get an out-of-range voffset and the hardware
+  // bounds check returns zeros (no exec-mask branches, no 64-bit address math).
+  __amdgpu_buffer_rsrc_t rsrc_a, rsrc_b;
+  int a_voff[A_ROWS];
+  unsigned a_taps[A_ROWS];  // bit t: filter tap t of this output pixel reads inside the image
+  int b_voff[B_ROWS];
+  int u_r = 0, u_q = 0, u_ci = 0;  // wave-uniform tap state of the next tile to fetch
+  if constexpr (AMODE == A_BUF) {
+    const long bias = ((long)p.pad * p.W + p.pad) * p.lda * 4;  // keeps voffsets non-negative
+    rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(p.A)) - bias, 0, (int)(p.a_bytes + bias),
+        0x00020000);
+    const int HoWo = p.Ho * p.Wo;
+#pragma unroll
+    for (int i = 0; i < A_ROWS; ++i) {
+      const int m = m0 + i * 32 + lrow;
+      a_voff[i] = BUF_OOB;
+      a_taps[i] = 0;
+      if (m < p.M) {
+        const int img = m / HoWo;
+        const int rem = m - img * HoWo;
+        const int ho = rem / p.Wo;
+        const int wo = rem - ho * p.Wo;
+        const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
+        a_voff[i] = (int)((((long)(img * p.H + hi0 + p.pad) * p.W + wi0 + p.pad) * p.lda + lk4) * 4);
+        unsigned mask = 0;
+        for (int r = 0; r < p.KH; ++r)
+          for (int q = 0; q < p.KW; ++q)
+            if ((unsigned)(hi0 + r) < (unsigned)p.H && (unsigned)(wi0 + q) < (unsigned)p.W)
+              mask |= 1u << (r * p.KW + q);
+        a_taps[i] = mask;
+      }
+    }
+    const int kfirst = kt0 * BK;
+    const int tap = kfirst / p.Cin;
+    u_ci = kfirst - tap * p.Cin;
+    u_r = tap / p.KW;
+    u_q = tap - u_r * p.KW;
+  }
+  if constexpr (BMODE == B_BUF) {
+    rsrc_b = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(p.B)), 0, (int)p.b_bytes, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < B_ROWS; ++i) {
+      const int n = n0 + i * 32 + lrow;
+      b_voff[i] = n < p.N ? (int)(((long)n * p.ldb + lk4) * 4) : BUF_OOB;
+    }
+  }
+
   // The operand transform (x*s+t, ReLU) is applied when the staged registers are written to
   // LDS, i.e. AFTER the MFMAs of the current tile: applying it right after the loads would
   // put the global-load latency in front of the MFMAs instead of behind them.
@@ -144,7 +200,31 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
   float pro_es[4], pro_et[4];
 
   auto load_a = [&](int k0) {
-    if constexpr (AMODE == A_IM2COL_V4) {
+    if constexpr (AMODE == A_BUF) {
+      const int tap = u_r * p.KW + u_q;
+      const int soff = ((u_r * p.W + u_q) * p.lda + u_ci) * 4;
+      if (p.in_scale != nullptr) {
+        pro_s = ldg4(p.in_scale + u_ci + lk4);
+        pro_t = ldg4(p.in_shift + u_ci + lk4);
+      }
+      a_okmask = 0;
+#pragma unroll
+      for (int i = 0; i < A_ROWS; ++i) {
+        const unsigned ok = (a_taps[i] >> tap) & 1u;
+        a_okmask |= ok << i;
+        a_reg[i] = __builtin_bit_cast(
+            f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, ok ? a_voff[i] : BUF_OOB, soff, 0));
+      }
+      // advance the uniform tap state by one K-tile (Cin % 32 == 0: at most one wrap)
+      u_ci += BK;
+      if (u_ci >= p.Cin) {
+        u_ci = 0;
+        if (++u_q == p.KW) {
+          u_q = 0;
+          ++u_r;
+        }
+      }
+    } else if constexpr (AMODE == A_IM2COL_V4) {
       const bool tap_ok = k_r < p.KH;
       if (p.in_scale != nullptr && tap_ok) {
         pro_s = ldg4(p.in_scale + k_ci);
@@ -239,7 +319,12 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
   };
 
   auto load_b = [&](int k0) {
-    if constexpr (BMODE == B_NK_V4) {
+    if constexpr (BMODE == B_BUF) {
+#pragma unroll
+      for (int i = 0; i < B_ROWS; ++i)
+        b_reg[i] = __builtin_bit_cast(
+            f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, b_voff[i], k0 * 4, 0));
+    } else if constexpr (BMODE == B_NK_V4) {
       const int k = k0 + lk4;
 #pragma unroll
       for (int i = 0; i < B_ROWS; ++i) {
@@ -311,7 +396,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
 #pragma unroll
         for (int i = 0; i < A_ROWS; ++i) {
           f32x4 v = a_reg[i];
-          if constexpr (AMODE == A_IM2COL_V4) {
+          if constexpr (AMODE == A_IM2COL_V4 || AMODE == A_BUF) {
             v = v * pro_s + pro_t;
             if (p.in_relu) {
               v.x = fmaxf(v.x, 0.f);
@@ -611,6 +696,14 @@ template <int AMODE, int BMODE>
 int dispatch_small(const IgemmParams& p, hipStream_t s) {
   return launch<64, 64, 2, 2, AMODE, BMODE>(p, s);
 }
+// buffer-descriptor hot path: channels-last im2col / row-major A with Cin % 32 == 0, at most
+// 32 filter taps, [N,K] weights, operands below 2 GiB
+bool buf_ok(const IgemmParams& p) {
+  static const bool off = getenv("VLNCE_IGEMM_NOBUF") != nullptr;
+  const long bias = ((long)p.pad * p.W + p.pad) * p.lda * 4;
+  return !off && (p.Cin % 32 == 0) && (p.K % 32 == 0) && (p.lda % 4 == 0) && (p.ldb % 4 == 0) &&
+         p.KH * p.KW <= 32 && p.a_bytes + bias < 0x7fffffffL && p.b_bytes < 0x7fffffffL;
+}
 // 7x7 stems: scalar loaders with compile-time Cin / KW
 template <int CIN_C>
 int dispatch_stem(const IgemmParams& p, hipStream_t s) {
@@ -696,7 +789,10 @@ extern "C" int vlnce_conv2d_fwd(const float* x, const float* w, float* y, const 
   const bool v4 = (d->Cin % 4 == 0) && (p.lda % 4 == 0) && aligned16(x) && aligned16(w) &&
                   (!p.in_scale || (aligned16(p.in_scale) && aligned16(p.in_shift)));
   p.splitk = 1;
+  p.a_bytes = (((long)d->N * d->H * d->W - 1) * p.lda + d->Cin) * 4;
+  p.b_bytes = (long)d->Cout * p.K * 4;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (v4 && buf_ok(p)) return dispatch_tiles<A_BUF, B_BUF>(p, s);
   if (v4) return dispatch_tiles<A_IM2COL_V4, B_NK_V4>(p, s);
   if (d->KW == 7 && d->Cin == 3) return dispatch_stem<3>(p, s);
   if (d->KW == 7 && d->Cin == 1) return dispatch_stem<1>(p, s);
@@ -753,7 +849,11 @@ extern "C" int vlnce_gemm(const float* A, int lda, int transA, const float* B, i
     const bool av4 = (K % 4 == 0) && (lda % 4 == 0) && aligned16(A);
     if (!transB) {
       const bool bv4 = (K % 4 == 0) && (ldb % 4 == 0) && aligned16(B);
-      if (av4 && bv4)
+      p.a_bytes = (((long)M - 1) * lda + K) * 4;
+      p.b_bytes = (((long)N - 1) * ldb + K) * 4;
+      if (av4 && bv4 && buf_ok(p))
+        rc = p.splitk > 1 ? dispatch_small<A_BUF, B_BUF>(p, s) : dispatch_tiles<A_BUF, B_BUF>(p, s);
+      else if (av4 && bv4)
         rc = p.splitk > 1 ? dispatch_small<A_IM2COL_V4, B_NK_V4>(p, s)
                           : dispatch_tiles<A_IM2COL_V4, B_NK_V4>(p, s);
       else
