@@ -195,12 +195,15 @@ def main():
     # separate, untimed-for-throughput pass to attribute time to the dominant kernel
     # (graph replay hides the individual launches from the host, so this pass runs eagerly)
     import vlnce_amd.encoders.resnet_encoders as enc
+    # and on ONE stream, so concurrent branches do not stretch each other's kernel durations
     os.environ["VLNCE_HIP_GRAPHS"] = "0"
+    os.environ["VLNCE_SIDE_STREAMS"] = "0"
     enc.ops.conv2d_nhwc = timed_conv
     step()
     torch.cuda.synchronize()
     enc.ops.conv2d_nhwc = orig_conv
     os.environ.pop("VLNCE_HIP_GRAPHS")
+    os.environ.pop("VLNCE_SIDE_STREAMS")
     conv_ms = sum(a.elapsed_time(b) for a, b in conv_events)
     n_conv = len(conv_events)
 

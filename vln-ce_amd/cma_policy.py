@@ -148,7 +148,7 @@ class CMANet(Net):
         self._output_size = hidden_size
         self._branches = BranchStreams()
         # kept out of the module tree (shares our sub-modules): see _CMATail
-        object.__setattr__(self, "_tail", GraphedTail(_CMATail(self)))
+        object.__setattr__(self, "_tail", GraphedTail(lambda: _CMATail(self)))
         self.progress_monitor = nn.Linear(self.output_size, 1)
         if model_config.PROGRESS_MONITOR.use:
             nn.init.kaiming_normal_(self.progress_monitor.weight, nonlinearity="tanh")

@@ -70,8 +70,11 @@ class GraphedTail:
 
     MAX_GRAPHS = 8
 
-    def __init__(self, module):
-        self.module = module
+    def __init__(self, make_module):
+        # make_graphed_callables patches the module's forward in place, so every captured
+        # signature gets its own (cheap: it only references the shared sub-modules) instance
+        self.make_module = make_module
+        self.module = make_module()
         self.entries = {}
 
     def __call__(self, *tensors):
@@ -89,6 +92,7 @@ class GraphedTail:
             return self.module(*tensors)
         if ent == "seen":
             sample = tuple(t.detach().clone().requires_grad_(t.requires_grad) for t in tensors)
-            ent = torch.cuda.make_graphed_callables(self.module, sample, allow_unused_input=True)
+            ent = torch.cuda.make_graphed_callables(self.make_module(), sample,
+                                                    allow_unused_input=True)
             self.entries[key] = ent
         return ent(*tensors)
