@@ -207,6 +207,20 @@ def main():
     conv_ms = sum(a.elapsed_time(b) for a, b in conv_events)
     n_conv = len(conv_events)
 
+    # secondary figure: forward-only act() under no_grad in eval mode
+    policy.eval()
+    h0 = torch.zeros(args.num_envs, 2, 512, device=dev)
+    with torch.no_grad():
+        for _ in range(3):
+            policy.act(batch[0], h0, batch[1], batch[2], deterministic=True)
+        sync()
+        ta = time.perf_counter()
+        for _ in range(args.steps):
+            policy.act(batch[0], h0, batch[1], batch[2], deterministic=True)
+        sync()
+        act_s = (time.perf_counter() - ta) / args.steps
+    policy.train()
+
     if rank == 0:
         ms = 1e3 * elapsed / args.steps
         value = args.num_envs * world * args.steps / elapsed
@@ -221,7 +235,8 @@ def main():
                                    f"BatchNorm={args.bn}, num_envs={args.num_envs}/GPU, "
                                    f"{args.hw}x{args.hw} RGB-D, {args.tokens}-token instruction",
                        "global_batch": args.num_envs * world, "parallelism": f"dp{world}",
-                       "whole_step_tflops": round(CMA_FWD_BWD_FROZEN_GFLOP * value / 1e3, 2)},
+                       "whole_step_tflops": round(CMA_FWD_BWD_FROZEN_GFLOP * value / 1e3, 2),
+                       "act_fwd_only_eval_steps_per_sec_per_gpu": round(args.num_envs / act_s, 1)},
             "roofline": {"bound": "mfma", "kernel": "igemm_kernel (conv2d fwd, fp32 32x32x2 MFMA)",
                          "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
