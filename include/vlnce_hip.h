@@ -48,11 +48,13 @@ typedef struct {
 
 typedef struct {
   /* input transform applied in the A-operand loader BEFORE zero padding:
-   *   x' = act(x * in_scale[ci] + in_shift[ci]);  NULL = identity.
+   *   x' = act((x - in_center[ci]) * in_scale[ci] + in_shift[ci]);  NULL scale = identity,
+   *   NULL center = 0.
    * Used for the RGB stem's /255 (+ImageNet mean/std, resnet_encoders.py:171-192)
    * and to apply the previous layer's BatchNorm+ReLU on the fly. */
   const float* in_scale;
   const float* in_shift;
+  const float* in_center;
   int in_relu;
 } vlnce_prologue;
 
@@ -107,18 +109,21 @@ int vlnce_bn_finalize(const float* stat_partial, int tiles_m, int tile_rows, int
                       void* workspace, size_t workspace_bytes, /* caller-allocated scratch */
                       vlnce_stream_t stream);
 
-/* y = act(x * scale[s, c] + shift[s, c] + residual)   with s = row / rows_per_sample
- * (rows_per_sample = 0 => one scale/shift vector for all rows: BatchNorm apply;
- *  > 0 => per-sample vectors [Nsamples, C]: GroupNorm apply). */
+/* y = act((x - center[s, c]) * scale[s, c] + shift[s, c] + residual)   with s = row / rows_per_sample
+ * (rows_per_sample = 0 => one vector for all rows: BatchNorm apply; > 0 => per-sample vectors
+ * [Nsamples, C]: GroupNorm apply).  center may be NULL (= 0).  Batch-statistics normalisation
+ * passes center = mean, scale = gamma*rstd, shift = beta: the reference's own arithmetic
+ * ((x - mean) * rstd * gamma + beta), which keeps fp32 accuracy when |mean| >> std. */
 int vlnce_scale_shift_act(const float* x, const float* scale, const float* shift,
-                          int rows_per_sample, const float* residual, float* y,
-                          long M, int C, int act, vlnce_stream_t stream);
+                          const float* center, int rows_per_sample, const float* residual,
+                          float* y, long M, int C, int act, vlnce_stream_t stream);
 
 /* y = act(x1*scale1[c]+shift1[c] + x2*scale2[c]+shift2[c]); y may alias x1.  End of a residual
  * block with a conv+BatchNorm downsample: both raw conv outputs normalised in one pass. */
 int vlnce_scale_shift_add_act(const float* x1, const float* scale1, const float* shift1,
-                              const float* x2, const float* scale2, const float* shift2,
-                              float* y, long M, int C, int act, vlnce_stream_t stream);
+                              const float* center1, const float* x2, const float* scale2,
+                              const float* shift2, const float* center2, float* y, long M, int C,
+                              int act, vlnce_stream_t stream);
 
 /* GroupNorm (habitat depth trunk: ngroups 16, and GroupNorm(1,C) in the
  * compression block; eps 1e-5).  Two launches: partial sums per
@@ -130,6 +135,8 @@ int vlnce_gn_partial(const float* x, int Nimg, int HW, int C, float* partial /* 
 int vlnce_gn_finalize(const float* partial, int Nimg, int HW, int C, int groups,
                       const float* gamma, const float* beta, float eps,
                       float* scale_out, float* shift_out, /* [N,C] */
+                      float* center_out, /* [N,C] or NULL: if given, shift_out = beta and
+                                            center_out = mean (unfolded form) */
                       float* mean_out, float* rstd_out,   /* [N,groups] or NULL */
                       vlnce_stream_t stream);
 
@@ -140,11 +147,41 @@ int vlnce_gn_finalize(const float* partial, int Nimg, int HW, int C, int groups,
 /* maxpool over act(x*in_scale[c]+in_shift[c]) when in_scale != NULL: the stem's BatchNorm+ReLU
  * is applied on the fly to the raw conv output (train mode), saving one HBM round trip. */
 int vlnce_maxpool3x3s2(const float* x, float* y, int N, int H, int W, int C, int Ho, int Wo,
-                       const float* in_scale, const float* in_shift, int in_relu,
-                       vlnce_stream_t stream);
+                       const float* in_scale, const float* in_shift, const float* in_center,
+                       int in_relu, vlnce_stream_t stream);
 int vlnce_avgpool2x2(const float* x, float* y, int N, int H, int W, int C, vlnce_stream_t stream);
 int vlnce_adaptive_avgpool(const float* x, float* y, int N, int H, int W, int C, int OH, int OW,
                            int ldy, vlnce_stream_t stream);
+
+/* ------------------------------------------------- backward of the visual trunks
+ * (only reached with MODEL.RGB_ENCODER / DEPTH_ENCODER .trainable = True; the reference
+ * default keeps both encoders frozen).  Data gradients of stride-1 convolutions reuse
+ * vlnce_conv2d_fwd with the flipped / transposed weights. */
+/* dW[Cout,KH,KW,Cin] = sum_m dY[m,co] * im2col(X)[m,(r,q,ci)]   (split-K over output pixels) */
+int vlnce_conv2d_wgrad(const float* x, const float* dy, float* dw_ohwi, const vlnce_conv_desc* d,
+                       vlnce_stream_t stream);
+/* BatchNorm2d backward through y = act(x*gamma*rstd + (beta - mean*gamma*rstd) (+ residual)):
+ * g = dy*[y>0] when relu; dbeta = sum g; dgamma = sum g*xhat;
+ * dx = gamma*rstd*(g - dbeta/M - xhat*dgamma/M) with batch statistics, gamma*rstd*g with
+ * running statistics (use_batch_stats = 0).  dres (may be NULL) receives g. */
+int vlnce_bn_bwd(const float* dy, const float* y, const float* x, const float* mean,
+                 const float* rstd, const float* gamma, long M, int C, int relu,
+                 int use_batch_stats, float* dx, float* dres, float* dgamma, float* dbeta,
+                 vlnce_stream_t stream);
+/* GroupNorm backward (same conventions; mean/rstd are [N,groups]); workspace from
+ * vlnce_gn_bwd_workspace_floats() floats. */
+size_t vlnce_gn_bwd_workspace_floats(int Nimg, int HW, int C, int groups);
+int vlnce_gn_bwd(const float* dy, const float* y, const float* x, const float* mean,
+                 const float* rstd, const float* gamma, int Nimg, int HW, int C, int groups,
+                 int relu, float* dx, float* dres, float* dgamma, float* dbeta, float* workspace,
+                 vlnce_stream_t stream);
+/* max-pool forward that also records the arg-max tap (0..8), and its backward */
+int vlnce_maxpool3x3s2_argmax(const float* x, float* y, uint8_t* argmax, int N, int H, int W,
+                              int C, int Ho, int Wo, vlnce_stream_t stream);
+int vlnce_maxpool3x3s2_bwd(const float* dy, const uint8_t* argmax, float* dx, int N, int H, int W,
+                           int C, int Ho, int Wo, vlnce_stream_t stream);
+int vlnce_adaptive_avgpool_bwd(const float* dy, float* dx, int N, int H, int W, int C, int OH,
+                               int OW, vlnce_stream_t stream);
 
 /* ---------------------------------------------------------------- attention
  * One query per batch row against P keys:  logits[i] = <q, K[i]>;

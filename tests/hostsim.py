@@ -37,11 +37,12 @@ class HostSim:
         return (M + self.TILE_ROWS - 1) // self.TILE_ROWS, self.TILE_ROWS
 
     def conv2d_fwd(self, x, w, y, g, in_scale=None, in_shift=None, in_relu=0, scale=None,
-                   shift=None, residual=None, ldr=0, act=0, accumulate=0, stat_partial=None):
+                   shift=None, residual=None, ldr=0, act=0, accumulate=0, stat_partial=None,
+                   in_center=None):
         N, H, W, Cin, Cout = g["N"], g["H"], g["W"], g["Cin"], g["Cout"]
         xi = x.as_strided((N, H, W, Cin), (H * W * g["ldx"], W * g["ldx"], g["ldx"], 1))
         if in_scale is not None:
-            xi = xi * in_scale + in_shift
+            xi = (xi - in_center if in_center is not None else xi) * in_scale + in_shift
             if in_relu:
                 xi = torch.relu(xi)
         wk = w.view(Cout, g["KH"], g["KW"], Cin).permute(0, 3, 1, 2)
@@ -119,14 +120,17 @@ class HostSim:
             running_mean.mul_(1 - momentum).add_(momentum * mean.float())
             running_var.mul_(1 - momentum).add_(momentum * unb.float())
 
-    def scale_shift_act(self, x, scale, shift, rows_per_sample, residual, y, M, Cc, act):
+    def scale_shift_act(self, x, scale, shift, rows_per_sample, residual, y, M, Cc, act,
+                        center=None):
         v = x.reshape(M, Cc)
         if rows_per_sample > 0:
             S = M // rows_per_sample
-            v = v.view(S, rows_per_sample, Cc) * scale.view(S, 1, Cc) + shift.view(S, 1, Cc)
-            v = v.view(M, Cc)
+            v = v.view(S, rows_per_sample, Cc)
+            if center is not None:
+                v = v - center.view(S, 1, Cc)
+            v = (v * scale.view(S, 1, Cc) + shift.view(S, 1, Cc)).reshape(M, Cc)
         else:
-            v = v * scale + shift
+            v = (v - center if center is not None else v) * scale + shift
         if residual is not None:
             v = v + residual.reshape(M, Cc)
         y.view(M, Cc).copy_(_act(v, act))
@@ -142,7 +146,7 @@ class HostSim:
             partial[:, c, :, 1] = (blk * blk).sum(1)
 
     def gn_finalize(self, partial, Nimg, HW, Cc, groups, gamma, beta, eps, scale_out, shift_out,
-                    mean_out=None, rstd_out=None):
+                    mean_out=None, rstd_out=None, center_out=None):
         cpg = Cc // groups
         p = partial.double().sum(1).view(Nimg, groups, cpg, 2).sum(2)
         cnt = HW * cpg
@@ -151,23 +155,30 @@ class HostSim:
         rstd = (1.0 / torch.sqrt(var + eps)).float()
         sc = rstd.repeat_interleave(cpg, dim=1) * (gamma if gamma is not None else 1.0)
         scale_out.copy_(sc)
-        shift_out.copy_((beta if beta is not None else 0.0)
-                        - mean.float().repeat_interleave(cpg, dim=1) * sc)
+        if center_out is not None:
+            center_out.copy_(mean.float().repeat_interleave(cpg, dim=1))
+            shift_out.copy_((beta if beta is not None else torch.zeros(Cc)).expand(Nimg, Cc))
+        else:
+            shift_out.copy_((beta if beta is not None else 0.0)
+                            - mean.float().repeat_interleave(cpg, dim=1) * sc)
         if mean_out is not None:
             mean_out.copy_(mean.float())
         if rstd_out is not None:
             rstd_out.copy_(rstd)
 
     # ---- pools
-    def maxpool3x3s2(self, x, y, N, H, W, Cc, Ho, Wo, in_scale=None, in_shift=None, in_relu=0):
+    def maxpool3x3s2(self, x, y, N, H, W, Cc, Ho, Wo, in_scale=None, in_shift=None, in_relu=0,
+                     in_center=None):
         if in_scale is not None:
-            x = x * in_scale + in_shift
+            x = (x - in_center if in_center is not None else x) * in_scale + in_shift
             if in_relu:
                 x = torch.relu(x)
         y.copy_(F.max_pool2d(x.permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1))
 
-    def scale_shift_add_act(self, x1, s1, t1, x2, s2, t2, y, M, Cc, act):
-        v = x1.reshape(M, Cc) * s1 + t1 + x2.reshape(M, Cc) * s2 + t2
+    def scale_shift_add_act(self, x1, s1, t1, x2, s2, t2, y, M, Cc, act, c1=None, c2=None):
+        a = x1.reshape(M, Cc) - (c1 if c1 is not None else 0.0)
+        b = x2.reshape(M, Cc) - (c2 if c2 is not None else 0.0)
+        v = a * s1 + t1 + b * s2 + t2
         y.view(M, Cc).copy_(_act(v, act))
 
     def avgpool2x2(self, x, y, N, H, W, Cc):
@@ -262,6 +273,82 @@ class HostSim:
         dgates.copy_(torch.cat([dc * g * i * (1 - i), dc * cp * f * (1 - f), dc * i * (1 - g * g),
                                 dh * tc * o * (1 - o)], 1))
         dc_prev.copy_(dc * f * mk)
+
+    # ---- backward of the visual trunks (contracts of csrc/bwd.hip, vlnce_conv2d_wgrad)
+    def conv2d_wgrad(self, x, dy, dw, g):
+        N, H, W, Cin, Cout = g["N"], g["H"], g["W"], g["Cin"], g["Cout"]
+        xi = x.as_strided((N, H, W, Cin), (H * W * g["ldx"], W * g["ldx"], g["ldx"], 1))
+        xi = xi.permute(0, 3, 1, 2).contiguous()
+        gy = dy.reshape(N, g["Ho"], g["Wo"], Cout).permute(0, 3, 1, 2).contiguous()
+        gw = torch.nn.grad.conv2d_weight(xi, (Cout, Cin, g["KH"], g["KW"]), gy,
+                                         stride=g["stride"], padding=g["pad"])
+        dw.view(Cout, g["KH"], g["KW"], Cin).copy_(gw.permute(0, 2, 3, 1))
+
+    def bn_bwd(self, dy, y, x, mean, rstd, gamma, M, Cc, relu, use_batch_stats, dx, dres, dgamma,
+               dbeta):
+        g = dy.reshape(M, Cc)
+        if relu:
+            g = g * (y.reshape(M, Cc) > 0)
+        xh = (x.reshape(M, Cc) - mean) * rstd
+        db, dg = g.sum(0), (g * xh).sum(0)
+        dbeta.copy_(db)
+        dgamma.copy_(dg)
+        k = (gamma if gamma is not None else 1.0) * rstd
+        v = g - db / M - xh * dg / M if use_batch_stats else g
+        dx.view(M, Cc).copy_(k * v)
+        if dres is not None:
+            dres.view(M, Cc).copy_(g)
+
+    def gn_bwd_workspace_floats(self, Nimg, HW, Cc, groups):
+        return 1
+
+    def gn_bwd(self, dy, y, x, mean, rstd, gamma, Nimg, HW, Cc, groups, relu, dx, dres, dgamma,
+               dbeta, workspace):
+        cpg = Cc // groups
+        g = dy.reshape(Nimg, HW, groups, cpg)
+        if relu:
+            g = g * (y.reshape(Nimg, HW, groups, cpg) > 0)
+        xh = (x.reshape(Nimg, HW, groups, cpg) - mean.view(Nimg, 1, groups, 1)) * rstd.view(
+            Nimg, 1, groups, 1)
+        ga = (gamma if gamma is not None else torch.ones(Cc)).view(1, 1, groups, cpg)
+        dbeta.copy_(g.sum((0, 1)).reshape(Cc))
+        dgamma.copy_((g * xh).sum((0, 1)).reshape(Cc))
+        cnt = HW * cpg
+        s1 = (g * ga).sum((1, 3), keepdim=True)
+        s2 = (g * ga * xh).sum((1, 3), keepdim=True)
+        v = rstd.view(Nimg, 1, groups, 1) * (g * ga - s1 / cnt - xh * s2 / cnt)
+        dx.view(Nimg, HW, groups, cpg).copy_(v)
+        if dres is not None:
+            dres.view(Nimg, HW, groups, cpg).copy_(g)
+
+    def maxpool3x3s2_argmax(self, x, y, argmax, N, H, W, Cc, Ho, Wo):
+        xp = F.pad(x.permute(0, 3, 1, 2), (1, 1, 1, 1), value=float("-inf"))
+        win = xp.unfold(2, 3, 2).unfold(3, 3, 2).reshape(N, Cc, Ho, Wo, 9)
+        m, a = win.max(dim=4)
+        # torch.max returns the first maximal index for ties on CPU, matching the scan order;
+        # padded (-inf) taps can only win when the whole window is -inf, which cannot happen
+        y.copy_(m.permute(0, 2, 3, 1))
+        argmax.copy_(a.permute(0, 2, 3, 1).to(torch.uint8))
+
+    def maxpool3x3s2_bwd(self, dy, argmax, dx, N, H, W, Cc, Ho, Wo):
+        gx = torch.zeros(N, Cc, H + 2, W + 2)
+        a = argmax.permute(0, 3, 1, 2).long()
+        gy = dy.permute(0, 3, 1, 2)
+        ho = torch.arange(Ho).view(1, 1, Ho, 1)
+        wo = torch.arange(Wo).view(1, 1, 1, Wo)
+        hi = (ho * 2 + a // 3).expand_as(a)
+        wi = (wo * 2 + a % 3).expand_as(a)
+        n = torch.arange(N).view(N, 1, 1, 1).expand_as(a)
+        c = torch.arange(Cc).view(1, Cc, 1, 1).expand_as(a)
+        gx.index_put_((n, c, hi, wi), gy, accumulate=True)
+        dx.copy_(gx[:, :, 1:-1, 1:-1].permute(0, 2, 3, 1))
+
+    def adaptive_avgpool_bwd(self, dy, dx, N, H, W, Cc, OH, OW):
+        with torch.enable_grad():
+            xin = torch.zeros(N, Cc, H, W, requires_grad=True)
+            out = F.adaptive_avg_pool2d(xin, (OH, OW))
+            (gx,) = torch.autograd.grad(out, xin, dy.permute(0, 3, 1, 2).contiguous())
+        dx.copy_(gx.permute(0, 2, 3, 1))
 
     # ---- packed-sequence RNN (contract of csrc/rnn_seq.hip)
     def rnn_seq_supported(self, kind, H):

@@ -60,6 +60,9 @@ CONV_CASES = [
     ("big_128x64",    16, 32, 32,  64,  64, 3, 1, 1, dict(stats=True)),      # 128x64 tiles
     ("ragged",         3,  7,  9,  36,  48, 3, 1, 1, dict(scale=True, residual=True, relu=True)),
     ("prologue_v4",    2, 12, 12,  32,  64, 3, 1, 1, dict(prologue=True, in_relu=True)),
+    ("prologue_v4_c",  2, 12, 12,  32,  64, 3, 1, 1, dict(prologue=True, in_relu=True, center=True)),
+    ("prologue_s_c",   2, 12, 12,   6,  64, 3, 1, 1, dict(prologue=True, in_relu=True, center=True)),
+    ("prologue_buf_c", 2, 14, 14,  64, 128, 3, 2, 1, dict(prologue=True, in_relu=True, center=True)),
     ("compress_1024",  2,  4,  4, 1024, 128, 3, 1, 1, dict()),
 ]
 
@@ -74,6 +77,7 @@ def test_conv2d_fwd(hip, case):
     t = dict(x=x, w=w, y=torch.zeros(N, g["Ho"], g["Wo"], Cout))
     t["in_scale"] = rnd(Cin, seed=3).abs() + 0.5 if ex.get("prologue") else None
     t["in_shift"] = rnd(Cin, seed=4) * 0.3 if ex.get("prologue") else None
+    t["in_center"] = rnd(Cin, seed=14) * 0.5 if ex.get("center") else None
     t["scale"] = rnd(Cout, seed=5).abs() + 0.5 if ex.get("scale") else None
     t["shift"] = rnd(Cout, seed=6) if ex.get("scale") else None
     t["residual"] = rnd(N, g["Ho"], g["Wo"], Cout, seed=7) if ex.get("residual") else None
@@ -87,8 +91,8 @@ def test_conv2d_fwd(hip, case):
         y, stats = ops.conv2d_nhwc(x_d, w_d, s, p, want_stats=True)
         gamma, beta = (rnd(Cout, seed=8).abs() + 0.5).to(DEV), rnd(Cout, seed=9).to(DEV)
         rm, rv = torch.zeros(Cout, device=DEV), torch.ones(Cout, device=DEV)
-        scale, shift = ops.bn_finalize(stats, M, gamma, beta, 1e-5, 0.1, rm, rv)
-        out = ops.scale_shift_act(y, scale, shift, act=1)
+        scale, shift, center = ops.bn_finalize(stats, M, gamma, beta, 1e-5, 0.1, rm, rv)
+        out = ops.scale_shift_act(y, scale, shift, center=center, act=1)
         raw = cpu["y"].reshape(M, Cout)
         rm_ref, rv_ref = torch.zeros(Cout), torch.ones(Cout)
         ref = F.batch_norm(raw.t().reshape(1, Cout, M), rm_ref, rv_ref, gamma.cpu(), beta.cpu(),
@@ -404,6 +408,10 @@ def test_fused_bn_consumers(hip):
     ref = F.max_pool2d(torch.relu(x * sc + sh).permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1)
     got = ops.maxpool3x3s2(x.to(DEV), sc.to(DEV), sh.to(DEV), in_relu=True)
     close(got, ref, 1e-6, what="maxpool(bn+relu)")
+    ce = rnd(64, seed=33)
+    ref = F.max_pool2d(torch.relu((x - ce) * sc + sh).permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1)
+    got = ops.maxpool3x3s2(x.to(DEV), sc.to(DEV), sh.to(DEV), in_relu=True, in_center=ce.to(DEV))
+    close(got, ref, 1e-6, what="maxpool(centered bn+relu)")
     a, b = rnd(3, 5, 7, 128, seed=4), rnd(3, 5, 7, 128, seed=5)
     s1, t1, s2, t2 = (rnd(128, seed=6 + i) for i in range(4))
     ref = torch.relu(a * s1 + t1 + b * s2 + t2)
@@ -411,3 +419,167 @@ def test_fused_bn_consumers(hip):
     got = ops.scale_shift_add_act(ad, s1.to(DEV), t1.to(DEV), b.to(DEV), s2.to(DEV), t2.to(DEV),
                                   act=1, out=ad)
     close(got, ref, 1e-6, what="dual-input block end")
+    c1, c2 = rnd(128, seed=20), rnd(128, seed=21)
+    ref = torch.relu((a - c1) * s1 + t1 + (b - c2) * s2 + t2)
+    got = ops.scale_shift_add_act(a.to(DEV), s1.to(DEV), t1.to(DEV), b.to(DEV), s2.to(DEV),
+                                  t2.to(DEV), act=1, c1=c1.to(DEV), c2=c2.to(DEV))
+    close(got, ref, 1e-6, what="dual-input block end (centered)")
+    # centered single-input apply, per-channel and per-sample vectors
+    xs = rnd(3, 35, 128, seed=22)
+    got = ops.scale_shift_act(xs.to(DEV), s1.to(DEV), t1.to(DEV), center=c1.to(DEV), act=1)
+    close(got, torch.relu((xs - c1) * s1 + t1), 1e-6, what="centered apply")
+    sN, tN, cN = rnd(3, 128, seed=23), rnd(3, 128, seed=24), rnd(3, 128, seed=25)
+    got = ops.scale_shift_act(xs.to(DEV), sN.to(DEV), tN.to(DEV), center=cN.to(DEV),
+                              rows_per_sample=35)
+    close(got, (xs - cN[:, None]) * sN[:, None] + tN[:, None], 1e-6, what="centered per-sample")
+
+
+# ------------------------------------------------------------------ trunk backward kernels
+WGRAD_CASES = [
+    # name,        N,  H,  W, Cin, Cout, k, s, p
+    ("1x1",        2, 16, 16,  64, 128, 1, 1, 0),
+    ("3x3",        2, 16, 16,  64,  64, 3, 1, 1),
+    ("3x3s2",      3, 15, 17,  64, 128, 3, 2, 1),
+    ("1x1s2",      2, 16, 16, 128, 256, 1, 2, 0),
+    ("stem_rgb",   2, 64, 64,   3,  64, 7, 2, 3),
+    ("stem_depth", 2, 32, 32,   1,  32, 7, 2, 3),
+    ("ragged",     3,  7,  9,  36,  48, 3, 1, 1),
+    ("deep",       4,  8,  8, 512, 512, 3, 1, 1),
+    ("many_rows", 16, 32, 32,  64,  64, 3, 1, 1),     # split-K over 16384 pixels
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_CASES, ids=[c[0] for c in WGRAD_CASES])
+def test_conv2d_wgrad(hip, case):
+    name, N, H, W, Cin, Cout, k, s, p = case
+    x = rnd(N, H, W, Cin, seed=1)
+    g = ops.conv_geometry(x, torch.empty(Cout, k, k, Cin), s, p)
+    t = dict(x=x, dy=rnd(N, g["Ho"], g["Wo"], Cout, seed=2), dw=torch.zeros(Cout, k, k, Cin))
+    cpu, gpu = both("conv2d_wgrad", t, dict(g=g))
+    close(gpu["dw"], cpu["dw"], what="wgrad/" + name)
+
+
+@pytest.mark.parametrize("stride,k,pad", [(1, 3, 1), (2, 3, 1), (2, 1, 0), (1, 1, 0), (2, 7, 3)])
+def test_conv_backward_matches_autograd(hip, stride, k, pad):
+    """data + weight gradient of the host-side conv_backward (dgrad via the forward kernel
+    on flipped taps / zero-inserted dY) against torch autograd."""
+    from vlnce_amd.encoders import trunk_backward as tb
+    N, H, W, Cin, Cout = 2, 14, 18, 32, 64
+    x = rnd(N, H, W, Cin, seed=3)
+    w = rnd(Cout, k, k, Cin, seed=4) * 0.2
+    xr = x.permute(0, 3, 1, 2).clone().requires_grad_(True)
+    wr = w.permute(0, 3, 1, 2).clone().requires_grad_(True)
+    y = F.conv2d(xr, wr, None, stride, pad)
+    dy = rnd(*y.shape, seed=5)
+    y.backward(dy)
+    dx, dw = tb.conv_backward(x.to(DEV), w.to(DEV), dy.permute(0, 2, 3, 1).contiguous().to(DEV),
+                              stride, pad, True)
+    close(dx, xr.grad.permute(0, 2, 3, 1), what="dgrad")
+    close(dw, wr.grad, what="wgrad")
+
+
+@pytest.mark.parametrize("M,Cc", [(512, 64), (1031, 48), (70000, 256), (9, 512), (300, 5)])
+@pytest.mark.parametrize("relu,batch,res", [(1, 1, 1), (1, 1, 0), (0, 0, 1), (0, 1, 0)])
+def test_bn_bwd(hip, M, Cc, relu, batch, res):
+    x = rnd(M, Cc, seed=1) * 2 + 0.5
+    mean, var = x.mean(0), x.var(0, unbiased=False)
+    rstd = torch.rsqrt(var + 1e-5)
+    gamma = rnd(Cc, seed=2).abs() + 0.5
+    y = (x - mean) * rstd * gamma + rnd(Cc, seed=3)
+    if relu:
+        y = torch.relu(y)
+    t = dict(dy=rnd(M, Cc, seed=4), y=y, x=x, mean=mean, rstd=rstd, gamma=gamma,
+             dx=torch.zeros(M, Cc), dres=torch.zeros(M, Cc) if res else None,
+             dgamma=torch.zeros(Cc), dbeta=torch.zeros(Cc))
+    cpu, gpu = both("bn_bwd", t, dict(M=M, Cc=Cc, relu=relu, use_batch_stats=batch))
+    for k in ("dx", "dgamma", "dbeta") + (("dres",) if res else ()):
+        close(gpu[k], cpu[k], 2e-4, what=f"bn_bwd/{k}")
+
+
+def test_bn_bwd_matches_autograd(hip):
+    M, Cc = 777, 96
+    x = rnd(M, Cc, seed=1) * 1.5 - 0.3
+    gamma, beta = rnd(Cc, seed=2).abs() + 0.5, rnd(Cc, seed=3)
+    xr, gr, br = (v.clone().requires_grad_(True) for v in (x, gamma, beta))
+    y = torch.relu(F.batch_norm(xr, None, None, gr, br, True, 0.1, 1e-5))
+    dy = rnd(M, Cc, seed=4)
+    y.backward(dy)
+    mean, rstd = x.mean(0), torch.rsqrt(x.var(0, unbiased=False) + 1e-5)
+    dx, dg, db = torch.zeros(M, Cc, device=DEV), torch.zeros(Cc, device=DEV), torch.zeros(Cc, device=DEV)
+    hip.bn_bwd(dy.to(DEV), y.detach().to(DEV), x.to(DEV), mean.to(DEV), rstd.to(DEV),
+               gamma.to(DEV), M, Cc, 1, 1, dx, None, dg, db)
+    close(dx, xr.grad, 2e-4, what="bn dx")
+    close(dg, gr.grad, 2e-4, what="bn dgamma")
+    close(db, br.grad, 2e-4, what="bn dbeta")
+
+
+@pytest.mark.parametrize("N,HW,Cc,groups", [(3, 64, 32, 16), (2, 1024, 64, 32), (5, 16, 256, 128),
+                                            (2, 49, 128, 1), (1, 4096, 32, 16)])
+@pytest.mark.parametrize("relu,res", [(1, 1), (0, 0)])
+def test_gn_bwd(hip, N, HW, Cc, groups, relu, res):
+    x = rnd(N, HW, Cc, seed=1) * 2 + 0.3
+    cpg = Cc // groups
+    xg = x.view(N, HW, groups, cpg)
+    mean = xg.mean((1, 3))
+    rstd = torch.rsqrt(xg.var((1, 3), unbiased=False) + 1e-5)
+    gamma = rnd(Cc, seed=2).abs() + 0.5
+    y = ((xg - mean.view(N, 1, groups, 1)) * rstd.view(N, 1, groups, 1)).reshape(N, HW, Cc) * gamma \
+        + rnd(Cc, seed=3)
+    if relu:
+        y = torch.relu(y)
+    ws = _lib.get_lib().gn_bwd_workspace_floats(N, HW, Cc, groups)
+    t = dict(dy=rnd(N, HW, Cc, seed=4), y=y.contiguous(), x=x, mean=mean.contiguous(),
+             rstd=rstd.contiguous(), gamma=gamma, dx=torch.zeros(N, HW, Cc),
+             dres=torch.zeros(N, HW, Cc) if res else None, dgamma=torch.zeros(Cc),
+             dbeta=torch.zeros(Cc), workspace=torch.zeros(max(ws, 1)))
+    cpu, gpu = both("gn_bwd", t, dict(Nimg=N, HW=HW, Cc=Cc, groups=groups, relu=relu))
+    for k in ("dx", "dgamma", "dbeta") + (("dres",) if res else ()):
+        close(gpu[k], cpu[k], 2e-4, what=f"gn_bwd/{k}")
+
+
+def test_gn_bwd_matches_autograd(hip):
+    N, H, W, Cc, groups = 2, 6, 5, 64, 16
+    x = rnd(N, Cc, H, W, seed=1)
+    gamma, beta = rnd(Cc, seed=2).abs() + 0.5, rnd(Cc, seed=3)
+    xr, gr, br = (v.clone().requires_grad_(True) for v in (x, gamma, beta))
+    y = torch.relu(F.group_norm(xr, groups, gr, br, 1e-5))
+    dy = rnd(N, Cc, H, W, seed=4)
+    y.backward(dy)
+    nhwc = lambda v: v.detach().permute(0, 2, 3, 1).contiguous()
+    xg = nhwc(x).view(N, H * W, groups, Cc // groups)
+    mean = xg.mean((1, 3)).contiguous()
+    rstd = torch.rsqrt(xg.var((1, 3), unbiased=False) + 1e-5).contiguous()
+    dx, dg, db = torch.zeros(N, H, W, Cc, device=DEV), torch.zeros(Cc, device=DEV), \
+        torch.zeros(Cc, device=DEV)
+    ws = torch.zeros(max(hip.gn_bwd_workspace_floats(N, H * W, Cc, groups), 1), device=DEV)
+    hip.gn_bwd(nhwc(dy).to(DEV), nhwc(y).to(DEV), nhwc(x).to(DEV), mean.to(DEV), rstd.to(DEV),
+               gamma.to(DEV), N, H * W, Cc, groups, 1, dx, None, dg, db, ws)
+    close(dx, nhwc(xr.grad), 2e-4, what="gn dx")
+    close(dg, gr.grad, 2e-4, what="gn dgamma")
+    close(db, br.grad, 2e-4, what="gn dbeta")
+
+
+@pytest.mark.parametrize("N,H,W,Cc", [(2, 16, 16, 64), (3, 15, 17, 32), (1, 5, 7, 6), (2, 64, 64, 64)])
+def test_maxpool_argmax_and_bwd(hip, N, H, W, Cc):
+    x = rnd(N, H, W, Cc, seed=1)
+    x[0, :4, :4] = 0.25  # ties: the first tap in scan order wins, as in torch
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    t = dict(x=x, y=torch.zeros(N, Ho, Wo, Cc), argmax=torch.zeros(N, Ho, Wo, Cc, dtype=torch.uint8))
+    cpu, gpu = both("maxpool3x3s2_argmax", t, dict(N=N, H=H, W=W, Cc=Cc, Ho=Ho, Wo=Wo))
+    assert torch.equal(gpu["y"].cpu(), cpu["y"])
+    assert torch.equal(gpu["argmax"].cpu(), cpu["argmax"])
+    t = dict(dy=rnd(N, Ho, Wo, Cc, seed=2), argmax=cpu["argmax"], dx=torch.zeros(N, H, W, Cc))
+    cpu2, gpu2 = both("maxpool3x3s2_bwd", t, dict(N=N, H=H, W=W, Cc=Cc, Ho=Ho, Wo=Wo))
+    close(gpu2["dx"], cpu2["dx"], 1e-6, what="maxpool bwd")
+    # and against autograd end to end
+    xr = x.permute(0, 3, 1, 2).clone().requires_grad_(True)
+    F.max_pool2d(xr, 3, 2, 1).backward(t["dy"].permute(0, 3, 1, 2))
+    close(gpu2["dx"], xr.grad.permute(0, 2, 3, 1), 1e-6, what="maxpool bwd vs autograd")
+
+
+@pytest.mark.parametrize("N,H,W,Cc,OH,OW", [(2, 8, 8, 128, 4, 4), (2, 7, 7, 64, 4, 4),
+                                            (3, 4, 4, 512, 1, 1), (1, 8, 8, 2048, 4, 4)])
+def test_adaptive_avgpool_bwd(hip, N, H, W, Cc, OH, OW):
+    t = dict(dy=rnd(N, OH, OW, Cc, seed=1), dx=torch.zeros(N, H, W, Cc))
+    cpu, gpu = both("adaptive_avgpool_bwd", t, dict(N=N, H=H, W=W, Cc=Cc, OH=OH, OW=OW))
+    close(gpu["dx"], cpu["dx"], 1e-6, what="adaptive avgpool bwd")

@@ -27,7 +27,7 @@ class ConvDesc(C.Structure):
 
 
 class Prologue(C.Structure):
-    _fields_ = [("in_scale", _P), ("in_shift", _P), ("in_relu", _I)]
+    _fields_ = [("in_scale", _P), ("in_shift", _P), ("in_center", _P), ("in_relu", _I)]
 
 
 class Epilogue(C.Structure):
@@ -47,12 +47,12 @@ _SIGNATURES = {
     "vlnce_bn_finalize_workspace_bytes": (C.c_size_t, [_I, _I]),
     "vlnce_bn_finalize": (_I, [_P, _I, _I, _I, _I, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P,
                                C.c_size_t, _P]),
-    "vlnce_scale_shift_act": (_I, [_P, _P, _P, _I, _P, _P, _L, _I, _I, _P]),
+    "vlnce_scale_shift_act": (_I, [_P, _P, _P, _P, _I, _P, _P, _L, _I, _I, _P]),
     "vlnce_gn_chunks": (_I, [_I]),
     "vlnce_gn_partial": (_I, [_P, _I, _I, _I, _P, _P]),
-    "vlnce_gn_finalize": (_I, [_P, _I, _I, _I, _I, _P, _P, _F, _P, _P, _P, _P, _P]),
-    "vlnce_maxpool3x3s2": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P]),
-    "vlnce_scale_shift_add_act": (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P]),
+    "vlnce_gn_finalize": (_I, [_P, _I, _I, _I, _I, _P, _P, _F, _P, _P, _P, _P, _P, _P]),
+    "vlnce_maxpool3x3s2": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P]),
+    "vlnce_scale_shift_add_act": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P]),
     "vlnce_avgpool2x2": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "vlnce_adaptive_avgpool": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "vlnce_attn_fwd": (_I, [_P, _P, _I, _P, _I, _P, _I, _F, _P, _P, _I, _I, _I, _I, _P]),
@@ -65,6 +65,13 @@ _SIGNATURES = {
     "vlnce_lstm_gates_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "vlnce_mean_rows": (_I, [_P, _P, _I, _I, _I, _P]),
     "vlnce_mask_rows": (_I, [_P, _P, _P, _I, _I, _P]),
+    "vlnce_conv2d_wgrad": (_I, [_P, _P, _P, C.POINTER(ConvDesc), _P]),
+    "vlnce_bn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P, _P, _P, _P, _P]),
+    "vlnce_gn_bwd_workspace_floats": (C.c_size_t, [_I, _I, _I, _I]),
+    "vlnce_gn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
+    "vlnce_maxpool3x3s2_argmax": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "vlnce_maxpool3x3s2_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "vlnce_adaptive_avgpool_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "vlnce_rnn_seq_supported": (_I, [_I, _I]),
     "vlnce_rnn_seq_fwd": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "vlnce_rnn_seq_bwd": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
@@ -125,9 +132,10 @@ class HipLib:
         return self.dll.vlnce_conv2d_tiles_m(C.byref(d)), self.dll.vlnce_conv2d_tile_rows(C.byref(d))
 
     def conv2d_fwd(self, x, w, y, g, in_scale=None, in_shift=None, in_relu=0, scale=None,
-                   shift=None, residual=None, ldr=0, act=0, accumulate=0, stat_partial=None):
+                   shift=None, residual=None, ldr=0, act=0, accumulate=0, stat_partial=None,
+                   in_center=None):
         d = self._desc(g)
-        pro = Prologue(_ptr(in_scale), _ptr(in_shift), int(in_relu))
+        pro = Prologue(_ptr(in_scale), _ptr(in_shift), _ptr(in_center), int(in_relu))
         epi = Epilogue(_ptr(scale), _ptr(shift), _ptr(residual), int(ldr), int(act),
                        int(accumulate), _ptr(stat_partial))
         self._check(self.dll.vlnce_conv2d_fwd(_ptr(x), _ptr(w), _ptr(y), C.byref(d), C.byref(pro),
@@ -157,10 +165,11 @@ class HipLib:
             _ptr(running_mean), _ptr(running_var), _ptr(scale_out), _ptr(shift_out),
             _ptr(mean_out), _ptr(rstd_out), _ptr(workspace), wb, _stream()), "vlnce_bn_finalize")
 
-    def scale_shift_act(self, x, scale, shift, rows_per_sample, residual, y, M, Cc, act):
+    def scale_shift_act(self, x, scale, shift, rows_per_sample, residual, y, M, Cc, act,
+                        center=None):
         self._check(self.dll.vlnce_scale_shift_act(
-            _ptr(x), _ptr(scale), _ptr(shift), rows_per_sample, _ptr(residual), _ptr(y), M, Cc,
-            act, _stream()), "vlnce_scale_shift_act")
+            _ptr(x), _ptr(scale), _ptr(shift), _ptr(center), rows_per_sample, _ptr(residual),
+            _ptr(y), M, Cc, act, _stream()), "vlnce_scale_shift_act")
 
     def gn_chunks(self, HW):
         return self.dll.vlnce_gn_chunks(HW)
@@ -170,21 +179,23 @@ class HipLib:
                     "vlnce_gn_partial")
 
     def gn_finalize(self, partial, Nimg, HW, Cc, groups, gamma, beta, eps, scale_out, shift_out,
-                    mean_out=None, rstd_out=None):
+                    mean_out=None, rstd_out=None, center_out=None):
         self._check(self.dll.vlnce_gn_finalize(
             _ptr(partial), Nimg, HW, Cc, groups, _ptr(gamma), _ptr(beta), eps, _ptr(scale_out),
-            _ptr(shift_out), _ptr(mean_out), _ptr(rstd_out), _stream()), "vlnce_gn_finalize")
+            _ptr(shift_out), _ptr(center_out), _ptr(mean_out), _ptr(rstd_out), _stream()),
+            "vlnce_gn_finalize")
 
     # ---- pools
-    def maxpool3x3s2(self, x, y, N, H, W, Cc, Ho, Wo, in_scale=None, in_shift=None, in_relu=0):
+    def maxpool3x3s2(self, x, y, N, H, W, Cc, Ho, Wo, in_scale=None, in_shift=None, in_relu=0,
+                     in_center=None):
         self._check(self.dll.vlnce_maxpool3x3s2(_ptr(x), _ptr(y), N, H, W, Cc, Ho, Wo,
-                                                _ptr(in_scale), _ptr(in_shift), int(in_relu),
-                                                _stream()), "vlnce_maxpool3x3s2")
+                                                _ptr(in_scale), _ptr(in_shift), _ptr(in_center),
+                                                int(in_relu), _stream()), "vlnce_maxpool3x3s2")
 
-    def scale_shift_add_act(self, x1, s1, t1, x2, s2, t2, y, M, Cc, act):
+    def scale_shift_add_act(self, x1, s1, t1, x2, s2, t2, y, M, Cc, act, c1=None, c2=None):
         self._check(self.dll.vlnce_scale_shift_add_act(
-            _ptr(x1), _ptr(s1), _ptr(t1), _ptr(x2), _ptr(s2), _ptr(t2), _ptr(y), M, Cc, act,
-            _stream()), "vlnce_scale_shift_add_act")
+            _ptr(x1), _ptr(s1), _ptr(t1), _ptr(c1), _ptr(x2), _ptr(s2), _ptr(t2), _ptr(c2),
+            _ptr(y), M, Cc, act, _stream()), "vlnce_scale_shift_add_act")
 
     def avgpool2x2(self, x, y, N, H, W, Cc):
         self._check(self.dll.vlnce_avgpool2x2(_ptr(x), _ptr(y), N, H, W, Cc, _stream()),
@@ -240,6 +251,42 @@ class HipLib:
     def mask_rows(self, x, mask, out, B, H):
         self._check(self.dll.vlnce_mask_rows(_ptr(x), _ptr(mask), _ptr(out), B, H, _stream()),
                     "vlnce_mask_rows")
+
+    # ---- backward of the visual trunks
+    def conv2d_wgrad(self, x, dy, dw, g):
+        d = self._desc(g)
+        self._check(self.dll.vlnce_conv2d_wgrad(_ptr(x), _ptr(dy), _ptr(dw), C.byref(d), _stream()),
+                    "vlnce_conv2d_wgrad")
+
+    def bn_bwd(self, dy, y, x, mean, rstd, gamma, M, Cc, relu, use_batch_stats, dx, dres, dgamma,
+               dbeta):
+        self._check(self.dll.vlnce_bn_bwd(_ptr(dy), _ptr(y), _ptr(x), _ptr(mean), _ptr(rstd),
+                                          _ptr(gamma), M, Cc, int(relu), int(use_batch_stats),
+                                          _ptr(dx), _ptr(dres), _ptr(dgamma), _ptr(dbeta),
+                                          _stream()), "vlnce_bn_bwd")
+
+    def gn_bwd_workspace_floats(self, Nimg, HW, Cc, groups):
+        return int(self.dll.vlnce_gn_bwd_workspace_floats(Nimg, HW, Cc, groups))
+
+    def gn_bwd(self, dy, y, x, mean, rstd, gamma, Nimg, HW, Cc, groups, relu, dx, dres, dgamma,
+               dbeta, workspace):
+        self._check(self.dll.vlnce_gn_bwd(_ptr(dy), _ptr(y), _ptr(x), _ptr(mean), _ptr(rstd),
+                                          _ptr(gamma), Nimg, HW, Cc, groups, int(relu), _ptr(dx),
+                                          _ptr(dres), _ptr(dgamma), _ptr(dbeta), _ptr(workspace),
+                                          _stream()), "vlnce_gn_bwd")
+
+    def maxpool3x3s2_argmax(self, x, y, argmax, N, H, W, Cc, Ho, Wo):
+        self._check(self.dll.vlnce_maxpool3x3s2_argmax(_ptr(x), _ptr(y), _ptr(argmax), N, H, W, Cc,
+                                                       Ho, Wo, _stream()),
+                    "vlnce_maxpool3x3s2_argmax")
+
+    def maxpool3x3s2_bwd(self, dy, argmax, dx, N, H, W, Cc, Ho, Wo):
+        self._check(self.dll.vlnce_maxpool3x3s2_bwd(_ptr(dy), _ptr(argmax), _ptr(dx), N, H, W, Cc,
+                                                    Ho, Wo, _stream()), "vlnce_maxpool3x3s2_bwd")
+
+    def adaptive_avgpool_bwd(self, dy, dx, N, H, W, Cc, OH, OW):
+        self._check(self.dll.vlnce_adaptive_avgpool_bwd(_ptr(dy), _ptr(dx), N, H, W, Cc, OH, OW,
+                                                        _stream()), "vlnce_adaptive_avgpool_bwd")
 
     @staticmethod
     def _parr(ts, n):

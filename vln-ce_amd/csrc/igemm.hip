@@ -29,7 +29,7 @@ constexpr int BK = 32;
 constexpr int LDP = 36;  // LDS row pitch in floats (32 + 4 pad)
 
 enum { A_IM2COL_V4 = 0, A_IM2COL_S = 1, A_TRANS = 2, A_BUF = 3 };
-enum { B_NK_V4 = 0, B_NK_S = 1, B_KN = 2, B_BUF = 3 };
+enum { B_NK_V4 = 0, B_NK_S = 1, B_KN = 2, B_BUF = 3, B_IM2COL = 4 };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int BUF_OOB = (int)0x80000000;  // voffset beyond any buffer: the load returns zeros
@@ -43,6 +43,7 @@ struct IgemmParams {
   int lda, ldb, ldc;
   const float* in_scale;
   const float* in_shift;
+  const float* in_center;  // optional: x' = (x - center) * scale + shift
   int in_relu;
   const float* scale;
   const float* shift;
@@ -192,10 +193,32 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
     }
   }
 
+  // ---- weight-gradient GEMM (B_IM2COL): C[Cout, K] = dY^T[Cout, M] * im2col(X)[M, K].  The
+  // reduction index is the output pixel m; this block's N range [n0, n0+BN) of K = (r, q, ci)
+  // lies inside one filter tap when Cin % BN == 0 (vector path), else elements are decoded
+  // one by one (7x7 stems).  Each thread keeps the (img, ho, wo) of its rows and advances
+  // them by 32 pixels per K-tile.
+  constexpr int WG_TPR = BN / 4;          // threads per reduction row
+  constexpr int WG_KPP = 256 / WG_TPR;    // reduction rows per pass
+  int wg_img[B_ROWS], wg_ho[B_ROWS], wg_wo[B_ROWS];
+  if constexpr (BMODE == B_IM2COL) {
+    const int HoWo = p.Ho * p.Wo;
+#pragma unroll
+    for (int i = 0; i < B_ROWS; ++i) {
+      const int m = kt0 * BK + i * WG_KPP + tid / WG_TPR;
+      wg_img[i] = m / HoWo;
+      const int rem = m - wg_img[i] * HoWo;
+      wg_ho[i] = rem / p.Wo;
+      wg_wo[i] = rem - wg_ho[i] * p.Wo;
+    }
+  }
+
   // The operand transform (x*s+t, ReLU) is applied when the staged registers are written to
   // LDS, i.e. AFTER the MFMAs of the current tile: applying it right after the loads would
   // put the global-load latency in front of the MFMAs instead of behind them.
   f32x4 pro_s, pro_t;       // V4 mode: scale/shift of this thread's 4 channels (current stage)
+  f32x4 pro_c = {0.f, 0.f, 0.f, 0.f};
+  float pro_ec[4] = {0.f, 0.f, 0.f, 0.f};
   unsigned a_okmask = 0;    // bit i (V4) / bit 4*i+e (scalar): element is inside the image
   float pro_es[4], pro_et[4];
 
@@ -206,6 +229,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
       if (p.in_scale != nullptr) {
         pro_s = ldg4(p.in_scale + u_ci + lk4);
         pro_t = ldg4(p.in_shift + u_ci + lk4);
+        if (p.in_center) pro_c = ldg4(p.in_center + u_ci + lk4);
       }
       a_okmask = 0;
 #pragma unroll
@@ -229,6 +253,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
       if (p.in_scale != nullptr && tap_ok) {
         pro_s = ldg4(p.in_scale + k_ci);
         pro_t = ldg4(p.in_shift + k_ci);
+        if (p.in_center) pro_c = ldg4(p.in_center + k_ci);
       }
       a_okmask = 0;
 #pragma unroll
@@ -266,9 +291,11 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
         eq[e] = tap - er[e] * kw;
         pro_es[e] = 1.f;
         pro_et[e] = 0.f;
+        pro_ec[e] = 0.f;
         if (p.in_scale != nullptr && k < p.K) {
           pro_es[e] = p.in_scale[eci[e]];
           pro_et[e] = p.in_shift[eci[e]];
+          if (p.in_center) pro_ec[e] = p.in_center[eci[e]];
         }
       }
       a_okmask = 0;
@@ -348,6 +375,54 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
         }
         b_reg[i] = v;
       }
+    } else if constexpr (BMODE == B_IM2COL) {
+      const int n4 = (tid % WG_TPR) * 4;
+      const bool vec = (p.Cin % BN) == 0;  // whole N tile inside one tap, 16-byte aligned
+      const int n = n0 + n4;
+      int tap = 0, ci = 0;
+      if (vec) {
+        tap = n0 / p.Cin;
+        ci = n - tap * p.Cin;
+      }
+#pragma unroll
+      for (int i = 0; i < B_ROWS; ++i) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        // p.K is the reduction length here (number of output pixels N*Ho*Wo)
+        const bool row_ok = ((long)(wg_img[i] * p.Ho + wg_ho[i]) * p.Wo + wg_wo[i]) < (long)p.K;
+        if (row_ok) {
+          if (vec) {
+            const int r = tap / p.KW, q = tap - r * p.KW;
+            const int hi = wg_ho[i] * p.stride - p.pad + r;
+            const int wi = wg_wo[i] * p.stride - p.pad + q;
+            if (n < p.N && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
+              v = ldg4(p.B + (((long)wg_img[i] * p.H + hi) * p.W + wi) * p.ldb + ci);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int ne = n + e;
+              if (ne < p.N) {
+                const int tp = ne / p.Cin;
+                const int ce = ne - tp * p.Cin;
+                const int r = tp / p.KW, q = tp - r * p.KW;
+                const int hi = wg_ho[i] * p.stride - p.pad + r;
+                const int wi = wg_wo[i] * p.stride - p.pad + q;
+                if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
+                  v[e] = p.B[(((long)wg_img[i] * p.H + hi) * p.W + wi) * p.ldb + ce];
+              }
+            }
+          }
+        }
+        b_reg[i] = v;
+        // advance this row by one K-tile (32 output pixels)
+        wg_wo[i] += BK;
+        while (wg_wo[i] >= p.Wo) {
+          wg_wo[i] -= p.Wo;
+          if (++wg_ho[i] == p.Ho) {
+            wg_ho[i] = 0;
+            ++wg_img[i];
+          }
+        }
+      }
     } else {  // B_KN: B[k][n] at B[k*ldb + n]
       constexpr int TPR = BN / 4;
       constexpr int KPP = 256 / TPR;
@@ -397,7 +472,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
         for (int i = 0; i < A_ROWS; ++i) {
           f32x4 v = a_reg[i];
           if constexpr (AMODE == A_IM2COL_V4 || AMODE == A_BUF) {
-            v = v * pro_s + pro_t;
+            v = (v - pro_c) * pro_s + pro_t;
             if (p.in_relu) {
               v.x = fmaxf(v.x, 0.f);
               v.y = fmaxf(v.y, 0.f);
@@ -408,7 +483,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
           } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              float x = v[e] * pro_es[e] + pro_et[e];
+              float x = (v[e] - pro_ec[e]) * pro_es[e] + pro_et[e];
               if (p.in_relu) x = fmaxf(x, 0.f);
               v[e] = ((a_okmask >> (4 * i + e)) & 1u) ? x : 0.f;
             }
@@ -420,7 +495,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
       for (int i = 0; i < A_ROWS; ++i)
         *reinterpret_cast<f32x4*>(As + (i * 32 + lrow) * LDP + lk4) = a_reg[i];
     }
-    if constexpr (BMODE == B_KN) {
+    if constexpr (BMODE == B_KN || BMODE == B_IM2COL) {
       constexpr int TPR = BN / 4;
       constexpr int KPP = 256 / TPR;
       const int kn = tid / TPR;
@@ -782,12 +857,14 @@ extern "C" int vlnce_conv2d_fwd(const float* x, const float* w, float* y, const 
   p.ldc = d->ldy ? d->ldy : d->Cout;
   p.in_scale = pro ? pro->in_scale : nullptr;
   p.in_shift = pro ? pro->in_shift : nullptr;
+  p.in_center = pro ? pro->in_center : nullptr;
   p.in_relu = pro ? pro->in_relu : 0;
   VLNCE_CHECK_ARG((p.in_scale == nullptr) == (p.in_shift == nullptr),
                   "conv2d_fwd: in_scale and in_shift must come together");
   fill_epilogue(p, epi);
   const bool v4 = (d->Cin % 4 == 0) && (p.lda % 4 == 0) && aligned16(x) && aligned16(w) &&
-                  (!p.in_scale || (aligned16(p.in_scale) && aligned16(p.in_shift)));
+                  (!p.in_scale || (aligned16(p.in_scale) && aligned16(p.in_shift))) &&
+                  (!p.in_center || aligned16(p.in_center));
   p.splitk = 1;
   p.a_bytes = (((long)d->N * d->H * d->W - 1) * p.lda + d->Cin) * 4;
   p.b_bytes = (long)d->Cout * p.K * 4;
@@ -879,4 +956,46 @@ extern "C" int vlnce_gemm(const float* A, int lda, int transA, const float* B, i
     VLNCE_CHECK_LAUNCH("gemm bias/act");
   }
   return 0;
+}
+
+// dW[Cout, KH, KW, Cin] = sum over output pixels of dY[m, co] * im2col(X)[m, (r,q,ci)]
+extern "C" int vlnce_conv2d_wgrad(const float* x, const float* dy, float* dw_ohwi,
+                                  const vlnce_conv_desc* d, vlnce_stream_t stream) {
+  VLNCE_CHECK_ARG(x && dy && dw_ohwi && d, "conv2d_wgrad: null argument");
+  const long Mrows = (long)d->N * d->Ho * d->Wo;
+  VLNCE_CHECK_ARG(Mrows > 0 && Mrows < 0x7fffffffL, "conv2d_wgrad: bad shape");
+  IgemmParams p{};
+  p.A = dy;
+  p.B = x;
+  p.C = dw_ohwi;
+  p.M = d->Cout;
+  p.N = d->KH * d->KW * d->Cin;
+  p.K = (int)Mrows;
+  p.H = d->H;
+  p.W = d->W;
+  p.Cin = d->Cin;
+  p.KH = d->KH;
+  p.KW = d->KW;
+  p.stride = d->stride;
+  p.pad = d->pad;
+  p.Ho = d->Ho;
+  p.Wo = d->Wo;
+  p.lda = d->ldy ? d->ldy : d->Cout;
+  p.ldb = d->ldx ? d->ldx : d->Cin;
+  p.ldc = p.N;
+  VLNCE_CHECK_ARG(aligned16(dy) && aligned16(x) && aligned16(dw_ohwi),
+                  "conv2d_wgrad: operands must be 16-byte aligned");
+  fill_epilogue(p, nullptr);
+  const long tiles = (long)ceil_div(p.M, 64) * ceil_div(p.N, 64);
+  const int KT = ceil_div(p.K, BK);
+  long sk = (1024 + tiles - 1) / tiles;
+  if (sk > KT / 4) sk = KT / 4;
+  if (sk > 512) sk = 512;
+  p.splitk = sk < 2 ? 1 : (int)sk;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (p.splitk > 1) {
+    hipError_t e = hipMemsetAsync(dw_ohwi, 0, (size_t)p.M * p.N * sizeof(float), s);
+    VLNCE_CHECK_ARG(e == hipSuccess, "conv2d_wgrad: memset failed: %s", hipGetErrorString(e));
+  }
+  return launch<64, 64, 2, 2, A_TRANS, B_IM2COL>(p, s);
 }

@@ -100,8 +100,8 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(
 template <bool VEC>
 __global__ __launch_bounds__(256) void scale_shift_act_kernel(
     const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
-    int rows_per_sample, const float* __restrict__ residual, float* __restrict__ y, long M, int C,
-    int act) {
+    const float* __restrict__ center, int rows_per_sample, const float* __restrict__ residual,
+    float* __restrict__ y, long M, int C, int act) {
   if constexpr (VEC) {
     const int C4 = C >> 2;
     const long total = M * C4;
@@ -113,6 +113,7 @@ __global__ __launch_bounds__(256) void scale_shift_act_kernel(
       f32x4 v = *reinterpret_cast<const f32x4*>(x + i * 4);
       const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + so);
       const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + so);
+      if (center) v -= *reinterpret_cast<const f32x4*>(center + so);
       v = v * sc + sh;
       if (residual) v += *reinterpret_cast<const f32x4*>(residual + i * 4);
       v.x = apply_act(v.x, act);
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(256) void scale_shift_act_kernel(
       const long row = i / C;
       const int c = (int)(i - row * C);
       const long so = rows_per_sample > 0 ? (row / rows_per_sample) * C + c : c;
-      float v = x[i] * scale[so] + shift[so];
+      float v = (center ? x[i] - center[so] : x[i]) * scale[so] + shift[so];
       if (residual) v += residual[i];
       y[i] = apply_act(v, act);
     }
@@ -139,18 +140,20 @@ __global__ __launch_bounds__(256) void scale_shift_act_kernel(
 // (conv + BatchNorm) downsample -- both raw conv outputs are normalised in one pass
 __global__ __launch_bounds__(256) void scale_shift_add_act_kernel(
     const float* __restrict__ x1, const float* __restrict__ s1, const float* __restrict__ t1,
-    const float* __restrict__ x2, const float* __restrict__ s2, const float* __restrict__ t2,
-    float* __restrict__ y, long M, int C, int act) {
+    const float* __restrict__ c1, const float* __restrict__ x2, const float* __restrict__ s2,
+    const float* __restrict__ t2, const float* __restrict__ c2, float* __restrict__ y, long M,
+    int C, int act) {
   const int C4 = C >> 2;
   const long total = M * C4;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (long)gridDim.x * blockDim.x) {
     const int c = (int)(i % C4) * 4;
-    f32x4 v = *reinterpret_cast<const f32x4*>(x1 + i * 4) *
-                  *reinterpret_cast<const f32x4*>(s1 + c) +
-              *reinterpret_cast<const f32x4*>(t1 + c);
-    v += *reinterpret_cast<const f32x4*>(x2 + i * 4) * *reinterpret_cast<const f32x4*>(s2 + c) +
-         *reinterpret_cast<const f32x4*>(t2 + c);
+    f32x4 a = *reinterpret_cast<const f32x4*>(x1 + i * 4);
+    f32x4 b = *reinterpret_cast<const f32x4*>(x2 + i * 4);
+    if (c1) a -= *reinterpret_cast<const f32x4*>(c1 + c);
+    if (c2) b -= *reinterpret_cast<const f32x4*>(c2 + c);
+    f32x4 v = a * *reinterpret_cast<const f32x4*>(s1 + c) + *reinterpret_cast<const f32x4*>(t1 + c);
+    v += b * *reinterpret_cast<const f32x4*>(s2 + c) + *reinterpret_cast<const f32x4*>(t2 + c);
     v.x = apply_act(v.x, act);
     v.y = apply_act(v.y, act);
     v.z = apply_act(v.z, act);
@@ -221,8 +224,8 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict
 __global__ __launch_bounds__(256) void gn_finalize_kernel(
     const float* __restrict__ partial, int Nimg, int HW, int C, int groups, int chunks,
     const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-    float* __restrict__ scale_out, float* __restrict__ shift_out, float* mean_out,
-    float* rstd_out) {
+    float* __restrict__ scale_out, float* __restrict__ shift_out, float* center_out,
+    float* mean_out, float* rstd_out) {
   const int lane = threadIdx.x & 63;
   const int pair = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (pair >= Nimg * groups) return;
@@ -252,7 +255,12 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(
     const int c = g * cpg + i;
     const float sc = (gamma ? gamma[c] : 1.f) * rstd;
     scale_out[(long)n * C + c] = sc;
-    shift_out[(long)n * C + c] = (beta ? beta[c] : 0.f) - (float)mean * sc;
+    if (center_out) {  // y = (x - center) * scale + shift: the reference's own arithmetic
+      center_out[(long)n * C + c] = (float)mean;
+      shift_out[(long)n * C + c] = beta ? beta[c] : 0.f;
+    } else {
+      shift_out[(long)n * C + c] = (beta ? beta[c] : 0.f) - (float)mean * sc;
+    }
   }
   if (lane == 0) {
     if (mean_out) mean_out[pair] = (float)mean;
@@ -301,37 +309,40 @@ extern "C" int vlnce_bn_finalize(const float* stat_partial, int tiles_m, int til
 }
 
 extern "C" int vlnce_scale_shift_act(const float* x, const float* scale, const float* shift,
-                                     int rows_per_sample, const float* residual, float* y, long M,
-                                     int C, int act, vlnce_stream_t stream) {
+                                     const float* center, int rows_per_sample,
+                                     const float* residual, float* y, long M, int C, int act,
+                                     vlnce_stream_t stream) {
   VLNCE_CHECK_ARG(x && scale && shift && y, "scale_shift_act: null argument");
   VLNCE_CHECK_ARG(M > 0 && C > 0, "scale_shift_act: bad shape");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   const bool vec = (C % 4 == 0) && al(x) && al(y) && al(scale) && al(shift) &&
-                   (!residual || al(residual));
+                   (!residual || al(residual)) && (!center || al(center));
   const long work = vec ? M * (C / 4) : M * (long)C;
   const int grid = (int)(work / 256 + 1 < 8192 ? work / 256 + 1 : 8192);
   if (vec)
     hipLaunchKernelGGL(scale_shift_act_kernel<true>, dim3(grid), dim3(256), 0, s, x, scale, shift,
-                       rows_per_sample, residual, y, M, C, act);
+                       center, rows_per_sample, residual, y, M, C, act);
   else
     hipLaunchKernelGGL(scale_shift_act_kernel<false>, dim3(grid), dim3(256), 0, s, x, scale, shift,
-                       rows_per_sample, residual, y, M, C, act);
+                       center, rows_per_sample, residual, y, M, C, act);
   VLNCE_CHECK_LAUNCH("scale_shift_act");
   return 0;
 }
 
 extern "C" int vlnce_scale_shift_add_act(const float* x1, const float* scale1, const float* shift1,
-                                         const float* x2, const float* scale2, const float* shift2,
-                                         float* y, long M, int C, int act, vlnce_stream_t stream) {
+                                         const float* center1, const float* x2,
+                                         const float* scale2, const float* shift2,
+                                         const float* center2, float* y, long M, int C, int act,
+                                         vlnce_stream_t stream) {
   VLNCE_CHECK_ARG(x1 && scale1 && shift1 && x2 && scale2 && shift2 && y,
                   "scale_shift_add_act: null argument");
   VLNCE_CHECK_ARG(M > 0 && C > 0 && C % 4 == 0, "scale_shift_add_act: C must be a multiple of 4");
   const long work = M * (C / 4);
   const int grid = (int)(work / 256 + 1 < 8192 ? work / 256 + 1 : 8192);
   hipLaunchKernelGGL(scale_shift_add_act_kernel, dim3(grid), dim3(256), 0,
-                     reinterpret_cast<hipStream_t>(stream), x1, scale1, shift1, x2, scale2, shift2,
-                     y, M, C, act);
+                     reinterpret_cast<hipStream_t>(stream), x1, scale1, shift1, center1, x2, scale2,
+                     shift2, center2, y, M, C, act);
   VLNCE_CHECK_LAUNCH("scale_shift_add_act");
   return 0;
 }
@@ -351,14 +362,14 @@ extern "C" int vlnce_gn_partial(const float* x, int Nimg, int HW, int C, float* 
 
 extern "C" int vlnce_gn_finalize(const float* partial, int Nimg, int HW, int C, int groups,
                                  const float* gamma, const float* beta, float eps,
-                                 float* scale_out, float* shift_out, float* mean_out,
-                                 float* rstd_out, vlnce_stream_t stream) {
+                                 float* scale_out, float* shift_out, float* center_out,
+                                 float* mean_out, float* rstd_out, vlnce_stream_t stream) {
   VLNCE_CHECK_ARG(partial && scale_out && shift_out, "gn_finalize: null argument");
   VLNCE_CHECK_ARG(groups > 0 && C % groups == 0, "gn_finalize: C %% groups != 0");
   const int chunks = ceil_div(HW, GN_CHUNK);
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(ceil_div((long)Nimg * groups, 4)), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), partial, Nimg, HW, C, groups, chunks,
-                     gamma, beta, eps, scale_out, shift_out, mean_out, rstd_out);
+                     gamma, beta, eps, scale_out, shift_out, center_out, mean_out, rstd_out);
   VLNCE_CHECK_LAUNCH("gn_finalize");
   return 0;
 }

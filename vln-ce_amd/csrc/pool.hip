@@ -9,6 +9,7 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const float* __restri
                                                            int W, int C, int Ho, int Wo,
                                                            const float* __restrict__ in_scale,
                                                            const float* __restrict__ in_shift,
+                                                           const float* __restrict__ in_center,
                                                            int in_relu) {
   constexpr int V = VEC ? 4 : 1;
   const int Cv = C / V;
@@ -21,11 +22,12 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const float* __restri
     t /= Wo;
     const int ho = (int)(t % Ho);
     const int n = (int)(t / Ho);
-    float m[V], sc[V], sh[V];
+    float m[V], sc[V], sh[V], ce[V];
     for (int e = 0; e < V; ++e) {
       m[e] = -INFINITY;
       sc[e] = in_scale ? in_scale[cv * V + e] : 1.f;
       sh[e] = in_scale ? in_shift[cv * V + e] : 0.f;
+      ce[e] = in_center ? in_center[cv * V + e] : 0.f;
     }
     for (int r = 0; r < 3; ++r) {
       const int hi = ho * 2 - 1 + r;
@@ -37,12 +39,12 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const float* __restri
         if constexpr (VEC) {
           const f32x4 v = *reinterpret_cast<const f32x4*>(src);
           for (int e = 0; e < 4; ++e) {
-            float t = v[e] * sc[e] + sh[e];
+            float t = (v[e] - ce[e]) * sc[e] + sh[e];
             if (in_relu) t = fmaxf(t, 0.f);
             m[e] = fmaxf(m[e], t);
           }
         } else {
-          float t = src[0] * sc[0] + sh[0];
+          float t = (src[0] - ce[0]) * sc[0] + sh[0];
           if (in_relu) t = fmaxf(t, 0.f);
           m[0] = fmaxf(m[0], t);
         }
@@ -125,7 +127,7 @@ inline int grid_for(long work) {
 
 extern "C" int vlnce_maxpool3x3s2(const float* x, float* y, int N, int H, int W, int C, int Ho,
                                   int Wo, const float* in_scale, const float* in_shift,
-                                  int in_relu, vlnce_stream_t stream) {
+                                  const float* in_center, int in_relu, vlnce_stream_t stream) {
   VLNCE_CHECK_ARG(x && y, "maxpool: null argument");
   VLNCE_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr),
                   "maxpool: in_scale and in_shift come together");
@@ -134,10 +136,10 @@ extern "C" int vlnce_maxpool3x3s2(const float* x, float* y, int N, int H, int W,
   const bool vec = (C % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0;
   if (vec)
     hipLaunchKernelGGL(maxpool3x3s2_kernel<true>, dim3(grid_for((long)N * Ho * Wo * C / 4)),
-                       dim3(256), 0, s, x, y, N, H, W, C, Ho, Wo, in_scale, in_shift, in_relu);
+                       dim3(256), 0, s, x, y, N, H, W, C, Ho, Wo, in_scale, in_shift, in_center, in_relu);
   else
     hipLaunchKernelGGL(maxpool3x3s2_kernel<false>, dim3(grid_for((long)N * Ho * Wo * C)), dim3(256),
-                       0, s, x, y, N, H, W, C, Ho, Wo, in_scale, in_shift, in_relu);
+                       0, s, x, y, N, H, W, C, Ho, Wo, in_scale, in_shift, in_center, in_relu);
   VLNCE_CHECK_LAUNCH("maxpool3x3s2");
   return 0;
 }

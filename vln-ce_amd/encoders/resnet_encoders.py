@@ -24,6 +24,7 @@ import torch.nn as nn
 
 from .. import ops
 from ..config import Box, Dict
+from . import trunk_backward as tb
 
 
 # ------------------------------------------------------------------ helpers
@@ -222,14 +223,15 @@ class HipResNetTrunk(nn.Sequential):
     def _conv_stats(self, x, conv, bn, touched, prologue=None, in_relu=False):
         pro = {}
         if prologue is not None:
-            pro = dict(in_scale=prologue[0], in_shift=prologue[1], in_relu=in_relu)
+            pro = dict(in_scale=prologue[0], in_shift=prologue[1], in_relu=in_relu,
+                       in_center=prologue[2] if len(prologue) > 2 else None)
         y, stats = ops.conv2d_nhwc(x, self._cache.conv(conv), conv.stride[0], conv.padding[0],
                                    want_stats=True, **pro)
         assert bn.momentum is not None
-        scale, shift = ops.bn_finalize(stats, y.numel() // y.size(-1), bn.weight, bn.bias, bn.eps,
-                                       bn.momentum, bn.running_mean, bn.running_var)
+        pend = ops.bn_finalize(stats, y.numel() // y.size(-1), bn.weight, bn.bias, bn.eps,
+                               bn.momentum, bn.running_mean, bn.running_var)
         touched.append(bn.num_batches_tracked)
-        return y, (scale, shift)
+        return y, pend  # (scale, shift, center)
 
     def _block_train(self, x, blk, touched):
         st = blk.stages()
@@ -239,8 +241,9 @@ class HipResNetTrunk(nn.Sequential):
         if blk.downsample is not None:
             rd, pd = self._conv_stats(x, blk.downsample[0], blk.downsample[1], touched)
             return ops.scale_shift_add_act(raw, pend[0], pend[1], rd, pd[0], pd[1],
-                                           act=ops.ACT_RELU, out=raw)
-        return ops.scale_shift_act(raw, pend[0], pend[1], residual=x, act=ops.ACT_RELU, out=raw)
+                                           act=ops.ACT_RELU, out=raw, c1=pend[2], c2=pd[2])
+        return ops.scale_shift_act(raw, pend[0], pend[1], center=pend[2], residual=x,
+                                   act=ops.ACT_RELU, out=raw)
 
     def _block_eval(self, x, blk):
         identity = x
@@ -254,8 +257,10 @@ class HipResNetTrunk(nn.Sequential):
     def forward(self, x_nhwc_raw):
         """x: [B,H,W,3] pixel values 0..255 (channels-last as the simulator
         delivers them); returns logical NCHW features."""
-        _require_frozen(self, "TorchVisionResNet.cnn")
         x = ops._f32c(x_nhwc_raw)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            # trainable encoder: layer-by-layer forward that records what backward needs
+            return tb.TrunkFn.apply(self, x, *self.trainable_params()).permute(0, 3, 1, 2)
         modes = tuple(m.training for m in self._norms)
         if any(modes) and not all(modes):
             raise NotImplementedError("mixed train/eval BatchNorm modes inside one trunk")
@@ -275,7 +280,7 @@ class HipResNetTrunk(nn.Sequential):
             if train:
                 raw, pend = self._conv_stats(x, kids[0], kids[1], touched,
                                              prologue=self.input_scale)
-                x = ops.maxpool3x3s2(raw, pend[0], pend[1], in_relu=True)
+                x = ops.maxpool3x3s2(raw, pend[0], pend[1], in_relu=True, in_center=pend[2])
             else:
                 x = self._conv_bn_eval(x, kids[0], kids[1], True, prologue=self.input_scale)
                 x = ops.maxpool3x3s2(x)
@@ -287,6 +292,102 @@ class HipResNetTrunk(nn.Sequential):
             if touched:
                 torch._foreach_add_(touched, 1)
         return x
+
+
+    # ------------------------------------------------------------------ trainable mode
+    def trainable_params(self):
+        return [p for p in self.parameters() if p.requires_grad]
+
+    def _rec_conv_bn(self, x, conv, bn, relu, residual, tape, touched):
+        w = self._cache.conv(conv)
+        stride, pad = conv.stride[0], conv.padding[0]
+        if bn.training:
+            raw, stats = ops.conv2d_nhwc(x, w, stride, pad, want_stats=True)
+        else:
+            raw, stats = ops.conv2d_nhwc(x, w, stride, pad), None
+        y, sv = tb.bn_forward(raw, bn, relu, residual, stats, touched)
+        tape.append(("conv_bn", x, conv, bn, w, sv))
+        return y
+
+    def run_recording(self, x):
+        kids = list(self.children())
+        tape, touched = [], []
+        sc, sh = self.input_scale
+        x = ops.scale_shift_act(x, sc, sh)  # /255 (+mean/std) materialised: wgrad reads it
+        x = self._rec_conv_bn(x, kids[0], kids[1], True, None, tape, touched)
+        x, saved = tb.maxpool_forward(x)
+        tape.append(("maxpool", saved))
+        for stage in kids[4:8]:
+            for blk in stage:
+                block_in = x
+                identity = x
+                tape.append(("block_begin", blk.downsample is not None))
+                if blk.downsample is not None:
+                    identity = self._rec_conv_bn(block_in, blk.downsample[0], blk.downsample[1],
+                                                 False, None, tape, touched)
+                tape.append(("main_begin",))
+                st = blk.stages()
+                cur = block_in
+                for conv, bn in st[:-1]:
+                    cur = self._rec_conv_bn(cur, conv, bn, True, None, tape, touched)
+                x = self._rec_conv_bn(cur, st[-1][0], st[-1][1], True, identity, tape, touched)
+                tape.append(("block_end",))
+        for pool in kids[8:]:
+            tape.append(("avgpool", tuple(x.shape), pool.out_hw))
+            x = ops.adaptive_avgpool(x, *pool.out_hw)
+        if touched:
+            torch._foreach_add_(touched, 1)
+        if any(m.training for m in self._norms):
+            self._bn_gen += 1
+        return x, tape
+
+    def backward_from_tape(self, tape, dout):
+        """Replays the tape in reverse.  Block structure on the tape:
+        block_begin, [downsample conv_bn], main_begin, conv_bn*, block_end."""
+        grads = {}
+
+        def conv_bn_back(entry, dy, need_dx=True):
+            _, x_in, conv, bn, w, sv = entry
+            draw, dres, dg, db = tb.bn_backward(dy, sv)
+            dx, dw = tb.conv_backward(x_in, w, draw, conv.stride[0], conv.padding[0], need_dx)
+            for prm, g in ((conv.weight, dw), (bn.weight, dg), (bn.bias, db)):
+                if prm.requires_grad:
+                    grads[id(prm)] = g
+            return dx, dres
+
+        i = len(tape) - 1
+        d = dout
+        while i >= 0:
+            kind = tape[i][0]
+            if kind == "avgpool":
+                d = tb.avgpool_backward(d, tape[i][1], tape[i][2])
+                i -= 1
+            elif kind == "block_end":
+                # main path convs back to main_begin
+                i -= 1
+                d_main, d_skip = conv_bn_back(tape[i], d)  # last conv: residual gradient
+                i -= 1
+                while tape[i][0] != "main_begin":
+                    d_main, _ = conv_bn_back(tape[i], d_main)
+                    i -= 1
+                i -= 1  # past main_begin
+                if tape[i][0] == "conv_bn":  # downsample branch
+                    d_ds, _ = conv_bn_back(tape[i], d_skip)
+                    d = d_main + d_ds
+                    i -= 1
+                else:
+                    d = d_main + d_skip
+                assert tape[i][0] == "block_begin"
+                i -= 1
+            elif kind == "maxpool":
+                d = tb.maxpool_backward(d, tape[i][1])
+                i -= 1
+            elif kind == "conv_bn":  # the stem: its input is the image, no data gradient
+                conv_bn_back(tape[i], d, need_dx=False)
+                i -= 1
+            else:
+                raise AssertionError(kind)
+        return grads
 
 
 class TorchVisionResNet(nn.Module):
@@ -472,8 +573,9 @@ class HipResNetEncoder(nn.Module):
         return x
 
     def forward(self, observations):
-        _require_frozen(self, "VlnResnetDepthEncoder.visual_encoder")
         x = ops._f32c(observations["depth"])  # [B,H,W,1] is already channels-last
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            return tb.TrunkFn.apply(self, x, *self.trainable_params()).permute(0, 3, 1, 2)
         key = (tuple(x.shape), tuple(p._version for p in self.parameters()))
         return self._graphs(x, key).permute(0, 3, 1, 2)
 
@@ -491,6 +593,99 @@ class HipResNetEncoder(nn.Module):
                     x = self._run_convs(x, blk.convs, identity)
             x = self._conv_gn(x, self.compression[0], self.compression[1], True)
         return x
+
+
+# ---- trainable mode of HipResNetEncoder (methods attached below the class for readability)
+def _depth_trainable_params(self):
+    return [p for p in self.parameters() if p.requires_grad]
+
+
+def _depth_rec_conv_gn(self, x, conv, gn, relu, residual, tape):
+    w = self._cache.conv(conv)
+    raw = ops.conv2d_nhwc(x, w, conv.stride[0], conv.padding[0])
+    y, sv = tb.gn_forward(raw, gn, relu, residual)
+    tape.append(("conv_gn", x, conv, gn, w, sv))
+    return y
+
+
+def _depth_run_recording(self, x):
+    tape = []
+    x = ops.avgpool2x2(x)
+    bb = self.backbone
+    x = self._rec_conv_gn(x, bb.conv1[0], bb.conv1[1], True, None, tape)
+    x, saved = tb.maxpool_forward(x)
+    tape.append(("maxpool", saved))
+    for stage in (bb.layer1, bb.layer2, bb.layer3, bb.layer4):
+        for blk in stage:
+            block_in, identity = x, x
+            tape.append(("block_begin",))
+            if blk.downsample is not None:
+                identity = self._rec_conv_gn(block_in, blk.downsample[0], blk.downsample[1], False,
+                                             None, tape)
+            tape.append(("main_begin",))
+            mods, pairs, i = list(blk.convs), [], 0
+            while i < len(mods):
+                relu = i + 2 < len(mods) and isinstance(mods[i + 2], nn.ReLU)
+                pairs.append((mods[i], mods[i + 1]))
+                i += 3 if relu else 2
+            cur = block_in
+            for conv, gn in pairs[:-1]:
+                cur = self._rec_conv_gn(cur, conv, gn, True, None, tape)
+            x = self._rec_conv_gn(cur, pairs[-1][0], pairs[-1][1], True, identity, tape)
+            tape.append(("block_end",))
+    x = self._rec_conv_gn(x, self.compression[0], self.compression[1], True, None, tape)
+    return x, tape
+
+
+def _depth_backward_from_tape(self, tape, dout):
+    grads = {}
+
+    def back(entry, dy, need_dx=True):
+        _, x_in, conv, gn, w, sv = entry
+        draw, dres, dg, db = tb.gn_backward(dy, sv)
+        dx, dw = tb.conv_backward(x_in, w, draw, conv.stride[0], conv.padding[0], need_dx)
+        for prm, g in ((conv.weight, dw), (gn.weight, dg), (gn.bias, db)):
+            if prm.requires_grad:
+                grads[id(prm)] = g
+        return dx, dres
+
+    i = len(tape) - 1
+    d = dout
+    while i >= 0:
+        kind = tape[i][0]
+        if kind == "block_end":
+            i -= 1
+            d_main, d_skip = back(tape[i], d)
+            i -= 1
+            while tape[i][0] != "main_begin":
+                d_main, _ = back(tape[i], d_main)
+                i -= 1
+            i -= 1
+            if tape[i][0] == "conv_gn":
+                d_ds, _ = back(tape[i], d_skip)
+                d = d_main + d_ds
+                i -= 1
+            else:
+                d = d_main + d_skip
+            assert tape[i][0] == "block_begin"
+            i -= 1
+        elif kind == "maxpool":
+            d = tb.maxpool_backward(d, tape[i][1])
+            i -= 1
+        elif kind == "conv_gn":
+            # compression conv (has a data gradient) or the stem (input is the depth image)
+            is_stem = i == 0
+            d, _ = back(tape[i], d, need_dx=not is_stem)
+            i -= 1
+        else:
+            raise AssertionError(kind)
+    return grads
+
+
+HipResNetEncoder.trainable_params = _depth_trainable_params
+HipResNetEncoder._rec_conv_gn = _depth_rec_conv_gn
+HipResNetEncoder.run_recording = _depth_run_recording
+HipResNetEncoder.backward_from_tape = _depth_backward_from_tape
 
 
 def single_frame_box_shape(box):

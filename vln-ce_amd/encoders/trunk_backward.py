@@ -1,0 +1,200 @@
+"""Autograd for the visual trunks when MODEL.{RGB,DEPTH}_ENCODER.trainable=True.
+
+The frozen (default) trunks run a fused forward-only plan (resnet_encoders.py).
+With trainable encoders the trunk runs layer by layer, keeps the raw conv
+outputs and the normalised activations, and this module's `TrunkFn` replays the
+layers in reverse on the hand-written backward kernels:
+
+  conv  : data gradient  = vlnce_conv2d_fwd with the flipped/transposed weights
+                           (stride-2 3x3: zero-inserted dY; stride-2 1x1: strided scatter)
+          weight gradient = vlnce_conv2d_wgrad (dY^T x im2col(X), split-K over pixels)
+  BatchNorm / GroupNorm (+ReLU, +residual) : vlnce_bn_bwd / vlnce_gn_bwd
+  max-pool (arg-max tap saved in forward), adaptive average pool.
+"""
+import torch
+from torch.autograd import Function
+
+from .. import ops
+
+
+def L():
+    return ops.L()
+
+
+# ------------------------------------------------------------------ layer primitives
+def conv_raw(x, w_ohwi, stride, pad):
+    return ops.conv2d_nhwc(x, w_ohwi, stride, pad)
+
+
+def conv_backward(x, w_ohwi, dy, stride, pad, need_dx):
+    """returns (dx | None, dW in OIHW)."""
+    lib = L()
+    g = ops.conv_geometry(x, w_ohwi, stride, pad)
+    Cout, KH, KW, Cin = w_ohwi.shape
+    dw = torch.empty_like(w_ohwi)
+    dy = dy.contiguous()
+    lib.conv2d_wgrad(x, dy, dw, g)
+    dw_oihw = dw.permute(0, 3, 1, 2).contiguous()
+    if not need_dx:
+        return None, dw_oihw
+    N, H, W, _ = x.shape
+    # flipped taps, in/out channels swapped: [Cin, KH, KW, Cout]
+    wt = w_ohwi.flip(1, 2).permute(3, 1, 2, 0).contiguous()
+    if stride == 1:
+        dx = ops.conv2d_nhwc(dy, wt, 1, KH - 1 - pad)
+    elif KH == 1:
+        # 1x1 / stride s: only the sampled pixels receive gradient
+        small = ops.conv2d_nhwc(dy, wt, 1, 0)
+        dx = torch.zeros((N, H, W, Cin), device=x.device, dtype=torch.float32)
+        dx[:, ::stride, ::stride] = small
+    else:
+        # general stride: dY zero-inserted on the stride grid, then a stride-1 correlation
+        # with the flipped taps and padding KH-1-pad lands exactly on the input pixels
+        Hu, Wu = H + 2 * pad - KH + 1, W + 2 * pad - KW + 1
+        up = torch.zeros((N, Hu, Wu, Cout), device=x.device, dtype=torch.float32)
+        up[:, ::stride, ::stride] = dy
+        dx = ops.conv2d_nhwc(up, wt, 1, KH - 1 - pad)
+    return dx, dw_oihw
+
+
+class BNSaved:
+    __slots__ = ("raw", "y", "mean", "rstd", "gamma", "relu", "batch_stats", "has_res")
+
+
+def bn_forward(raw, bn, relu, residual, stats, touched):
+    """normalise+activate the raw conv output, keeping what backward needs."""
+    lib = L()
+    Cc = raw.size(-1)
+    M = raw.numel() // Cc
+    dev = raw.device
+    sv = BNSaved()
+    sv.raw, sv.relu, sv.has_res, sv.gamma = raw, relu, residual is not None, bn.weight
+    scale = torch.empty(Cc, device=dev, dtype=torch.float32)
+    shift = torch.empty_like(scale)
+    sv.mean = torch.empty_like(scale)
+    sv.rstd = torch.empty_like(scale)
+    if bn.training:
+        partial, tiles_m, tile_rows = stats
+        wb = lib.bn_finalize_workspace_bytes(tiles_m, Cc)
+        ws = torch.empty(wb // 8, device=dev, dtype=torch.float64) if wb else None
+        lib.bn_finalize(partial, tiles_m, tile_rows, M, Cc, bn.weight, bn.bias, float(bn.eps),
+                        float(bn.momentum), bn.running_mean, bn.running_var, scale, shift,
+                        sv.mean, sv.rstd, workspace=ws)
+        touched.append(bn.num_batches_tracked)
+        sv.batch_stats = True
+        # the reference's arithmetic: (x - mean) * (gamma*rstd) + beta
+        sv.y = ops.scale_shift_act(raw, scale, bn.bias.detach(), center=sv.mean,
+                                   residual=residual,
+                                   act=ops.ACT_RELU if relu else ops.ACT_NONE)
+        return sv.y, sv
+    else:
+        sv.mean.copy_(bn.running_mean)
+        sv.rstd.copy_(torch.rsqrt(bn.running_var + bn.eps))
+        scale = (bn.weight.detach() * sv.rstd).contiguous()
+        shift = (bn.bias.detach() - sv.mean * scale).contiguous()
+        sv.batch_stats = False
+    sv.y = ops.scale_shift_act(raw, scale, shift, residual=residual,
+                               act=ops.ACT_RELU if relu else ops.ACT_NONE)
+    return sv.y, sv
+
+
+def bn_backward(dy, sv):
+    """returns (d raw, d residual | None, dgamma, dbeta)."""
+    Cc = sv.raw.size(-1)
+    M = sv.raw.numel() // Cc
+    dev = sv.raw.device
+    dx = torch.empty_like(sv.raw)
+    dres = torch.empty_like(sv.raw) if sv.has_res else None
+    dg = torch.empty(Cc, device=dev, dtype=torch.float32)
+    db = torch.empty_like(dg)
+    L().bn_bwd(dy.contiguous(), sv.y, sv.raw, sv.mean, sv.rstd, sv.gamma.detach(), M, Cc, sv.relu,
+               sv.batch_stats, dx, dres, dg, db)
+    return dx, dres, dg, db
+
+
+class GNSaved:
+    __slots__ = ("raw", "y", "mean", "rstd", "gamma", "groups", "relu", "has_res")
+
+
+def gn_forward(raw, gn, relu, residual):
+    lib = L()
+    N, H, W, Cc = raw.shape
+    HW = H * W
+    dev = raw.device
+    sv = GNSaved()
+    sv.raw, sv.relu, sv.has_res, sv.gamma, sv.groups = raw, relu, residual is not None, gn.weight, \
+        gn.num_groups
+    chunks = lib.gn_chunks(HW)
+    partial = torch.empty((N, chunks, Cc, 2), device=dev, dtype=torch.float32)
+    lib.gn_partial(raw, N, HW, Cc, partial)
+    scale = torch.empty((N, Cc), device=dev, dtype=torch.float32)
+    shift = torch.empty_like(scale)
+    center = torch.empty_like(scale)
+    sv.mean = torch.empty((N, gn.num_groups), device=dev, dtype=torch.float32)
+    sv.rstd = torch.empty_like(sv.mean)
+    lib.gn_finalize(partial, N, HW, Cc, gn.num_groups, gn.weight, gn.bias, float(gn.eps), scale,
+                    shift, sv.mean, sv.rstd, center_out=center)
+    sv.y = ops.scale_shift_act(raw, scale, shift, center=center, rows_per_sample=HW,
+                               residual=residual, act=ops.ACT_RELU if relu else ops.ACT_NONE)
+    return sv.y, sv
+
+
+def gn_backward(dy, sv):
+    lib = L()
+    N, H, W, Cc = sv.raw.shape
+    dev = sv.raw.device
+    dx = torch.empty_like(sv.raw)
+    dres = torch.empty_like(sv.raw) if sv.has_res else None
+    dg = torch.empty(Cc, device=dev, dtype=torch.float32)
+    db = torch.empty_like(dg)
+    ws = torch.empty(lib.gn_bwd_workspace_floats(N, H * W, Cc, sv.groups), device=dev,
+                     dtype=torch.float32)
+    lib.gn_bwd(dy.contiguous(), sv.y, sv.raw, sv.mean, sv.rstd, sv.gamma.detach(), N, H * W, Cc,
+               sv.groups, sv.relu, dx, dres, dg, db, ws)
+    return dx, dres, dg, db
+
+
+def maxpool_forward(x):
+    N, H, W, Cc = x.shape
+    Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+    y = torch.empty((N, Ho, Wo, Cc), device=x.device, dtype=torch.float32)
+    arg = torch.empty((N, Ho, Wo, Cc), device=x.device, dtype=torch.uint8)
+    L().maxpool3x3s2_argmax(x, y, arg, N, H, W, Cc, Ho, Wo)
+    return y, (arg, x.shape)
+
+
+def maxpool_backward(dy, saved):
+    arg, (N, H, W, Cc) = saved
+    dx = torch.empty((N, H, W, Cc), device=dy.device, dtype=torch.float32)
+    L().maxpool3x3s2_bwd(dy.contiguous(), arg, dx, N, H, W, Cc, dy.size(1), dy.size(2))
+    return dx
+
+
+def avgpool_backward(dy, in_shape, out_hw):
+    N, H, W, Cc = in_shape
+    dx = torch.empty(in_shape, device=dy.device, dtype=torch.float32)
+    L().adaptive_avgpool_bwd(dy.contiguous(), dx, N, H, W, Cc, out_hw[0], out_hw[1])
+    return dx
+
+
+# ------------------------------------------------------------------ the trunk Function
+class TrunkFn(Function):
+    """forward(plan, x, *params): plan.run(x) -> (out, tape); backward replays the tape.
+    `plan` is the owning trunk module (it knows its layer structure); `params` are its
+    trainable parameters in `plan.trainable_params()` order so autograd routes the
+    returned gradients to them."""
+
+    @staticmethod
+    def forward(ctx, plan, x, *params):
+        out, tape = plan.run_recording(x)
+        ctx.plan = plan
+        ctx.tape = tape
+        ctx.n_params = len(params)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        grads = ctx.plan.backward_from_tape(ctx.tape, dout.contiguous())
+        ctx.tape = None
+        plist = ctx.plan.trainable_params()
+        return (None, None) + tuple(grads.get(id(p)) for p in plist)

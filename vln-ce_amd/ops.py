@@ -43,9 +43,11 @@ def conv_geometry(x, w, stride, pad, ldx=None):
                 Ho=Ho, Wo=Wo, ldx=ldx or Cin, ldy=Cout)
 
 
-def conv2d_nhwc(x, w_ohwi, stride, pad, *, in_scale=None, in_shift=None, in_relu=False,
-                scale=None, shift=None, residual=None, act=ACT_NONE, want_stats=False):
-    """y[N,Ho,Wo,Cout] = act((conv(prologue(x), w)) * scale + shift + residual).
+def conv2d_nhwc(x, w_ohwi, stride, pad, *, in_scale=None, in_shift=None, in_center=None,
+                in_relu=False, scale=None, shift=None, residual=None, act=ACT_NONE,
+                want_stats=False):
+    """y[N,Ho,Wo,Cout] = act((conv(prologue(x), w)) * scale + shift + residual), with
+    prologue(x) = act((x - in_center) * in_scale + in_shift).
     want_stats=True additionally returns the BatchNorm partials of the RAW
     accumulator: (partial[tiles_m, Cout, 2], tiles_m, tile_rows)."""
     assert x.is_contiguous() and w_ohwi.is_contiguous()
@@ -59,32 +61,39 @@ def conv2d_nhwc(x, w_ohwi, stride, pad, *, in_scale=None, in_shift=None, in_relu
         stats = (partial, tiles_m, tile_rows)
     if residual is not None:
         assert residual.is_contiguous() and residual.shape == y.shape
-    L().conv2d_fwd(x, w_ohwi, y, g, in_scale=in_scale, in_shift=in_shift, in_relu=int(in_relu),
-                   scale=scale, shift=shift, residual=residual, ldr=g["Cout"], act=act,
+    L().conv2d_fwd(x, w_ohwi, y, g, in_scale=in_scale, in_shift=in_shift, in_center=in_center,
+                   in_relu=int(in_relu), scale=scale, shift=shift, residual=residual, ldr=g["Cout"], act=act,
                    stat_partial=partial)
     return (y, stats) if want_stats else y
 
 
 def bn_finalize(stats, M, gamma, beta, eps, momentum, running_mean, running_var):
+    """batch-statistics BatchNorm from the conv's tile moments; updates the running stats.
+    Returns the apply triple (scale, shift, center) = (gamma*rstd, beta, mean): consumers
+    compute (x - center) * scale + shift, the reference's own arithmetic (the folded
+    x*scale + (beta - mean*scale) loses bits when |mean| >> std)."""
     partial, tiles_m, tile_rows = stats
     Cc = partial.size(1)
     scale = torch.empty(Cc, device=partial.device, dtype=torch.float32)
-    shift = torch.empty_like(scale)
+    folded = torch.empty_like(scale)
+    mean = torch.empty_like(scale)
     lib = L()
     wb = lib.bn_finalize_workspace_bytes(tiles_m, Cc)
     ws = torch.empty(wb // 8, device=partial.device, dtype=torch.float64) if wb else None
     lib.bn_finalize(partial, tiles_m, tile_rows, M, Cc, gamma, beta, float(eps), float(momentum),
-                    running_mean, running_var, scale, shift, workspace=ws)
-    return scale, shift
+                    running_mean, running_var, scale, folded, mean, None, workspace=ws)
+    return scale, beta.detach(), mean
 
 
-def scale_shift_act(x, scale, shift, *, rows_per_sample=0, residual=None, act=ACT_NONE, out=None):
-    """x: [..., C] contiguous; scale/shift: [C] (rows_per_sample=0) or [S, C]."""
+def scale_shift_act(x, scale, shift, *, center=None, rows_per_sample=0, residual=None,
+                    act=ACT_NONE, out=None):
+    """act((x - center) * scale + shift + residual); x: [..., C] contiguous; vectors: [C]
+    (rows_per_sample=0) or [S, C]."""
     assert x.is_contiguous()
     Cc = x.size(-1)
     M = x.numel() // Cc
     y = out if out is not None else torch.empty_like(x)
-    L().scale_shift_act(x, scale, shift, rows_per_sample, residual, y, M, Cc, act)
+    L().scale_shift_act(x, scale, shift, rows_per_sample, residual, y, M, Cc, act, center=center)
     return y
 
 
@@ -99,25 +108,29 @@ def group_norm_act(x, groups, gamma, beta, eps, *, residual=None, act=ACT_NONE):
     lib.gn_partial(x, N, HW, Cc, partial)
     scale = torch.empty((N, Cc), device=x.device, dtype=torch.float32)
     shift = torch.empty_like(scale)
-    lib.gn_finalize(partial, N, HW, Cc, groups, gamma, beta, float(eps), scale, shift)
-    return scale_shift_act(x, scale, shift, rows_per_sample=HW, residual=residual, act=act)
+    center = torch.empty_like(scale)
+    lib.gn_finalize(partial, N, HW, Cc, groups, gamma, beta, float(eps), scale, shift,
+                    center_out=center)
+    return scale_shift_act(x, scale, shift, center=center, rows_per_sample=HW, residual=residual,
+                           act=act)
 
 
-def maxpool3x3s2(x, in_scale=None, in_shift=None, in_relu=False):
-    """3x3/s2/p1 max pool of act(x*in_scale+in_shift) (transform optional)."""
+def maxpool3x3s2(x, in_scale=None, in_shift=None, in_relu=False, in_center=None):
+    """3x3/s2/p1 max pool of act((x-in_center)*in_scale+in_shift) (transform optional)."""
     N, H, W, Cc = x.shape
     Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
     y = torch.empty((N, Ho, Wo, Cc), device=x.device, dtype=torch.float32)
-    L().maxpool3x3s2(x, y, N, H, W, Cc, Ho, Wo, in_scale, in_shift, int(in_relu))
+    L().maxpool3x3s2(x, y, N, H, W, Cc, Ho, Wo, in_scale, in_shift, int(in_relu),
+                     in_center=in_center)
     return y
 
 
-def scale_shift_add_act(x1, s1, t1, x2, s2, t2, act=ACT_NONE, out=None):
-    """act(x1*s1+t1 + x2*s2+t2), per-channel vectors; `out` may alias x1."""
+def scale_shift_add_act(x1, s1, t1, x2, s2, t2, act=ACT_NONE, out=None, c1=None, c2=None):
+    """act((x1-c1)*s1+t1 + (x2-c2)*s2+t2), per-channel vectors; `out` may alias x1."""
     assert x1.is_contiguous() and x2.is_contiguous() and x1.shape == x2.shape
     Cc = x1.size(-1)
     y = out if out is not None else torch.empty_like(x1)
-    L().scale_shift_add_act(x1, s1, t1, x2, s2, t2, y, x1.numel() // Cc, Cc, act)
+    L().scale_shift_add_act(x1, s1, t1, x2, s2, t2, y, x1.numel() // Cc, Cc, act, c1=c1, c2=c2)
     return y
 
 
