@@ -34,6 +34,7 @@ FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, de
 CMA_FWD_GFLOP = 11.461
 CMA_FWD_BWD_FROZEN_GFLOP = 11.630
 CONV_GFLOP_PER_ENV = 10.677 + 0.699  # RGB ResNet-50 + depth ResNet-50 trunks (conv MACs x2)
+STEM_GFLOP_PER_ENV = 0.308 + 0.051   # 7x7/s2 stems at 256x256 (3->64 and 1->32 channels)
 
 
 def log(msg):
@@ -105,6 +106,22 @@ def cpu_baseline(num_envs, hw, L, timeout_s=100):
                 "sample": f"cpu baseline did not finish within {timeout_s}s ({type(e).__name__})"}
 
 
+def pmc_traffic(n_conv):
+    """HBM bytes per conv launch from the committed rocprofv3 PMC passes of this same
+    workload (profiles/r01_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate
+    passes of `bench.py --pmc-step`, gfx950 corrections applied as MI355X_MICROARCH.md
+    prescribes).  None when the file is absent or was taken for a different launch count."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
+                        "r01_pmc_traffic.json")
+    try:
+        rec = json.load(open(path))
+    except OSError:
+        return None
+    if rec.get("igemm_launches_per_step") != n_conv:
+        return None
+    return rec.get("hbm_bytes_per_launch")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -116,6 +133,11 @@ def main():
     ap.add_argument("--bn", choices=["train", "eval"], default="train",
                     help="train = as constructed by the reference (batch statistics)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--trainable-encoders", action="store_true",
+                    help="MODEL.{RGB,DEPTH}_ENCODER.trainable=True: trunks get dgrad/wgrad too")
+    ap.add_argument("--pmc-step", action="store_true",
+                    help="for rocprofv3 --pmc passes: 1 warm-up + 1 eager single-stream step, "
+                         "nothing else")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--threads", type=int, default=8, help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -138,7 +160,13 @@ def main():
     from vlnce_amd.il_harness import update_agent
 
     torch.manual_seed(0)
-    cfg = vlnce_amd.make_config("CMAPolicy")
+    over = {}
+    if args.trainable_encoders:
+        over = {"RGB_ENCODER.trainable": True, "DEPTH_ENCODER.trainable": True}
+    cfg = vlnce_amd.make_config("CMAPolicy", **over)
+    if args.pmc_step:
+        os.environ["VLNCE_HIP_GRAPHS"] = "0"
+        os.environ["VLNCE_SIDE_STREAMS"] = "0"
     policy = vlnce_amd.build_model(cfg, *vlnce_amd.make_spaces(args.hw, args.hw)).to(dev)
     if args.bn == "eval":
         policy.net.rgb_encoder.eval()
@@ -156,6 +184,25 @@ def main():
         obs, prev, masks, tgt, w = batch
         update_agent(policy, opt, obs, prev, masks, tgt, w, 512, grad_hook=grad_hook)
 
+    if args.pmc_step:
+        # layout of the profiled run:  warm-up | marker | calibration copy (a known 256 MiB
+        # read + 256 MiB write) | marker | the two visual trunks' forward, eager, one stream
+        # (= exactly the conv launches the roofline line times) | marker | one whole step
+        step()
+        torch.cuda.synchronize()
+        obs = batch[0]
+        src = torch.randn(1 << 26, device=dev)
+        torch.cuda._sleep(1000)
+        dst = src.clone()
+        torch.cuda._sleep(1000)
+        with torch.no_grad():
+            policy.net.rgb_encoder(obs)
+            policy.net.depth_encoder(obs)
+        torch.cuda._sleep(1000)
+        step()
+        torch.cuda.synchronize()
+        del dst
+        return
     log("policy built, starting warm-up")
     for i in range(args.warmup):
         t0 = time.perf_counter()
@@ -225,24 +272,33 @@ def main():
         ms = 1e3 * elapsed / args.steps
         value = args.num_envs * world * args.steps / elapsed
         conv_flop = CONV_GFLOP_PER_ENV * 1e9 * args.num_envs
+        step_gflop = CMA_FWD_BWD_FROZEN_GFLOP
+        if args.trainable_encoders:
+            # the timed launches are forward + data-gradient convs (algorithmic flops; the
+            # stems need no dX); the weight-gradient kernel adds another forward's worth
+            conv_flop = (2 * CONV_GFLOP_PER_ENV - STEM_GFLOP_PER_ENV) * 1e9 * args.num_envs
+            step_gflop += 2 * CONV_GFLOP_PER_ENV - STEM_GFLOP_PER_ENV
         achieved = conv_flop / (conv_ms * 1e-3) / 1e12
         line = {
             "metric": "policy-steps/sec (fwd+bwd)", "value": round(value, 1),
             "unit": "policy-steps/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "CMA policy DAgger update (fwd+bwd+Adam), frozen encoders, "
+            "config": {"workload": "CMA policy DAgger update (fwd+bwd+Adam), "
+                                   + ("trainable" if args.trainable_encoders else "frozen")
+                                   + " encoders, "
                                    f"BatchNorm={args.bn}, num_envs={args.num_envs}/GPU, "
                                    f"{args.hw}x{args.hw} RGB-D, {args.tokens}-token instruction",
                        "global_batch": args.num_envs * world, "parallelism": f"dp{world}",
-                       "whole_step_tflops": round(CMA_FWD_BWD_FROZEN_GFLOP * value / 1e3, 2),
+                       "whole_step_tflops": round(step_gflop * value / 1e3, 2),
                        "act_fwd_only_eval_steps_per_sec_per_gpu": round(args.num_envs / act_s, 1)},
             "roofline": {"bound": "mfma", "kernel": "igemm_kernel (conv2d fwd, fp32 32x32x2 MFMA)",
                          "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
                          "launches_per_step": n_conv,
                          "avg_launch_ms": round(conv_ms / max(n_conv, 1), 4),
-                         "kernel_ms_per_step": round(conv_ms, 3), "traffic": None},
+                         "kernel_ms_per_step": round(conv_ms, 3),
+                         "traffic": pmc_traffic(n_conv)},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.num_envs, args.hw, args.tokens)

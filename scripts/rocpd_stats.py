@@ -1,6 +1,6 @@
 """Kernel statistics from a rocprofv3 rocpd sqlite database (the --stats view).
 
-   python tools/dev/rocpd_stats.py <results.db> [out.md|-] [skip_first_n_dispatches]
+   python scripts/rocpd_stats.py <results.db> [out.md|-] [skip_first_n_dispatches]
 """
 import re
 import sqlite3
