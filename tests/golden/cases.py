@@ -47,9 +47,19 @@ CASES = {
         policy="WaypointPolicy", hw=64, N=2, T=1, lengths=[3, 6], mode="eval", call="waypoint",
         overrides={"WAYPOINT.continuous_distance": False, "WAYPOINT.continuous_offset": False},
     ),
+    # H2: one WDDPPO minibatch update (ddppo_alg.py:38-149) on a 3-step x 2-env rollout,
+    # encoders in eval mode as ddppo_waypoint_trainer.py:526-530 sets them
+    "waypoint_ppo_update_64": dict(
+        policy="WaypointPolicy", hw=64, N=2, T=3, lengths=[9, 14], mode="ppo", call="ppo_update",
+    ),
 }
 
 VOCAB = 2504
+
+# RL.PPO defaults of the reference (vlnce_baselines/config/default.py:180-201)
+PPO = dict(clip_param=0.2, value_loss_coef=0.5, entropy_coef=0.01, pano_entropy_coef=1.0,
+           offset_entropy_coef=0.0, distance_entropy_coef=0.0, offset_regularize_coef=0.1146,
+           use_clipped_value_loss=True)
 
 
 def build_inputs(case):
@@ -105,6 +115,14 @@ def build_inputs(case):
         w[-1, 0] = 0.0  # padded step of a shorter episode
     extra["weights"] = w
     extra["h0"] = 0.1 * torch.randn(N, 2, extra["hidden"], generator=g)
+    if c["call"] == "ppo_update":
+        # rollout statistics of the minibatch; the action components themselves are filled
+        # in by make_goldens.py from the reference's own act() (they must lie inside the
+        # truncated-normal supports) and stored with the inputs
+        extra["value_preds"] = torch.randn(B, 1, generator=g) * 0.5
+        extra["returns"] = extra["value_preds"] + torch.randn(B, 1, generator=g) * 0.3
+        extra["old_logp"] = -2.0 + torch.randn(B, 1, generator=g) * 0.2
+        extra["adv"] = torch.randn(B, 1, generator=g)
     return obs, prev, masks, extra
 
 
@@ -131,6 +149,10 @@ def build_policy(ns, case, make_config, make_spaces, synth_state_dict):
     policy.load_state_dict(synth_state_dict(policy))
     if case["mode"] == "eval":
         policy.eval()
+    elif case["mode"] == "ppo":  # agent.train(); visual encoders .eval()
+        policy.train()
+        policy.net.rgb_encoder.eval()
+        policy.net.depth_encoder.eval()
     # mode == "train": leave exactly as constructed (Net.__init__ ends with
     # self.train(): frozen CNN's BatchNorm runs on batch statistics, App. B-1)
     return policy, cfg
@@ -145,7 +167,14 @@ _BN_PROBES = [
 ]
 
 
-def run_case(policy, case, obs, prev, masks, extra, update_fn=None, aux=None):
+def ppo_sample(obs, prev, masks, extra, h0):
+    """the 9-tuple RolloutStorage.recurrent_generator yields (one minibatch = all envs)."""
+    actions = {k[4:]: v for k, v in extra.items() if k.startswith("act_")}
+    return (obs, h0, actions, prev, extra["value_preds"], extra["returns"], masks,
+            extra["old_logp"], extra["adv"])
+
+
+def run_case(policy, case, obs, prev, masks, extra, update_fn=None, aux=None, ppo_fn=None):
     """Runs one case through any implementation of the policy surface and
     returns {name: tensor}.  `update_fn(policy, obs, prev, masks, targets,
     weights) -> (loss, action_loss, aux_loss)` must leave .grad populated and
@@ -201,6 +230,20 @@ def run_case(policy, case, obs, prev, masks, extra, update_fn=None, aux=None):
                 out["ent_" + k] = v
             pa = {k: v.clone() for k, v in prev.items()}
             out["get_value"] = policy.get_value(obs, h0, pa, masks)
+    elif call == "ppo_update":
+        # ppo_fn(policy, sample) -> the 6 floats WDDPPO.update returns; leaves .grad populated
+        pa = {k: v.clone() for k, v in prev.items()}
+        stats = ppo_fn(policy, ppo_sample(obs, pa, masks, extra, h0))
+        out["ppo_stats"] = torch.tensor(list(stats), dtype=torch.float64)
+        names, norms = [], []
+        for n, p in policy.named_parameters():
+            if p.grad is not None:
+                names.append(n)
+                norms.append(p.grad.double().norm().item())
+        out["grad_names"] = np.array(names)
+        out["grad_norms"] = torch.tensor(norms, dtype=torch.float64)
+        out["grad_critic_w"] = policy.critic.fc.weight.grad
+        out["grad_ins_w_hh"] = policy.net.instruction_encoder.encoder_rnn.weight_hh_l0.grad
     else:
         raise ValueError(call)
     if case["mode"] == "train" and not case.get("cached"):

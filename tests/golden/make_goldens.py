@@ -40,6 +40,41 @@ def reference_update_agent(ref):
     return scope["_update_agent"]
 
 
+def reference_wddppo_update():
+    """WDDPPO.update (ddppo_alg.py:38-149) extracted with ast and executed unbound."""
+    path = os.path.join(shims.REFERENCE_ROOT, "vlnce_baselines/common/ddppo_alg.py")
+    tree = ast.parse(open(path).read())
+    fn = None
+    for node in ast.walk(tree):
+        if isinstance(node, ast.FunctionDef) and node.name == "update":
+            fn = node
+    mod = ast.Module(body=[fn], type_ignores=[])
+    from typing import Tuple
+
+    scope = {"torch": torch, "Tuple": Tuple, "Tensor": torch.Tensor, "l1_loss": F.l1_loss}
+    exec(compile(mod, path, "exec"), scope)
+    return scope["update"]
+
+
+class _NoStepOptimizer:
+    def zero_grad(self):
+        pass
+
+    def step(self):
+        pass
+
+
+def reference_ppo_fn(policy, sample):
+    upd = reference_wddppo_update()
+    noop = lambda *a, **k: None
+    rollouts = types.SimpleNamespace(recurrent_generator=lambda adv, nmb: iter([sample]))
+    fake_self = types.SimpleNamespace(
+        actor_critic=policy, ppo_epoch=1, num_mini_batch=1, optimizer=_NoStepOptimizer(),
+        get_advantages=lambda r: sample[-1], before_backward=noop, after_backward=noop,
+        before_step=noop, after_step=noop, **cases.PPO)
+    return upd(fake_self, rollouts)
+
+
 def main(names):
     torch.set_num_threads(8)
     ref = shims.load_reference()
@@ -58,7 +93,21 @@ def main(names):
             )
             return upd(fake_self, obs, prev, masks, targets, weights, step_grad=False)
 
-        outs = cases.run_case(policy, case, obs, prev, masks, extra, update_fn, ref.AuxLosses)
+        if case["call"] == "ppo_update":
+            # action components: the reference's own deterministic act() on these inputs,
+            # with one STOP row so the pano mask is exercised
+            with torch.no_grad():
+                L = policy.net.num_recurrent_layers
+                pa = {k: v.clone() for k, v in prev.items()}
+                elems = policy.act(obs, extra["h0"][:, :L].contiguous(), pa, masks,
+                                   deterministic=True)[2]
+            for k, v in elems.items():
+                extra["act_" + k] = v.clone()
+            # spread the pano choices (the synthetic weights pick STOP everywhere); keep one
+            # STOP row (= num_panos) so the distance/offset mask is exercised
+            extra["act_pano"] = torch.tensor([[3], [12], [0], [7], [11], [5]])
+        outs = cases.run_case(policy, case, obs, prev, masks, extra, update_fn, ref.AuxLosses,
+                              ppo_fn=reference_ppo_fn)
         path = os.path.join(HERE, name + ".npz")
         cases.save_case(path, name, obs, prev, masks, extra, outs)
         print(f"{name}: wrote {os.path.getsize(path)/1e3:.0f} kB;",

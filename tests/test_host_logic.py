@@ -37,6 +37,14 @@ def product_update(policy, obs, prev, masks, targets, weights):
     return loss.item(), al.item(), (xl.item() if isinstance(xl, torch.Tensor) else xl)
 
 
+def product_ppo(policy, sample):
+    from vlnce_amd.ppo_harness import PPOConfig, wddppo_minibatch_update
+
+    stats = wddppo_minibatch_update(policy, None, sample, PPOConfig(**cases.PPO), step_grad=False,
+                                    clip_grads=False)
+    return [float(v) for v in stats]
+
+
 @pytest.mark.parametrize("name", IL_CASES)
 def test_host_logic_matches_golden(sim, name):
     case = cases.CASES[name]
@@ -44,7 +52,7 @@ def test_host_logic_matches_golden(sim, name):
     policy, _ = cases.build_policy(vlnce_amd, case, vlnce_amd.make_config, vlnce_amd.make_spaces,
                                    tp.synth_state_dict)
     outs = cases.run_case(policy, case, obs, prev, masks, extra, product_update,
-                          vlnce_amd.AuxLosses)
+                          vlnce_amd.AuxLosses, ppo_fn=product_ppo)
     compare(outs, gold, atol=1e-4, rtol=1e-4)
 
 
@@ -60,3 +68,26 @@ def test_cpu_tensors_are_rejected_by_the_binding():
         pytest.skip("library not built")
     with pytest.raises(RuntimeError, match="not on a GPU"):
         _lib._ptr(torch.zeros(4))
+
+
+def test_ppo_harness_clips_and_steps(sim):
+    """max_grad_norm clipping (habitat PPO.before_step) and the optimizer step of the H2 harness."""
+    from vlnce_amd.ppo_harness import PPOConfig, normalized_advantages, wddppo_minibatch_update
+
+    name = "waypoint_ppo_update_64"
+    case = cases.CASES[name]
+    obs, prev, masks, extra, _ = cases.load_case(os.path.join(GOLD, name + ".npz"))
+    policy, _ = cases.build_policy(vlnce_amd, case, vlnce_amd.make_config, vlnce_amd.make_spaces,
+                                   tp.synth_state_dict)
+    h0 = extra["h0"][:, :policy.net.num_recurrent_layers].contiguous()
+    opt = torch.optim.Adam([p for p in policy.parameters() if p.requires_grad], lr=1e-3)
+    before = policy.critic.fc.weight.detach().clone()
+    wddppo_minibatch_update(policy, opt, cases.ppo_sample(obs, prev, masks, extra, h0),
+                            PPOConfig(max_grad_norm=0.2))
+    total = torch.sqrt(sum(p.grad.double().pow(2).sum() for p in policy.parameters()
+                           if p.grad is not None))
+    assert total <= 0.2 * (1 + 1e-4)
+    assert not torch.equal(policy.critic.fc.weight.detach(), before)
+    r, v = torch.arange(8.0).view(4, 2, 1), torch.ones(4, 2, 1)
+    a = normalized_advantages(r, v, normalize=True)
+    assert a.shape == (3, 2, 1) and abs(a.mean().item()) < 1e-6

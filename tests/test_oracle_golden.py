@@ -21,6 +21,10 @@ def _oracle_update(policy, obs, prev, masks, targets, weights):
     return oc.il_update(policy, None, obs, prev, masks, targets, weights, hs, step_grad=False)
 
 
+def _oracle_ppo(policy, sample):
+    return oc.ppo_update(policy, None, sample, step_grad=False, **cases.PPO)
+
+
 def compare(outs, gold, atol, rtol=1e-5):
     assert set(gold) <= set(outs), set(gold) - set(outs)
     for k, g in gold.items():
@@ -49,7 +53,8 @@ def test_oracle_matches_reference_golden(name):
     for k in obs:
         assert torch.equal(obs[k].float(), obs2[k].float()), k
     policy, _ = cases.build_policy(oc, case, tp.make_config, tp.make_spaces, tp.synth_state_dict)
-    outs = cases.run_case(policy, case, obs, prev, masks, extra, _oracle_update, oc.AuxLosses)
+    outs = cases.run_case(policy, case, obs, prev, masks, extra, _oracle_update, oc.AuxLosses,
+                          ppo_fn=_oracle_ppo)
     compare(outs, gold, atol=2e-5)
 
 
