@@ -140,6 +140,9 @@ def main():
                          "nothing else")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--threads", type=int, default=8, help=argparse.SUPPRESS)
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise RCCL and run the gradient all-reducer even with one rank "
+                         "(exercises the N>1 code path on a 1-GPU box)")
     args = ap.parse_args()
     if args.cpu_baseline_only:
         cpu_baseline_worker(args.num_envs, args.hw, args.tokens, args.threads)
@@ -151,8 +154,10 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import vlnce_amd
@@ -172,7 +177,7 @@ def main():
         policy.net.rgb_encoder.eval()
     opt = torch.optim.Adam(policy.parameters(), lr=2.5e-4)
     grad_hook = None
-    if world > 1:
+    if use_dist:
         from vlnce_amd.distributed import GradientAllReducer
 
         reducer = GradientAllReducer(policy)
@@ -223,7 +228,7 @@ def main():
         return out
 
     def sync():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -234,7 +239,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     log(f"timed region: {args.steps} steps in {elapsed:.3f}s")
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([elapsed], device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = tmax.item()
@@ -303,7 +308,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.num_envs, args.hw, args.tokens)
         print(json.dumps(line))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -192,3 +192,43 @@ def test_rgb_encoder_train_then_eval_vs_oracle(version, spatial):
     for k in ("cnn.1.running_var", "cnn.7.1.bn2.running_mean", "cnn.1.num_batches_tracked"):
         a, b = hip.state_dict()[k].cpu().double(), ref.state_dict()[k].double()
         assert (a - b).abs().max().item() < 1e-4 * max(1.0, b.abs().max().item()), k
+
+
+def test_rccl_single_rank_reducer_is_identity():
+    """the N>1 code path on one GPU: a 1-rank RCCL group, coalesced in-place AVG all-reduce of
+    the .grad tensors launched from the autograd hooks -> gradients unchanged."""
+    import socket
+
+    import torch.distributed as dist
+    from vlnce_amd.distributed import GradientAllReducer
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        case = cases.CASES["cma_update_64"]
+        obs, prev, masks, extra, _ = cases.load_case(os.path.join(GOLD, "cma_update_64.npz"))
+        grads = []
+        for use in (False, True):
+            policy, _ = cases.build_policy(vlnce_amd, case, vlnce_amd.make_config,
+                                           vlnce_amd.make_spaces, tp.synth_state_dict)
+            policy.to(DEV)
+            red = GradientAllReducer(policy, bucket_bytes=1 << 20) if use else None
+            vlnce_amd.AuxLosses.activate()
+            update_agent(policy, None, to_dev(obs), to_dev(prev), to_dev(masks),
+                         to_dev(extra["targets"]), to_dev(extra["weights"]), 512, step_grad=False,
+                         grad_hook=red.finish if use else None)
+            vlnce_amd.AuxLosses.deactivate()
+            torch.cuda.synchronize()
+            grads.append({n: p.grad.clone() for n, p in policy.named_parameters()
+                          if p.grad is not None})
+            if red is not None:
+                assert len(red.buckets) > 2
+                red.remove()
+        assert set(grads[0]) == set(grads[1]) and len(grads[0]) > 20
+        for n in grads[0]:
+            assert torch.allclose(grads[0][n], grads[1][n], rtol=1e-5, atol=1e-7), n
+    finally:
+        dist.destroy_process_group()

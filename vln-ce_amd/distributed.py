@@ -7,9 +7,9 @@ the only exchange step is a sum-all-reduce (then / world) of the gradients of
 the TRAINABLE tensors (25.1 MB for CMA with frozen encoders).
 
 Buckets are filled in reverse parameter order -- the order backward produces
-gradients -- and each bucket's all-reduce is launched asynchronously from a
-post-accumulate-grad hook the moment its last gradient lands, so it overlaps
-with the rest of backward.  xGMI is point-to-point (7 links x ~153 GB/s per
+gradients -- and each bucket's (coalesced, in-place) all-reduce is launched
+asynchronously from a post-accumulate-grad hook the moment its last gradient
+lands, so it overlaps with the rest of backward.  xGMI is point-to-point (7 links x ~153 GB/s per
 GPU): few, large collectives beat many small ones, hence 8 MiB buckets rather
 than DDP's NVSwitch-era 25 MB first/1 MB rest heuristics being copied.
 Parameters that never receive a gradient (WaypointPolicy's unused
@@ -20,18 +20,26 @@ Semantics preserved (base_il_trainer.py:159-165): the IL loss is normalised
 per episode and then .mean()'d over episodes, so equal-sized shards + gradient
 averaging reproduce the single-process gradient exactly.
 """
+import warnings
+
 import torch
 import torch.distributed as dist
 
 
 class _Bucket:
-    __slots__ = ("params", "flat", "views", "pending", "work")
+    __slots__ = ("params", "pending", "work", "tensors")
 
 
 class GradientAllReducer:
+    """Zero-copy bucketed gradient averaging: each bucket is ONE coalesced collective over the
+    .grad tensors themselves (ncclGroupStart/End underneath, no flatten / unflatten copies and,
+    on RCCL, ReduceOp.AVG so there is no scaling pass either)."""
+
     def __init__(self, module, bucket_bytes=8 << 20, process_group=None):
         self.group = process_group
         self.world = dist.get_world_size(process_group)
+        # gloo (CPU tests) has no AVG: sum, then one fused multiply
+        self.avg = dist.get_backend(process_group) == "nccl"
         params = [p for p in module.parameters() if p.requires_grad]
         params.reverse()
         self.buckets = []
@@ -46,6 +54,12 @@ class GradientAllReducer:
             self.buckets.append(self._make_bucket(cur))
         self._bucket_of = {}
         self._handles = []
+        self._zeros = {}
+        # the hooks pin every AccumulateGrad node to the stream current here, which is what
+        # orders gradients produced on side streams before the collective; the engine's
+        # warning about that (intended) stream hand-over is noise
+        if hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
+            torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
         for b in self.buckets:
             for p in b.params:
                 self._bucket_of[p] = b
@@ -55,23 +69,26 @@ class GradientAllReducer:
     def _make_bucket(params):
         b = _Bucket()
         b.params = list(params)
-        n = sum(p.numel() for p in params)
-        b.flat = torch.zeros(n, device=params[0].device, dtype=torch.float32)
-        b.views, off = [], 0
-        for p in params:
-            b.views.append(b.flat[off:off + p.numel()].view_as(p))
-            off += p.numel()
         b.pending = len(params)
         b.work = None
+        b.tensors = None
         return b
 
+    def _zero_like(self, p):
+        z = self._zeros.get(p)
+        if z is None:
+            z = self._zeros[p] = torch.zeros_like(p)
+        else:
+            z.zero_()
+        return z
+
     def _launch(self, b):
-        have = [(v, p.grad) for v, p in zip(b.views, b.params) if p.grad is not None]
-        if len(have) != len(b.params):
-            b.flat.zero_()
-        if have:
-            torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
-        b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        # a parameter without a gradient this step contributes zeros (and keeps .grad None)
+        b.tensors = [p.grad if p.grad is not None else self._zero_like(p) for p in b.params]
+        op = dist.ReduceOp.AVG if self.avg else dist.ReduceOp.SUM
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            b.work = dist.all_reduce_coalesced(b.tensors, op=op, group=self.group, async_op=True)
 
     def _on_grad(self, p):
         b = self._bucket_of[p]
@@ -80,20 +97,19 @@ class GradientAllReducer:
             self._launch(b)
 
     def finish(self):
-        """Call after loss.backward(): waits for every bucket, writes the averaged
-        gradients back into .grad and re-arms the hooks for the next step."""
+        """Call after loss.backward(): waits for every bucket (the gradients were averaged in
+        place) and re-arms the hooks for the next step."""
         for b in self.buckets:
             if b.work is None:  # some parameter never produced a gradient this step
                 self._launch(b)
-        inv = 1.0 / self.world
         for b in self.buckets:
             b.work.wait()
-            b.flat.mul_(inv)
-            have = [(p.grad, v) for v, p in zip(b.views, b.params) if p.grad is not None]
-            if have:
-                torch._foreach_copy_([g for g, _ in have], [v for _, v in have])
+            if not self.avg:
+                torch._foreach_mul_([t for t, p in zip(b.tensors, b.params) if p.grad is not None],
+                                    1.0 / self.world)
             b.pending = len(b.params)
             b.work = None
+            b.tensors = None
 
     def remove(self):
         for h in self._handles:

@@ -13,9 +13,54 @@ import os
 import torch
 
 
+_SIDE_STREAMS = {}  # (idx, device index) -> stream; one set per process, shared by all policies
+
+
+def _elapsed_two_spins(a, b, cycles):
+    """wall time (ms) of one spin kernel on stream `a` and, if given, one on `b`, started together."""
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(a)
+    if b is not None:
+        b.wait_event(e0)
+        with torch.cuda.stream(b):
+            torch.cuda._sleep(cycles)
+    with torch.cuda.stream(a):
+        torch.cuda._sleep(cycles)
+    if b is not None:
+        a.wait_stream(b)
+    e1.record(a)
+    e1.synchronize()
+    return e0.elapsed_time(e1)
+
+
+def pick_concurrent_stream(device, others=(), priority=-1, candidates=12):
+    """A stream whose kernels really overlap with the current stream's (and `others`').
+
+    HIP streams are multiplexed onto a handful of hardware queues (4 by default); two streams
+    that land on the same queue serialise, and which pool stream lands where depends on how
+    many streams the process created before (graph capture, RCCL, other policies).  Instead of
+    guessing the runtime's mapping this measures it: a candidate is accepted when two spin
+    kernels, one per stream, take the time of one."""
+    with torch.cuda.device(device):
+        cur = torch.cuda.current_stream(device)
+        cycles = 200_000
+        _elapsed_two_spins(cur, None, cycles)  # warm-up (module load)
+        t1 = min(_elapsed_two_spins(cur, None, cycles) for _ in range(2))
+        last = None
+        for _ in range(candidates):
+            cand = torch.cuda.Stream(device=device, priority=priority)
+            _elapsed_two_spins(cur, cand, cycles)  # first use binds the stream to a queue
+            ok = all(min(_elapsed_two_spins(ref, cand, cycles) for _ in range(2)) < 1.5 * t1
+                     for ref in (cur, *others))
+            last = cand
+            if ok:
+                return cand
+        return last  # no concurrency available (single hardware queue): still correct
+
+
 class BranchStreams:
     def __init__(self):
-        self._streams = {}
+        self._streams = _SIDE_STREAMS
 
     @staticmethod
     def enabled(device):
@@ -28,7 +73,8 @@ class BranchStreams:
             # high priority: the branch kernels are small; without it the hardware only
             # admits them at the boundaries of the saturating RGB-trunk kernels
             prio = int(os.environ.get("VLNCE_SIDE_PRIORITY", "-1"))
-            self._streams[key] = torch.cuda.Stream(device=device, priority=prio)
+            others = [st for (i, d), st in self._streams.items() if d == device.index]
+            self._streams[key] = pick_concurrent_stream(device, others, prio)
         return self._streams[key]
 
     def fork(self, device):
