@@ -140,6 +140,9 @@ def main():
                          "nothing else")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--threads", type=int, default=8, help=argparse.SUPPRESS)
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="do not start the next step's frozen visual trunks (encode_ahead) "
+                         "before enqueuing the current step's update")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise RCCL and run the gradient all-reducer even with one rank "
                          "(exercises the N>1 code path on a 1-GPU box)")
@@ -189,6 +192,25 @@ def main():
         obs, prev, masks, tgt, w = batch
         update_agent(policy, opt, obs, prev, masks, tgt, w, 512, grad_hook=grad_hook)
 
+    # Frozen encoders do not depend on the weights an update changes, so the trunks of step
+    # k+1 are issued (on their own streams) BEFORE step k's update is enqueued and overlap its
+    # latency-bound tail.  Every step still runs its own trunk pass, tail forward, backward and
+    # Adam; trainable encoders cannot run ahead and fall back to the plain loop.
+    pipeline = not (args.no_pipeline or args.trainable_encoders)
+
+    def run_steps(n):
+        obs, prev, masks, tgt, w = batch
+        if not pipeline:
+            for _ in range(n):
+                step()
+            return
+        nxt = policy.encode_ahead(obs)
+        for k in range(n):
+            cur = nxt
+            if k + 1 < n:
+                nxt = policy.encode_ahead(obs)
+            update_agent(policy, opt, cur, prev, masks, tgt, w, 512, grad_hook=grad_hook)
+
     if args.pmc_step:
         # layout of the profiled run:  warm-up | marker | calibration copy (a known 256 MiB
         # read + 256 MiB write) | marker | the two visual trunks' forward, eager, one stream
@@ -211,7 +233,10 @@ def main():
     log("policy built, starting warm-up")
     for i in range(args.warmup):
         t0 = time.perf_counter()
-        step()
+        if pipeline and i >= 2:
+            run_steps(2)  # warms the run-ahead path (its graphs are captured on the side stream)
+        else:
+            step()
         torch.cuda.synchronize()
         log(f"warm-up step {i}: {1e3 * (time.perf_counter() - t0):.1f} ms")
 
@@ -234,8 +259,7 @@ def main():
 
     sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    run_steps(args.steps)
     sync()
     elapsed = time.perf_counter() - t0
     log(f"timed region: {args.steps} steps in {elapsed:.3f}s")
@@ -291,7 +315,9 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "CMA policy DAgger update (fwd+bwd+Adam), "
                                    + ("trainable" if args.trainable_encoders else "frozen")
-                                   + " encoders, "
+                                   + " encoders"
+                                   + (" (next step's trunks issued ahead)" if pipeline else "")
+                                   + ", "
                                    f"BatchNorm={args.bn}, num_envs={args.num_envs}/GPU, "
                                    f"{args.hw}x{args.hw} RGB-D, {args.tokens}-token instruction",
                        "global_batch": args.num_envs * world, "parallelism": f"dp{world}",

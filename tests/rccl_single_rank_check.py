@@ -1,0 +1,60 @@
+"""Single-rank RCCL check, run as a script by test_policy_gpu.py (own process)."""
+import os
+import socket
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path[:0] = [os.path.dirname(HERE), HERE, os.path.join(HERE, "golden")]
+import torch
+import torch.distributed as dist
+
+import cases
+import vlnce_amd
+from oracle import thirdparty as tp
+from vlnce_amd.distributed import GradientAllReducer
+from vlnce_amd.il_harness import update_agent
+
+DEV = "cuda:0"
+GOLD = os.path.join(HERE, "golden")
+
+
+def to_dev(x):
+    if isinstance(x, dict):
+        return {k: to_dev(v) for k, v in x.items()}
+    return x.to(DEV) if isinstance(x, torch.Tensor) else x
+
+
+def main():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    case = cases.CASES["cma_update_64"]
+    obs, prev, masks, extra, _ = cases.load_case(os.path.join(GOLD, "cma_update_64.npz"))
+    grads = []
+    for use in (False, True):
+        policy, _ = cases.build_policy(vlnce_amd, case, vlnce_amd.make_config,
+                                       vlnce_amd.make_spaces, tp.synth_state_dict)
+        policy.to(DEV)
+        red = GradientAllReducer(policy, bucket_bytes=1 << 20) if use else None
+        vlnce_amd.AuxLosses.activate()
+        update_agent(policy, None, to_dev(obs), to_dev(prev), to_dev(masks),
+                     to_dev(extra["targets"]), to_dev(extra["weights"]), 512, step_grad=False,
+                     grad_hook=red.finish if use else None)
+        vlnce_amd.AuxLosses.deactivate()
+        torch.cuda.synchronize()
+        grads.append({n: p.grad.clone() for n, p in policy.named_parameters()
+                      if p.grad is not None})
+        if red is not None:
+            assert len(red.buckets) > 2
+            red.remove()
+    assert set(grads[0]) == set(grads[1]) and len(grads[0]) > 20
+    for n in grads[0]:
+        assert torch.allclose(grads[0][n], grads[1][n], rtol=1e-5, atol=1e-7), n
+    print("RCCL-SINGLE-RANK-OK", flush=True)
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

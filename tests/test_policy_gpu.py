@@ -196,39 +196,57 @@ def test_rgb_encoder_train_then_eval_vs_oracle(version, spatial):
 
 def test_rccl_single_rank_reducer_is_identity():
     """the N>1 code path on one GPU: a 1-rank RCCL group, coalesced in-place AVG all-reduce of
-    the .grad tensors launched from the autograd hooks -> gradients unchanged."""
-    import socket
+    the .grad tensors launched from the autograd hooks -> gradients unchanged.  Runs in its own
+    process: a process group's lifetime is the process's (tests/rccl_single_rank_check.py)."""
+    import subprocess
+    import sys
 
-    import torch.distributed as dist
-    from vlnce_amd.distributed import GradientAllReducer
+    script = os.path.join(os.path.dirname(__file__), "rccl_single_rank_check.py")
+    r = subprocess.run([sys.executable, script], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "RCCL-SINGLE-RANK-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
-    try:
-        case = cases.CASES["cma_update_64"]
-        obs, prev, masks, extra, _ = cases.load_case(os.path.join(GOLD, "cma_update_64.npz"))
-        grads = []
-        for use in (False, True):
-            policy, _ = cases.build_policy(vlnce_amd, case, vlnce_amd.make_config,
-                                           vlnce_amd.make_spaces, tp.synth_state_dict)
-            policy.to(DEV)
-            red = GradientAllReducer(policy, bucket_bytes=1 << 20) if use else None
-            vlnce_amd.AuxLosses.activate()
-            update_agent(policy, None, to_dev(obs), to_dev(prev), to_dev(masks),
-                         to_dev(extra["targets"]), to_dev(extra["weights"]), 512, step_grad=False,
-                         grad_hook=red.finish if use else None)
-            vlnce_amd.AuxLosses.deactivate()
-            torch.cuda.synchronize()
-            grads.append({n: p.grad.clone() for n, p in policy.named_parameters()
-                          if p.grad is not None})
-            if red is not None:
-                assert len(red.buckets) > 2
-                red.remove()
-        assert set(grads[0]) == set(grads[1]) and len(grads[0]) > 20
-        for n in grads[0]:
-            assert torch.allclose(grads[0][n], grads[1][n], rtol=1e-5, atol=1e-7), n
-    finally:
-        dist.destroy_process_group()
+
+def test_encode_ahead_pipeline_equals_plain_loop():
+    """policy.encode_ahead(): the next step's frozen trunks issued on side streams before the
+    current update is enqueued -> same losses, weights and BatchNorm running statistics as the
+    plain sequential loop (6 SGD steps, batch-statistics BatchNorm).  The first two passes of a
+    new input signature (eager, graph capture) run inline inside encode_ahead itself, so the
+    trunk passes keep the call order from the first batch on."""
+    case = cases.CASES["cma_update_64"]
+    _, prev, masks, extra, _ = cases.load_case(os.path.join(GOLD, "cma_update_64.npz"))
+    obs_list = []
+    for seed in range(6):
+        o, _, _ = synth_batch(6, 64, 12, seed=10 + seed, ragged=True)
+        o["progress"] = torch.rand(6, 1, generator=torch.Generator().manual_seed(seed))
+        obs_list.append(to_dev(o))
+    T, N = 3, 2
+    prev_d, masks_d = to_dev(prev), to_dev(masks)
+    tgt, w = to_dev(extra["targets"]), to_dev(extra["weights"])
+    results = []
+    for ahead in (False, True):
+        policy, _ = cases.build_policy(vlnce_amd, case, vlnce_amd.make_config,
+                                       vlnce_amd.make_spaces, tp.synth_state_dict)
+        policy.to(DEV)
+        # plain SGD: Adam's normalisation would amplify the 1e-7 run-to-run differences of the
+        # split-K atomics into 1e-5 within a few steps
+        opt = torch.optim.SGD(policy.parameters(), lr=0.05)
+        losses = []
+        nxt = policy.encode_ahead(obs_list[0]) if ahead else obs_list[0]
+        for k in range(6):
+            cur = nxt
+            if k + 1 < 6:
+                nxt = policy.encode_ahead(obs_list[k + 1]) if ahead else obs_list[k + 1]
+            if ahead:
+                assert "rgb_features" in cur and "depth_features" in cur
+            loss, _, _ = update_agent(policy, opt, cur, prev_d, masks_d, tgt, w, 512)
+            losses.append(loss.item())
+        torch.cuda.synchronize()
+        sd = {k: v.detach().clone() for k, v in policy.state_dict().items()}
+        results.append((losses, sd))
+    (l0, s0), (l1, s1) = results
+    assert all(abs(a - b) <= 2e-5 * max(1.0, abs(a)) for a, b in zip(l0, l1)), (l0, l1)
+    for k in s0:
+        if s0[k].is_floating_point():
+            assert torch.allclose(s0[k], s1[k], rtol=1e-4, atol=1e-5), k
+        else:
+            assert torch.equal(s0[k], s1[k]), k

@@ -24,6 +24,7 @@ import torch.nn as nn
 
 from .. import ops
 from ..config import Box, Dict
+from ..streams import wait_ready
 from . import trunk_backward as tb
 
 
@@ -83,6 +84,9 @@ class _GraphRunner:
     def enabled():
         return os.environ.get("VLNCE_HIP_GRAPHS", "1") != "0"
 
+    def captured(self, key):
+        return not self.enabled() or isinstance(self.entries.get(key), list)
+
     def __call__(self, x, key):
         if (not self.enabled() or not x.is_cuda or torch.cuda.is_current_stream_capturing()):
             return self.fn(x)
@@ -93,17 +97,26 @@ class _GraphRunner:
             self.entries[key] = "seen"
             return self.fn(x)
         self.entries.move_to_end(key)
+        cur = torch.cuda.current_stream(x.device)
         if ent == "seen":
             static_in = x.clone()
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 static_out = self.fn(static_in)
-            ent = (graph, static_in, static_out)
+            ent = [graph, static_in, static_out, None]
             self.entries[key] = ent
         else:
+            # one graph = one set of static buffers: a replay issued from another stream (the
+            # run-ahead path next to an inline call) must wait for the previous one to be
+            # done with them
+            if ent[3] is not None:
+                cur.wait_event(ent[3])
             ent[1].copy_(x)
         ent[0].replay()
-        return ent[2].clone()
+        out = ent[2].clone()
+        ent[3] = torch.cuda.Event()
+        ent[3].record(cur)
+        return out
 
 
 def _require_frozen(module, what):
@@ -261,16 +274,24 @@ class HipResNetTrunk(nn.Sequential):
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             # trainable encoder: layer-by-layer forward that records what backward needs
             return tb.TrunkFn.apply(self, x, *self.trainable_params()).permute(0, 3, 1, 2)
+        key, train = self._graph_key(x.shape)
+        y = self._graphs(x, key)
+        if train:
+            self._bn_gen += 1
+        return y.permute(0, 3, 1, 2)
+
+    def _graph_key(self, shape):
         modes = tuple(m.training for m in self._norms)
         if any(modes) and not all(modes):
             raise NotImplementedError("mixed train/eval BatchNorm modes inside one trunk")
-        key = (tuple(x.shape), modes[0], tuple(p._version for p in self.parameters()),
+        key = (tuple(shape), modes[0], tuple(p._version for p in self.parameters()),
                id(self.input_scale[0]), len(list(self.children())),
                0 if modes[0] else self._bn_gen)
-        y = self._graphs(x, key)
-        if modes[0]:
-            self._bn_gen += 1
-        return y.permute(0, 3, 1, 2)
+        return key, modes[0]
+
+    def graph_ready(self, shape):
+        """True when a forward with this input shape would only replay a captured graph."""
+        return self._graphs.captured(self._graph_key(shape)[0])
 
     def _forward_impl(self, x):
         with torch.no_grad():
@@ -433,13 +454,25 @@ class TorchVisionResNet(nn.Module):
             self._in_cache = (sc.contiguous(), sh.contiguous())
         return self._in_cache
 
+    def trunk_features(self, observations):
+        """output of the torchvision trunk (what dagger_trainer.py:300-314 caches as
+        `rgb_features`): logical [B, C, h, w]."""
+        rgb = observations["rgb"]
+        self.cnn.input_scale = self._input_transform(rgb.device)
+        return self.cnn(rgb)
+
+    def trunk_parameters(self):
+        return self.cnn.parameters()
+
+    def trunk_ready(self, observations):
+        self.cnn.input_scale = self._input_transform(observations["rgb"].device)
+        return self.cnn.graph_ready(observations["rgb"].shape)
+
     def forward(self, observations):
         if "rgb_features" in observations:
-            feats = observations["rgb_features"]
+            feats = wait_ready(observations["rgb_features"])
         else:
-            rgb = observations["rgb"]
-            self.cnn.input_scale = self._input_transform(rgb.device)
-            feats = self.cnn(rgb)
+            feats = self.trunk_features(observations)
         if not self.spatial_output:
             return ops.linear(feats.reshape(feats.size(0), -1), self.fc[1].weight, self.fc[1].bias,
                               ops.ACT_RELU)
@@ -576,8 +609,13 @@ class HipResNetEncoder(nn.Module):
         x = ops._f32c(observations["depth"])  # [B,H,W,1] is already channels-last
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             return tb.TrunkFn.apply(self, x, *self.trainable_params()).permute(0, 3, 1, 2)
-        key = (tuple(x.shape), tuple(p._version for p in self.parameters()))
-        return self._graphs(x, key).permute(0, 3, 1, 2)
+        return self._graphs(x, self._graph_key(x.shape)).permute(0, 3, 1, 2)
+
+    def _graph_key(self, shape):
+        return (tuple(shape), tuple(p._version for p in self.parameters()))
+
+    def graph_ready(self, shape):
+        return self._graphs.captured(self._graph_key(shape))
 
     def _forward_impl(self, x):
         with torch.no_grad():
@@ -734,11 +772,21 @@ class VlnResnetDepthEncoder(nn.Module):
         wt = self.visual_fc[1].weight
         return wt.view(wt.size(0), c, h * w).permute(0, 2, 1).reshape(wt.size(0), h * w * c)
 
+    def trunk_features(self, observations):
+        """output of the habitat ResNetEncoder (cached upstream as `depth_features`)."""
+        return self.visual_encoder(observations)
+
+    def trunk_parameters(self):
+        return self.visual_encoder.parameters()
+
+    def trunk_ready(self, observations):
+        return self.visual_encoder.graph_ready(observations["depth"].shape)
+
     def forward(self, observations):
         if "depth_features" in observations:
-            x = observations["depth_features"]
+            x = wait_ready(observations["depth_features"])
         else:
-            x = self.visual_encoder(observations)
+            x = self.trunk_features(observations)
         b, c, h, w = x.shape
         if self.spatial_output:
             y = torch.cat([_as_nhwc(x), _grid_embedding_nhwc(self.spatial_embeddings, b, h, w)],

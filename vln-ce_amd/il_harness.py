@@ -28,4 +28,7 @@ def update_agent(policy, optimizer, observations, prev_actions, not_done_masks,
     if step_grad:
         optimizer.step()
         optimizer.zero_grad()
-    return loss, action_loss, aux_loss
+    # detached: a caller that keeps the returned loss must not keep this step's autograd graph
+    # (and its AccumulateGrad nodes) alive into the next step
+    aux_out = aux_loss.detach() if isinstance(aux_loss, torch.Tensor) else aux_loss
+    return loss.detach(), action_loss.detach(), aux_out

@@ -74,3 +74,14 @@ class ILPolicy(Policy):
     def build_distribution(self, observations, rnn_states, prev_actions, masks):
         features, rnn_states = self.net(observations, rnn_states, prev_actions, masks)
         return self.action_distribution(features)
+
+    def encode_ahead(self, observations):
+        """Optional (not in the reference): start the frozen visual trunks of a FUTURE batch on
+        side HIP streams now and get back the observation dict to pass to act() /
+        build_distribution() later (it carries `rgb_features` / `depth_features`).  Issued
+        before the update on the current batch, the next batch's trunks overlap that update's
+        tail; results are identical to calling without it.  See streams.BranchStreams."""
+        branches = getattr(self.net, "_branches", None)
+        if branches is None:
+            return observations
+        return branches.encode_visual_ahead(self.net, observations)

@@ -9,11 +9,30 @@ RGB trunk; autograd replays each branch's backward on the stream its forward
 used, so the BPTT kernel overlaps the tail's backward as well.
 Set VLNCE_SIDE_STREAMS=0 to serialise everything on the current stream."""
 import os
+import weakref
 
 import torch
 
 
 _SIDE_STREAMS = {}  # (idx, device index) -> stream; one set per process, shared by all policies
+_READY = {}  # id(tensor) -> (weakref, event): tensors produced ahead of time on a side stream
+
+
+def mark_ready(t, event):
+    """remember that `t` is complete once `event` has fired (see wait_ready)."""
+    key = id(t)
+    _READY[key] = (weakref.ref(t, lambda _r, k=key: _READY.pop(k, None)), event)
+
+
+def wait_ready(t):
+    """orders the current stream after the side-stream producer of `t` (no-op for ordinary
+    tensors); every consumer of a tensor handed out by encode_ahead() calls this."""
+    ent = _READY.get(id(t))
+    if ent is not None and ent[0]() is t:
+        cur = torch.cuda.current_stream(t.device)
+        cur.wait_event(ent[1])
+        t.record_stream(cur)
+    return t
 
 
 def _elapsed_two_spins(a, b, cycles):
@@ -59,6 +78,11 @@ def pick_concurrent_stream(device, others=(), priority=-1, candidates=12):
 
 
 class BranchStreams:
+    # 0: inline branches of a forward (instruction RNN, depth trunk); 1 / 2: the RGB / depth
+    # trunks of a batch that runs ahead (encode_visual_ahead).  With the main stream that is
+    # one stream per hardware queue of the default HIP runtime configuration.
+    NUM_STREAMS = 3
+
     def __init__(self):
         self._streams = _SIDE_STREAMS
 
@@ -82,6 +106,10 @@ class BranchStreams:
         token wait for it (and NOT for work enqueued on the current stream afterwards)."""
         if not self.enabled(device):
             return None
+        # both side streams are created (and their hardware-queue placement measured) on the
+        # very first use, i.e. before any HIP graph of this process is captured
+        for idx in range(self.NUM_STREAMS):
+            self._stream(idx, device)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(device))
         return ev
@@ -91,19 +119,64 @@ class BranchStreams:
         (result, join) -- call join() before consuming the result on the current stream."""
         if token is None:
             return fn(), (lambda: None)
-        cur = torch.cuda.current_stream(device)
-        side = self._stream(idx, device)
-        side.wait_event(token)
-        with torch.cuda.stream(side):
-            out = fn()
+        out, done = self.launch(token, idx, device, fn)
 
         def join():
-            cur.wait_stream(side)
+            # waits for THIS branch only (an event, not the whole side stream: work that was
+            # queued behind it, e.g. the next step's trunk, must not hold the consumer back)
+            cur = torch.cuda.current_stream(device)
+            cur.wait_event(done)
             for t in (out if isinstance(out, (tuple, list)) else (out,)):
                 if isinstance(t, torch.Tensor) and t.is_cuda:
                     t.record_stream(cur)
 
         return out, join
+
+    def launch(self, token, idx, device, fn):
+        """fn() on side stream `idx` after the fork point; returns (result, completion event)."""
+        side = self._stream(idx, device)
+        side.wait_event(token)
+        with torch.cuda.stream(side):
+            out = fn()
+            done = torch.cuda.Event()
+            done.record(side)
+        return out, done
+
+    def encode_visual_ahead(self, net, observations):
+        """Starts the FROZEN visual trunks of `observations` on side streams and returns a copy
+        of the dict carrying their outputs as `rgb_features` / `depth_features` -- the same
+        bypass keys the reference's DAgger feature cache feeds (resnet_encoders.py:70-72,
+        193-195), so the policy consumes them through its normal path.  Nothing downstream of
+        the trunks runs here: every trainable module still sees the weights of the step that
+        consumes the features.  Stream-ordered after the caller's current stream; the consumer
+        waits on the completion events, so the call can be issued a whole update earlier
+        (e.g. for batch k+1 before the update on batch k is enqueued) and the trunk then
+        overlaps that update's latency-bound tail."""
+        out = dict(observations)
+        probe = next((v for v in observations.values() if isinstance(v, torch.Tensor)), None)
+        if probe is None or not self.enabled(probe.device):
+            return out
+        dev = probe.device
+        fork = None
+        plan = (("rgb", "rgb_features", 1, getattr(net, "rgb_encoder", None)),
+                ("depth", "depth_features", 2, getattr(net, "depth_encoder", None)))
+        for src, key, idx, enc in plan:
+            if (enc is None or key in out or src not in out or getattr(enc, "is_blind", False)
+                    or not hasattr(enc, "trunk_features")
+                    or any(p.requires_grad for p in enc.trunk_parameters())):
+                continue
+            if not enc.trunk_ready(observations):
+                # a new input signature: its eager pass and its graph-capturing pass run right
+                # here on the caller's stream (capture starts from an idle device), so trunk
+                # passes -- and the BatchNorm running-stat updates -- keep the call order
+                out[key] = enc.trunk_features(observations)
+                continue
+            if fork is None:
+                fork = self.fork(dev)
+            feats, done = self.launch(fork, idx, dev, lambda e=enc: e.trunk_features(observations))
+            mark_ready(feats, done)
+            out[key] = feats
+        return out
 
 
 class GraphedTail:
