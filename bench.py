@@ -263,6 +263,13 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     log(f"timed region: {args.steps} steps in {elapsed:.3f}s")
+    from vlnce_amd import streams as _st
+    if _st.TIMING:
+        per = {}
+        for idx, e0, e1 in _st.TIMING[-3 * args.steps:]:
+            per.setdefault(idx, []).append(e0.elapsed_time(e1))
+        log("side-stream branch durations (ms, mean over the timed launches): "
+            + ", ".join(f"stream{idx}: {sum(v) / len(v):.2f} x{len(v)}" for idx, v in sorted(per.items())))
     if use_dist:
         tmax = torch.tensor([elapsed], device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

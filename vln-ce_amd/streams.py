@@ -14,6 +14,7 @@ import weakref
 import torch
 
 
+TIMING = [] if os.environ.get("VLNCE_STREAM_TIMING") else None  # (idx, start, end) events
 _SIDE_STREAMS = {}  # (idx, device index) -> stream; one set per process, shared by all policies
 _READY = {}  # id(tensor) -> (weakref, event): tensors produced ahead of time on a side stream
 
@@ -136,10 +137,16 @@ class BranchStreams:
         """fn() on side stream `idx` after the fork point; returns (result, completion event)."""
         side = self._stream(idx, device)
         side.wait_event(token)
+        timing = TIMING is not None
         with torch.cuda.stream(side):
+            if timing:
+                t0 = torch.cuda.Event(enable_timing=True)
+                t0.record(side)
             out = fn()
-            done = torch.cuda.Event()
+            done = torch.cuda.Event(enable_timing=timing)
             done.record(side)
+        if timing:
+            TIMING.append((idx, t0, done))
         return out, done
 
     def encode_visual_ahead(self, net, observations):
