@@ -150,6 +150,18 @@ int vlnce_maxpool3x3s2(const float* x, float* y, int N, int H, int W, int C, int
                        const float* in_scale, const float* in_shift, const float* in_center,
                        int in_relu, vlnce_stream_t stream);
 int vlnce_avgpool2x2(const float* x, float* y, int N, int H, int W, int C, vlnce_stream_t stream);
+
+/* 2x2 space-to-depth with explicit zero border and optional per-channel input transform:
+ *   y[n, pb_h, pb_w, (dy*2+dx)*C + c] = x[n, 2*(pb_h-pad_lo)+dy, 2*(pb_w-pad_lo)+dx, c]*scale[c]+shift[c]
+ * y is [N, H/2+pad_lo+pad_hi, W/2+pad_lo+pad_hi, 4C].  With pad_lo=2, pad_hi=1 a 7x7/stride-2/pad-3
+ * stem convolution (torchvision ResNet conv1, resnet_encoders.py:136-139; habitat ResNet conv1)
+ * over x equals a 4x4/stride-1/pad-0 convolution over y with the taps regrouped: the 3-channel
+ * gather becomes contiguous 16-byte loads (K = 64*C instead of 49*C scattered elements).  The
+ * transform (/255, ImageNet mean/std: resnet_encoders.py:184-190) is applied before the zero
+ * border, exactly like the reference normalises before the padded convolution. */
+int vlnce_space_to_depth2(const float* x, float* y, int N, int H, int W, int C, int pad_lo,
+                          int pad_hi, const float* scale, const float* shift,
+                          vlnce_stream_t stream);
 int vlnce_adaptive_avgpool(const float* x, float* y, int N, int H, int W, int C, int OH, int OW,
                            int ldy, vlnce_stream_t stream);
 

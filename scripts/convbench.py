@@ -16,6 +16,7 @@ from vlnce_amd import ops  # noqa: E402
 # name, H(=W) in, Cin, Cout, k, stride, count in the trunk
 R50 = [
     ("stem7x7s2_3_64", 256, 3, 64, 7, 2, 1),
+    ("stem_s2d_12_64", 131, 12, 64, 4, 1, 0),   # same layer as a 4x4 conv over 2x2 blocks (pad 0)
     ("l1_1x1_64_64", 64, 64, 64, 1, 1, 1),
     ("l1_3x3_64_64", 64, 64, 64, 3, 1, 3),
     ("l1_1x1_64_256", 64, 64, 256, 1, 1, 4),
@@ -58,7 +59,7 @@ def main():
         w = torch.randn(cout, k, k, cin, device=dev) * (cin * k * k) ** -0.5
         sc = torch.rand(cout, device=dev) + 0.5
         sh = torch.randn(cout, device=dev)
-        pad = k // 2
+        pad = k // 2 if k % 2 else 0
         kw = dict(want_stats=True) if args.mode == "train" else dict(scale=sc, shift=sh, act=1)
         if cin == 3:
             kw.update(in_scale=torch.full((3,), 1 / 255.0, device=dev),

@@ -181,6 +181,16 @@ class HostSim:
         v = a * s1 + t1 + b * s2 + t2
         y.view(M, Cc).copy_(_act(v, act))
 
+    def space_to_depth2(self, x, y, N, H, W, Cc, pad_lo, pad_hi, scale=None, shift=None):
+        v = x.reshape(N, H, W, Cc)
+        if scale is not None:
+            v = v * scale + shift
+        v = v.view(N, H // 2, 2, W // 2, 2, Cc).permute(0, 1, 3, 2, 4, 5).reshape(
+            N, H // 2, W // 2, 4 * Cc)
+        y.zero_()
+        y.view(N, H // 2 + pad_lo + pad_hi, W // 2 + pad_lo + pad_hi, 4 * Cc)[
+            :, pad_lo:pad_lo + H // 2, pad_lo:pad_lo + W // 2] = v
+
     def avgpool2x2(self, x, y, N, H, W, Cc):
         y.copy_(F.avg_pool2d(x.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1))
 

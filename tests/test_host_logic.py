@@ -91,3 +91,20 @@ def test_ppo_harness_clips_and_steps(sim):
     r, v = torch.arange(8.0).view(4, 2, 1), torch.ones(4, 2, 1)
     a = normalized_advantages(r, v, normalize=True)
     assert a.shape == (3, 2, 1) and abs(a.mean().item()) < 1e-6
+
+
+def test_s2d_stem_equals_direct_7x7(sim):
+    """space-to-depth formulation of the 7x7/s2/p3 stems (RGB: 3 channels with /255 folded
+    in; depth: 1 channel) against the direct convolution, on the ABI simulator."""
+    import torch.nn.functional as F
+    from vlnce_amd import ops
+
+    for Cc, Cout, hw in ((3, 16, 20), (1, 8, 12)):
+        g = torch.Generator().manual_seed(Cc)
+        x = torch.rand(2, hw, hw + 4, Cc, generator=g) * 255
+        w = torch.randn(Cout, 7, 7, Cc, generator=g) * 0.1
+        sc, sh = torch.rand(Cc, generator=g) / 255 + 0.001, torch.randn(Cc, generator=g) * 0.1
+        ref = F.conv2d((x * sc + sh).permute(0, 3, 1, 2), w.permute(0, 3, 1, 2), None, 2, 3)
+        y = ops.conv2d_nhwc(ops.space_to_depth2(x, 2, 1, sc, sh), ops.stem_weight_s2d(w), 1, 0)
+        assert y.shape == (2, hw // 2, (hw + 4) // 2, Cout)
+        assert torch.allclose(y.permute(0, 3, 1, 2), ref, atol=2e-5, rtol=1e-5)

@@ -583,3 +583,26 @@ def test_adaptive_avgpool_bwd(hip, N, H, W, Cc, OH, OW):
     t = dict(dy=rnd(N, OH, OW, Cc, seed=1), dx=torch.zeros(N, H, W, Cc))
     cpu, gpu = both("adaptive_avgpool_bwd", t, dict(N=N, H=H, W=W, Cc=Cc, OH=OH, OW=OW))
     close(gpu["dx"], cpu["dx"], 1e-6, what="adaptive avgpool bwd")
+
+
+@pytest.mark.parametrize("N,H,W,Cc", [(2, 16, 20, 3), (3, 8, 8, 1), (1, 64, 64, 3)])
+def test_space_to_depth2(hip, N, H, W, Cc):
+    x = rnd(N, H, W, Cc, seed=1) * 100
+    sc, sh = rnd(Cc, seed=2) * 0.01, rnd(Cc, seed=3)
+    for scale, shift in ((sc, sh), (None, None)):
+        t = dict(x=x, y=torch.full((N, H // 2 + 3, W // 2 + 3, 4 * Cc), 7.0), scale=scale,
+                 shift=shift)
+        cpu, gpu = both("space_to_depth2", t, dict(N=N, H=H, W=W, Cc=Cc, pad_lo=2, pad_hi=1))
+        close(gpu["y"], cpu["y"], 1e-6, what="space_to_depth2")
+
+
+@pytest.mark.parametrize("Cc,Cout,hw,N", [(3, 64, 64, 3), (1, 32, 32, 4)])
+def test_s2d_stem_matches_direct_conv(hip, Cc, Cout, hw, N):
+    """the frozen trunks' stem formulation (space-to-depth + 4x4 conv) vs F.conv2d 7x7/s2/p3."""
+    x = (rnd(N, hw, hw, Cc, seed=1).abs() * 80).clamp(0, 255)
+    w = rnd(Cout, 7, 7, Cc, seed=2) * 0.1
+    sc, sh = torch.full((Cc,), 1 / 255.0), torch.zeros(Cc)
+    ref = F.conv2d((x * sc + sh).permute(0, 3, 1, 2), w.permute(0, 3, 1, 2), None, 2, 3)
+    y, stats = ops.conv2d_nhwc(ops.space_to_depth2(x.to(DEV), 2, 1, sc.to(DEV), sh.to(DEV)),
+                               ops.stem_weight_s2d(w.to(DEV)), 1, 0, want_stats=True)
+    close(y.permute(0, 3, 1, 2), ref, what="s2d stem")

@@ -54,6 +54,7 @@ _SIGNATURES = {
     "vlnce_maxpool3x3s2": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P]),
     "vlnce_scale_shift_add_act": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P]),
     "vlnce_avgpool2x2": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "vlnce_space_to_depth2": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
     "vlnce_adaptive_avgpool": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "vlnce_attn_fwd": (_I, [_P, _P, _I, _P, _I, _P, _I, _F, _P, _P, _I, _I, _I, _I, _P]),
     "vlnce_attn_bwd": (_I, [_P, _P, _P, _I, _P, _I, _P, _I, _F, _P, _P, _P, _I, _P, _I,
@@ -196,6 +197,11 @@ class HipLib:
         self._check(self.dll.vlnce_scale_shift_add_act(
             _ptr(x1), _ptr(s1), _ptr(t1), _ptr(c1), _ptr(x2), _ptr(s2), _ptr(t2), _ptr(c2),
             _ptr(y), M, Cc, act, _stream()), "vlnce_scale_shift_add_act")
+
+    def space_to_depth2(self, x, y, N, H, W, Cc, pad_lo, pad_hi, scale=None, shift=None):
+        self._check(self.dll.vlnce_space_to_depth2(_ptr(x), _ptr(y), N, H, W, Cc, pad_lo, pad_hi,
+                                                   _ptr(scale), _ptr(shift), _stream()),
+                    "vlnce_space_to_depth2")
 
     def avgpool2x2(self, x, y, N, H, W, Cc):
         self._check(self.dll.vlnce_avgpool2x2(_ptr(x), _ptr(y), N, H, W, Cc, _stream()),

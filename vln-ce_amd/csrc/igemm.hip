@@ -753,10 +753,16 @@ struct TileChoice {
   int bm, bn;
 };
 TileChoice choose_tile(long M, int N) {
+  static const int force = getenv("VLNCE_IGEMM_TILE") ? atoi(getenv("VLNCE_IGEMM_TILE")) : 0;
+  if (force == 1) return {128, 128};  // tuning knob (scripts/convbench.py)
+  if (force == 2) return {128, 64};
+  if (force == 3) return {64, 64};
   const long want = 512;
   auto tiles = [&](int bm, int bn) { return (long)ceil_div(M, bm) * ceil_div(N, bn); };
   if (N > 64 && M > 64 && tiles(128, 128) >= want) return {128, 128};
-  if (M > 64 && tiles(128, 64) >= want) return {128, 64};
+  // N <= 64: 64x64 tiles (4 workgroups per CU out of phase) measured 5-15 % ahead of 128x64
+  // on the layer1 shapes (scripts/convbench.py, VLNCE_IGEMM_TILE sweep)
+  if (N > 64 && M > 64 && tiles(128, 64) >= want) return {128, 64};
   return {64, 64};
 }
 

@@ -144,6 +144,45 @@ extern "C" int vlnce_maxpool3x3s2(const float* x, float* y, int N, int H, int W,
   return 0;
 }
 
+// y[n, pb_h, pb_w, (dy*2+dx)*C + c] = x[n, 2*(pb_h-pad_lo)+dy, 2*(pb_w-pad_lo)+dx, c] * scale[c] + shift[c]
+// and 0 in the pad_lo leading / pad_hi trailing border blocks.
+__global__ __launch_bounds__(256) void space_to_depth2_kernel(
+    const float* __restrict__ x, float* __restrict__ y, int N, int H, int W, int C, int pad_lo,
+    int Hb, int Wb, const float* __restrict__ scale, const float* __restrict__ shift) {
+  const int C4 = 4 * C, C2 = 2 * C;
+  const long total = (long)N * Hb * Wb * C4;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int q = (int)(i % C4);
+    long t = i / C4;
+    const int pbw = (int)(t % Wb);
+    t /= Wb;
+    const int pbh = (int)(t % Hb);
+    const int n = (int)(t / Hb);
+    const int dy = q / C2, r = q - dy * C2, dx = r / C, c = r - dx * C;
+    const int ih = 2 * (pbh - pad_lo) + dy, iw = 2 * (pbw - pad_lo) + dx;
+    float v = 0.f;
+    if (ih >= 0 && ih < H && iw >= 0 && iw < W) {
+      v = x[(((long)n * H + ih) * W + iw) * C + c];
+      if (scale) v = v * scale[c] + shift[c];
+    }
+    y[i] = v;
+  }
+}
+
+extern "C" int vlnce_space_to_depth2(const float* x, float* y, int N, int H, int W, int C,
+                                     int pad_lo, int pad_hi, const float* scale,
+                                     const float* shift, vlnce_stream_t stream) {
+  VLNCE_CHECK_ARG(x && y && N > 0 && C > 0 && H >= 2 && W >= 2 && (H % 2) == 0 && (W % 2) == 0 &&
+                      pad_lo >= 0 && pad_hi >= 0 && (!scale == !shift),
+                  "space_to_depth2: bad argument");
+  const int Hb = H / 2 + pad_lo + pad_hi, Wb = W / 2 + pad_lo + pad_hi;
+  hipLaunchKernelGGL(space_to_depth2_kernel, dim3(grid_for((long)N * Hb * Wb * 4 * C)), dim3(256),
+                     0, reinterpret_cast<hipStream_t>(stream), x, y, N, H, W, C, pad_lo, Hb, Wb,
+                     scale, shift);
+  VLNCE_CHECK_LAUNCH("space_to_depth2");
+  return 0;
+}
+
 extern "C" int vlnce_avgpool2x2(const float* x, float* y, int N, int H, int W, int C,
                                 vlnce_stream_t stream) {
   VLNCE_CHECK_ARG(x && y && H >= 2 && W >= 2, "avgpool2x2: bad argument");

@@ -51,6 +51,15 @@ class _WeightCache:
             self._packed[id(conv)] = hit
         return hit[1]
 
+    def stem_s2d(self, conv):
+        """7x7/s2/p3 stem taps regrouped for the space-to-depth formulation (ops.stem_weight_s2d)."""
+        k = self._key(conv.weight)
+        hit = self._packed.get(("s2d", id(conv)))
+        if hit is None or hit[0] != k:
+            hit = (k, ops.stem_weight_s2d(self.conv(conv)))
+            self._packed[("s2d", id(conv))] = hit
+        return hit[1]
+
     def bn_eval(self, bn, gen=0):
         # `gen` counts train-mode forwards: the HIP kernels update the running statistics
         # through raw pointers, which torch's version counters do not see
@@ -125,6 +134,14 @@ def _require_frozen(module, what):
             f"{what}: trainable visual encoders need the conv dgrad/wgrad kernels, which this "
             "build does not have yet; keep MODEL.*_ENCODER.trainable=False (the reference default)"
         )
+
+
+def _stem_is_s2d(conv, x):
+    """the frozen trunks run a 7x7/stride-2/pad-3 stem as a 4x4 convolution over 2x2
+    space-to-depth blocks (contiguous 16-byte operand loads instead of a 3- or 1-channel gather)."""
+    return (conv.kernel_size == (7, 7) and conv.stride == (2, 2) and conv.padding == (3, 3)
+            and x.size(1) % 2 == 0 and x.size(2) % 2 == 0
+            and os.environ.get("VLNCE_STEM_S2D", "1") != "0")
 
 
 def _as_nhwc(t_nchw_logical):
@@ -222,24 +239,26 @@ class HipResNetTrunk(nn.Sequential):
         self._norms = [m for m in self.modules() if isinstance(m, nn.BatchNorm2d)]
 
     # ---- eval mode: BatchNorm folded to a per-channel scale/shift in the conv epilogue
-    def _conv_bn_eval(self, x, conv, bn, relu, residual=None, prologue=None):
+    def _conv_bn_eval(self, x, conv, bn, relu, residual=None, prologue=None, s2d=False):
         pro = {} if prologue is None else dict(in_scale=prologue[0], in_shift=prologue[1])
         scale, shift = self._cache.bn_eval(bn, self._bn_gen)
-        return ops.conv2d_nhwc(x, self._cache.conv(conv), conv.stride[0], conv.padding[0],
-                               scale=scale, shift=shift, residual=residual,
+        w, stride, pad = ((self._cache.stem_s2d(conv), 1, 0) if s2d else
+                          (self._cache.conv(conv), conv.stride[0], conv.padding[0]))
+        return ops.conv2d_nhwc(x, w, stride, pad, scale=scale, shift=shift, residual=residual,
                                act=ops.ACT_RELU if relu else ops.ACT_NONE, **pro)
 
     # ---- train mode: conv writes the RAW output + per-tile moments; the finalize kernel
     # turns them into (scale, shift) and updates the running statistics.  The pending
     # normalisation (+ReLU) is then applied by whoever consumes the raw tensor: the next
     # conv's operand loader, the max-pool, or the block-end add pass.
-    def _conv_stats(self, x, conv, bn, touched, prologue=None, in_relu=False):
+    def _conv_stats(self, x, conv, bn, touched, prologue=None, in_relu=False, s2d=False):
         pro = {}
         if prologue is not None:
             pro = dict(in_scale=prologue[0], in_shift=prologue[1], in_relu=in_relu,
                        in_center=prologue[2] if len(prologue) > 2 else None)
-        y, stats = ops.conv2d_nhwc(x, self._cache.conv(conv), conv.stride[0], conv.padding[0],
-                                   want_stats=True, **pro)
+        w, stride, pad = ((self._cache.stem_s2d(conv), 1, 0) if s2d else
+                          (self._cache.conv(conv), conv.stride[0], conv.padding[0]))
+        y, stats = ops.conv2d_nhwc(x, w, stride, pad, want_stats=True, **pro)
         assert bn.momentum is not None
         pend = ops.bn_finalize(stats, y.numel() // y.size(-1), bn.weight, bn.bias, bn.eps,
                                bn.momentum, bn.running_mean, bn.running_var)
@@ -298,12 +317,16 @@ class HipResNetTrunk(nn.Sequential):
             kids = list(self.children())
             train = kids[1].training
             touched = []
+            s2d = _stem_is_s2d(kids[0], x)
+            pro = self.input_scale
+            if s2d:  # /255 (+mean/std) applied while regrouping, before the zero border
+                x = ops.space_to_depth2(x, 2, 1, self.input_scale[0], self.input_scale[1])
+                pro = None
             if train:
-                raw, pend = self._conv_stats(x, kids[0], kids[1], touched,
-                                             prologue=self.input_scale)
+                raw, pend = self._conv_stats(x, kids[0], kids[1], touched, prologue=pro, s2d=s2d)
                 x = ops.maxpool3x3s2(raw, pend[0], pend[1], in_relu=True, in_center=pend[2])
             else:
-                x = self._conv_bn_eval(x, kids[0], kids[1], True, prologue=self.input_scale)
+                x = self._conv_bn_eval(x, kids[0], kids[1], True, prologue=pro, s2d=s2d)
                 x = ops.maxpool3x3s2(x)
             for stage in kids[4:8]:
                 for blk in stage:
@@ -586,7 +609,10 @@ class HipResNetEncoder(nn.Module):
         return self._n_input_rgb + self._n_input_depth == 0
 
     def _conv_gn(self, x, conv, gn, relu, residual=None):
-        y = ops.conv2d_nhwc(x, self._cache.conv(conv), conv.stride[0], conv.padding[0])
+        if _stem_is_s2d(conv, x):
+            y = ops.conv2d_nhwc(ops.space_to_depth2(x, 2, 1), self._cache.stem_s2d(conv), 1, 0)
+        else:
+            y = ops.conv2d_nhwc(x, self._cache.conv(conv), conv.stride[0], conv.padding[0])
         return ops.group_norm_act(y, gn.num_groups, gn.weight, gn.bias, gn.eps, residual=residual,
                                   act=ops.ACT_RELU if relu else ops.ACT_NONE)
 

@@ -134,6 +134,27 @@ def scale_shift_add_act(x1, s1, t1, x2, s2, t2, act=ACT_NONE, out=None, c1=None,
     return y
 
 
+def space_to_depth2(x, pad_lo, pad_hi, scale=None, shift=None):
+    """[N,H,W,C] -> [N,H/2+pad,W/2+pad,4C] (2x2 pixel blocks into channels, zero border)."""
+    assert x.is_contiguous()
+    N, H, W, Cc = x.shape
+    y = torch.empty((N, H // 2 + pad_lo + pad_hi, W // 2 + pad_lo + pad_hi, 4 * Cc),
+                    device=x.device, dtype=torch.float32)
+    L().space_to_depth2(x, y, N, H, W, Cc, pad_lo, pad_hi, scale, shift)
+    return y
+
+
+def stem_weight_s2d(w_ohwi):
+    """7x7 taps [Cout,7,7,C] regrouped for the 4x4 convolution over space_to_depth2(x, 2, 1):
+    pad to 8x8 with a zero first row/column, then (kh8, kw8) = (2*bh+dy, 2*bw+dx)."""
+    Cout, KH, KW, Cc = w_ohwi.shape
+    assert KH == 7 and KW == 7
+    w8 = torch.zeros((Cout, 8, 8, Cc), device=w_ohwi.device, dtype=w_ohwi.dtype)
+    w8[:, 1:, 1:] = w_ohwi
+    return (w8.view(Cout, 4, 2, 4, 2, Cc).permute(0, 1, 3, 2, 4, 5)
+            .reshape(Cout, 4, 4, 4 * Cc).contiguous())
+
+
 def avgpool2x2(x):
     N, H, W, Cc = x.shape
     y = torch.empty((N, H // 2, W // 2, Cc), device=x.device, dtype=torch.float32)
