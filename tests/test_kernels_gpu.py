@@ -175,8 +175,8 @@ def test_bn_finalize_contract(hip, tiles, Cc):
              scale_out=torch.zeros(Cc), shift_out=torch.zeros(Cc), mean_out=torch.zeros(Cc),
              rstd_out=torch.zeros(Cc))
     wb = _lib.get_lib().bn_finalize_workspace_bytes(tiles, Cc)
-    assert (wb > 0) == (tiles > 256)
-    t["workspace"] = torch.zeros(max(wb // 8, 1), dtype=torch.float64)
+    assert wb == 0  # the single-launch finalize needs no scratch
+    t["workspace"] = None
     sc = dict(tiles_m=tiles, tile_rows=rows, M=M, Cc=Cc, eps=1e-5, momentum=0.1)
     cpu, gpu = both("bn_finalize", t, sc)
     for k in ("scale_out", "shift_out", "mean_out", "rstd_out", "running_mean", "running_var"):

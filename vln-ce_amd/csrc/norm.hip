@@ -6,91 +6,93 @@
 namespace {
 
 // ---------------------------------------------------------------- BatchNorm finalize
-// partial: [tiles_m][C][2] = {sum, M2 about the tile mean}.  Tiles are merged with Chan's
-// parallel-variance update in fp64.  Up to 256 tiles: one launch; beyond that a first
-// launch reduces runs of 64 tiles into a workspace [slices][C][3] (n, mean, M2) so the
-// reduction is spread over (C/64) x slices workgroups instead of C/64.
-struct Moments {
-  double n, mean, m2;
-};
-__device__ __forceinline__ void merge(Moments& a, double n, double mean, double m2) {
-  if (n <= 0.0) return;
-  const double tot = a.n + n;
-  const double d = mean - a.mean;
-  a.mean += d * (n / tot);
-  a.m2 += m2 + d * d * (a.n * n / tot);
-  a.n = tot;
-}
-__device__ __forceinline__ Moments block_merge4(Moments m, Moments (*red)[64], int cl, int sl) {
-  red[sl][cl] = m;
-  __syncthreads();
-  Moments r = red[0][cl];
+// partial: [tiles_m][C][2] = {sum, M2 about the tile mean} written by the conv epilogue.
+// One launch, division-free, fp64: a workgroup owns 16 channels and spreads the tiles over
+// 64 lanes each.  Pass 1 adds the tile sums -> batch mean; pass 2 adds
+// M2_t + n_t * (mean_t - mean)^2 (Chan's pairwise update written for a known grand mean).
+// The partials of even the largest layer (4096 tiles x 256 channels) are L2-resident.
+// 1024 threads, lane = slice * BNF_CH + channel; <4, 256> for many tiles, <16, 64> for <= 256 tiles
+
+// sum over the 256 slices of each channel: xor-shuffles across the 16 slices a wave holds,
+// then 16 wave results through LDS
+template <int BNF_CH, int BNF_SL>
+__device__ __forceinline__ double slice_sum(double v, double (*red)[BNF_CH], int cl, int tid) {
 #pragma unroll
-  for (int i = 1; i < 4; ++i) merge(r, red[i][cl].n, red[i][cl].mean, red[i][cl].m2);
+  for (int off = BNF_CH; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);
+  const int wave = tid >> 6;
+  if ((tid & 63) < BNF_CH) red[wave][cl] = v;
+  __syncthreads();
+  double r = 0.0;
+#pragma unroll
+  for (int w = 0; w < (BNF_CH * BNF_SL) / 64; ++w) r += red[w][cl];
+  __syncthreads();
   return r;
 }
 
-constexpr int BN_RUN = 64;  // tiles per first-stage workgroup
-
-__global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict__ partial,
-                                                        int tiles_m, int tile_rows, int M, int C,
-                                                        double* __restrict__ ws) {
-  __shared__ Moments red[4][64];
-  const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cl;
-  const int t0 = blockIdx.y * BN_RUN;
-  const int t1 = min(tiles_m, t0 + BN_RUN);
-  Moments m{0.0, 0.0, 0.0};
-  if (c < C)
-    for (int t = t0 + sl; t < t1; t += 4) {
-      const float* q = partial + ((long)t * C + c) * 2;
-      const double nt = (double)min(tile_rows, M - t * tile_rows);
-      merge(m, nt, (double)q[0] / nt, (double)q[1]);
-    }
-  m = block_merge4(m, red, cl, sl);
-  if (sl == 0 && c < C) {
-    double* dst = ws + ((long)blockIdx.y * C + c) * 3;
-    dst[0] = m.n;
-    dst[1] = m.mean;
-    dst[2] = m.m2;
-  }
-}
-
-template <bool FROM_WS>
-__global__ __launch_bounds__(256) void bn_finalize_kernel(
-    const float* __restrict__ partial, const double* __restrict__ ws, int items, int tile_rows,
-    int M, int C, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-    float momentum, float* running_mean, float* running_var, float* scale_out, float* shift_out,
-    float* mean_out, float* rstd_out) {
-  __shared__ Moments red[4][64];
-  const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cl;
-  Moments m{0.0, 0.0, 0.0};
-  if (c < C)
-    for (int t = sl; t < items; t += 4) {
-      if (FROM_WS) {
-        const double* q = ws + ((long)t * C + c) * 3;
-        merge(m, q[0], q[1], q[2]);
-      } else {
-        const float* q = partial + ((long)t * C + c) * 2;
-        const double nt = (double)min(tile_rows, M - t * tile_rows);
-        merge(m, nt, (double)q[0] / nt, (double)q[1]);
+template <int BNF_CH, int BNF_SL>
+__global__ __launch_bounds__(BNF_CH* BNF_SL) void bn_finalize_kernel(
+    const float* __restrict__ partial, int tiles_m, int tile_rows, int M, int C,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
+    float* running_mean, float* running_var, float* scale_out, float* shift_out, float* mean_out,
+    float* rstd_out) {
+  __shared__ double red[(BNF_CH * BNF_SL) / 64][BNF_CH];
+  const int tid = threadIdx.x;
+  const int cl = tid % BNF_CH, sl = tid / BNF_CH;
+  const int c = blockIdx.x * BNF_CH + cl;
+  const bool live = c < C;
+  const long stride = (long)BNF_SL * C * 2;
+  constexpr int HOLD = BNF_SL >= 256 ? 16 : 4;  // tiles a thread keeps in registers: one trip to memory
+  const bool held = tiles_m <= HOLD * BNF_SL;
+  float2 v[HOLD];
+  double s = 0.0;
+  if (live) {
+    const float* q = partial + ((long)sl * C + c) * 2;
+    if (held) {
+#pragma unroll
+      for (int i = 0; i < HOLD; ++i) {
+        v[i] = float2{0.f, 0.f};
+        if (sl + i * BNF_SL < tiles_m) v[i] = *reinterpret_cast<const float2*>(q + i * stride);
       }
+#pragma unroll
+      for (int i = 0; i < HOLD; ++i) s += (double)v[i].x;
+    } else {
+      for (int t = sl; t < tiles_m; t += BNF_SL, q += stride) s += (double)q[0];
     }
-  m = block_merge4(m, red, cl, sl);
-  if (sl == 0 && c < C) {
-    const double var = m.m2 / (double)M;  // biased, used for normalisation
+  }
+  const double mean = slice_sum<BNF_CH, BNF_SL>(s, red, cl, tid) / (double)M;
+  double m2 = 0.0;
+  if (live) {
+    const double inv_full = 1.0 / (double)tile_rows;
+    auto term = [&](float2 p, int t) {
+      const int nt = min(tile_rows, M - t * tile_rows);
+      const double mt = (double)p.x * (nt == tile_rows ? inv_full : 1.0 / (double)nt);
+      const double d = mt - mean;
+      return (double)p.y + (double)nt * d * d;
+    };
+    if (held) {
+#pragma unroll
+      for (int i = 0; i < HOLD; ++i)
+        if (sl + i * BNF_SL < tiles_m) m2 += term(v[i], sl + i * BNF_SL);
+    } else {
+      const float* q = partial + ((long)sl * C + c) * 2;
+      for (int t = sl; t < tiles_m; t += BNF_SL, q += stride)
+        m2 += term(*reinterpret_cast<const float2*>(q), t);
+    }
+  }
+  m2 = slice_sum<BNF_CH, BNF_SL>(m2, red, cl, tid);
+  if (sl == 0 && live) {
+    const double var = m2 / (double)M;  // biased, used for normalisation
     const float rstd = (float)(1.0 / sqrt(var + (double)eps));
     const float g = gamma ? gamma[c] : 1.f;
     const float b = beta ? beta[c] : 0.f;
     const float sc = g * rstd;
     scale_out[c] = sc;
-    shift_out[c] = b - (float)m.mean * sc;
-    if (mean_out) mean_out[c] = (float)m.mean;
+    shift_out[c] = b - (float)mean * sc;
+    if (mean_out) mean_out[c] = (float)mean;
     if (rstd_out) rstd_out[c] = rstd;
     if (running_mean) {
-      const double unbiased = M > 1 ? m.m2 / (double)(M - 1) : var;
-      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m.mean;
+      const double unbiased = M > 1 ? m2 / (double)(M - 1) : var;
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
       running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
     }
   }
@@ -271,8 +273,9 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(
 }  // namespace
 
 extern "C" size_t vlnce_bn_finalize_workspace_bytes(int tiles_m, int C) {
-  if (tiles_m <= 256) return 0;
-  return (size_t)ceil_div(tiles_m, BN_RUN) * (size_t)C * 3 * sizeof(double);
+  (void)tiles_m;
+  (void)C;
+  return 0;  // the single-launch finalize needs no scratch (kept in the ABI for callers)
 }
 
 extern "C" int vlnce_bn_finalize(const float* stat_partial, int tiles_m, int tile_rows, int M,
@@ -281,29 +284,23 @@ extern "C" int vlnce_bn_finalize(const float* stat_partial, int tiles_m, int til
                                  float* scale_out, float* shift_out, float* mean_out,
                                  float* rstd_out, void* workspace, size_t workspace_bytes,
                                  vlnce_stream_t stream) {
+  (void)workspace;
+  (void)workspace_bytes;
   VLNCE_CHECK_ARG(stat_partial && scale_out && shift_out, "bn_finalize: null argument");
   VLNCE_CHECK_ARG(tiles_m > 0 && tile_rows > 0 && M > 0 && C > 0, "bn_finalize: bad shape");
+  VLNCE_CHECK_ARG((long)(tiles_m - 1) * tile_rows < M && (long)tiles_m * tile_rows >= M,
+                  "bn_finalize: %d tiles of %d rows do not cover M=%d", tiles_m, tile_rows, M);
   VLNCE_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr),
                   "bn_finalize: running stats must come together");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  const size_t need = vlnce_bn_finalize_workspace_bytes(tiles_m, C);
-  if (need == 0) {
-    hipLaunchKernelGGL(bn_finalize_kernel<false>, dim3(ceil_div(C, 64)), dim3(256), 0, s,
-                       stat_partial, (const double*)nullptr, tiles_m, tile_rows, M, C, gamma, beta,
-                       eps, momentum, running_mean, running_var, scale_out, shift_out, mean_out,
-                       rstd_out);
-  } else {
-    VLNCE_CHECK_ARG(workspace && workspace_bytes >= need,
-                    "bn_finalize: workspace of %zu bytes required", need);
-    const int slices = ceil_div(tiles_m, BN_RUN);
-    double* ws = reinterpret_cast<double*>(workspace);
-    hipLaunchKernelGGL(bn_reduce_kernel, dim3(ceil_div(C, 64), slices), dim3(256), 0, s,
-                       stat_partial, tiles_m, tile_rows, M, C, ws);
-    hipLaunchKernelGGL(bn_finalize_kernel<true>, dim3(ceil_div(C, 64)), dim3(256), 0, s,
-                       stat_partial, (const double*)ws, slices, tile_rows, M, C, gamma, beta, eps,
-                       momentum, running_mean, running_var, scale_out, shift_out, mean_out,
-                       rstd_out);
-  }
+  if (tiles_m > 256)
+    hipLaunchKernelGGL((bn_finalize_kernel<4, 256>), dim3(ceil_div(C, 4)), dim3(1024), 0, s,
+                       stat_partial, tiles_m, tile_rows, M, C, gamma, beta, eps, momentum,
+                       running_mean, running_var, scale_out, shift_out, mean_out, rstd_out);
+  else
+    hipLaunchKernelGGL((bn_finalize_kernel<16, 64>), dim3(ceil_div(C, 16)), dim3(1024), 0, s,
+                       stat_partial, tiles_m, tile_rows, M, C, gamma, beta, eps, momentum,
+                       running_mean, running_var, scale_out, shift_out, mean_out, rstd_out);
   VLNCE_CHECK_LAUNCH("bn_finalize");
   return 0;
 }

@@ -24,7 +24,7 @@ import torch.nn as nn
 
 from .. import ops
 from ..config import Box, Dict
-from ..streams import wait_ready
+from ..streams import capture_guard, wait_ready
 from . import trunk_backward as tb
 
 
@@ -110,7 +110,7 @@ class _GraphRunner:
         if ent == "seen":
             static_in = x.clone()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with capture_guard(), torch.cuda.graph(graph):
                 static_out = self.fn(static_in)
             ent = [graph, static_in, static_out, None]
             self.entries[key] = ent
@@ -126,14 +126,6 @@ class _GraphRunner:
         ent[3] = torch.cuda.Event()
         ent[3].record(cur)
         return out
-
-
-def _require_frozen(module, what):
-    if torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters()):
-        raise NotImplementedError(
-            f"{what}: trainable visual encoders need the conv dgrad/wgrad kernels, which this "
-            "build does not have yet; keep MODEL.*_ENCODER.trainable=False (the reference default)"
-        )
 
 
 def _stem_is_s2d(conv, x):

@@ -8,6 +8,7 @@ CUs idle when run alone.  Running them on side streams overlaps them with the
 RGB trunk; autograd replays each branch's backward on the stream its forward
 used, so the BPTT kernel overlaps the tail's backward as well.
 Set VLNCE_SIDE_STREAMS=0 to serialise everything on the current stream."""
+import gc
 import os
 import weakref
 
@@ -17,6 +18,24 @@ import torch
 TIMING = [] if os.environ.get("VLNCE_STREAM_TIMING") else None  # (idx, start, end) events
 _SIDE_STREAMS = {}  # (idx, device index) -> stream; one set per process, shared by all policies
 _READY = {}  # id(tensor) -> (weakref, event): tensors produced ahead of time on a side stream
+
+
+class capture_guard:
+    """Around every HIP-graph capture: collect cyclic garbage first and keep the collector off
+    while the capture is open.  torch.cuda.graph no longer collects on entry, and a cycle that
+    dies mid-capture (an earlier policy with its graphs, events and pool memory) runs
+    hipGraphDestroy / hipEventDestroy inside the capture, which aborts the process."""
+
+    def __enter__(self):
+        gc.collect()
+        self.was_enabled = gc.isenabled()
+        gc.disable()
+        return self
+
+    def __exit__(self, *exc):
+        if self.was_enabled:
+            gc.enable()
+        return False
 
 
 def mark_ready(t, event):
@@ -218,7 +237,8 @@ class GraphedTail:
             return self.module(*tensors)
         if ent == "seen":
             sample = tuple(t.detach().clone().requires_grad_(t.requires_grad) for t in tensors)
-            ent = torch.cuda.make_graphed_callables(self.make_module(), sample,
-                                                    allow_unused_input=True)
+            with capture_guard():
+                ent = torch.cuda.make_graphed_callables(self.make_module(), sample,
+                                                        allow_unused_input=True)
             self.entries[key] = ent
         return ent(*tensors)
