@@ -56,6 +56,18 @@ typedef struct {
   const float* in_shift;
   const float* in_center;
   int in_relu;
+  /* Optional second input (1x1 / stride-1 / pad-0 convolutions with Cin % 32 == 0 only): the
+   * end of a residual block, out = relu(bn3(conv3) + identity) (torchvision Bottleneck.forward),
+   * is evaluated inside the NEXT block's first convolution instead of in a pass of its own:
+   *   x' = act((x - in_center)*in_scale + in_shift + ((x2 - in2_center)*in2_scale + in2_shift))
+   * x2 has the layout of x; in2_scale NULL = x2 is added as is (identity skip), non-NULL = the
+   * downsample branch's raw conv output with its BatchNorm.  side_out (same layout as x, or
+   * NULL) receives x' -- the block output the following layers read as their skip input. */
+  const float* x2;
+  const float* in2_scale;
+  const float* in2_shift;
+  const float* in2_center;
+  float* side_out;
 } vlnce_prologue;
 
 typedef struct {

@@ -38,13 +38,23 @@ class HostSim:
 
     def conv2d_fwd(self, x, w, y, g, in_scale=None, in_shift=None, in_relu=0, scale=None,
                    shift=None, residual=None, ldr=0, act=0, accumulate=0, stat_partial=None,
-                   in_center=None):
+                   in_center=None, x2=None, in2_scale=None, in2_shift=None, in2_center=None,
+                   side_out=None):
         N, H, W, Cin, Cout = g["N"], g["H"], g["W"], g["Cin"], g["Cout"]
         xi = x.as_strided((N, H, W, Cin), (H * W * g["ldx"], W * g["ldx"], g["ldx"], 1))
         if in_scale is not None:
             xi = (xi - in_center if in_center is not None else xi) * in_scale + in_shift
+            if x2 is not None:
+                assert g["KH"] == 1 and g["stride"] == 1 and g["pad"] == 0
+                x2i = x2.reshape(N, H, W, Cin)
+                if in2_scale is not None:
+                    x2i = (x2i - in2_center if in2_center is not None else x2i) * in2_scale \
+                        + in2_shift
+                xi = xi + x2i
             if in_relu:
                 xi = torch.relu(xi)
+            if side_out is not None:
+                side_out.view(N, H, W, Cin).copy_(xi)
         wk = w.view(Cout, g["KH"], g["KW"], Cin).permute(0, 3, 1, 2)
         raw = F.conv2d(xi.permute(0, 3, 1, 2), wk, stride=g["stride"], padding=g["pad"])
         raw = raw.permute(0, 2, 3, 1).reshape(-1, Cout)

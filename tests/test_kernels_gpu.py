@@ -63,6 +63,15 @@ CONV_CASES = [
     ("prologue_v4_c",  2, 12, 12,  32,  64, 3, 1, 1, dict(prologue=True, in_relu=True, center=True)),
     ("prologue_s_c",   2, 12, 12,   6,  64, 3, 1, 1, dict(prologue=True, in_relu=True, center=True)),
     ("prologue_buf_c", 2, 14, 14,  64, 128, 3, 2, 1, dict(prologue=True, in_relu=True, center=True)),
+    # dual-input prologue (block end evaluated in the next block's first 1x1 conv)
+    ("dual_identity",  2, 16, 16,  64,  64, 1, 1, 0, dict(prologue=True, in_relu=True, center=True,
+                                                          dual="identity")),
+    ("dual_bn",        3,  9, 11, 256, 128, 1, 1, 0, dict(prologue=True, in_relu=True, center=True,
+                                                          dual="bn")),
+    ("dual_big",      16, 64, 64, 256, 128, 1, 1, 0, dict(prologue=True, in_relu=True, center=True,
+                                                          dual="bn")),               # 128x128 tiles
+    ("dual_wide_n",    4, 16, 16, 128, 512, 1, 1, 0, dict(prologue=True, in_relu=True, center=True,
+                                                          dual="identity")),         # 4 n-tiles
     ("compress_1024",  2,  4,  4, 1024, 128, 3, 1, 1, dict()),
 ]
 
@@ -78,6 +87,13 @@ def test_conv2d_fwd(hip, case):
     t["in_scale"] = rnd(Cin, seed=3).abs() + 0.5 if ex.get("prologue") else None
     t["in_shift"] = rnd(Cin, seed=4) * 0.3 if ex.get("prologue") else None
     t["in_center"] = rnd(Cin, seed=14) * 0.5 if ex.get("center") else None
+    if ex.get("dual"):
+        t["x2"] = rnd(N, H, W, Cin, seed=15)
+        t["side_out"] = torch.zeros(N, H, W, Cin)
+        if ex["dual"] == "bn":
+            t["in2_scale"] = rnd(Cin, seed=16).abs() + 0.5
+            t["in2_shift"] = rnd(Cin, seed=17) * 0.3
+            t["in2_center"] = rnd(Cin, seed=18) * 0.5
     t["scale"] = rnd(Cout, seed=5).abs() + 0.5 if ex.get("scale") else None
     t["shift"] = rnd(Cout, seed=6) if ex.get("scale") else None
     t["residual"] = rnd(N, g["Ho"], g["Wo"], Cout, seed=7) if ex.get("residual") else None
@@ -86,6 +102,8 @@ def test_conv2d_fwd(hip, case):
     # statistics use each side's own tiling; compare after finalize
     cpu, gpu = both("conv2d_fwd", t, sc)
     close(gpu["y"], cpu["y"], what=name)
+    if ex.get("dual"):
+        close(gpu["side_out"], cpu["side_out"], 1e-6, what=name + "/side_out")
     if ex.get("stats"):
         x_d, w_d = x.to(DEV), w.to(DEV)
         y, stats = ops.conv2d_nhwc(x_d, w_d, s, p, want_stats=True)

@@ -27,7 +27,9 @@ class ConvDesc(C.Structure):
 
 
 class Prologue(C.Structure):
-    _fields_ = [("in_scale", _P), ("in_shift", _P), ("in_center", _P), ("in_relu", _I)]
+    _fields_ = [("in_scale", _P), ("in_shift", _P), ("in_center", _P), ("in_relu", _I),
+                ("x2", _P), ("in2_scale", _P), ("in2_shift", _P), ("in2_center", _P),
+                ("side_out", _P)]
 
 
 class Epilogue(C.Structure):
@@ -134,9 +136,11 @@ class HipLib:
 
     def conv2d_fwd(self, x, w, y, g, in_scale=None, in_shift=None, in_relu=0, scale=None,
                    shift=None, residual=None, ldr=0, act=0, accumulate=0, stat_partial=None,
-                   in_center=None):
+                   in_center=None, x2=None, in2_scale=None, in2_shift=None, in2_center=None,
+                   side_out=None):
         d = self._desc(g)
-        pro = Prologue(_ptr(in_scale), _ptr(in_shift), _ptr(in_center), int(in_relu))
+        pro = Prologue(_ptr(in_scale), _ptr(in_shift), _ptr(in_center), int(in_relu), _ptr(x2),
+                       _ptr(in2_scale), _ptr(in2_shift), _ptr(in2_center), _ptr(side_out))
         epi = Epilogue(_ptr(scale), _ptr(shift), _ptr(residual), int(ldr), int(act),
                        int(accumulate), _ptr(stat_partial))
         self._check(self.dll.vlnce_conv2d_fwd(_ptr(x), _ptr(w), _ptr(y), C.byref(d), C.byref(pro),

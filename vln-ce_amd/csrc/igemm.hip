@@ -45,6 +45,14 @@ struct IgemmParams {
   const float* in_shift;
   const float* in_center;  // optional: x' = (x - center) * scale + shift
   int in_relu;
+  // dual-input prologue (1x1 convolutions through the buffer loaders only):
+  //   x' = act((A - center)*scale + shift + ((A2 - center2)*scale2 + shift2  |  A2))
+  // and, when side_out is set, the n-tile-0 workgroups store x' to side_out[m, 0..K)
+  const float* A2;
+  const float* in2_scale;
+  const float* in2_shift;
+  const float* in2_center;
+  float* side_out;
   const float* scale;
   const float* shift;
   const float* residual;
@@ -61,8 +69,10 @@ __device__ __forceinline__ f32x4 ldg4(const float* p) { return *reinterpret_cast
 
 // CIN_C / KW_C: compile-time Cin and KW for the scalar im2col loader (0 = runtime values);
 // the 7x7 stems (Cin 3 / 1) use them so k -> (r, q, ci) is multiply-shift, not a division.
-template <int BM, int BN, int WM, int WN, int AMODE, int BMODE, int CIN_C = 0, int KW_C = 0>
+template <int BM, int BN, int WM, int WN, int AMODE, int BMODE, int CIN_C = 0, int KW_C = 0,
+          int DUAL = 0>
 __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
+  static_assert(!DUAL || AMODE == A_BUF, "dual-input prologue: buffer-loader path only");
   constexpr int WTM = BM / WM;  // rows per wave
   constexpr int WTN = BN / WN;
   constexpr int MT = WTM / 32;
@@ -146,7 +156,10 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
   // per-lane work is one bit test + select per row: the tap offset is a wave-uniform SGPR
   // (soffset), rows outside the image / matrix get an out-of-range voffset and the hardware
   // bounds check returns zeros (no exec-mask branches, no 64-bit address math).
-  __amdgpu_buffer_rsrc_t rsrc_a, rsrc_b;
+  __amdgpu_buffer_rsrc_t rsrc_a, rsrc_b, rsrc_a2;
+  f32x4 a2_reg[DUAL ? A_ROWS : 1];
+  f32x4 pro2_s = {1.f, 1.f, 1.f, 1.f}, pro2_t = {0.f, 0.f, 0.f, 0.f}, pro2_c = {0.f, 0.f, 0.f, 0.f};
+  int a_kcur = 0;  // K offset (= input channel of a 1x1 conv) of the staged tile
   int a_voff[A_ROWS];
   unsigned a_taps[A_ROWS];  // bit t: filter tap t of this output pixel reads inside the image
   int b_voff[B_ROWS];
@@ -156,6 +169,10 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
     rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char*>(reinterpret_cast<const char*>(p.A)) - bias, 0, (int)(p.a_bytes + bias),
         0x00020000);
+    if constexpr (DUAL)
+      rsrc_a2 = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<char*>(reinterpret_cast<const char*>(p.A2)) - bias, 0,
+          (int)(p.a_bytes + bias), 0x00020000);
     const int HoWo = p.Ho * p.Wo;
 #pragma unroll
     for (int i = 0; i < A_ROWS; ++i) {
@@ -231,6 +248,14 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
         pro_t = ldg4(p.in_shift + u_ci + lk4);
         if (p.in_center) pro_c = ldg4(p.in_center + u_ci + lk4);
       }
+      if constexpr (DUAL) {
+        a_kcur = u_ci;
+        if (p.in2_scale != nullptr) {
+          pro2_s = ldg4(p.in2_scale + u_ci + lk4);
+          pro2_t = ldg4(p.in2_shift + u_ci + lk4);
+          if (p.in2_center) pro2_c = ldg4(p.in2_center + u_ci + lk4);
+        }
+      }
       a_okmask = 0;
 #pragma unroll
       for (int i = 0; i < A_ROWS; ++i) {
@@ -238,6 +263,10 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
         a_okmask |= ok << i;
         a_reg[i] = __builtin_bit_cast(
             f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, ok ? a_voff[i] : BUF_OOB, soff, 0));
+        if constexpr (DUAL)
+          a2_reg[i] = __builtin_bit_cast(
+              f32x4,
+              __builtin_amdgcn_raw_buffer_load_b128(rsrc_a2, ok ? a_voff[i] : BUF_OOB, soff, 0));
       }
       // advance the uniform tap state by one K-tile (Cin % 32 == 0: at most one wrap)
       u_ci += BK;
@@ -473,6 +502,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
           f32x4 v = a_reg[i];
           if constexpr (AMODE == A_IM2COL_V4 || AMODE == A_BUF) {
             v = (v - pro_c) * pro_s + pro_t;
+            if constexpr (DUAL) v += (a2_reg[i] - pro2_c) * pro2_s + pro2_t;
             if (p.in_relu) {
               v.x = fmaxf(v.x, 0.f);
               v.y = fmaxf(v.y, 0.f);
@@ -480,6 +510,12 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
               v.w = fmaxf(v.w, 0.f);
             }
             if (!((a_okmask >> i) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (DUAL) {
+              // the materialised block output: written once, by the workgroups of n-tile 0
+              if (p.side_out != nullptr && n0 == 0 && ((a_okmask >> i) & 1u))
+                *reinterpret_cast<f32x4*>(p.side_out + (long)(m0 + i * 32 + lrow) * p.lda +
+                                          a_kcur + lk4) = v;
+            }
           } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -718,11 +754,12 @@ __global__ __launch_bounds__(256) void bias_act_kernel(float* __restrict__ c, in
   }
 }
 
-template <int BM, int BN, int WM, int WN, int AMODE, int BMODE, int CIN_C = 0, int KW_C = 0>
+template <int BM, int BN, int WM, int WN, int AMODE, int BMODE, int CIN_C = 0, int KW_C = 0,
+          int DUAL = 0>
 int launch(const IgemmParams& p, hipStream_t stream) {
   constexpr int smem_bytes = 2 * (BM + BN) * LDP * (int)sizeof(float);
   static_assert(BM * (BN + 4) * (int)sizeof(float) <= smem_bytes, "epilogue tile must fit");
-  auto kern = igemm_kernel<BM, BN, WM, WN, AMODE, BMODE, CIN_C, KW_C>;
+  auto kern = igemm_kernel<BM, BN, WM, WN, AMODE, BMODE, CIN_C, KW_C, DUAL>;
   static bool attr_set = false;  // per instantiation
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -772,6 +809,12 @@ int dispatch_tiles(const IgemmParams& p, hipStream_t s) {
   if (t.bm == 128 && t.bn == 128) return launch<128, 128, 2, 2, AMODE, BMODE>(p, s);
   if (t.bm == 128 && t.bn == 64) return launch<128, 64, 2, 2, AMODE, BMODE>(p, s);
   return launch<64, 64, 2, 2, AMODE, BMODE>(p, s);
+}
+int dispatch_dual(const IgemmParams& p, hipStream_t s) {
+  const TileChoice t = choose_tile(p.M, p.N);
+  if (t.bm == 128 && t.bn == 128) return launch<128, 128, 2, 2, A_BUF, B_BUF, 0, 0, 1>(p, s);
+  if (t.bm == 128 && t.bn == 64) return launch<128, 64, 2, 2, A_BUF, B_BUF, 0, 0, 1>(p, s);
+  return launch<64, 64, 2, 2, A_BUF, B_BUF, 0, 0, 1>(p, s);
 }
 template <int AMODE, int BMODE>
 int dispatch_small(const IgemmParams& p, hipStream_t s) {
@@ -865,6 +908,11 @@ extern "C" int vlnce_conv2d_fwd(const float* x, const float* w, float* y, const 
   p.in_shift = pro ? pro->in_shift : nullptr;
   p.in_center = pro ? pro->in_center : nullptr;
   p.in_relu = pro ? pro->in_relu : 0;
+  p.A2 = pro ? pro->x2 : nullptr;
+  p.in2_scale = pro ? pro->in2_scale : nullptr;
+  p.in2_shift = pro ? pro->in2_shift : nullptr;
+  p.in2_center = pro ? pro->in2_center : nullptr;
+  p.side_out = pro ? pro->side_out : nullptr;
   VLNCE_CHECK_ARG((p.in_scale == nullptr) == (p.in_shift == nullptr),
                   "conv2d_fwd: in_scale and in_shift must come together");
   fill_epilogue(p, epi);
@@ -875,6 +923,17 @@ extern "C" int vlnce_conv2d_fwd(const float* x, const float* w, float* y, const 
   p.a_bytes = (((long)d->N * d->H * d->W - 1) * p.lda + d->Cin) * 4;
   p.b_bytes = (long)d->Cout * p.K * 4;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (p.A2 != nullptr || p.side_out != nullptr) {
+    VLNCE_CHECK_ARG(p.A2 && p.in_scale && d->KH == 1 && d->KW == 1 && d->stride == 1 &&
+                        d->pad == 0 && v4 && buf_ok(p) && aligned16(p.A2) &&
+                        (!p.side_out || aligned16(p.side_out)) &&
+                        ((p.in2_scale == nullptr) == (p.in2_shift == nullptr)) &&
+                        (!p.in2_scale || (aligned16(p.in2_scale) && aligned16(p.in2_shift))) &&
+                        (!p.in2_center || (p.in2_scale && aligned16(p.in2_center))),
+                    "conv2d_fwd: the dual-input prologue needs x2 + in_scale on a 1x1/stride-1/"
+                    "pad-0 convolution with Cin %% 32 == 0 and 16-byte aligned operands");
+    return dispatch_dual(p, s);
+  }
   if (v4 && buf_ok(p)) return dispatch_tiles<A_BUF, B_BUF>(p, s);
   if (v4) return dispatch_tiles<A_IM2COL_V4, B_NK_V4>(p, s);
   if (d->KW == 7 && d->Cin == 3) return dispatch_stem<3>(p, s);

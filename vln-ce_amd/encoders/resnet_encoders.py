@@ -243,11 +243,17 @@ class HipResNetTrunk(nn.Sequential):
     # turns them into (scale, shift) and updates the running statistics.  The pending
     # normalisation (+ReLU) is then applied by whoever consumes the raw tensor: the next
     # conv's operand loader, the max-pool, or the block-end add pass.
-    def _conv_stats(self, x, conv, bn, touched, prologue=None, in_relu=False, s2d=False):
+    def _conv_stats(self, x, conv, bn, touched, prologue=None, in_relu=False, s2d=False,
+                    dual=None):
         pro = {}
         if prologue is not None:
             pro = dict(in_scale=prologue[0], in_shift=prologue[1], in_relu=in_relu,
                        in_center=prologue[2] if len(prologue) > 2 else None)
+        if dual is not None:  # (x2, pending norm of x2 | None, side_out)
+            x2, p2, side = dual
+            pro.update(x2=x2, side_out=side)
+            if p2 is not None:
+                pro.update(in2_scale=p2[0], in2_shift=p2[1], in2_center=p2[2])
         w, stride, pad = ((self._cache.stem_s2d(conv), 1, 0) if s2d else
                           (self._cache.conv(conv), conv.stride[0], conv.padding[0]))
         y, stats = ops.conv2d_nhwc(x, w, stride, pad, want_stats=True, **pro)
@@ -257,17 +263,45 @@ class HipResNetTrunk(nn.Sequential):
         touched.append(bn.num_batches_tracked)
         return y, pend  # (scale, shift, center)
 
-    def _block_train(self, x, blk, touched):
+    # A block's output relu(bn3(raw3) + skip) is kept PENDING as (raw3, pend3, skip, pend_skip)
+    # and evaluated inside the next block's first 1x1 convolution (dual-input operand loader,
+    # which also writes the materialised value once for the skip path): the separate
+    # read-2-write-1 pass per block disappears.  Blocks that cannot take it (BasicBlock's 3x3
+    # first conv, Cin not a multiple of 32) and the trunk's last block use _materialise.
+    @staticmethod
+    def _materialise(pending):
+        raw, pend, skip, pskip = pending
+        if pskip is not None:
+            return ops.scale_shift_add_act(raw, pend[0], pend[1], skip, pskip[0], pskip[1],
+                                           act=ops.ACT_RELU, out=raw, c1=pend[2], c2=pskip[2])
+        return ops.scale_shift_act(raw, pend[0], pend[1], center=pend[2], residual=skip,
+                                   act=ops.ACT_RELU, out=raw)
+
+    @staticmethod
+    def _takes_pending(blk, pending):
+        conv = blk.stages()[0][0]
+        return (conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.padding == (0, 0)
+                and conv.in_channels % 32 == 0 and pending[0].numel() * 4 < (1 << 31)
+                and os.environ.get("VLNCE_FUSE_BLOCK_END", "1") != "0")
+
+    def _block_train(self, x, pending, blk, touched):
+        """x: materialised block input or None when `pending` holds it; returns the new pending."""
         st = blk.stages()
-        raw, pend = self._conv_stats(x, st[0][0], st[0][1], touched)
+        if pending is not None and self._takes_pending(blk, pending):
+            raw3, pend3, skip, pskip = pending
+            x = torch.empty_like(raw3)
+            raw, pend = self._conv_stats(raw3, st[0][0], st[0][1], touched, prologue=pend3,
+                                         in_relu=True, dual=(skip, pskip, x))
+        else:
+            if pending is not None:
+                x = self._materialise(pending)
+            raw, pend = self._conv_stats(x, st[0][0], st[0][1], touched)
         for conv, bn in st[1:]:
             raw, pend = self._conv_stats(raw, conv, bn, touched, prologue=pend, in_relu=True)
         if blk.downsample is not None:
             rd, pd = self._conv_stats(x, blk.downsample[0], blk.downsample[1], touched)
-            return ops.scale_shift_add_act(raw, pend[0], pend[1], rd, pd[0], pd[1],
-                                           act=ops.ACT_RELU, out=raw, c1=pend[2], c2=pd[2])
-        return ops.scale_shift_act(raw, pend[0], pend[1], center=pend[2], residual=x,
-                                   act=ops.ACT_RELU, out=raw)
+            return raw, pend, rd, pd
+        return raw, pend, x, None
 
     def _block_eval(self, x, blk):
         identity = x
@@ -320,9 +354,16 @@ class HipResNetTrunk(nn.Sequential):
             else:
                 x = self._conv_bn_eval(x, kids[0], kids[1], True, prologue=pro, s2d=s2d)
                 x = ops.maxpool3x3s2(x)
+            pending = None
             for stage in kids[4:8]:
                 for blk in stage:
-                    x = self._block_train(x, blk, touched) if train else self._block_eval(x, blk)
+                    if train:
+                        pending = self._block_train(x, pending, blk, touched)
+                        x = None
+                    else:
+                        x = self._block_eval(x, blk)
+            if pending is not None:
+                x = self._materialise(pending)
             for pool in kids[8:]:
                 x = ops.adaptive_avgpool(x, *pool.out_hw)
             if touched:

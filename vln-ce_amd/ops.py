@@ -45,7 +45,8 @@ def conv_geometry(x, w, stride, pad, ldx=None):
 
 def conv2d_nhwc(x, w_ohwi, stride, pad, *, in_scale=None, in_shift=None, in_center=None,
                 in_relu=False, scale=None, shift=None, residual=None, act=ACT_NONE,
-                want_stats=False):
+                want_stats=False, x2=None, in2_scale=None, in2_shift=None, in2_center=None,
+                side_out=None):
     """y[N,Ho,Wo,Cout] = act((conv(prologue(x), w)) * scale + shift + residual), with
     prologue(x) = act((x - in_center) * in_scale + in_shift).
     want_stats=True additionally returns the BatchNorm partials of the RAW
@@ -61,8 +62,14 @@ def conv2d_nhwc(x, w_ohwi, stride, pad, *, in_scale=None, in_shift=None, in_cent
         stats = (partial, tiles_m, tile_rows)
     if residual is not None:
         assert residual.is_contiguous() and residual.shape == y.shape
+    dual = {}
+    if x2 is not None:  # dual-input prologue (+ materialised transformed input), see the header
+        assert x2.is_contiguous() and x2.shape == x.shape
+        assert side_out is None or (side_out.is_contiguous() and side_out.shape == x.shape)
+        dual = dict(x2=x2, in2_scale=in2_scale, in2_shift=in2_shift, in2_center=in2_center,
+                    side_out=side_out)
     L().conv2d_fwd(x, w_ohwi, y, g, in_scale=in_scale, in_shift=in_shift, in_center=in_center,
-                   in_relu=int(in_relu), scale=scale, shift=shift, residual=residual, ldr=g["Cout"], act=act,
+                   in_relu=int(in_relu), **dual, scale=scale, shift=shift, residual=residual, ldr=g["Cout"], act=act,
                    stat_partial=partial)
     return (y, stats) if want_stats else y
 
