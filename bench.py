@@ -192,6 +192,11 @@ def main():
         obs, prev, masks, tgt, w = batch
         update_agent(policy, opt, obs, prev, masks, tgt, w, 512, grad_hook=grad_hook)
 
+    if os.environ.get("VLNCE_BENCH_CACHED_DEPTH"):  # diagnostic: how much the depth trunk costs
+        with torch.no_grad():
+            feats = policy.net.depth_encoder.trunk_features(batch[0]).clone()
+        batch[0]["depth_features"] = feats
+
     # Frozen encoders do not depend on the weights an update changes, so the trunks of step
     # k+1 are issued (on their own streams) BEFORE step k's update is enqueued and overlap its
     # latency-bound tail.  Every step still runs its own trunk pass, tail forward, backward and
