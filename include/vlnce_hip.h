@@ -151,6 +151,13 @@ int vlnce_gn_finalize(const float* partial, int Nimg, int HW, int C, int groups,
                                             center_out = mean (unfolded form) */
                       float* mean_out, float* rstd_out,   /* [N,groups] or NULL */
                       vlnce_stream_t stream);
+/* Same result from the convolution epilogue's tile statistics (vlnce_epilogue.stat_partial,
+ * {sum, M2} per tile of tile_rows output pixels): usable when HW % tile_rows == 0, i.e. no tile
+ * straddles two samples; saves the vlnce_gn_partial pass over the activation. */
+int vlnce_gn_finalize_tiles(const float* stat_partial, int tile_rows, int Nimg, int HW, int C,
+                            int groups, const float* gamma, const float* beta, float eps,
+                            float* scale_out, float* shift_out, float* center_out,
+                            float* mean_out, float* rstd_out, vlnce_stream_t stream);
 
 /* ------------------------------------------------------------------ pooling
  * NHWC. maxpool 3x3/s2/p1 (torchvision + habitat stems), avg_pool2d(2)

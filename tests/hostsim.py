@@ -177,6 +177,33 @@ class HostSim:
             rstd_out.copy_(rstd)
 
     # ---- pools
+    def gn_finalize_tiles(self, partial, tile_rows, Nimg, HW, Cc, groups, gamma, beta, eps,
+                          scale_out, shift_out, mean_out=None, rstd_out=None, center_out=None):
+        assert HW % tile_rows == 0
+        T = HW // tile_rows
+        p = partial.double().view(Nimg, T, Cc, 2)
+        sums = p[..., 0]
+        sumsq = p[..., 1] + sums * sums / tile_rows
+        cpg = Cc // groups
+        cnt = HW * cpg
+        s = sums.sum(1).view(Nimg, groups, cpg).sum(2)
+        q = sumsq.sum(1).view(Nimg, groups, cpg).sum(2)
+        mean = s / cnt
+        var = (q / cnt - mean * mean).clamp_min(0)
+        rstd = (1.0 / torch.sqrt(var + eps)).float()
+        sc = (gamma if gamma is not None else torch.ones(Cc)) * rstd.repeat_interleave(cpg, dim=1)
+        scale_out.copy_(sc)
+        b = beta if beta is not None else torch.zeros(Cc)
+        if center_out is not None:
+            center_out.copy_(mean.float().repeat_interleave(cpg, dim=1))
+            shift_out.copy_(b.expand(Nimg, Cc))
+        else:
+            shift_out.copy_(b - mean.float().repeat_interleave(cpg, dim=1) * sc)
+        if mean_out is not None:
+            mean_out.copy_(mean.float())
+        if rstd_out is not None:
+            rstd_out.copy_(rstd)
+
     def maxpool3x3s2(self, x, y, N, H, W, Cc, Ho, Wo, in_scale=None, in_shift=None, in_relu=0,
                      in_center=None):
         if in_scale is not None:

@@ -624,3 +624,20 @@ def test_s2d_stem_matches_direct_conv(hip, Cc, Cout, hw, N):
     y, stats = ops.conv2d_nhwc(ops.space_to_depth2(x.to(DEV), 2, 1, sc.to(DEV), sh.to(DEV)),
                                ops.stem_weight_s2d(w.to(DEV)), 1, 0, want_stats=True)
     close(y.permute(0, 3, 1, 2), ref, what="s2d stem")
+
+
+@pytest.mark.parametrize("N,hw,Cin,Cout,k,groups", [(3, 32, 32, 32, 3, 16), (2, 16, 64, 128, 1, 16),
+                                                    (4, 8, 128, 256, 3, 16), (2, 4, 256, 512, 1, 16),
+                                                    (2, 16, 32, 64, 3, 1)])
+def test_conv_group_norm_from_epilogue_stats(hip, N, hw, Cin, Cout, k, groups):
+    """depth trunk: GroupNorm statistics taken from the convolution epilogue's tile moments
+    (falls back to the activation pass when a tile would straddle two samples: the 4x4 case)."""
+    x = rnd(N, hw, hw, Cin, seed=1)
+    w = rnd(Cout, k, k, Cin, seed=2) * (Cin * k * k) ** -0.5
+    gamma, beta = rnd(Cout, seed=3).abs() + 0.5, rnd(Cout, seed=4)
+    res = rnd(N, hw, hw, Cout, seed=5)
+    ref = F.conv2d(x.permute(0, 3, 1, 2), w.permute(0, 3, 1, 2), None, 1, k // 2)
+    ref = torch.relu(F.group_norm(ref, groups, gamma, beta, 1e-5) + res.permute(0, 3, 1, 2))
+    got = ops.conv_group_norm_act(x.to(DEV), w.to(DEV), 1, k // 2, groups, gamma.to(DEV),
+                                  beta.to(DEV), 1e-5, residual=res.to(DEV), act=1)
+    close(got.permute(0, 3, 1, 2), ref, what="conv+GN(from tiles)")

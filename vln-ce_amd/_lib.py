@@ -53,6 +53,7 @@ _SIGNATURES = {
     "vlnce_gn_chunks": (_I, [_I]),
     "vlnce_gn_partial": (_I, [_P, _I, _I, _I, _P, _P]),
     "vlnce_gn_finalize": (_I, [_P, _I, _I, _I, _I, _P, _P, _F, _P, _P, _P, _P, _P, _P]),
+    "vlnce_gn_finalize_tiles": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _F, _P, _P, _P, _P, _P, _P]),
     "vlnce_maxpool3x3s2": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P]),
     "vlnce_scale_shift_add_act": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P]),
     "vlnce_avgpool2x2": (_I, [_P, _P, _I, _I, _I, _I, _P]),
@@ -191,6 +192,13 @@ class HipLib:
             "vlnce_gn_finalize")
 
     # ---- pools
+    def gn_finalize_tiles(self, partial, tile_rows, Nimg, HW, Cc, groups, gamma, beta, eps,
+                          scale_out, shift_out, mean_out=None, rstd_out=None, center_out=None):
+        self._check(self.dll.vlnce_gn_finalize_tiles(
+            _ptr(partial), tile_rows, Nimg, HW, Cc, groups, _ptr(gamma), _ptr(beta), eps,
+            _ptr(scale_out), _ptr(shift_out), _ptr(center_out), _ptr(mean_out), _ptr(rstd_out),
+            _stream()), "vlnce_gn_finalize_tiles")
+
     def maxpool3x3s2(self, x, y, N, H, W, Cc, Ho, Wo, in_scale=None, in_shift=None, in_relu=0,
                      in_center=None):
         self._check(self.dll.vlnce_maxpool3x3s2(_ptr(x), _ptr(y), N, H, W, Cc, Ho, Wo,

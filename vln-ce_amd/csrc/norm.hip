@@ -223,8 +223,12 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict
 }
 
 // one wave per (sample, group)
+// tile_rows == 0: partial holds {sum, sum of squares} per (sample, pixel chunk, channel)
+// (gn_partial_kernel); tile_rows > 0: it holds the convolution epilogue's {sum, M2 about the tile
+// mean} per (M-tile of tile_rows pixels, channel), `chunks` tiles per sample.
 __global__ __launch_bounds__(256) void gn_finalize_kernel(
     const float* __restrict__ partial, int Nimg, int HW, int C, int groups, int chunks,
+    int tile_rows,
     const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
     float* __restrict__ scale_out, float* __restrict__ shift_out, float* center_out,
     float* mean_out, float* rstd_out) {
@@ -240,8 +244,9 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(
     const int ch = i / cpg;
     const int c = g * cpg + (i - ch * cpg);
     const float* src = partial + (((long)n * chunks + ch) * C + c) * 2;
-    s += (double)src[0];
-    q += (double)src[1];
+    const double si = (double)src[0];
+    s += si;
+    q += tile_rows > 0 ? (double)src[1] + si * si / (double)tile_rows : (double)src[1];
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -365,8 +370,26 @@ extern "C" int vlnce_gn_finalize(const float* partial, int Nimg, int HW, int C, 
   VLNCE_CHECK_ARG(groups > 0 && C % groups == 0, "gn_finalize: C %% groups != 0");
   const int chunks = ceil_div(HW, GN_CHUNK);
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(ceil_div((long)Nimg * groups, 4)), dim3(256), 0,
-                     reinterpret_cast<hipStream_t>(stream), partial, Nimg, HW, C, groups, chunks,
+                     reinterpret_cast<hipStream_t>(stream), partial, Nimg, HW, C, groups, chunks, 0,
                      gamma, beta, eps, scale_out, shift_out, center_out, mean_out, rstd_out);
   VLNCE_CHECK_LAUNCH("gn_finalize");
+  return 0;
+}
+
+extern "C" int vlnce_gn_finalize_tiles(const float* stat_partial, int tile_rows, int Nimg, int HW,
+                                       int C, int groups, const float* gamma, const float* beta,
+                                       float eps, float* scale_out, float* shift_out,
+                                       float* center_out, float* mean_out, float* rstd_out,
+                                       vlnce_stream_t stream) {
+  VLNCE_CHECK_ARG(stat_partial && scale_out && shift_out, "gn_finalize_tiles: null argument");
+  VLNCE_CHECK_ARG(groups > 0 && C % groups == 0, "gn_finalize_tiles: C %% groups != 0");
+  VLNCE_CHECK_ARG(tile_rows > 0 && HW % tile_rows == 0,
+                  "gn_finalize_tiles: the %d-row tiles must not straddle samples of %d pixels",
+                  tile_rows, HW);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(ceil_div((long)Nimg * groups, 4)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), stat_partial, Nimg, HW, C, groups,
+                     HW / tile_rows, tile_rows, gamma, beta, eps, scale_out, shift_out, center_out,
+                     mean_out, rstd_out);
+  VLNCE_CHECK_LAUNCH("gn_finalize_tiles");
   return 0;
 }

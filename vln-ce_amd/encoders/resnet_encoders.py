@@ -643,11 +643,12 @@ class HipResNetEncoder(nn.Module):
 
     def _conv_gn(self, x, conv, gn, relu, residual=None):
         if _stem_is_s2d(conv, x):
-            y = ops.conv2d_nhwc(ops.space_to_depth2(x, 2, 1), self._cache.stem_s2d(conv), 1, 0)
+            x, w, stride, pad = ops.space_to_depth2(x, 2, 1), self._cache.stem_s2d(conv), 1, 0
         else:
-            y = ops.conv2d_nhwc(x, self._cache.conv(conv), conv.stride[0], conv.padding[0])
-        return ops.group_norm_act(y, gn.num_groups, gn.weight, gn.bias, gn.eps, residual=residual,
-                                  act=ops.ACT_RELU if relu else ops.ACT_NONE)
+            w, stride, pad = self._cache.conv(conv), conv.stride[0], conv.padding[0]
+        return ops.conv_group_norm_act(x, w, stride, pad, gn.num_groups, gn.weight, gn.bias, gn.eps,
+                                       residual=residual,
+                                       act=ops.ACT_RELU if relu else ops.ACT_NONE)
 
     def _run_convs(self, x, seq, residual):
         """block.convs = [conv, GN, ReLU]* + [conv, GN]; the last GroupNorm output gets

@@ -122,6 +122,25 @@ def group_norm_act(x, groups, gamma, beta, eps, *, residual=None, act=ACT_NONE):
                            act=act)
 
 
+def conv_group_norm_act(x, w_ohwi, stride, pad, groups, gamma, beta, eps, *, residual=None,
+                        act=ACT_NONE):
+    """act(GroupNorm(conv(x)) + residual).  The GroupNorm statistics come from the convolution's
+    own epilogue when its M-tiles do not straddle samples; otherwise from a pass over y."""
+    y, stats = conv2d_nhwc(x, w_ohwi, stride, pad, want_stats=True)
+    partial, _tiles_m, tile_rows = stats
+    N, Ho, Wo, Cc = y.shape
+    HW = Ho * Wo
+    if HW % tile_rows != 0:
+        return group_norm_act(y, groups, gamma, beta, eps, residual=residual, act=act)
+    scale = torch.empty((N, Cc), device=y.device, dtype=torch.float32)
+    shift = torch.empty_like(scale)
+    center = torch.empty_like(scale)
+    L().gn_finalize_tiles(partial, tile_rows, N, HW, Cc, groups, gamma, beta, float(eps), scale,
+                          shift, center_out=center)
+    return scale_shift_act(y, scale, shift, center=center, rows_per_sample=HW, residual=residual,
+                           act=act)
+
+
 def maxpool3x3s2(x, in_scale=None, in_shift=None, in_relu=False, in_center=None):
     """3x3/s2/p1 max pool of act((x-in_center)*in_scale+in_shift) (transform optional)."""
     N, H, W, Cc = x.shape

@@ -114,10 +114,11 @@ class BranchStreams:
     def _stream(self, idx, device):
         key = (idx, device.index)
         if key not in self._streams:
-            # the run-ahead trunk streams get high priority: they are the critical path of a
-            # pipelined step and their kernels should not queue behind the tail's ~300 tiny
-            # dispatches (measured: "0,-1,-1" 5951, "-1,-1,-1" 5888, "0,0,0" 5282 steps/s)
-            prios = os.environ.get("VLNCE_SIDE_PRIORITY", "0,-1,-1").split(",")
+            # high priority for all three: the branch kernels are small and would otherwise only
+            # be admitted at the boundaries of the saturating RGB-trunk kernels.  Measured
+            # (steps/s, pipelined | plain loop): "-1,-1,-1" 5888 | 4716, "0,-1,-1" 5951 | 4385,
+            # "0,0,0" 5282 | -
+            prios = os.environ.get("VLNCE_SIDE_PRIORITY", "-1,-1,-1").split(",")
             prio = int(prios[min(idx, len(prios) - 1)])
             others = [st for (i, d), st in self._streams.items() if d == device.index]
             self._streams[key] = pick_concurrent_stream(device, others, prio)
