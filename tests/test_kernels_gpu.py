@@ -325,6 +325,10 @@ def test_row_utilities(hip):
     t = dict(x=rnd(301, 77, seed=3), out=torch.zeros(77))
     cpu, gpu = both("colsum", t, dict(ldx=77, M=301, N=77, accumulate=0))
     close(gpu["out"], cpu["out"], what="colsum")
+    for M_, acc in ((64, 0), (200, 1), (5000, 1)):  # direct (M <= 256) and sliced/atomic paths
+        t = dict(x=rnd(M_, 130, seed=6), out=rnd(130, seed=7))
+        cpu, gpu = both("colsum", t, dict(ldx=130, M=M_, N=130, accumulate=acc))
+        close(gpu["out"], cpu["out"], what=f"colsum M={M_} acc={acc}")
     for act in (1, 2, 3):
         yv = torch.sigmoid(rnd(50, 12, seed=4)) if act == 2 else torch.tanh(rnd(50, 12, seed=4))
         t = dict(dy=rnd(50, 12, seed=5), y=yv, dz=torch.zeros(50, 12))

@@ -161,9 +161,11 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
 
 // out[n] += sum_m x[m, n]: 64 columns x a slice of rows per block; slices combine with
 // atomics into an output the host entry has zeroed (unless accumulating).
+// DIRECT: one row slice covers all of M, the block owns its 64 outputs (no atomics, no memset).
+template <bool DIRECT>
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int ldx, int M,
                                                      int N, float* __restrict__ out,
-                                                     int rows_per_block) {
+                                                     int rows_per_block, int accumulate) {
   __shared__ float red[4][64];
   const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
   const int n = blockIdx.x * 64 + cl;
@@ -174,7 +176,13 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
     for (int m = m0 + sl; m < m1; m += 4) s += x[(long)m * ldx + n];
   red[sl][cl] = s;
   __syncthreads();
-  if (sl == 0 && n < N) atomicAdd(out + n, red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]);
+  if (sl == 0 && n < N) {
+    const float t = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
+    if (DIRECT)
+      out[n] = accumulate ? out[n] + t : t;
+    else
+      atomicAdd(out + n, t);
+  }
 }
 
 inline int grid_for(long work) {
@@ -245,16 +253,22 @@ extern "C" int vlnce_colsum(const float* x, int ldx, int M, int N, float* out, i
                             vlnce_stream_t stream) {
   VLNCE_CHECK_ARG(x && out && M > 0 && N > 0, "colsum: bad argument");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int col_blocks = ceil_div(N, 64);
+  if (M <= 256) {  // the tail's bias gradients (M = num_envs rows): one launch, nothing else
+    hipLaunchKernelGGL(colsum_kernel<true>, dim3(col_blocks, 1), dim3(256), 0, s, x, ldx, M, N,
+                       out, M, accumulate);
+    VLNCE_CHECK_LAUNCH("colsum");
+    return 0;
+  }
   if (!accumulate) {
     hipError_t e = hipMemsetAsync(out, 0, (size_t)N * sizeof(float), s);
     VLNCE_CHECK_ARG(e == hipSuccess, "colsum: memset failed: %s", hipGetErrorString(e));
   }
-  const int col_blocks = ceil_div(N, 64);
   int slices = ceil_div(256, col_blocks);
   if (slices > ceil_div(M, 32)) slices = ceil_div(M, 32);
   const int rows_per_block = ceil_div(M, slices);
-  hipLaunchKernelGGL(colsum_kernel, dim3(col_blocks, ceil_div(M, rows_per_block)), dim3(256), 0, s,
-                     x, ldx, M, N, out, rows_per_block);
+  hipLaunchKernelGGL(colsum_kernel<false>, dim3(col_blocks, ceil_div(M, rows_per_block)),
+                     dim3(256), 0, s, x, ldx, M, N, out, rows_per_block, accumulate);
   VLNCE_CHECK_LAUNCH("colsum");
   return 0;
 }
