@@ -41,6 +41,17 @@ class GradientAllReducer:
         # gloo (CPU tests) has no AVG: sum, then one fused multiply
         self.avg = dist.get_backend(process_group) == "nccl"
         params = [p for p in module.parameters() if p.requires_grad]
+        # RCCL's kernels go on a stream of OURS: c10d's own communication stream is a pool
+        # stream whose hardware queue we do not control -- if it shares the queue of the stream
+        # the next batch's RGB trunk runs on (streams.BranchStreams), every bucket would wait
+        # for a whole trunk.  Collectives issued with async_op=False run on the current stream
+        # (ProcessGroupNCCL), so they are issued under side stream 0, which is measured to be
+        # concurrent with the main stream and which the trunk streams are measured against.
+        self.comm = None
+        if self.avg and params and params[0].is_cuda:
+            from .streams import BranchStreams
+
+            self.comm = BranchStreams()._stream(0, params[0].device)
         params.reverse()
         self.buckets = []
         cur, cur_bytes = [], 0
@@ -88,7 +99,15 @@ class GradientAllReducer:
         op = dist.ReduceOp.AVG if self.avg else dist.ReduceOp.SUM
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
-            b.work = dist.all_reduce_coalesced(b.tensors, op=op, group=self.group, async_op=True)
+            if self.comm is None:
+                b.work = dist.all_reduce_coalesced(b.tensors, op=op, group=self.group,
+                                                   async_op=True)
+                return
+            self.comm.wait_stream(torch.cuda.current_stream(self.comm.device))
+            with torch.cuda.stream(self.comm):
+                dist.all_reduce_coalesced(b.tensors, op=op, group=self.group, async_op=False)
+                b.work = torch.cuda.Event()
+                b.work.record(self.comm)
 
     def _on_grad(self, p):
         b = self._bucket_of[p]
@@ -103,7 +122,10 @@ class GradientAllReducer:
             if b.work is None:  # some parameter never produced a gradient this step
                 self._launch(b)
         for b in self.buckets:
-            b.work.wait()
+            if self.comm is None:
+                b.work.wait()
+            else:
+                torch.cuda.current_stream(self.comm.device).wait_event(b.work)
             if not self.avg:
                 torch._foreach_mul_([t for t, p in zip(b.tensors, b.params) if p.grad is not None],
                                     1.0 / self.world)
