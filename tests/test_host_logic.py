@@ -108,3 +108,18 @@ def test_s2d_stem_equals_direct_7x7(sim):
         y = ops.conv2d_nhwc(ops.space_to_depth2(x, 2, 1, sc, sh), ops.stem_weight_s2d(w), 1, 0)
         assert y.shape == (2, hw // 2, (hw + 4) // 2, Cout)
         assert torch.allclose(y.permute(0, 3, 1, 2), ref, atol=2e-5, rtol=1e-5)
+
+
+def test_encode_ahead_is_transparent_without_side_streams(sim):
+    """On a device without side streams (the ABI simulator runs on CPU) encode_ahead() hands the
+    observations back unchanged and the policy output is the plain one."""
+    name = "cma_act_64"
+    case = cases.CASES[name]
+    obs, prev, masks, extra, gold = cases.load_case(os.path.join(GOLD, name + ".npz"))
+    policy, _ = cases.build_policy(vlnce_amd, case, vlnce_amd.make_config, vlnce_amd.make_spaces,
+                                   tp.synth_state_dict)
+    ahead = policy.encode_ahead(obs)
+    assert set(ahead) == set(obs) and all(ahead[k] is obs[k] for k in obs)
+    outs = cases.run_case(policy, case, ahead, prev, masks, extra, product_update,
+                          vlnce_amd.AuxLosses)
+    compare(outs, gold, atol=1e-4, rtol=1e-4)
