@@ -10,7 +10,10 @@ num_envs=64 rollouts PER GPU of synthetic 256x256 RGB + 256x256 depth +
 exactly as the reference constructs it: frozen visual encoders whose
 BatchNorm runs on batch statistics.  value = envs
 processed by all ranks per second (weak scaling, data parallel; gradients are
-all-reduced over RCCL by vlnce_amd.distributed when N > 1).
+all-reduced over RCCL by vlnce_amd.distributed when N > 1).  Every timed step does
+its own trunk passes, tail forward, backward and Adam; the frozen trunks of step k+1 are
+issued (policy.encode_ahead, side HIP streams) before step k's update is enqueued so that
+they overlap its latency-bound tail -- `--no-pipeline` times the plain loop.
 
 The JSON line also carries `roofline` (dominant kernel = the fp32-MFMA
 implicit-GEMM convolution, timed with HIP events on the launch stream) and,
@@ -125,8 +128,8 @@ def pmc_traffic(n_conv):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--num-envs", type=int, default=64)
     ap.add_argument("--hw", type=int, default=256)
     ap.add_argument("--tokens", type=int, default=80)
