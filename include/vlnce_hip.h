@@ -300,6 +300,26 @@ int vlnce_select_rows(const uint8_t* mask, const float* a, const float* b, float
 int vlnce_act_bwd(const float* dy, const float* y, float* dz, long n, int act,
                   vlnce_stream_t stream);
 
+/* ---- cached-feature DAgger data path ----------------------------------
+ * Replaces dagger_trainer.py:39-114 `collate_fn` (+ the .to(device, float32) that follows it at
+ * :562-571) and the inflection weights of IWTrajectoryDataset.__next__ (:196-208): B ragged
+ * trajectories, rows of all of them concatenated ([sum T_b, D], fp32 or fp16 as the LMDB cache
+ * stores them) and an offsets vector [B+1] on the device, become the padded time-major batch
+ * [Tmax*B, D] (row t*B + b) in one pass.  Observations are padded with 1.0 (sic, :77), actions
+ * and weights with 0. */
+enum { VLNCE_SRC_F32 = 0, VLNCE_SRC_F16 = 1, VLNCE_SRC_I64 = 2 };
+/* observation sensors: any source type -> fp32 (upstream casts every sensor, tokens included) */
+int vlnce_ragged_pad_rows(const void* src, int src_dtype, const int* offsets, int B, int Tmax,
+                          long D, float fill, float* dst, vlnce_stream_t stream);
+int vlnce_ragged_pad_rows_i64(const int64_t* src, const int* offsets, int B, int Tmax, long D,
+                              int64_t fill, int64_t* dst, vlnce_stream_t stream);
+/* corrected_actions [Tmax,B] (0 past the end), inflection weights [Tmax,B] (coef at t = 0 and
+ * where the oracle action changes, 1 elsewhere, 0 past the end), not_done_masks [Tmax,B]
+ * (0 in row t = 0, 1 elsewhere -- also past the end, as upstream). */
+int vlnce_dagger_targets(const int64_t* oracle_actions, const int* offsets, int B, int Tmax,
+                         float inflection_coef, int64_t* corrected_out, float* weights_out,
+                         uint8_t* masks_out, vlnce_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

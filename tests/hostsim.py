@@ -218,6 +218,36 @@ class HostSim:
         v = a * s1 + t1 + b * s2 + t2
         y.view(M, Cc).copy_(_act(v, act))
 
+    # ---- cached-feature DAgger data path
+    @staticmethod
+    def _pad_rows(src, offsets, B, Tmax, D, fill, dst):
+        out = dst.view(Tmax, B, D)
+        out.fill_(fill)
+        rows = src.reshape(-1, D)
+        for b in range(B):
+            o, e = int(offsets[b]), int(offsets[b + 1])
+            out[: e - o, b] = rows[o:e].to(dst.dtype)
+
+    def ragged_pad_rows(self, src, offsets, B, Tmax, D, fill, dst):
+        self._pad_rows(src, offsets, B, Tmax, D, fill, dst)
+
+    def ragged_pad_rows_i64(self, src, offsets, B, Tmax, D, fill, dst):
+        self._pad_rows(src, offsets, B, Tmax, D, fill, dst)
+
+    def dagger_targets(self, oracle, offsets, B, Tmax, coef, corrected, weights, masks):
+        corrected.view(Tmax, B).zero_()
+        weights.view(Tmax, B).zero_()
+        masks.view(Tmax, B).fill_(1)
+        masks.view(Tmax, B)[0] = 0
+        for b in range(B):
+            o, e = int(offsets[b]), int(offsets[b + 1])
+            a = oracle[o:e]
+            infl = torch.ones(e - o, dtype=torch.bool)
+            infl[1:] = a[1:] != a[:-1]
+            corrected.view(Tmax, B)[: e - o, b] = a
+            weights.view(Tmax, B)[: e - o, b] = torch.where(infl, torch.tensor(float(coef)),
+                                                           torch.tensor(1.0))
+
     def space_to_depth2(self, x, y, N, H, W, Cc, pad_lo, pad_hi, scale=None, shift=None):
         v = x.reshape(N, H, W, Cc)
         if scale is not None:

@@ -1,0 +1,108 @@
+"""Cached-feature DAgger data path: device-side collate vs goldens produced by
+the reference's own collate_fn / __next__ / _block_shuffle (tests/golden/make_goldens_data.py).
+Pure data movement + exact fp16->fp32 widening: every comparison is bit-exact."""
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+import cases_data
+import hostsim
+from oracle import data_cpu as od
+from vlnce_amd import _lib, data_path
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+NAMES = list(cases_data.CASES)
+
+
+def as_samples(trajs, coef):
+    out = []
+    for obs, prev, oracle in trajs:
+        o = {k: torch.from_numpy(v.copy()) for k, v in obs.items()}
+        a = torch.from_numpy(oracle.copy())
+        out.append((o, torch.from_numpy(prev.copy()), a, od.inflection_weights(a, coef)))
+    return out
+
+
+def check(result, gold):
+    obs, prev, masks, corrected, weights = result
+    assert set(obs) == {k[4:] for k in gold if k.startswith("obs/")}
+    for k, v in obs.items():
+        g = torch.from_numpy(gold["obs/" + k])
+        assert v.dtype == torch.float32 and tuple(v.shape) == tuple(g.shape), k
+        assert torch.equal(v.cpu(), g), k
+    for got, name, dt in ((prev, "prev_actions", torch.int64), (masks, "not_done_masks", torch.uint8),
+                          (corrected, "corrected_actions", torch.int64),
+                          (weights, "weights", torch.float32)):
+        g = torch.from_numpy(gold[name])
+        assert got.dtype == dt and tuple(got.shape) == tuple(g.shape), name
+        assert torch.equal(got.cpu(), g), name
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_oracle_collate_matches_reference_golden(name):
+    spec = cases_data.CASES[name]
+    trajs, gold = cases_data.load(os.path.join(GOLD, name + ".npz"))
+    # fixture recipe guard: stored inputs == regenerated inputs
+    for (o1, p1, a1), (o2, p2, a2) in zip(trajs, cases_data.build_trajectories(spec)):
+        assert all(np.array_equal(o1[k], o2[k]) for k in o2) and np.array_equal(a1, a2)
+    check(od.collate(as_samples(trajs, spec["coef"])), gold)
+    random.seed(spec["seed"])
+    assert od.block_shuffle(list(range(23)), 4) == list(gold["block_shuffle"])
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_host_logic_collate_matches_golden(monkeypatch, name):
+    monkeypatch.setattr(_lib, "_LIB", hostsim.HostSim())
+    spec = cases_data.CASES[name]
+    trajs, gold = cases_data.load(os.path.join(GOLD, name + ".npz"))
+    check(data_path.collate_trajectories(trajs, "cpu", inflection_coef=spec["coef"]), gold)
+
+
+def test_bucketed_order_groups_similar_lengths():
+    rng = random.Random(5)
+    lengths = [rng.randint(3, 60) for _ in range(40)]
+    for fn in (od.bucketed_order, data_path.bucketed_order):
+        order = fn(lengths, 5, random.Random(7))
+        assert sorted(order) == list(range(40))
+        # every consecutive block of 5 is a contiguous run of the length-sorted sequence
+        ranks = {k: r for r, k in enumerate(sorted(range(40), key=lambda k: lengths[k]))}
+        for i in range(0, 40, 5):
+            blk = sorted(lengths[k] for k in order[i:i + 5])
+            others = sorted(lengths)
+            j = others.index(blk[0])
+            assert blk[-1] <= others[min(j + 2 * 5, 39)]
+    a = od.bucketed_order(lengths, 5, random.Random(9))
+    assert a == data_path.bucketed_order(lengths, 5, random.Random(9))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", NAMES)
+def test_hip_collate_matches_reference_golden(name):
+    spec = cases_data.CASES[name]
+    trajs, gold = cases_data.load(os.path.join(GOLD, name + ".npz"))
+    check(data_path.collate_trajectories(trajs, "cuda:0", inflection_coef=spec["coef"]), gold)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fp16", [True, False])
+def test_hip_collate_full_size_vs_oracle(fp16):
+    """real cache shapes: rgb_features [T,2048,4,4], depth_features [T,128,4,4], 200 tokens,
+    IL.batch_size = 5 episodes of up to 120 steps."""
+    rng = np.random.RandomState(3)
+    ft = np.float16 if fp16 else np.float32
+    trajs = []
+    for T in (120, 37, 64, 119, 1):
+        obs = {"rgb_features": rng.rand(T, 2048, 4, 4).astype(ft),
+               "depth_features": rng.rand(T, 128, 4, 4).astype(ft),
+               "instruction": np.tile(rng.randint(0, 2504, size=(1, 200)), (T, 1)).astype(np.int64)}
+        oracle = rng.randint(0, 4, size=T).astype(np.int64)
+        trajs.append((obs, np.concatenate([[0], oracle[:-1]]).astype(np.int64), oracle))
+    want = od.collate(as_samples(trajs, 3.2))
+    got = data_path.collate_trajectories(trajs, "cuda:0", inflection_coef=3.2)
+    for k in want[0]:
+        assert torch.equal(got[0][k].cpu(), want[0][k]), k
+    for g, w in zip(got[1:], want[1:]):
+        assert g.dtype == w.dtype and torch.equal(g.cpu(), w)

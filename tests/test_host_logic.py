@@ -123,3 +123,47 @@ def test_encode_ahead_is_transparent_without_side_streams(sim):
     outs = cases.run_case(policy, case, ahead, prev, masks, extra, product_update,
                           vlnce_amd.AuxLosses)
     compare(outs, gold, atol=1e-4, rtol=1e-4)
+
+
+@pytest.mark.parametrize("lstm", [False, True])
+def test_masked_rnn_rollout_matches_torch_cells(sim, lstm):
+    """ops.MaskedRNNSeqFn (T-step rollout, one autograd node) against torch GRUCell / LSTMCell
+    stepped with the not-done masks (habitat RNNStateEncoder.seq_forward semantics), forward and
+    every gradient, with an episode boundary in the middle of the rollout."""
+    from vlnce_amd import ops
+
+    torch.manual_seed(3)
+    T, N, D, H = 5, 3, 7, 16
+    cell = (torch.nn.LSTMCell if lstm else torch.nn.GRUCell)(D, H)
+    x = torch.randn(T * N, D, requires_grad=True)
+    h0 = torch.randn(N, H, requires_grad=True)
+    c0 = torch.randn(N, H, requires_grad=True) if lstm else None
+    masks = torch.ones(T, N, dtype=torch.uint8)
+    masks[0] = 0
+    masks[2, 1] = 0
+    masks[3, 0] = 0
+    wts = torch.randn(T * N, H)
+    wh, wc = torch.randn(N, H), torch.randn(N, H)
+
+    # torch reference
+    h, c, outs = h0, c0, []
+    for t in range(T):
+        m = masks[t].float().unsqueeze(1)
+        if lstm:
+            h, c = cell(x[t * N:(t + 1) * N], (h * m, c * m))
+        else:
+            h = cell(x[t * N:(t + 1) * N], h * m)
+        outs.append(h)
+    loss = (torch.cat(outs) * wts).sum() + (h * wh).sum() + ((c * wc).sum() if lstm else 0)
+    params = [cell.weight_ih, cell.weight_hh, cell.bias_ih, cell.bias_hh]
+    inputs = [x, h0] + ([c0] if lstm else [])
+    ref = torch.autograd.grad(loss, inputs + params)
+
+    gi = ops.linear(x, cell.weight_ih, cell.bias_ih)
+    y, hT, cT = ops.MaskedRNNSeqFn.apply(lstm, gi, h0, c0, masks.view(-1), cell.weight_hh,
+                                         cell.bias_hh)
+    assert torch.allclose(y, torch.cat(outs), atol=1e-5)
+    loss2 = (y * wts).sum() + (hT * wh).sum() + ((cT * wc).sum() if lstm else 0)
+    got = torch.autograd.grad(loss2, inputs + params)
+    for g, r_ in zip(got, ref):
+        assert torch.allclose(g, r_, atol=2e-5, rtol=1e-4)

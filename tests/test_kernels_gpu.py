@@ -645,3 +645,54 @@ def test_conv_group_norm_from_epilogue_stats(hip, N, hw, Cin, Cout, k, groups):
     got = ops.conv_group_norm_act(x.to(DEV), w.to(DEV), 1, k // 2, groups, gamma.to(DEV),
                                   beta.to(DEV), 1e-5, residual=res.to(DEV), act=1)
     close(got.permute(0, 3, 1, 2), ref, what="conv+GN(from tiles)")
+
+
+@pytest.mark.parametrize("lstm", [False, True])
+@pytest.mark.parametrize("T,N,H", [(40, 5, 512), (7, 64, 256)])
+def test_masked_rnn_rollout_vs_torch_cells(hip, lstm, T, N, H):
+    """ops.MaskedRNNSeqFn on the GPU (the T-step state-encoder rollout of a cached-feature DAgger
+    batch / DD-PPO minibatch) against torch cells stepped on the CPU, forward and all gradients."""
+    torch.manual_seed(5)
+    D = 24
+    cell = (torch.nn.LSTMCell if lstm else torch.nn.GRUCell)(D, H)
+    x = torch.randn(T * N, D) * 0.5
+    h0, c0 = torch.randn(N, H) * 0.3, torch.randn(N, H) * 0.3
+    masks = (torch.rand(T, N) > 0.15).to(torch.uint8)
+    masks[0] = 0
+    wts, wh = torch.randn(T * N, H), torch.randn(N, H)
+
+    def run(dev):
+        xs = x.to(dev).requires_grad_(True)
+        h = h0.to(dev).requires_grad_(True)
+        c = c0.to(dev).requires_grad_(True) if lstm else None
+        ps = [p.detach().to(dev).requires_grad_(True)
+              for p in (cell.weight_ih, cell.weight_hh, cell.bias_ih, cell.bias_hh)]
+        if dev == "cpu":
+            hh, cc, outs = h, c, []
+            for t in range(T):
+                m = masks[t].float().unsqueeze(1)
+                gi = xs[t * N:(t + 1) * N] @ ps[0].t() + ps[2]
+                gh = (hh * m) @ ps[1].t() + ps[3]
+                if lstm:
+                    i, f, g, o = (gi + gh).chunk(4, 1)
+                    cc = torch.sigmoid(f) * (cc * m) + torch.sigmoid(i) * torch.tanh(g)
+                    hh = torch.sigmoid(o) * torch.tanh(cc)
+                else:
+                    ir, iz, inn = gi.chunk(3, 1)
+                    hr, hz, hn = gh.chunk(3, 1)
+                    r, z = torch.sigmoid(ir + hr), torch.sigmoid(iz + hz)
+                    hh = (1 - z) * torch.tanh(inn + r * hn) + z * (hh * m)
+                outs.append(hh)
+            y, hT = torch.cat(outs), hh
+        else:
+            gi = ops.linear(xs, ps[0], ps[2])
+            y, hT, _ = ops.MaskedRNNSeqFn.apply(lstm, gi, h, c, masks.view(-1).to(dev), ps[1], ps[3])
+        loss = (y * wts.to(dev)).sum() + (hT * wh.to(dev)).sum()
+        grads = torch.autograd.grad(loss, [xs, h] + ([c] if lstm else []) + ps)
+        return y.detach(), [g.detach() for g in grads]
+
+    y_ref, g_ref = run("cpu")
+    y_hip, g_hip = run(DEV)
+    close(y_hip, y_ref, what="rollout outputs")
+    for i, (a, b) in enumerate(zip(g_hip, g_ref)):
+        close(a, b, 3e-4, what=f"rollout grad {i}")

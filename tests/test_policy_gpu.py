@@ -250,3 +250,45 @@ def test_encode_ahead_pipeline_equals_plain_loop():
             assert torch.allclose(s0[k], s1[k], rtol=1e-4, atol=1e-5), k
         else:
             assert torch.equal(s0[k], s1[k]), k
+
+
+def test_graph_replay_equals_eager_on_a_rollout_batch():
+    """T > 1 (cached-feature DAgger batch): the tail's HIP-graph replay (3rd call) must reproduce
+    the eager result (1st call) -- logits and every gradient -- for the rollout state encoders."""
+    torch.manual_seed(0)
+    T, N = 12, 3
+    g = torch.Generator().manual_seed(4)
+    obs = {"rgb_features": torch.rand(T * N, 2048, 4, 4, generator=g),
+           "depth_features": torch.rand(T * N, 128, 4, 4, generator=g),
+           "instruction": torch.zeros(T * N, 200, dtype=torch.long)}
+    obs["instruction"][:, :30] = torch.randint(1, 2504, (1, 30), generator=g)
+    obs = to_dev(obs)
+    prev = torch.randint(0, 4, (T * N, 1), generator=g).to(DEV)
+    masks = torch.ones(T, N, dtype=torch.uint8)
+    masks[0] = 0
+    masks[5, 1] = 0
+    masks = masks.view(-1, 1).to(DEV)
+    tgt = torch.randint(0, 4, (T, N), generator=g).to(DEV)
+    w = (torch.rand(T, N, generator=g) + 0.5).to(DEV)
+    policy = vlnce_amd.build_model(vlnce_amd.make_config("CMAPolicy"),
+                                   *vlnce_amd.make_spaces(256, 256)).to(DEV)
+    runs = []
+    for _ in range(3):
+        policy.zero_grad(set_to_none=True)
+        loss, _, _ = update_agent(policy, None, obs, prev, masks, tgt, w, 512, step_grad=False)
+        torch.cuda.synchronize()
+        runs.append((loss.item(), {n: p.grad.clone() for n, p in policy.named_parameters()
+                                   if p.grad is not None}))
+    (l0, g0), (_, _), (l2, g2) = runs
+    assert abs(l0 - l2) <= 1e-5 * max(1.0, abs(l0)), (l0, l2)
+    assert set(g0) == set(g2)
+    # (analytically-zero gradients such as the attention key bias are pure rounding noise of the
+    # atomics' order: compare on the scale of the largest gradient as well)
+    gmax = max(v.abs().max().item() for v in g0.values())
+    bad = []
+    for n in g0:
+        scale = max(g0[n].abs().max().item(), 1e-6)
+        err = (g0[n] - g2[n]).abs().max().item()
+        if err > 2e-4 * scale + 1e-5 * gmax:
+            bad.append((n, err, scale))
+    assert not bad, (bad[:6], gmax)

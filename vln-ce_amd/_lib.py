@@ -57,6 +57,9 @@ _SIGNATURES = {
     "vlnce_maxpool3x3s2": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P]),
     "vlnce_scale_shift_add_act": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P]),
     "vlnce_avgpool2x2": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "vlnce_ragged_pad_rows": (_I, [_P, _I, _P, _I, _I, _L, _F, _P, _P]),
+    "vlnce_ragged_pad_rows_i64": (_I, [_P, _P, _I, _I, _L, _L, _P, _P]),
+    "vlnce_dagger_targets": (_I, [_P, _P, _I, _I, _F, _P, _P, _P, _P]),
     "vlnce_space_to_depth2": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
     "vlnce_adaptive_avgpool": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "vlnce_attn_fwd": (_I, [_P, _P, _I, _P, _I, _P, _I, _F, _P, _P, _I, _I, _I, _I, _P]),
@@ -209,6 +212,26 @@ class HipLib:
         self._check(self.dll.vlnce_scale_shift_add_act(
             _ptr(x1), _ptr(s1), _ptr(t1), _ptr(c1), _ptr(x2), _ptr(s2), _ptr(t2), _ptr(c2),
             _ptr(y), M, Cc, act, _stream()), "vlnce_scale_shift_add_act")
+
+    # ---- cached-feature DAgger data path
+    _SRC = {torch.float32: 0, torch.float16: 1, torch.int64: 2}
+
+    def ragged_pad_rows(self, src, offsets, B, Tmax, D, fill, dst):
+        assert offsets.dtype == torch.int32 and dst.dtype == torch.float32
+        self._check(self.dll.vlnce_ragged_pad_rows(
+            _ptr(src), self._SRC[src.dtype], _ptr(offsets), B, Tmax, D, float(fill),
+            _ptr(dst), _stream()), "vlnce_ragged_pad_rows")
+
+    def ragged_pad_rows_i64(self, src, offsets, B, Tmax, D, fill, dst):
+        assert src.dtype == torch.int64 and dst.dtype == torch.int64
+        self._check(self.dll.vlnce_ragged_pad_rows_i64(
+            _ptr(src), _ptr(offsets), B, Tmax, D, int(fill), _ptr(dst), _stream()),
+            "vlnce_ragged_pad_rows_i64")
+
+    def dagger_targets(self, oracle, offsets, B, Tmax, coef, corrected, weights, masks):
+        self._check(self.dll.vlnce_dagger_targets(
+            _ptr(oracle), _ptr(offsets), B, Tmax, float(coef), _ptr(corrected),
+            _ptr(weights), _ptr(masks), _stream()), "vlnce_dagger_targets")
 
     def space_to_depth2(self, x, y, N, H, W, Cc, pad_lo, pad_hi, scale=None, shift=None):
         self._check(self.dll.vlnce_space_to_depth2(_ptr(x), _ptr(y), N, H, W, Cc, pad_lo, pad_hi,

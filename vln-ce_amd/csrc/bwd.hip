@@ -257,9 +257,8 @@ extern "C" int vlnce_bn_bwd(const float* dy, const float* y, const float* x, con
   VLNCE_CHECK_ARG(dy && x && mean && rstd && dx && dgamma && dbeta, "bn_bwd: null argument");
   VLNCE_CHECK_ARG(!relu || y, "bn_bwd: ReLU backward needs the forward output y");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  hipError_t e = hipMemsetAsync(dgamma, 0, (size_t)C * sizeof(float), s);
-  if (e == hipSuccess) e = hipMemsetAsync(dbeta, 0, (size_t)C * sizeof(float), s);
-  VLNCE_CHECK_ARG(e == hipSuccess, "bn_bwd: memset failed: %s", hipGetErrorString(e));
+  vlnce_zero(dgamma, 1, C, C, s);
+  vlnce_zero(dbeta, 1, C, C, s);
   const int col_blocks = ceil_div(C, 64);
   long slices = (1024 + col_blocks - 1) / col_blocks;
   if (slices > (M + 63) / 64) slices = (M + 63) / 64;
@@ -283,9 +282,8 @@ extern "C" int vlnce_gn_bwd(const float* dy, const float* y, const float* x, con
   VLNCE_CHECK_ARG(!relu || y, "gn_bwd: ReLU backward needs the forward output y");
   VLNCE_CHECK_ARG(groups > 0 && C % groups == 0, "gn_bwd: C %% groups != 0");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  hipError_t e = hipMemsetAsync(dgamma, 0, (size_t)C * sizeof(float), s);
-  if (e == hipSuccess) e = hipMemsetAsync(dbeta, 0, (size_t)C * sizeof(float), s);
-  VLNCE_CHECK_ARG(e == hipSuccess, "gn_bwd: memset failed: %s", hipGetErrorString(e));
+  vlnce_zero(dgamma, 1, C, C, s);
+  vlnce_zero(dbeta, 1, C, C, s);
   const int chunks = ceil_div(HW, GN_CHUNK);
   float* partial = workspace;
   float* s12 = workspace + (size_t)Nimg * chunks * C * 2;

@@ -30,6 +30,26 @@ void vlnce_set_error(const char* fmt, ...);
 
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 
+// Zero-fill as a KERNEL, never hipMemset*Async: inside a captured HIP graph the runtime's memset
+// nodes were observed to race with the neighbouring kernels when the same buffer is zeroed and
+// accumulated into repeatedly (a T-step rollout re-uses one split-K output ~200 times per
+// graph: run-to-run different results, eager correct).  A kernel node orders like any other.
+template <int UNUSED = 0>
+__global__ __launch_bounds__(256) void vlnce_zero_kernel(float* __restrict__ p, long ld, int cols,
+                                                         long total) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long r = i / cols;
+    p[r * ld + (i - r * cols)] = 0.f;
+  }
+}
+static inline void vlnce_zero(float* p, long rows, int cols, long ld, hipStream_t s) {
+  const long total = rows * cols;
+  long g = (total + 255) / 256;
+  if (g > 2048) g = 2048;
+  if (g < 1) g = 1;
+  hipLaunchKernelGGL(vlnce_zero_kernel<0>, dim3((unsigned)g), dim3(256), 0, s, p, ld, cols, total);
+}
+
 __device__ __forceinline__ float apply_act(float v, int act) {
   if (act == VLNCE_ACT_RELU) return v > 0.f ? v : 0.f;
   if (act == VLNCE_ACT_SIGMOID) return 1.f / (1.f + __expf(-v));

@@ -849,6 +849,8 @@ int dispatch_stem(const IgemmParams& p, hipStream_t s) {
 
 // split-K factor for a plain GEMM with few output tiles and a long reduction
 int choose_splitk(const IgemmParams& p) {
+  static const bool off = getenv("VLNCE_IGEMM_NO_SPLITK") != nullptr;  // diagnostic switch
+  if (off) return 1;
   const long tiles = (long)ceil_div(p.M, 64) * ceil_div(p.N, 64);
   const int KT = ceil_div(p.K, BK);
   if (tiles >= 128 || KT < 8) return 1;
@@ -993,9 +995,7 @@ extern "C" int vlnce_gemm(const float* A, int lda, int transA, const float* B, i
     act2 = p.act;
     p.shift = nullptr;
     p.act = 0;
-    hipError_t e = hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float),
-                                    (size_t)M, s);
-    VLNCE_CHECK_ARG(e == hipSuccess, "gemm: memset failed: %s", hipGetErrorString(e));
+    vlnce_zero(C, M, N, ldc, s);
   }
   int rc;
   if (!transA) {
@@ -1070,8 +1070,7 @@ extern "C" int vlnce_conv2d_wgrad(const float* x, const float* dy, float* dw_ohw
   p.splitk = sk < 2 ? 1 : (int)sk;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (p.splitk > 1) {
-    hipError_t e = hipMemsetAsync(dw_ohwi, 0, (size_t)p.M * p.N * sizeof(float), s);
-    VLNCE_CHECK_ARG(e == hipSuccess, "conv2d_wgrad: memset failed: %s", hipGetErrorString(e));
+    vlnce_zero(dw_ohwi, 1, p.M * p.N, (long)p.M * p.N, s);
   }
   return launch<64, 64, 2, 2, A_TRANS, B_IM2COL>(p, s);
 }

@@ -261,8 +261,7 @@ extern "C" int vlnce_colsum(const float* x, int ldx, int M, int N, float* out, i
     return 0;
   }
   if (!accumulate) {
-    hipError_t e = hipMemsetAsync(out, 0, (size_t)N * sizeof(float), s);
-    VLNCE_CHECK_ARG(e == hipSuccess, "colsum: memset failed: %s", hipGetErrorString(e));
+    vlnce_zero(out, 1, N, N, s);
   }
   int slices = ceil_div(256, col_blocks);
   if (slices > ceil_div(M, 32)) slices = ceil_div(M, 32);

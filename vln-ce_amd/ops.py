@@ -438,6 +438,90 @@ def lstm_cell(x_gates, h_prev, c_prev, w_hh, b_hh):
     return LSTMGatesFn.apply(x_gates, gh, c_prev)
 
 
+class MaskedRNNSeqFn(Function):
+    """T > 1 steps of a masked GRU / LSTM state encoder as ONE autograd node (habitat
+    RNNStateEncoder.seq_forward semantics: h (and c) are multiplied by the not-done mask of step
+    t before step t).  A T-step rollout of N episodes -- the cached-feature DAgger batch
+    (dagger_trainer.py:39-114) or a DD-PPO minibatch (rollout_storage.py:154-276) -- costs
+    3 launches per step forward (mask, h W_hh^T, gates) and 3 backward (gates', dgates W_hh,
+    mask + skip add) instead of one autograd cell per step, and the recurrent weight / bias
+    gradients are ONE GEMM / column sum over all T*N rows instead of T accumulated ones.
+
+    forward(lstm, gi [T*N, G*H], h0 [N,H], c0 [N,H] | None, mask_u8 [T*N], w_hh [G*H,H], b_hh)
+      -> out [T*N, H], h_T [N,H], c_T [N,H] (c_T = h_T for a GRU)."""
+
+    @staticmethod
+    def forward(ctx, lstm, gi, h0, c0, mask, w_hh, b_hh):
+        lib = L()
+        gi, h0, w_hh = _f32c(gi), _f32c(h0), _f32c(w_hh)
+        N, H = h0.shape
+        T = gi.size(0) // N
+        GH = gi.size(1)
+        dev = gi.device
+        hp = torch.empty((T, N, H), device=dev, dtype=torch.float32)   # masked h_{t-1}
+        out = torch.empty((T, N, H), device=dev, dtype=torch.float32)
+        gates = torch.empty((T, N, GH), device=dev, dtype=torch.float32)
+        aux = torch.empty((T, N, H), device=dev, dtype=torch.float32)  # GRU: hn; LSTM: c_t
+        gh = torch.empty((N, GH), device=dev, dtype=torch.float32)
+        gi3, m2 = gi.view(T, N, GH), mask.view(T, N)
+        h, c = h0, (_f32c(c0) if lstm else None)
+        for t in range(T):
+            lib.mask_rows(h, m2[t], hp[t], N, H)
+            lib.gemm(hp[t], H, 0, w_hh, H, 0, gh, GH, N, GH, H, shift=b_hh)
+            if lstm:
+                lib.lstm_gates_fwd(gi3[t], gh, c, m2[t], out[t], aux[t], gates[t], N, H)
+                c = aux[t]
+            else:
+                lib.gru_gates_fwd(gi3[t], gh, hp[t], None, out[t], gates[t], aux[t], N, H)
+            h = out[t]
+        ctx.lstm, ctx.dims = lstm, (T, N, H, GH)
+        ctx.save_for_backward(hp, gates, aux, m2, w_hh, _f32c(c0) if lstm else h0)
+        return out.view(T * N, H), out[T - 1], (aux[T - 1] if lstm else out[T - 1])
+
+    @staticmethod
+    def backward(ctx, dout, dh_fin, dc_fin):
+        lib = L()
+        hp, gates, aux, m2, w_hh, c0 = ctx.saved_tensors
+        T, N, H, GH = ctx.dims
+        lstm = ctx.lstm
+        dev = hp.device
+        dout = _f32c(dout).view(T, N, H)
+        mf = m2.to(torch.float32).unsqueeze(-1)                        # [T, N, 1]
+        dgi = torch.empty((T, N, GH), device=dev, dtype=torch.float32)
+        dgh = dgi if lstm else torch.empty_like(dgi)                   # LSTM: same pre-activation
+        carry = torch.zeros((N, H), device=dev, dtype=torch.float32) if dh_fin is None \
+            else _f32c(dh_fin).clone()
+        if not lstm and dc_fin is not None:  # the GRU's second output aliases h_T
+            carry = carry + dc_fin
+        dc = None
+        if lstm:
+            dc = torch.zeros((N, H), device=dev, dtype=torch.float32) if dc_fin is None \
+                else _f32c(dc_fin).clone()
+        dh_t = torch.empty((N, H), device=dev, dtype=torch.float32)
+        acc = torch.empty((N, H), device=dev, dtype=torch.float32)
+        dc_prev = torch.empty((N, H), device=dev, dtype=torch.float32) if lstm else None
+        for t in range(T - 1, -1, -1):
+            torch.add(dout[t], carry, out=dh_t)
+            if lstm:
+                c_prev = aux[t - 1] if t > 0 else c0
+                lib.lstm_gates_bwd(dh_t, dc, gates[t], c_prev, aux[t], m2[t], dgi[t], dc_prev,
+                                   N, H)
+                dc, dc_prev = dc_prev, dc
+                # dh_{t-1} = m_t * (dgates W_hh)
+                lib.gemm(dgi[t], GH, 0, w_hh, H, 1, acc, H, N, H, GH)
+            else:
+                lib.gru_gates_bwd(dh_t, gates[t], aux[t], hp[t], None, dgi[t], dgh[t], acc, N, H)
+                # acc = dh_t * z; += dgh W_hh; then the step's mask
+                lib.gemm(dgh[t], GH, 0, w_hh, H, 1, acc, H, N, H, GH, accumulate=1)
+            torch.mul(acc, mf[t], out=carry)
+        dw = torch.empty_like(w_hh)
+        lib.gemm(dgh.view(T * N, GH), GH, 1, hp.view(T * N, H), H, 1, dw, H, GH, H, T * N)
+        db = torch.empty((GH,), device=dev, dtype=torch.float32)
+        lib.colsum(dgh.view(T * N, GH), GH, T * N, GH, db, 0)
+        dc0 = dc if lstm else None
+        return None, dgi.view(T * N, GH), carry, dc0, None, dw, db
+
+
 # ----------------------------------------------------------------- packed-sequence RNN
 class RNNSeqFn(Function):
     """Whole packed (bi)directional LSTM/GRU recurrence in one launch (+ one for BPTT).

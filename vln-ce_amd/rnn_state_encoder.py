@@ -5,7 +5,8 @@ cma_policy.py:126-131,172-177; waypoint_predictors.py:69-74,157-162).
 hidden_states are batch-first [N, L, H] (LSTM packs (h, c) as two layers).
 x is [N, D] for one step or the time-major flattening [T*N, D]; the input
 projection of all T steps is a single MFMA GEMM, each step then runs
-mask -> h W_hh^T (GEMM) -> fused gate kernel.
+mask -> h W_hh^T (GEMM) -> fused gate kernel.  T > 1 (cached-feature DAgger batches,
+DD-PPO minibatches) goes through ops.MaskedRNNSeqFn: one autograd node for the rollout.
 """
 import torch
 import torch.nn as nn
@@ -35,6 +36,12 @@ class RNNStateEncoder(nn.Module):
         gi = ops.linear(x, r.weight_ih_l0, r.bias_ih_l0)
         h = hidden_states[:, 0]
         c = hidden_states[:, 1] if self.is_lstm else None
+        if t_steps > 1 and r.bias_hh_l0 is not None:
+            # a whole rollout: one autograd node, batched recurrent-weight gradients
+            y, h, c = ops.MaskedRNNSeqFn.apply(self.is_lstm, gi, h, c, m_u8, r.weight_hh_l0,
+                                               r.bias_hh_l0)
+            new_states = torch.stack([h, c], dim=1) if self.is_lstm else h.unsqueeze(1)
+            return y, new_states
         outs = []
         for t in range(t_steps):
             m = m_u8[t * n:(t + 1) * n]
