@@ -180,6 +180,16 @@ def test_gemm_accumulate_and_strided_views(hip):
     Cg = C0.to(DEV)
     _lib.get_lib().gemm(bg[:, K:], 2 * K, 0, B.to(DEV), K, 0, Cg, N, M, N, K, accumulate=1)
     close(Cg, cpu["Cm"], what="accumulate")
+    # skinny shapes take the split-K path: C += A B (+ bias) with atomics into the existing C
+    for (M2, N2, K2, tb) in ((5, 512, 1536, 1), (5, 1536, 512, 0), (3, 64, 4096, 0)):
+        A2, C2, bias = rnd(M2, K2, seed=4), rnd(M2, N2, seed=6), rnd(N2, seed=7)
+        B2 = rnd(K2, N2, seed=5) if tb else rnd(N2, K2, seed=5)
+        ref = C2.clone()
+        SIM.gemm(A2, K2, 0, B2, N2 if tb else K2, tb, ref, N2, M2, N2, K2, shift=bias, accumulate=1)
+        got = C2.to(DEV)
+        _lib.get_lib().gemm(A2.to(DEV), K2, 0, B2.to(DEV), N2 if tb else K2, tb, got, N2, M2, N2,
+                            K2, shift=bias.to(DEV), accumulate=1)
+        close(got, ref, what=f"split-K accumulate {M2}x{N2}x{K2}")
 
 
 # ------------------------------------------------------------------ norms / pools

@@ -986,7 +986,10 @@ extern "C" int vlnce_gemm(const float* A, int lda, int transA, const float* B, i
   // split-K: few output tiles + long reduction (tail GEMMs at num_envs rows, dW GEMMs).
   // The K ranges add atomically into a zeroed C; bias / activation run as a second pass.
   p.splitk = 1;
-  const bool plain = !p.scale && !p.residual && !p.accumulate;
+  // split-K: K ranges accumulate with atomics.  C += A B (accumulate without an activation) is
+  // the same thing minus the zero-fill -- the recurrent dgrad of a T-step rollout,
+  // dh += dgates W_hh with 5 x 512 outputs and K = 1536, is 8 workgroups otherwise.
+  const bool plain = !p.scale && !p.residual && !(p.accumulate && p.act);
   if (plain) p.splitk = choose_splitk(p);
   const float* bias2 = nullptr;
   int act2 = 0;
@@ -995,7 +998,8 @@ extern "C" int vlnce_gemm(const float* A, int lda, int transA, const float* B, i
     act2 = p.act;
     p.shift = nullptr;
     p.act = 0;
-    vlnce_zero(C, M, N, ldc, s);
+    if (!p.accumulate) vlnce_zero(C, M, N, ldc, s);
+    p.accumulate = 0;
   }
   int rc;
   if (!transA) {
