@@ -2,7 +2,6 @@
 and habitat-lab v0.1.7 rl/ppo/policy.py + utils/common.py)."""
 import abc
 
-import torch
 import torch.nn as nn
 
 from . import ops
