@@ -74,3 +74,76 @@ def test_two_rank_gradients_equal_single_process(tmp_path):
     assert set(got) == set(want) and "unused.weight" not in got
     for n in want:
         assert torch.allclose(got[n], want[n], atol=1e-6), n
+
+
+# ------------------------------------------------------------------ the real policy, sharded
+def _policy_and_batch():
+    import cases
+    import vlnce_amd
+    from oracle import thirdparty as tp
+
+    case = dict(cases.CASES["cma_update_64"], N=4, lengths=[6, 10, 3, 8], mode="eval")
+    policy, _ = cases.build_policy(vlnce_amd, case, vlnce_amd.make_config, vlnce_amd.make_spaces,
+                                   tp.synth_state_dict)
+    policy.train()
+    policy.net.rgb_encoder.eval()   # frozen trunks on running statistics: shard-independent
+    policy.net.depth_encoder.eval()
+    obs, prev, masks, extra = cases.build_inputs(case)
+    return policy, obs, prev, masks, extra, case
+
+
+def _shard(t, T, N, sl):
+    """time-major rows t*N + n -> the rows of envs `sl`."""
+    return t.view(T, N, *t.shape[1:])[:, sl].reshape(-1, *t.shape[1:])
+
+
+def policy_worker(rank, world, port, out):
+    import hostsim
+    from vlnce_amd import _lib
+    from vlnce_amd.il_harness import update_agent
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    _lib._LIB = hostsim.HostSim()
+    policy, obs, prev, masks, extra, case = _policy_and_batch()
+    T, N = case["T"], case["N"]
+    sl = shard_rows(N, rank, world)
+    red = GradientAllReducer(policy, bucket_bytes=1 << 18)
+    update_agent(policy, None, {k: _shard(v, T, N, sl) for k, v in obs.items()},
+                 _shard(prev, T, N, sl), _shard(masks, T, N, sl), extra["targets"][:, sl],
+                 extra["weights"][:, sl], 512, step_grad=False, grad_hook=red.finish)
+    if rank == 0:
+        torch.save({n: p.grad for n, p in policy.named_parameters() if p.grad is not None}, out)
+    dist.destroy_process_group()
+
+
+def test_sharded_policy_update_equals_full_batch(tmp_path, monkeypatch):
+    """CMA DAgger update of 4 episodes on 2 gloo ranks (2 episodes each, the ABI simulator under
+    the HIP host path) == the single-process update of all 4: the IL loss is normalised per
+    episode, so equal shards + gradient averaging are exact (base_il_trainer.py:159-165)."""
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (os.path.dirname(here), here, os.path.join(here, "golden")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import hostsim
+    from vlnce_amd import _lib
+    from vlnce_amd.il_harness import update_agent
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "policy_grads.pt")
+    mp.spawn(policy_worker, args=(2, port, out), nprocs=2, join=True)
+    got = torch.load(out)
+    monkeypatch.setattr(_lib, "_LIB", hostsim.HostSim())
+    policy, obs, prev, masks, extra, case = _policy_and_batch()
+    update_agent(policy, None, obs, prev, masks, extra["targets"], extra["weights"], 512,
+                 step_grad=False)
+    want = {n: p.grad for n, p in policy.named_parameters() if p.grad is not None}
+    assert set(got) == set(want) and len(want) > 20
+    gmax = max(v.abs().max().item() for v in want.values())
+    for n in want:
+        assert torch.allclose(got[n], want[n], rtol=1e-4, atol=1e-6 * max(gmax, 1.0)), n
