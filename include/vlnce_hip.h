@@ -320,6 +320,14 @@ int vlnce_dagger_targets(const int64_t* oracle_actions, const int* offsets, int 
                          float inflection_coef, int64_t* corrected_out, float* weights_out,
                          uint8_t* masks_out, vlnce_stream_t stream);
 
+/* DD-PPO returns: RolloutStorage.compute_returns (rollout_storage.py:127-152).
+ * rewards [T,N]; value_preds, masks, returns [T+1,N]; next_value [N].  GAE: value_preds[T] is set
+ * to next_value and returns[0..T) = gae + value_preds; otherwise returns[T] = next_value and the
+ * discounted sum runs backwards. */
+int vlnce_ppo_returns(const float* rewards, float* value_preds, const float* masks,
+                      const float* next_value, float* returns, int T, int N, float gamma, float tau,
+                      int use_gae, vlnce_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

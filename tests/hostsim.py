@@ -248,6 +248,21 @@ class HostSim:
             weights.view(Tmax, B)[: e - o, b] = torch.where(infl, torch.tensor(float(coef)),
                                                            torch.tensor(1.0))
 
+    def ppo_returns(self, rewards, value_preds, masks, next_value, returns, T, N, gamma, tau,
+                    use_gae):
+        r, v, m, ret = (t.view(-1, N) for t in (rewards, value_preds, masks, returns))
+        if use_gae:
+            v[T] = next_value.view(N)
+            gae = torch.zeros(N)
+            for s in reversed(range(T)):
+                delta = r[s] + gamma * v[s + 1] * m[s + 1] - v[s]
+                gae = delta + gamma * tau * m[s + 1] * gae
+                ret[s] = gae + v[s]
+        else:
+            ret[T] = next_value.view(N)
+            for s in reversed(range(T)):
+                ret[s] = ret[s + 1] * gamma * m[s + 1] + r[s]
+
     def space_to_depth2(self, x, y, N, H, W, Cc, pad_lo, pad_hi, scale=None, shift=None):
         v = x.reshape(N, H, W, Cc)
         if scale is not None:

@@ -106,3 +106,46 @@ def test_hip_collate_full_size_vs_oracle(fp16):
         assert torch.equal(got[0][k].cpu(), want[0][k]), k
     for g, w in zip(got[1:], want[1:]):
         assert g.dtype == w.dtype and torch.equal(g.cpu(), w)
+
+
+# ------------------------------------------------------------------ DD-PPO returns (N4)
+def _returns_case():
+    z = np.load(os.path.join(GOLD, "ppo_returns.npz"))
+    return {k: (torch.from_numpy(z[k]) if z[k].ndim else float(z[k])) for k in z.files}
+
+
+@pytest.mark.parametrize("use_gae", [True, False])
+def test_oracle_returns_match_reference_golden(use_gae):
+    from oracle import policy_cpu as oc
+
+    c = _returns_case()
+    vp = c["value_preds"].clone()
+    ret = oc.compute_returns(c["rewards"], vp, c["masks"], c["next_value"], c["gamma"], c["tau"],
+                             use_gae)
+    assert torch.equal(ret, c[f"returns_gae{int(use_gae)}"])
+    assert torch.equal(vp, c[f"value_preds_after_gae{int(use_gae)}"])
+
+
+def _product_returns(device, use_gae):
+    from vlnce_amd.ppo_harness import compute_returns
+
+    c = _returns_case()
+    vp = c["value_preds"].clone().to(device)
+    ret = compute_returns(c["rewards"].to(device), vp, c["masks"].to(device),
+                          c["next_value"].to(device), c["gamma"], c["tau"], use_gae)
+    want = c[f"returns_gae{int(use_gae)}"]
+    rows = slice(0, want.shape[0] - 1) if use_gae else slice(0, want.shape[0])
+    assert torch.allclose(ret.cpu()[rows], want[rows], rtol=1e-5, atol=1e-5)
+    assert torch.allclose(vp.cpu(), c[f"value_preds_after_gae{int(use_gae)}"])
+
+
+@pytest.mark.parametrize("use_gae", [True, False])
+def test_host_logic_returns_match_golden(monkeypatch, use_gae):
+    monkeypatch.setattr(_lib, "_LIB", hostsim.HostSim())
+    _product_returns("cpu", use_gae)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("use_gae", [True, False])
+def test_hip_returns_match_reference_golden(use_gae):
+    _product_returns("cuda:0", use_gae)

@@ -60,6 +60,7 @@ _SIGNATURES = {
     "vlnce_ragged_pad_rows": (_I, [_P, _I, _P, _I, _I, _L, _F, _P, _P]),
     "vlnce_ragged_pad_rows_i64": (_I, [_P, _P, _I, _I, _L, _L, _P, _P]),
     "vlnce_dagger_targets": (_I, [_P, _P, _I, _I, _F, _P, _P, _P, _P]),
+    "vlnce_ppo_returns": (_I, [_P, _P, _P, _P, _P, _I, _I, _F, _F, _I, _P]),
     "vlnce_space_to_depth2": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
     "vlnce_adaptive_avgpool": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "vlnce_attn_fwd": (_I, [_P, _P, _I, _P, _I, _P, _I, _F, _P, _P, _I, _I, _I, _I, _P]),
@@ -232,6 +233,13 @@ class HipLib:
         self._check(self.dll.vlnce_dagger_targets(
             _ptr(oracle), _ptr(offsets), B, Tmax, float(coef), _ptr(corrected),
             _ptr(weights), _ptr(masks), _stream()), "vlnce_dagger_targets")
+
+    def ppo_returns(self, rewards, value_preds, masks, next_value, returns, T, N, gamma, tau,
+                    use_gae):
+        self._check(self.dll.vlnce_ppo_returns(_ptr(rewards), _ptr(value_preds), _ptr(masks),
+                                               _ptr(next_value), _ptr(returns), T, N, float(gamma),
+                                               float(tau), int(use_gae), _stream()),
+                    "vlnce_ppo_returns")
 
     def space_to_depth2(self, x, y, N, H, W, Cc, pad_lo, pad_hi, scale=None, shift=None):
         self._check(self.dll.vlnce_space_to_depth2(_ptr(x), _ptr(y), N, H, W, Cc, pad_lo, pad_hi,

@@ -157,3 +157,48 @@ extern "C" int vlnce_dagger_targets(const int64_t* oracle_actions, const int* of
   VLNCE_CHECK_LAUNCH("dagger_targets");
   return 0;
 }
+
+// ---- DD-PPO returns: RolloutStorage.compute_returns, rollout_storage.py:127-152.
+// One thread per environment walks its T steps backwards; rewards [T,N], value_preds / masks /
+// returns [T+1,N] (value_preds[T] = the bootstrap value, written here as upstream does).
+namespace {
+__global__ __launch_bounds__(256) void ppo_returns_kernel(const float* __restrict__ rewards,
+                                                          float* __restrict__ value_preds,
+                                                          const float* __restrict__ masks,
+                                                          const float* __restrict__ next_value,
+                                                          float* __restrict__ returns, int T, int N,
+                                                          float gamma, float gamma_tau, int use_gae) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  if (use_gae) {
+    value_preds[(long)T * N + n] = next_value[n];
+    float gae = 0.f;
+    for (int s = T - 1; s >= 0; --s) {
+      const float v1 = value_preds[(long)(s + 1) * N + n], m1 = masks[(long)(s + 1) * N + n];
+      const float v0 = value_preds[(long)s * N + n];
+      const float delta = rewards[(long)s * N + n] + gamma * v1 * m1 - v0;
+      gae = delta + gamma_tau * m1 * gae;
+      returns[(long)s * N + n] = gae + v0;
+    }
+  } else {
+    float ret = next_value[n];
+    returns[(long)T * N + n] = ret;
+    for (int s = T - 1; s >= 0; --s) {
+      ret = ret * gamma * masks[(long)(s + 1) * N + n] + rewards[(long)s * N + n];
+      returns[(long)s * N + n] = ret;
+    }
+  }
+}
+}  // namespace
+
+extern "C" int vlnce_ppo_returns(const float* rewards, float* value_preds, const float* masks,
+                                 const float* next_value, float* returns, int T, int N,
+                                 float gamma, float tau, int use_gae, vlnce_stream_t stream) {
+  VLNCE_CHECK_ARG(rewards && value_preds && masks && next_value && returns && T > 0 && N > 0,
+                  "ppo_returns: bad argument");
+  hipLaunchKernelGGL(ppo_returns_kernel, dim3(ceil_div(N, 256)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), rewards, value_preds, masks, next_value,
+                     returns, T, N, gamma, (float)((double)gamma * (double)tau), use_gae);
+  VLNCE_CHECK_LAUNCH("ppo_returns");
+  return 0;
+}

@@ -31,6 +31,21 @@ def normalized_advantages(returns, value_preds, normalize=False, eps=1e-5):
     return (adv - adv.mean()) / (adv.std() + eps) if normalize else adv
 
 
+def compute_returns(rewards, value_preds, masks, next_value, gamma, tau, use_gae=True):
+    """RolloutStorage.compute_returns (rollout_storage.py:127-152) on the device, one launch.
+    rewards [T,N,1]; value_preds, masks [T+1,N,1] (value_preds[T] is overwritten with next_value
+    under GAE, as upstream); next_value [N,1].  Returns `returns` [T+1,N,1]."""
+    from . import ops
+
+    T, N = rewards.shape[0], rewards.shape[1]
+    rewards, masks = rewards.contiguous().float(), masks.contiguous().float()
+    assert value_preds.is_contiguous() and value_preds.dtype == torch.float32
+    returns = torch.zeros_like(value_preds)
+    ops.L().ppo_returns(rewards, value_preds, masks, next_value.contiguous().float(), returns, T, N,
+                        gamma, tau, use_gae)
+    return returns
+
+
 def wddppo_minibatch_update(policy, optimizer, sample, cfg=PPOConfig(), *, step_grad=True,
                             clip_grads=True, grad_hook=None):
     (obs, h0, actions, prev_actions, value_preds, returns, masks, old_logp, adv) = sample
