@@ -47,6 +47,14 @@ CASES = {
         policy="WaypointPolicy", hw=64, N=2, T=1, lengths=[3, 6], mode="eval", call="waypoint",
         overrides={"WAYPOINT.continuous_distance": False, "WAYPOINT.continuous_offset": False},
     ),
+    # RxR: precomputed 768-d multilingual-BERT token features instead of token ids
+    # (rxr_baselines/rxr_cma_en.yaml:45-48), zero rows past each instruction's length
+    "cma_rxr_features_64": dict(
+        policy="CMAPolicy", hw=64, N=3, T=2, lengths=[11, 5, 8], mode="train", call="update",
+        overrides={"INSTRUCTION_ENCODER.sensor_uuid": "rxr_instruction",
+                   "INSTRUCTION_ENCODER.embedding_size": 768},
+        rxr=True,
+    ),
     # H2: one WDDPPO minibatch update (ddppo_alg.py:38-149) on a 3-step x 2-env rollout,
     # encoders in eval mode as ddppo_waypoint_trainer.py:526-530 sets them
     "waypoint_ppo_update_64": dict(
@@ -74,6 +82,12 @@ def build_inputs(case):
     for i, L in enumerate(c["lengths"]):
         tok[i, :L] = torch.randint(1, VOCAB, (L,), generator=g)
     obs["instruction"] = tok.repeat(T, 1)  # time-major rows: row = t*N + n
+    if c.get("rxr"):
+        feats = torch.zeros(N, 32, 768)
+        for i, L in enumerate(c["lengths"]):
+            feats[i, :L] = torch.randn(L, 768, generator=g) * 0.5
+        obs["rxr_instruction"] = feats.repeat(T, 1, 1)
+        del obs["instruction"]
     if c.get("cached"):
         # hooks at dagger_trainer.py:300-314 cache the CNN trunk outputs
         obs["rgb_features"] = torch.rand(B, 2048, 4, 4, generator=g) * 2.0
