@@ -47,6 +47,11 @@ CASES = {
         policy="WaypointPolicy", hw=64, N=2, T=1, lengths=[3, 6], mode="eval", call="waypoint",
         overrides={"WAYPOINT.continuous_distance": False, "WAYPOINT.continuous_offset": False},
     ),
+    # the reference's real sensor geometry: RGB 224x224, depth 256x256
+    # (habitat_extensions/config/vlnce_task.yaml:12-19): 7x7 trunk map -> adaptive pool to 4x4
+    "cma_act_rgb224_depth256": dict(
+        policy="CMAPolicy", hw=256, rgb_hw=224, N=2, T=1, lengths=[9, 6], mode="train", call="act",
+    ),
     # RxR: precomputed 768-d multilingual-BERT token features instead of token ids
     # (rxr_baselines/rxr_cma_en.yaml:45-48), zero rows past each instruction's length
     "cma_rxr_features_64": dict(
@@ -99,7 +104,8 @@ def build_inputs(case):
         obs["depth_history"] = torch.rand(B, hw, hw, 1, generator=g)
         obs["angle_features"] = torch.randn(B, 12, 4, generator=g)
     else:
-        obs["rgb"] = torch.randint(0, 256, (B, hw, hw, 3), generator=g).float()
+        rhw = c.get("rgb_hw", hw)
+        obs["rgb"] = torch.randint(0, 256, (B, rhw, rhw, 3), generator=g).float()
         obs["depth"] = torch.rand(B, hw, hw, 1, generator=g)
     obs["progress"] = torch.rand(B, 1, generator=g)
     masks = torch.ones(T, N, 1, dtype=torch.uint8)
@@ -159,6 +165,10 @@ def build_policy(ns, case, make_config, make_spaces, synth_state_dict):
     cfg = make_config(case["policy"], **case.get("overrides", {}))
     pano = case["policy"] == "WaypointPolicy"
     obs_space, act_space = make_spaces(case["hw"], case["hw"], pano=pano)
+    if "rgb_hw" in case:  # RGB sensor of a different size than depth
+        r = case["rgb_hw"]
+        rgb_space, _ = make_spaces(r, r, pano=pano)
+        obs_space.spaces["rgb"] = rgb_space.spaces["rgb"]
     policy = getattr(ns, case["policy"]).from_config(cfg, obs_space, act_space)
     policy.load_state_dict(synth_state_dict(policy))
     if case["mode"] == "eval":
