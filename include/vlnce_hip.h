@@ -28,7 +28,7 @@ typedef void* vlnce_stream_t;
 
 enum { VLNCE_ACT_NONE = 0, VLNCE_ACT_RELU = 1, VLNCE_ACT_SIGMOID = 2, VLNCE_ACT_TANH = 3 };
 
-int vlnce_version(void);
+int vlnce_version(void); /* major*100 + minor; 110 = this header */
 const char* vlnce_last_error(void);
 
 /* ---------------------------------------------------------------- conv / GEMM
