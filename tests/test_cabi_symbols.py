@@ -46,3 +46,11 @@ def test_kernels_are_gfx950_code_objects(dll):
         pytest.skip("llvm-readelf unavailable")
     blob = open(ge.OUT, "rb").read()
     assert b"gfx950" in blob
+
+
+def test_binding_refuses_a_library_of_another_abi(dll, monkeypatch):
+    lib = _lib.HipLib()  # loads and checks vlnce_version() (no GPU needed)
+    assert lib.dll.vlnce_version() == _lib.HipLib.ABI
+    monkeypatch.setattr(_lib.HipLib, "ABI", _lib.HipLib.ABI + 1)
+    with pytest.raises(RuntimeError, match="rebuild"):
+        _lib.HipLib()

@@ -123,8 +123,14 @@ class HipLib:
 
     name = "hip"
 
+    ABI = 110  # include/vlnce_hip.h
+
     def __init__(self, path=LIB_PATH):
         self.dll = load_cdll(path)
+        have = int(self.dll.vlnce_version())
+        if have != self.ABI:  # struct layouts / signatures moved: a stale .so would corrupt memory
+            raise RuntimeError(f"{path} has ABI {have}, this package binds ABI {self.ABI}: "
+                               "rebuild it (python __graft_entry__.py)")
 
     def _check(self, rc, what):
         if rc != 0:
