@@ -167,3 +167,39 @@ def test_masked_rnn_rollout_matches_torch_cells(sim, lstm):
     got = torch.autograd.grad(loss2, inputs + params)
     for g, r_ in zip(got, ref):
         assert torch.allclose(g, r_, atol=2e-5, rtol=1e-4)
+
+
+def test_edge_cases_match_reference_behaviour(sim):
+    """empty instruction -> the reference's pack_padded_sequence error (message kept);
+    a 200-token (maximum length) instruction next to a 1-token one; batch of one."""
+    from oracle import policy_cpu as oc
+
+    case = cases.CASES["cma_act_64"]
+    ref, _ = cases.build_policy(oc, case, tp.make_config, tp.make_spaces, tp.synth_state_dict)
+    hip, _ = cases.build_policy(vlnce_amd, case, vlnce_amd.make_config, vlnce_amd.make_spaces,
+                                tp.synth_state_dict)
+    obs, prev, masks, extra = cases.build_inputs(case)
+    h0 = extra["h0"][:, :hip.net.num_recurrent_layers].contiguous()
+
+    bad = dict(obs)
+    bad["instruction"] = obs["instruction"].clone()
+    bad["instruction"][1] = 0  # an all-padding instruction
+    for policy in (ref, hip):
+        with pytest.raises(RuntimeError, match="greater than 0"):
+            with torch.no_grad():
+                policy.act(bad, h0, prev, masks, deterministic=True)
+
+    g = torch.Generator().manual_seed(9)
+    ragged = dict(obs)
+    ragged["instruction"] = torch.zeros_like(obs["instruction"])
+    ragged["instruction"][0, :200] = torch.randint(1, 2504, (200,), generator=g)  # maximum length
+    ragged["instruction"][1, :1] = 7                                               # minimum length
+    ragged["instruction"][2, :33] = torch.randint(1, 2504, (33,), generator=g)
+    with torch.no_grad():
+        a_ref = ref.build_distribution(ragged, h0, prev, masks).logits
+        a_hip = hip.build_distribution(ragged, h0, prev, masks).logits
+        one = {k: v[:1] for k, v in ragged.items()}
+        b_ref = ref.build_distribution(one, h0[:1], prev[:1], masks[:1]).logits
+        b_hip = hip.build_distribution(one, h0[:1], prev[:1], masks[:1]).logits
+    assert torch.allclose(a_hip, a_ref, atol=1e-4, rtol=1e-4)
+    assert torch.allclose(b_hip, b_ref, atol=1e-4, rtol=1e-4)
