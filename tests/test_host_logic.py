@@ -203,3 +203,24 @@ def test_edge_cases_match_reference_behaviour(sim):
         b_hip = hip.build_distribution(one, h0[:1], prev[:1], masks[:1]).logits
     assert torch.allclose(a_hip, a_ref, atol=1e-4, rtol=1e-4)
     assert torch.allclose(b_hip, b_ref, atol=1e-4, rtol=1e-4)
+
+
+@pytest.mark.parametrize("discrete", [False, True])
+def test_waypoint_switched_off_components_match_oracle(sim, discrete):
+    """WAYPOINT.predict_distance / predict_offset = False (waypoint_policy.py:93-134): the
+    constants handed to the simulator and stored in the rollout, zeroed variances, and the
+    log-probability / entropy masks, against the oracle restatement."""
+    from oracle import policy_cpu as oc
+
+    over = {"WAYPOINT.predict_distance": False, "WAYPOINT.predict_offset": False}
+    if discrete:
+        over.update({"WAYPOINT.continuous_distance": False, "WAYPOINT.continuous_offset": False})
+    case = dict(cases.CASES["waypoint_64"], overrides=over)
+    ref, _ = cases.build_policy(oc, case, tp.make_config, tp.make_spaces, tp.synth_state_dict)
+    hip, _ = cases.build_policy(vlnce_amd, case, vlnce_amd.make_config, vlnce_amd.make_spaces,
+                                tp.synth_state_dict)
+    obs, prev, masks, extra = cases.build_inputs(case)
+    a = cases.run_case(ref, case, obs, prev, masks, extra)
+    b = cases.run_case(hip, case, obs, prev, masks, extra)
+    compare(b, a, atol=1e-4, rtol=1e-4)
+    assert float(b["elem_distance"].float().abs().max()) in (0.0, 0.25)

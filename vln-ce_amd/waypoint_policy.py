@@ -1,8 +1,16 @@
-"""Waypoint actor-critic policy (reference: vlnce_baselines/models/
-waypoint_policy.py:19-347): pano / offset / distance action components with a
-composite log-probability and entropy.  The distribution math is O(N x 13)
-scalars and stays in torch; the net runs on the HIP kernels."""
-import numpy as np
+"""Waypoint actor-critic policy: one categorical choice over the 12 panorama headings + STOP and,
+for the chosen heading, a distance and a heading-offset component (continuous: truncated normal,
+discrete: categorical), with a composite log-probability and per-component entropies.
+
+Plugin-surface mirror of vlnce_baselines/models/waypoint_policy.py:19-347 (`from_config`, `act`,
+`get_value`, `evaluate_actions` and their return tuples are what ddppo_waypoint_trainer.py and
+WDDPPO call).  The two sub-actions are handled by ONE table-driven code path here instead of a
+pair of parallel methods each; the distribution math is O(N x 13) scalars and stays in torch
+(SURVEY.md 2.1), the net runs on the HIP kernels.
+"""
+import math
+from typing import NamedTuple
+
 import torch
 
 from .policy import Policy
@@ -10,17 +18,33 @@ from .registry import baseline_registry
 from .utils import CustomFixedCategorical, TruncatedNormal, batched_index_select
 from .waypoint_predictors import WaypointPredictionNet
 
+TWO_PI = 2.0 * math.pi
+
+
+class _Draw(NamedTuple):
+    """one sub-action of one act() call"""
+    element: torch.Tensor   # what is stored in the rollout (network units / class index)
+    metric: torch.Tensor    # metres or radians handed to the simulator
+    log_prob: torch.Tensor
+    variance: torch.Tensor
+    mode: torch.Tensor
+
 
 @baseline_registry.register_policy
 class WaypointPolicy(Policy):
+    # (config flag "continuous_*", config flag "predict_*", value the simulator gets when the
+    # component is switched off, value stored in the rollout when switched off and continuous)
+    _PARTS = {
+        "distance": ("continuous_distance", "predict_distance", 0.25, 0.25),
+        "offset": ("continuous_offset", "predict_offset", 0.0, 0.0),
+    }
+
     def __init__(self, observation_space, action_space, model_config):
-        super().__init__(
-            WaypointPredictionNet(observation_space=observation_space, model_config=model_config),
-            1,  # the inherited 1-way action_distribution is never used (App. B-6)
-        )
+        net = WaypointPredictionNet(observation_space=observation_space, model_config=model_config)
+        super().__init__(net, 1)  # the inherited 1-way action head is never used (App. B-6)
         self._config = model_config
         self.wypt_cfg = model_config.WAYPOINT
-        self._offset_limit = np.pi / self._config.num_panos
+        self._offset_limit = math.pi / model_config.num_panos
 
     @classmethod
     def from_config(cls, config, observation_space, action_space):
@@ -30,120 +54,93 @@ class WaypointPolicy(Policy):
         return cls(observation_space=observation_space, action_space=action_space,
                    model_config=config.MODEL)
 
-    def _create_distance_distribution(self, var1, var2, pano):
-        if self.wypt_cfg.continuous_distance:
-            return TruncatedNormal(
-                loc=torch.gather(var1, dim=1, index=pano),
-                scale=torch.sqrt(torch.gather(var2, dim=1, index=pano)),
-                smin=self.wypt_cfg.min_distance_prediction,
-                smax=self.wypt_cfg.max_distance_prediction)
-        return CustomFixedCategorical(logits=batched_index_select(var1, dim=1, index=pano))
+    # ------------------------------------------------------------------ sub-action plumbing
+    def _bounds(self, part):
+        if part == "distance":
+            return self.wypt_cfg.min_distance_prediction, self.wypt_cfg.max_distance_prediction
+        return -self._offset_limit, self._offset_limit
 
-    def _create_offset_distribution(self, var1, var2, pano):
-        if self.wypt_cfg.continuous_offset:
-            return TruncatedNormal(
-                loc=torch.gather(var1, dim=1, index=pano),
-                scale=torch.sqrt(torch.gather(var2, dim=1, index=pano)),
-                smin=-self._offset_limit, smax=self._offset_limit)
-        return CustomFixedCategorical(logits=batched_index_select(var1, dim=1, index=pano))
+    def _to_metric(self, part, element):
+        fn = self.net.distance_to_continuous if part == "distance" else self.net.offset_to_continuous
+        return fn(element)
 
-    def get_offset_prediction(self, offset_distribution, deterministic=False):
-        offset = offset_distribution.mode() if deterministic else offset_distribution.sample()
-        offset_log_prob = offset_distribution.log_prob(offset)
-        action_offset = self.net.offset_to_continuous(offset)
-        variance = offset_distribution.variance
-        mode = offset_distribution.mode()
-        if not self.wypt_cfg.predict_offset:
-            action_offset = torch.zeros_like(action_offset)
-            offset = torch.zeros_like(offset)
-            if offset.dtype == torch.int64:
-                offset *= self.wypt_cfg.discrete_offsets // 2
-            variance = torch.zeros_like(variance)
-        return offset, action_offset, offset_log_prob, variance, mode
+    def _distribution(self, part, first, second, heading):
+        """distribution of `part` for the chosen heading: `first`/`second` are the per-heading
+        (mean, variance) maps of a continuous head or the per-heading logits of a discrete one."""
+        if getattr(self.wypt_cfg, self._PARTS[part][0]):
+            lo, hi = self._bounds(part)
+            return TruncatedNormal(loc=first.gather(1, heading),
+                                   scale=second.gather(1, heading).sqrt(), smin=lo, smax=hi)
+        return CustomFixedCategorical(logits=batched_index_select(first, dim=1, index=heading))
 
-    def get_distance_prediction(self, distance_distribution, deterministic=False):
-        distance = distance_distribution.mode() if deterministic else distance_distribution.sample()
-        distance_log_prob = distance_distribution.log_prob(distance)
-        action_distance = self.net.distance_to_continuous(distance)
-        variance = distance_distribution.variance
-        mode = distance_distribution.mode()
-        if not self.wypt_cfg.predict_distance:
-            action_distance = torch.zeros_like(action_distance) + 0.25
-            distance = torch.zeros_like(distance)
-            if distance.dtype != torch.int64:
-                distance = torch.zeros_like(distance) + 0.25
-            variance = torch.zeros_like(variance)
-        return distance, action_distance, distance_log_prob, variance, mode
+    def _draw(self, part, dist, deterministic):
+        element = dist.mode() if deterministic else dist.sample()
+        out = _Draw(element, self._to_metric(part, element), dist.log_prob(element), dist.variance,
+                    dist.mode())
+        _, enabled_flag, off_metric, off_element = self._PARTS[part]
+        if getattr(self.wypt_cfg, enabled_flag):
+            return out
+        # component switched off: constants go to the simulator and into the rollout.  A class
+        # index is stored as 0 (upstream scales a zero tensor by discrete_offsets // 2, which
+        # leaves it zero: waypoint_policy.py:108-110), a continuous element as the constant.
+        stored = torch.full_like(element, 0 if element.dtype == torch.int64 else off_element)
+        return out._replace(element=stored, metric=torch.full_like(out.metric, off_metric),
+                            variance=torch.zeros_like(out.variance))
 
+    @staticmethod
+    def _simulator_actions(stop, radius, theta):
+        # one batched D2H copy instead of three .item() syncs per environment
+        rows = torch.cat([stop.float(), radius.float(), theta.float()], dim=1).tolist()
+        return [{"action": "STOP"} if s else
+                {"action": {"action": "GO_TOWARD_POINT", "action_args": {"r": r, "theta": th}}}
+                for s, r, th in rows]
+
+    # ------------------------------------------------------------------ plugin surface
     def act(self, observations, rnn_states, prev_actions, masks, deterministic=False):
-        P = self._config.num_panos
-        (pano_stop_distribution, offset_variable1, offset_variable2, distance_variable1,
-         distance_variable2, x, rnn_states_out) = self.net(observations, rnn_states,
-                                                           prev_actions, masks)
-        pano_stop = (pano_stop_distribution.mode() if deterministic
-                     else pano_stop_distribution.sample())
-        stop = (pano_stop == P).to(torch.uint8)
-        pano = pano_stop % P
-        distance_distribution = self._create_distance_distribution(
-            distance_variable1, distance_variable2, pano)
-        offset_distribution = self._create_offset_distribution(
-            offset_variable1, offset_variable2, pano)
-        (distance, action_distance, distance_log_probs, dist_var,
-         dist_mode) = self.get_distance_prediction(distance_distribution, deterministic)
-        (offset, action_offset, offset_log_probs, ofst_var,
-         ofst_mode) = self.get_offset_prediction(offset_distribution, deterministic)
+        n_pano = self._config.num_panos
+        (heading_dist, off_a, off_b, dist_a, dist_b, features, rnn_states_out) = self.net(
+            observations, rnn_states, prev_actions, masks)
+        choice = heading_dist.mode() if deterministic else heading_dist.sample()
+        heading = choice % n_pano
+        going = choice != n_pano
+        draws = {
+            "distance": self._draw("distance", self._distribution("distance", dist_a, dist_b, heading),
+                                   deterministic),
+            "offset": self._draw("offset", self._distribution("offset", off_a, off_b, heading),
+                                 deterministic),
+        }
+        theta = (heading * (TWO_PI / n_pano) + draws["offset"].metric) % TWO_PI
+        actions = self._simulator_actions((~going).to(torch.uint8), draws["distance"].metric, theta)
 
-        radians_per_pano = 2 * np.pi / P
-        theta = (pano * radians_per_pano + action_offset) % (2 * np.pi)
-        # one batched D2H instead of 3 .item() syncs per env (waypoint_policy.py:191-208)
-        host = torch.cat([stop.float(), action_distance.float(), theta.float()], dim=1).tolist()
-        actions = []
-        for s, r, th in host:
-            if s:
-                actions.append({"action": "STOP"})
-            else:
-                actions.append({"action": {"action": "GO_TOWARD_POINT",
-                                           "action_args": {"r": r, "theta": th}}})
-
-        action_log_probs = pano_stop_distribution.log_prob(pano_stop)
-        pano_mask = (pano_stop != P).to(action_log_probs.dtype)
-        if self.wypt_cfg.predict_distance:
-            action_log_probs = action_log_probs + (
-                pano_mask * self.wypt_cfg.predict_distance * distance_log_probs)
-        if self.wypt_cfg.predict_offset:
-            action_log_probs = action_log_probs + (
-                pano_mask * self.wypt_cfg.predict_offset * offset_log_probs)
-        value = self.critic(x)
-        action_elements = {"pano": pano_stop, "offset": offset, "distance": distance}
-        variances = {"distance": dist_var, "offset": ofst_var}
-        modes = {"offset": ofst_mode, "distance": dist_mode}
-        return (value, actions, action_elements, modes, variances, action_log_probs,
-                rnn_states_out, pano_stop_distribution)
+        log_prob = heading_dist.log_prob(choice)
+        gate = going.to(log_prob.dtype)
+        for part, d in draws.items():
+            enabled = getattr(self.wypt_cfg, self._PARTS[part][1])
+            if enabled:
+                log_prob = log_prob + gate * enabled * d.log_prob
+        elements = {"pano": choice, "offset": draws["offset"].element,
+                    "distance": draws["distance"].element}
+        modes = {part: d.mode for part, d in draws.items()}
+        variances = {part: d.variance for part, d in draws.items()}
+        return (self.critic(features), actions, elements, modes, variances, log_prob,
+                rnn_states_out, heading_dist)
 
     def get_value(self, observations, rnn_states, prev_actions, masks):
-        return self.critic(self.net(observations, rnn_states, prev_actions, masks)[5])
+        features = self.net(observations, rnn_states, prev_actions, masks)[5]
+        return self.critic(features)
 
     def evaluate_actions(self, observations, rnn_states, prev_actions, masks, action_components):
-        P = self._config.num_panos
-        (pano_stop_distribution, offset_variable1, offset_variable2, distance_variable1,
-         distance_variable2, x, rnn_states_out) = self.net(observations, rnn_states,
-                                                           prev_actions, masks)
-        value = self.critic(x)
-        pano_log_probs = pano_stop_distribution.log_prob(action_components["pano"])
-        idx = action_components["pano"].to(torch.int64) % P
-        distance_distribution = self._create_distance_distribution(
-            distance_variable1, distance_variable2, idx)
-        offset_distribution = self._create_offset_distribution(
-            offset_variable1, offset_variable2, idx)
-        pano_mask = (action_components["pano"] != P).to(pano_log_probs.dtype)
-        d_mask = pano_mask * self.wypt_cfg.predict_distance
-        o_mask = pano_mask * self.wypt_cfg.predict_offset
-        distance_log_probs = d_mask * distance_distribution.log_prob(action_components["distance"])
-        offset_log_probs = o_mask * offset_distribution.log_prob(action_components["offset"])
-        action_log_probs = pano_log_probs + distance_log_probs + offset_log_probs
-        entropy = {
-            "pano": pano_stop_distribution.entropy(),
-            "offset": (o_mask * offset_distribution.entropy()).squeeze(1),
-            "distance": (d_mask * distance_distribution.entropy()).squeeze(1),
-        }
-        return value, action_log_probs, entropy, rnn_states_out
+        n_pano = self._config.num_panos
+        (heading_dist, off_a, off_b, dist_a, dist_b, features, rnn_states_out) = self.net(
+            observations, rnn_states, prev_actions, masks)
+        choice = action_components["pano"]
+        heading = choice.to(torch.int64) % n_pano
+        log_prob = heading_dist.log_prob(choice)
+        gate = (choice != n_pano).to(log_prob.dtype)
+        entropy = {"pano": heading_dist.entropy()}
+        for part, (first, second) in (("distance", (dist_a, dist_b)), ("offset", (off_a, off_b))):
+            dist = self._distribution(part, first, second, heading)
+            weight = gate * getattr(self.wypt_cfg, self._PARTS[part][1])
+            log_prob = log_prob + weight * dist.log_prob(action_components[part])
+            entropy[part] = (weight * dist.entropy()).squeeze(1)
+        return self.critic(features), log_prob, entropy, rnn_states_out
