@@ -8,12 +8,12 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
-from .encoders import resnet_encoders
 from .encoders.instruction_encoder import InstructionEncoder
+from .net_parts import (apply_ablations, build_depth_encoder, build_rgb_encoder,
+                        encode_three_branches, prev_action_index, register_progress_loss)
 from .policy import ILPolicy, Net
 from .registry import baseline_registry
 from .rnn_state_encoder import build_rnn_state_encoder
-from .seq2seq_policy import prev_action_index, register_progress_loss
 from .streams import BranchStreams, GraphedTail
 
 
@@ -101,22 +101,9 @@ class CMANet(Net):
         model_config.INSTRUCTION_ENCODER.final_state_only = False
         model_config.freeze()
         self.instruction_encoder = InstructionEncoder(model_config.INSTRUCTION_ENCODER)
-        assert model_config.DEPTH_ENCODER.cnn_type in ["VlnResnetDepthEncoder"]
-        self.depth_encoder = getattr(resnet_encoders, model_config.DEPTH_ENCODER.cnn_type)(
-            observation_space,
-            output_size=model_config.DEPTH_ENCODER.output_size,
-            checkpoint=model_config.DEPTH_ENCODER.ddppo_checkpoint,
-            backbone=model_config.DEPTH_ENCODER.backbone,
-            trainable=model_config.DEPTH_ENCODER.trainable,
-            spatial_output=True,
-        )
-        assert model_config.RGB_ENCODER.cnn_type in ["TorchVisionResNet18", "TorchVisionResNet50"]
-        self.rgb_encoder = getattr(resnet_encoders, model_config.RGB_ENCODER.cnn_type)(
-            model_config.RGB_ENCODER.output_size,
-            normalize_visual_inputs=model_config.normalize_rgb,
-            trainable=model_config.RGB_ENCODER.trainable,
-            spatial_output=True,
-        )
+        self.depth_encoder = build_depth_encoder(observation_space, model_config,
+                                                 spatial_output=True)
+        self.rgb_encoder = build_rgb_encoder(model_config, spatial_output=True)
         self.prev_action_embedding = nn.Embedding(num_actions + 1, 32)
         hidden_size = model_config.STATE_ENCODER.hidden_size
         self._hidden_size = hidden_size
@@ -173,30 +160,14 @@ class CMANet(Net):
         return ops.attention(q, k, v, mask, 1, self._scale_f)
 
     def forward(self, observations, rnn_states, prev_actions, masks):
-        mc = self.model_config
-        # the three encoders are independent.  The RGB trunk (long MFMA kernels) is enqueued
-        # first on the current stream; the instruction RNN (whose length computation needs
-        # one host sync, as upstream) and the depth trunk (~200 small launches) follow on a
-        # side stream and overlap with it.  The host sync therefore happens while the GPU
-        # already has the RGB trunk queued.
-        dev = rnn_states.device
-        fork = self._branches.fork(dev)
-        rgb = rows_of(self.rgb_encoder(observations))  # [B, 16, 2112]
-        ins, join_i = self._branches.run(fork, 0, dev,
-                                         lambda: self.instruction_encoder(observations))
-        dep, join_d = self._branches.run(fork, 0, dev, lambda: self.depth_encoder(observations))
-        join_i()
-        join_d()
-        ins = ins.permute(0, 2, 1)  # [B, L, 2H]
-        dep = rows_of(dep)  # [B, P, 192]
+        # three independent encoders: RGB trunk on this stream, instruction RNN + depth trunk on
+        # a side stream (net_parts.encode_three_branches); then everything as [B, rows, C]
+        ins, dep, rgb = encode_three_branches(self, observations, rnn_states.device)
+        ins, dep, rgb = apply_ablations(self.model_config, ins.permute(0, 2, 1),  # [B, L, 2H]
+                                        rows_of(dep),                             # [B, P, 192]
+                                        rows_of(rgb))                             # [B, 16, 2112]
         act = F.embedding(prev_action_index(prev_actions, masks),
                           self.prev_action_embedding.weight)
-        if mc.ablate_instruction:
-            ins = ins * 0
-        if mc.ablate_depth:
-            dep = dep * 0
-        if mc.ablate_rgb:
-            rgb = rgb * 0
         masks_u8 = masks.reshape(-1).to(torch.uint8)
         x, rnn_states_out = self._tail(ins.contiguous(), dep.contiguous(), rgb.contiguous(), act,
                                        rnn_states.contiguous(), masks_u8)

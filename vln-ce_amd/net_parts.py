@@ -1,0 +1,74 @@
+"""Pieces the Seq2Seq, CMA and waypoint nets share: construction of the visual encoders from
+`config.MODEL`, the three-branch encoder pass on side HIP streams, ablation switches, the
+previous-action index and the progress-monitor auxiliary loss."""
+import torch
+
+from . import ops
+from .aux_losses import AuxLosses
+from .encoders import resnet_encoders
+
+_DEPTH_TYPES = ("VlnResnetDepthEncoder",)
+_RGB_TYPES = ("TorchVisionResNet18", "TorchVisionResNet50")
+
+
+def build_depth_encoder(observation_space, model_config, **extra):
+    """MODEL.DEPTH_ENCODER -> encoder module (seq2seq_policy.py:69-81, cma_policy.py:69-82,
+    waypoint_predictors.py:41-52)."""
+    cfg = model_config.DEPTH_ENCODER
+    if cfg.cnn_type not in _DEPTH_TYPES:
+        raise AssertionError(f"DEPTH_ENCODER.cnn_type must be one of {_DEPTH_TYPES}")
+    cls = getattr(resnet_encoders, cfg.cnn_type)
+    return cls(observation_space, output_size=cfg.output_size, checkpoint=cfg.ddppo_checkpoint,
+               backbone=cfg.backbone, trainable=cfg.trainable, **extra)
+
+
+def build_rgb_encoder(model_config, **extra):
+    """MODEL.RGB_ENCODER -> encoder module (seq2seq_policy.py:83-93, cma_policy.py:84-96)."""
+    cfg = model_config.RGB_ENCODER
+    if cfg.cnn_type not in _RGB_TYPES:
+        raise AssertionError(f"RGB_ENCODER.cnn_type must be one of {_RGB_TYPES}")
+    cls = getattr(resnet_encoders, cfg.cnn_type)
+    return cls(cfg.output_size, normalize_visual_inputs=model_config.normalize_rgb,
+               trainable=cfg.trainable, **extra)
+
+
+def encode_three_branches(net, observations, device):
+    """RGB encoder on the caller's stream; instruction encoder (one host sync for the lengths,
+    as upstream) and depth encoder on a side stream, overlapping the RGB trunk's long MFMA
+    kernels.  Returns (instruction, depth, rgb) with the side-stream results joined."""
+    branches = net._branches
+    fork = branches.fork(device)
+    rgb = net.rgb_encoder(observations)
+    ins, join_ins = branches.run(fork, 0, device, lambda: net.instruction_encoder(observations))
+    dep, join_dep = branches.run(fork, 0, device, lambda: net.depth_encoder(observations))
+    join_ins()
+    join_dep()
+    return ins, dep, rgb
+
+
+def apply_ablations(model_config, ins, dep, rgb):
+    """MODEL.ablate_{instruction,depth,rgb}: the feature is multiplied by zero, not removed."""
+    if model_config.ablate_instruction:
+        ins = ins * 0
+    if model_config.ablate_depth:
+        dep = dep * 0
+    if model_config.ablate_rgb:
+        rgb = rgb * 0
+    return ins, dep, rgb
+
+
+def prev_action_index(prev_actions, masks):
+    """((a + 1) * mask).long(): embedding row 0 = first step of an episode (cma_policy.py:233-235)."""
+    return ((prev_actions.float() + 1) * masks).long().view(-1)
+
+
+def register_progress_loss(net, features, observations):
+    """Progress monitor: tanh(Linear(features)) against observations["progress"], including the
+    [B] x [B,1] -> [B,B] broadcast of the reference's F.mse_loss call."""
+    cfg = net.model_config.PROGRESS_MONITOR
+    if not (cfg.use and AuxLosses.is_active()):
+        return
+    head = net.progress_monitor
+    estimate = ops.linear(features, head.weight, head.bias, ops.ACT_TANH).squeeze(1)
+    estimate, target = torch.broadcast_tensors(estimate, observations["progress"])
+    AuxLosses.register_loss("progress_monitor", (estimate - target) ** 2, cfg.alpha)

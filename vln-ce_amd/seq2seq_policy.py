@@ -3,30 +3,13 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import ops
-from .aux_losses import AuxLosses
-from .encoders import resnet_encoders
 from .encoders.instruction_encoder import InstructionEncoder
+from .net_parts import (apply_ablations, build_depth_encoder, build_rgb_encoder,
+                        encode_three_branches, prev_action_index, register_progress_loss)
 from .policy import ILPolicy, Net
 from .registry import baseline_registry
 from .rnn_state_encoder import build_rnn_state_encoder
 from .streams import BranchStreams
-
-
-def prev_action_index(prev_actions, masks):
-    """((a + 1) * mask).long(): index 0 = episode start (cma_policy.py:233-235)."""
-    return ((prev_actions.float() + 1) * masks).long().view(-1)
-
-
-def register_progress_loss(net, x, observations):
-    """tanh(Linear(x)) vs observations["progress"], including F.mse_loss's
-    [B] x [B,1] -> [B,B] broadcast of the reference."""
-    cfg = net.model_config
-    if cfg.PROGRESS_MONITOR.use and AuxLosses.is_active():
-        hat = ops.linear(x, net.progress_monitor.weight, net.progress_monitor.bias, ops.ACT_TANH)
-        hat_b, tgt_b = torch.broadcast_tensors(hat.squeeze(1), observations["progress"])
-        AuxLosses.register_loss("progress_monitor", (hat_b - tgt_b) ** 2,
-                                cfg.PROGRESS_MONITOR.alpha)
 
 
 @baseline_registry.register_policy
@@ -53,32 +36,19 @@ class Seq2SeqNet(Net):
     def __init__(self, observation_space, model_config, num_actions):
         super().__init__()
         self.model_config = model_config
+        # (attribute order = state_dict / parameter order of the reference)
         self.instruction_encoder = InstructionEncoder(model_config.INSTRUCTION_ENCODER)
-        assert model_config.DEPTH_ENCODER.cnn_type in ["VlnResnetDepthEncoder"]
-        self.depth_encoder = getattr(resnet_encoders, model_config.DEPTH_ENCODER.cnn_type)(
-            observation_space,
-            output_size=model_config.DEPTH_ENCODER.output_size,
-            checkpoint=model_config.DEPTH_ENCODER.ddppo_checkpoint,
-            backbone=model_config.DEPTH_ENCODER.backbone,
-            trainable=model_config.DEPTH_ENCODER.trainable,
-        )
-        assert model_config.RGB_ENCODER.cnn_type in ["TorchVisionResNet18", "TorchVisionResNet50"]
-        self.rgb_encoder = getattr(resnet_encoders, model_config.RGB_ENCODER.cnn_type)(
-            model_config.RGB_ENCODER.output_size,
-            normalize_visual_inputs=model_config.normalize_rgb,
-            trainable=model_config.RGB_ENCODER.trainable,
-            spatial_output=False,
-        )
+        self.depth_encoder = build_depth_encoder(observation_space, model_config)
+        self.rgb_encoder = build_rgb_encoder(model_config, spatial_output=False)
+        widths = [self.instruction_encoder.output_size, model_config.DEPTH_ENCODER.output_size,
+                  model_config.RGB_ENCODER.output_size]
         if model_config.SEQ2SEQ.use_prev_action:
             self.prev_action_embedding = nn.Embedding(num_actions + 1, 32)
-        rnn_input_size = (self.instruction_encoder.output_size
-                          + model_config.DEPTH_ENCODER.output_size
-                          + model_config.RGB_ENCODER.output_size)
-        if model_config.SEQ2SEQ.use_prev_action:
-            rnn_input_size += self.prev_action_embedding.embedding_dim
+            widths.append(self.prev_action_embedding.embedding_dim)
+        state_cfg = model_config.STATE_ENCODER
         self.state_encoder = build_rnn_state_encoder(
-            input_size=rnn_input_size, hidden_size=model_config.STATE_ENCODER.hidden_size,
-            rnn_type=model_config.STATE_ENCODER.rnn_type, num_layers=1)
+            input_size=sum(widths), hidden_size=state_cfg.hidden_size,
+            rnn_type=state_cfg.rnn_type, num_layers=1)
         self._branches = BranchStreams()
         self.progress_monitor = nn.Linear(model_config.STATE_ENCODER.hidden_size, 1)
         nn.init.kaiming_normal_(self.progress_monitor.weight, nonlinearity="tanh")
@@ -99,25 +69,11 @@ class Seq2SeqNet(Net):
 
     def forward(self, observations, rnn_states, prev_actions, masks):
         mc = self.model_config
-        dev = rnn_states.device
-        fork = self._branches.fork(dev)
-        rgb_embedding = self.rgb_encoder(observations)
-        instruction_embedding, join_i = self._branches.run(
-            fork, 0, dev, lambda: self.instruction_encoder(observations))
-        depth_embedding, join_d = self._branches.run(
-            fork, 0, dev, lambda: self.depth_encoder(observations))
-        join_i()
-        join_d()
-        if mc.ablate_instruction:
-            instruction_embedding = instruction_embedding * 0
-        if mc.ablate_depth:
-            depth_embedding = depth_embedding * 0
-        if mc.ablate_rgb:
-            rgb_embedding = rgb_embedding * 0
-        parts = [instruction_embedding, depth_embedding, rgb_embedding]
+        feats = list(apply_ablations(
+            mc, *encode_three_branches(self, observations, rnn_states.device)))
         if mc.SEQ2SEQ.use_prev_action:
-            parts.append(F.embedding(prev_action_index(prev_actions, masks),
+            feats.append(F.embedding(prev_action_index(prev_actions, masks),
                                      self.prev_action_embedding.weight))
-        x, rnn_states_out = self.state_encoder(torch.cat(parts, dim=1), rnn_states, masks)
-        register_progress_loss(self, x, observations)
-        return x, rnn_states_out
+        state, rnn_states_out = self.state_encoder(torch.cat(feats, dim=1), rnn_states, masks)
+        register_progress_loss(self, state, observations)
+        return state, rnn_states_out
