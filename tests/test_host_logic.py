@@ -224,3 +224,29 @@ def test_waypoint_switched_off_components_match_oracle(sim, discrete):
     b = cases.run_case(hip, case, obs, prev, masks, extra)
     compare(b, a, atol=1e-4, rtol=1e-4)
     assert float(b["elem_distance"].float().abs().max()) in (0.0, 0.25)
+
+
+def test_truncated_normal_matches_oracle_including_sampling():
+    """vlnce_amd.utils.TruncatedNormal (own formulation through the standardised window) against
+    the oracle restatement of utils.py:24-152: moments, entropy, log-probability, and the
+    rejection sampler draw for draw under the same seed."""
+    from oracle import policy_cpu as oc
+    from vlnce_amd.utils import TruncatedNormal
+
+    g = torch.Generator().manual_seed(2)
+    loc = (torch.rand(64, 1, generator=g) - 0.5) * 0.4
+    scale = torch.rand(64, 1, generator=g) * 0.3 + 0.02
+    lo, hi = -0.26, 0.26
+    a, b = TruncatedNormal(loc, scale, lo, hi), oc.TruncatedNormal(loc, scale, lo, hi)
+    for got, want in ((a.mean, b.mean), (a.variance, b.variance), (a.entropy(), b.entropy()),
+                      (a.mode(), b.mode())):
+        assert torch.allclose(got, want, atol=1e-6, rtol=1e-5)
+    v = (torch.rand(64, 1, generator=g) - 0.5) * 0.5
+    assert torch.allclose(a.log_prob(v), b.log_prob(v), atol=1e-5, rtol=1e-5)
+    torch.manual_seed(11)
+    sa = a.sample()
+    torch.manual_seed(11)
+    sb = b.sample()
+    assert torch.equal(sa, sb) and bool(((sa >= lo) & (sa <= hi)).all())
+    with pytest.raises(AssertionError):
+        a.log_prob(torch.full((64, 1), 0.3))

@@ -1,178 +1,206 @@
-"""Distributions and small heads of the policies (reference:
-vlnce_baselines/models/utils.py:12-317).  The categorical / truncated-normal
-math is O(N x 13) scalar work and stays in torch; the
-attention classes run the fused HIP attention kernel."""
-import math
-from numbers import Number
+"""Distributions and small heads of the policies.
 
-import numpy as np
+Plugin-surface mirror of vlnce_baselines/models/utils.py:12-317 (class / method / parameter
+names are what the policies, checkpoints and habitat's PPO code touch).  The categorical and
+truncated-normal math is O(N x 13) scalars per step and stays in torch;
+the attention modules run the fused HIP attention kernel on [B, rows, C] tensors.
+"""
+import math
+
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from . import ops
 
+_SQRT_2PI = math.sqrt(2.0 * math.pi)
+_HALF_LOG_2PIE = 0.5 * math.log(2.0 * math.pi * math.e)
+
 
 class TemperatureTanh(nn.Module):
+    """tanh(x / T): squashes a head's output into (-1, 1) with an adjustable slope."""
+
     def __init__(self, temperature=1.0):
         super().__init__()
-        assert temperature != 0.0, "temperature must be nonzero."
+        if temperature == 0.0:
+            raise AssertionError("temperature must be nonzero.")
         self._T = temperature
 
     def forward(self, x):
         return torch.tanh(x / self._T)
 
 
-def _phi(x):
-    return (np.e ** (-0.5 * (x ** 2))) / math.sqrt(2 * math.pi)
+def _pdf(z):
+    """standard normal density"""
+    return torch.exp(-0.5 * z * z) / _SQRT_2PI
 
 
-def _Phi(x):
-    return 0.5 * (1 + torch.erf(x / math.sqrt(2.0)))
+def _cdf(z):
+    """standard normal distribution function"""
+    return 0.5 * (1.0 + torch.erf(z / math.sqrt(2.0)))
 
 
 class TruncatedNormal(nn.Module):
-    """Two-sided truncated normal (utils.py:24-152): mean/variance/entropy are
-    precomputed at construction; mode() = loc; sampling is rejection."""
+    """N(loc, scale) restricted to [smin, smax] (reference utils.py:24-152).
 
-    def __init__(self, loc, scale, smin=-np.inf, smax=np.inf, validate_args=None):
+    Everything is expressed through the standardised window [a, b] = ([smin, smax] - loc) / scale
+    and its probability mass under the parent normal:
+        mean     = loc + scale (pdf(a) - pdf(b)) / mass
+        variance = scale^2 [1 + (a pdf(a) - b pdf(b)) / mass - ((pdf(a) - pdf(b)) / mass)^2]
+        entropy  = log(sqrt(2 pi e) scale mass) + (a pdf(a) - b pdf(b)) / (2 mass)
+        log p(v) = -z^2 / 2 - log(sqrt(2 pi) scale mass),  z = (v - loc) / scale
+    mode() is loc (the constructor requires loc inside the window); sampling is by rejection."""
+
+    def __init__(self, loc, scale, smin=-math.inf, smax=math.inf, validate_args=None):
         super().__init__()
-        assert smin < smax, "smin must be less than smax"
-        assert np.isfinite(smin) and np.isfinite(smax), "two-sided truncation is required"
-        assert (loc >= smin).all() and (loc <= smax).all(), f"loc is out of range ({smin}, {smax})"
-        if isinstance(scale, Number):
-            assert scale >= 0.0, "scale is negative"
-        else:
-            assert (scale >= 0.0).all(), "scale is negative"
-        self._normal = torch.distributions.Normal(loc, scale, validate_args=False)
-        self._loc, self._scale, self._smin, self._smax = loc, scale, smin, smax
-        self.A = 1 / (scale * math.sqrt(2 * math.pi))
-        hi = torch.as_tensor(smax, dtype=loc.dtype, device=loc.device)
-        lo = torch.as_tensor(smin, dtype=loc.dtype, device=loc.device)
-        self.Z = self._normal.cdf(hi) - self._normal.cdf(lo)
-        alpha = (smin - loc) / scale
-        beta = (smax - loc) / scale
-        a_pdf, b_pdf = _phi(alpha), _phi(beta)
-        z = _Phi(beta) - _Phi(alpha)
-        self._mean = loc - scale * ((b_pdf - a_pdf) / z)
-        t1 = (beta * b_pdf - alpha * a_pdf) / z
-        t2 = ((b_pdf - a_pdf) / z) ** 2
-        self._variance = (scale ** 2) * (1 - t1 - t2)
-        ent = 0.5 * np.log(2 * np.pi * np.e) + torch.log(scale * z)
-        self._entropy = ent + (alpha * a_pdf - beta * b_pdf) / (2 * z)
+        if not (smin < smax):
+            raise AssertionError("smin must be less than smax")
+        if not (math.isfinite(smin) and math.isfinite(smax)):
+            raise AssertionError("two-sided truncation is required")
+        if not bool(((loc >= smin) & (loc <= smax)).all()):
+            raise AssertionError(f"loc is out of range ({smin}, {smax})")
+        if not bool(torch.as_tensor(scale >= 0.0).all()):
+            raise AssertionError("scale is negative")
+        self._loc, self._scale = loc, scale
+        self._window = (smin, smax)
+        self._a = (smin - loc) / scale
+        self._b = (smax - loc) / scale
+        self._mass = _cdf(self._b) - _cdf(self._a)
+        self._parent = torch.distributions.Normal(loc, scale, validate_args=False)
+
+    # -- moments ---------------------------------------------------------------------------
+    def _edge_terms(self):
+        pa, pb = _pdf(self._a), _pdf(self._b)
+        return (pa - pb) / self._mass, (self._a * pa - self._b * pb) / self._mass
 
     @property
     def mean(self):
-        return self._mean
+        first, _ = self._edge_terms()
+        return self._loc + self._scale * first
 
     @property
     def variance(self):
-        return self._variance
+        first, second = self._edge_terms()
+        return self._scale ** 2 * (1.0 + second - first ** 2)
 
-    def sample(self, resample_limit=10000):
-        s = self._normal.sample()
-        bad = (s < self._smin).logical_or(s > self._smax)
-        n = 0
-        while bad.any():
-            assert n < resample_limit, f"Hit resample limit of {resample_limit}"
-            n += 1
-            s[bad] = self._normal.sample()[bad]
-            bad = (s < self._smin).logical_or(s > self._smax)
-        return s
-
-    def log_prob(self, value):
-        msg = "value is out of truncation range and has an undefined log_prob."
-        if isinstance(value, Number):
-            assert self._smin <= value <= self._smax, msg
-        else:
-            assert (value >= self._smin).all() and (value <= self._smax).all(), msg
-        dens = self.A * np.e ** (-0.5 * ((value - self._loc) / self._scale) ** 2)
-        dens = dens / self.Z
-        return np.log(dens) if isinstance(dens, Number) else dens.log()
+    def entropy(self):
+        _, second = self._edge_terms()
+        return _HALF_LOG_2PIE + torch.log(self._scale * self._mass) + 0.5 * second
 
     def mode(self):
         return self._loc
 
-    def entropy(self):
-        return self._entropy
+    # -- density / sampling ----------------------------------------------------------------
+    def _inside(self, value):
+        lo, hi = self._window
+        return (value >= lo) & (value <= hi)
+
+    def log_prob(self, value):
+        value = torch.as_tensor(value, dtype=self._loc.dtype, device=self._loc.device)
+        if not bool(self._inside(value).all()):
+            raise AssertionError("value is out of truncation range and has an undefined log_prob.")
+        z = (value - self._loc) / self._scale
+        return -0.5 * z * z - torch.log(_SQRT_2PI * self._scale * self._mass)
+
+    def sample(self, resample_limit=10000):
+        draw = self._parent.sample()
+        for _ in range(resample_limit):
+            outside = ~self._inside(draw)
+            if not bool(outside.any()):
+                return draw
+            draw = torch.where(outside, self._parent.sample(), draw)
+        raise AssertionError(f"Hit resample limit of {resample_limit}")
+
+
+def _attend(query, keys_cl, values_cl, mask, scale):
+    """softmax over positions of (q.k) * mask * scale, applied to the values.  keys / values are
+    channels-last [B, P, C]; the mask is MULTIPLICATIVE on the energies."""
+    m = None if mask is None else mask.to(torch.uint8).contiguous()
+    return ops.attention(query, keys_cl, values_cl, m, 2, scale)
 
 
 class DotProductAttention(nn.Module):
-    """utils.py:155-178.  Q [B,Dk], K [B,Dk,P], V [B,Dv,P] (logical layouts of
-    the reference); the mask is MULTIPLICATIVE on the energies (App. B-3)."""
+    """Single-head attention of the waypoint net (reference utils.py:155-178): Q [B, Dk],
+    K [B, Dk, P], V [B, Dv, P] in the reference's logical layouts."""
 
     def __init__(self, key_dimension):
         super().__init__()
-        self.scale = torch.tensor(1.0 / (key_dimension ** 0.5))
-        self._scale_f = 1.0 / (key_dimension ** 0.5)
+        self._scale_f = float(key_dimension) ** -0.5
+        self.scale = torch.tensor(self._scale_f)
 
     def forward(self, Q, K, V, mask=None):
-        m = None if mask is None else mask.to(torch.uint8).contiguous()
-        return ops.attention(Q, K.permute(0, 2, 1), V.permute(0, 2, 1), m, 2, self._scale_f)
+        return _attend(Q, K.transpose(1, 2), V.transpose(1, 2), mask, self._scale_f)
 
 
 class MultiHeadDotProductAttention(nn.Module):
-    """utils.py:181-266."""
+    """Projected multi-head attention with an optional LayerNorm on the output (reference
+    utils.py:181-266).  Heads are folded into the batch dimension of the HIP attention kernel."""
 
     def __init__(self, d_q_in, d_k_in, d_v_in, d_qk, d_v, num_heads, d_out, normalize=True,
                  dropout_p=0.0):
         super().__init__()
+        if dropout_p != 0.0:
+            raise AssertionError("the reference never enables attention dropout")
         self.num_heads = num_heads
         self.normalize = normalize
+        self.dropout = None
         self.q_linear = nn.Linear(d_q_in, d_qk * num_heads, bias=False)
         self.k_linear = nn.Linear(d_k_in, d_qk * num_heads, bias=False)
         self.v_linear = nn.Linear(d_v_in, d_v * num_heads, bias=False)
         self.attn = DotProductAttention(d_qk)
         self.final_linear = nn.Linear(d_v * num_heads, d_out, bias=False)
-        assert dropout_p == 0.0, "the reference never enables attention dropout"
-        self.dropout = None
-        if self.normalize:
+        if normalize:
             self.layer_norm = nn.LayerNorm(d_out, eps=1e-6)
 
+    def _heads_to_batch(self, t):
+        """[B, P, heads*d] -> [B*heads, P, d]"""
+        B, P, wide = t.shape
+        d = wide // self.num_heads
+        return t.view(B, P, self.num_heads, d).transpose(1, 2).reshape(B * self.num_heads, P, d)
+
     def forward(self, Q, K, V, mask=None):
-        """Q [B,d_q_in]; K [B,d_k_in,P]; V [B,d_v_in,P]."""
-        assert K.shape[2] == V.shape[2], "keys must be the same size as values"
-        nh = self.num_heads
-        B, P = K.shape[0], K.shape[2]
-        q = ops.linear(Q, self.q_linear.weight)                       # [B, nh*dqk]
-        k = ops.linear(K.permute(0, 2, 1), self.k_linear.weight)      # [B, P, nh*dqk]
-        v = ops.linear(V.permute(0, 2, 1), self.v_linear.weight)      # [B, P, nh*dv]
-        dqk, dv = q.shape[1] // nh, v.shape[2] // nh
-        if nh == 1:
-            a = ops.attention(q, k, v, mask, 2, self.attn._scale_f)
+        """Q [B, d_q_in]; K [B, d_k_in, P]; V [B, d_v_in, P]."""
+        if K.shape[2] != V.shape[2]:
+            raise AssertionError("keys must be the same size as values")
+        B = Q.shape[0]
+        query = ops.linear(Q, self.q_linear.weight)
+        keys = ops.linear(K.transpose(1, 2), self.k_linear.weight)
+        values = ops.linear(V.transpose(1, 2), self.v_linear.weight)
+        scale = self.attn._scale_f
+        if self.num_heads == 1:
+            mixed = _attend(query, keys, values, mask, scale)
         else:
-            qh = q.view(B * nh, dqk)
-            kh = k.view(B, P, nh, dqk).permute(0, 2, 1, 3).reshape(B * nh, P, dqk)
-            vh = v.view(B, P, nh, dv).permute(0, 2, 1, 3).reshape(B * nh, P, dv)
-            a = ops.attention(qh, kh, vh, mask, 2, self.attn._scale_f).view(B, nh * dv)
-        out = ops.linear(a, self.final_linear.weight)
+            per_head = _attend(query.view(B * self.num_heads, -1), self._heads_to_batch(keys),
+                               self._heads_to_batch(values), mask, scale)
+            mixed = per_head.view(B, -1)
+        out = ops.linear(mixed, self.final_linear.weight)
         if self.normalize:
-            out = torch.nn.functional.layer_norm(out, self.layer_norm.normalized_shape,
-                                                 self.layer_norm.weight, self.layer_norm.bias,
-                                                 self.layer_norm.eps)
+            ln = self.layer_norm
+            out = F.layer_norm(out, ln.normalized_shape, ln.weight, ln.bias, ln.eps)
         return out
 
 
 class CustomFixedCategorical(torch.distributions.Categorical):
-    """utils.py:269-289."""
+    """Categorical whose samples, modes and log-probabilities keep a trailing unit dimension
+    (reference utils.py:269-289; `log_probs` is the habitat-lab spelling)."""
 
     def sample(self, sample_shape=torch.Size()):
-        return super().sample(sample_shape).unsqueeze(-1)
-
-    def log_prob(self, actions):
-        return (super().log_prob(actions.squeeze(-1)).view(actions.size(0), -1).sum(-1)
-                .unsqueeze(-1))
-
-    def log_probs(self, actions):  # habitat-lab spelling
-        return self.log_prob(actions)
+        return super().sample(sample_shape)[..., None]
 
     def mode(self):
         return self.probs.argmax(dim=-1, keepdim=True)
 
+    def log_prob(self, actions):
+        flat = super().log_prob(actions.squeeze(-1))
+        return flat.reshape(actions.size(0), -1).sum(dim=-1, keepdim=True)
+
+    def log_probs(self, actions):
+        return self.log_prob(actions)
+
 
 def batched_index_select(x, dim, index):
-    """utils.py:292-317."""
-    views = [x.shape[0]] + [1 if i != dim else -1 for i in range(1, len(x.shape))]
-    expanse = list(x.shape)
-    expanse[0] = -1
-    expanse[dim] = -1
-    return torch.gather(x, dim, index.view(views).expand(expanse)).squeeze(dim)
+    """x[b].index_select(dim - 1, index[b]) for every batch row b, with `dim` squeezed away
+    (reference utils.py:292-317): x [B, ..., K(dim), ...], index [B] or [B, 1]."""
+    shape = [x.shape[0]] + [1] * (x.dim() - 1)
+    picker = index.reshape(shape).expand(*[-1 if i in (0, dim) else s for i, s in enumerate(x.shape)])
+    return torch.take_along_dim(x, picker, dim).squeeze(dim)
