@@ -18,8 +18,9 @@ def build_depth_encoder(observation_space, model_config, **extra):
     if cfg.cnn_type not in _DEPTH_TYPES:
         raise AssertionError(f"DEPTH_ENCODER.cnn_type must be one of {_DEPTH_TYPES}")
     cls = getattr(resnet_encoders, cfg.cnn_type)
+    trainable = extra.pop("trainable", cfg.trainable)  # the waypoint net never unfreezes it
     return cls(observation_space, output_size=cfg.output_size, checkpoint=cfg.ddppo_checkpoint,
-               backbone=cfg.backbone, trainable=cfg.trainable, **extra)
+               backbone=cfg.backbone, trainable=trainable, **extra)
 
 
 def build_rgb_encoder(model_config, **extra):
@@ -28,8 +29,15 @@ def build_rgb_encoder(model_config, **extra):
     if cfg.cnn_type not in _RGB_TYPES:
         raise AssertionError(f"RGB_ENCODER.cnn_type must be one of {_RGB_TYPES}")
     cls = getattr(resnet_encoders, cfg.cnn_type)
+    trainable = extra.pop("trainable", cfg.trainable)
     return cls(cfg.output_size, normalize_visual_inputs=model_config.normalize_rgb,
-               trainable=cfg.trainable, **extra)
+               trainable=trainable, **extra)
+
+
+def relu_fc(n_in, n_out, *front):
+    """[*front, Linear(n_in, n_out), ReLU]: the small projection blocks of the nets (the module
+    index of the Linear inside the Sequential is part of the checkpoint key)."""
+    return torch.nn.Sequential(*front, torch.nn.Linear(n_in, n_out), torch.nn.ReLU(True))
 
 
 def encode_three_branches(net, observations, device):

@@ -11,8 +11,8 @@ import torch.nn as nn
 
 from . import ops
 from .cma_policy import nchw_flat_weight, rows_of
-from .encoders import resnet_encoders
 from .encoders.instruction_encoder import InstructionEncoder
+from .net_parts import build_depth_encoder, build_rgb_encoder, relu_fc
 from .policy import Net
 from .rnn_state_encoder import build_rnn_state_encoder
 from .utils import (CustomFixedCategorical, DotProductAttention, MultiHeadDotProductAttention,
@@ -38,60 +38,48 @@ class WaypointPredictionNet(Net):
         r_out = model_config.RGB_ENCODER.output_size
         d_out = model_config.DEPTH_ENCODER.output_size
 
+        # attribute order below = parameter / state_dict order of the reference net
         self.instruction_encoder = InstructionEncoder(model_config.INSTRUCTION_ENCODER)
         ins = self.instruction_encoder.output_size
-        cnn_type = model_config.DEPTH_ENCODER.cnn_type
-        assert cnn_type in ["VlnResnetDepthEncoder"]
-        self.depth_encoder = getattr(resnet_encoders, cnn_type)(
-            observation_space,
-            output_size=d_out,
-            checkpoint=model_config.DEPTH_ENCODER.ddppo_checkpoint,
-            backbone=model_config.DEPTH_ENCODER.backbone,
-            spatial_output=True,
-        )
-        cnn_type = model_config.RGB_ENCODER.cnn_type
-        assert cnn_type in ["TorchVisionResNet18", "TorchVisionResNet50"]
-        self.rgb_encoder = getattr(resnet_encoders, cnn_type)(
-            r_out,
-            normalize_visual_inputs=model_config.normalize_rgb,
-            spatial_output=True,
-            single_spatial_filter=False,
-        )
+        self.depth_encoder = build_depth_encoder(observation_space, model_config,
+                                                 spatial_output=True, trainable=False)
+        self.rgb_encoder = build_rgb_encoder(model_config, spatial_output=True,
+                                             single_spatial_filter=False, trainable=False)
+        rnn_type = model_config.STATE_ENCODER.rnn_type
+        rgb_c = self.rgb_encoder.output_shape[0]
+        depth_c = self.depth_encoder.output_shape[0]
+        half = hs // 2
+        pano_width = r_out + d_out + ANGLE_FEATURE_SIZE      # one panorama slot's feature
+
+        # visual history (the frame the agent looked at last)
         self.visual_rnn = build_rnn_state_encoder(
-            input_size=r_out + PREV_ACTION_DIM + d_out + r_out, hidden_size=hs,
-            rnn_type=model_config.STATE_ENCODER.rnn_type, num_layers=1)
-        self.rgb_pool_linear = nn.Linear(self.rgb_encoder.resnet_layer_size, r_out)
-        self.rgb_hist_linear = nn.Sequential(
-            nn.AdaptiveAvgPool1d(1), nn.Flatten(),
-            nn.Linear(self.rgb_encoder.output_shape[0], r_out), nn.ReLU(True))
-        self.depth_hist_linear = nn.Sequential(
-            nn.Flatten(), nn.Linear(int(np.prod(self.depth_encoder.output_shape)), d_out),
-            nn.ReLU(True))
-        dk_inst = hs // 2
-        self.inst_attn_q = nn.Sequential(nn.Linear(hs, dk_inst), nn.ReLU(True))
-        self.inst_attn_k = nn.Conv1d(ins, dk_inst, 1)
-        self.inst_attn = DotProductAttention(dk_inst)
-        self.text_q_linear = nn.Linear(ins, hs // 2)
-        self.rgb_kv_spatial = nn.Conv1d(self.rgb_encoder.output_shape[0], hs // 2 + r_out, 1)
-        self.rgb_spatial_attn = DotProductAttention(hs // 2)
-        self.depth_kv_spatial = nn.Conv1d(self.depth_encoder.output_shape[0], hs // 2 + d_out, 1)
-        self.depth_spatial_attn = DotProductAttention(hs // 2)
-        d_kv_in = r_out + d_out + ANGLE_FEATURE_SIZE
-        self.pano_attn = MultiHeadDotProductAttention(
-            d_q_in=ins, d_k_in=d_kv_in, d_v_in=d_kv_in, d_qk=PANO_ATTN_KEY_DIM,
-            d_v=PANO_ATTN_KEY_DIM, num_heads=1, d_out=d_kv_in)
-        self.main_state_compress = nn.Sequential(
-            nn.Linear(ins + d_kv_in + hs + PREV_ACTION_DIM, hs), nn.ReLU(True))
-        self.main_state_encoder = build_rnn_state_encoder(
-            input_size=hs, hidden_size=hs, rnn_type=model_config.STATE_ENCODER.rnn_type,
+            input_size=r_out + PREV_ACTION_DIM + d_out + r_out, hidden_size=hs, rnn_type=rnn_type,
             num_layers=1)
-        final_feature_size = d_kv_in
+        self.rgb_pool_linear = nn.Linear(self.rgb_encoder.resnet_layer_size, r_out)
+        self.rgb_hist_linear = relu_fc(rgb_c, r_out, nn.AdaptiveAvgPool1d(1), nn.Flatten())
+        self.depth_hist_linear = relu_fc(int(np.prod(self.depth_encoder.output_shape)), d_out,
+                                         nn.Flatten())
+        # instruction attention, then spatial attention inside every panorama frame
+        self.inst_attn_q = relu_fc(hs, half)
+        self.inst_attn_k = nn.Conv1d(ins, half, 1)
+        self.inst_attn = DotProductAttention(half)
+        self.text_q_linear = nn.Linear(ins, half)
+        self.rgb_kv_spatial = nn.Conv1d(rgb_c, half + r_out, 1)
+        self.rgb_spatial_attn = DotProductAttention(half)
+        self.depth_kv_spatial = nn.Conv1d(depth_c, half + d_out, 1)
+        self.depth_spatial_attn = DotProductAttention(half)
+        # attention over the 12 panorama slots, main recurrent state, heads
+        self.pano_attn = MultiHeadDotProductAttention(
+            d_q_in=ins, d_k_in=pano_width, d_v_in=pano_width, d_qk=PANO_ATTN_KEY_DIM,
+            d_v=PANO_ATTN_KEY_DIM, num_heads=1, d_out=pano_width)
+        self.main_state_compress = relu_fc(ins + pano_width + hs + PREV_ACTION_DIM, hs)
+        self.main_state_encoder = build_rnn_state_encoder(
+            input_size=hs, hidden_size=hs, rnn_type=rnn_type, num_layers=1)
         self.stop_linear = nn.Linear(hs, 1)
         nn.init.constant_(self.stop_linear.bias, 0)
-        self.compress_x_linear = nn.Sequential(nn.Linear(hs, final_feature_size), nn.ReLU(True))
-        in_dim = hs + final_feature_size
-        self._init_distance_linear(in_dim, final_feature_size)
-        self._init_offset_linear(in_dim, final_feature_size)
+        self.compress_x_linear = relu_fc(hs, pano_width)
+        self._init_distance_linear(hs + pano_width, pano_width)
+        self._init_offset_linear(hs + pano_width, pano_width)
         self.train()
 
     # ---- reference helpers (waypoint_predictors.py:184-264)
