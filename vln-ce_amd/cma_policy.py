@@ -26,11 +26,6 @@ class CMAPolicy(ILPolicy):
             action_space.n,
         )
 
-    @classmethod
-    def from_config(cls, config, observation_space, action_space):
-        return cls(observation_space=observation_space, action_space=action_space,
-                   model_config=config.MODEL)
-
 
 def rows_of(feature_map):
     """logical [B, C, h, w] (NHWC memory) -> [B, h*w, C] rows without a copy."""

@@ -48,31 +48,43 @@ class Policy(nn.Module):
         raise NotImplementedError
 
 
+def _not_part_of_imitation_learning(self, *args, **kwargs):
+    raise NotImplementedError
+
+
 class ILPolicy(Policy):
-    """Imitation-learning policy: act() + build_distribution(); deliberately
-    skips Policy.__init__ so there is no critic (policy.py:15, App. B-6)."""
+    """Imitation-learning policy: net + categorical action head, NO critic -- Policy.__init__ is
+    deliberately bypassed as upstream (models/policy.py:10-23, App. B-6).  `act()` and
+    `build_distribution()` are what the DAgger / recollect trainers call."""
 
     def __init__(self, net, dim_actions):
         nn.Module.__init__(self)
-        self.net = net
-        self.dim_actions = dim_actions
-        self.action_distribution = CategoricalNet(self.net.output_size, self.dim_actions)
+        self.net, self.dim_actions = net, dim_actions
+        self.action_distribution = CategoricalNet(net.output_size, dim_actions)
 
-    def act(self, observations, rnn_states, prev_actions, masks, deterministic=False):
-        features, rnn_states = self.net(observations, rnn_states, prev_actions, masks)
-        distribution = self.action_distribution(features)
-        action = distribution.mode() if deterministic else distribution.sample()
-        return action, rnn_states
+    @classmethod
+    def from_config(cls, config, observation_space, action_space):
+        """baseline_registry entry point (base_il_trainer.py:61-66): MODEL gets the GPU id the
+        reference's nets read from it."""
+        config.defrost()
+        config.MODEL.TORCH_GPU_ID = config.TORCH_GPU_ID
+        config.freeze()
+        return cls(observation_space=observation_space, action_space=action_space,
+                   model_config=config.MODEL)
 
-    def get_value(self, *args, **kwargs):
-        raise NotImplementedError
-
-    def evaluate_actions(self, *args, **kwargs):
-        raise NotImplementedError
+    def _step(self, observations, rnn_states, prev_actions, masks):
+        features, new_states = self.net(observations, rnn_states, prev_actions, masks)
+        return self.action_distribution(features), new_states
 
     def build_distribution(self, observations, rnn_states, prev_actions, masks):
-        features, rnn_states = self.net(observations, rnn_states, prev_actions, masks)
-        return self.action_distribution(features)
+        return self._step(observations, rnn_states, prev_actions, masks)[0]
+
+    def act(self, observations, rnn_states, prev_actions, masks, deterministic=False):
+        dist, new_states = self._step(observations, rnn_states, prev_actions, masks)
+        return (dist.mode() if deterministic else dist.sample()), new_states
+
+    get_value = _not_part_of_imitation_learning
+    evaluate_actions = _not_part_of_imitation_learning
 
     def encode_ahead(self, observations):
         """Optional (not in the reference): start the frozen visual trunks of a FUTURE batch on

@@ -21,14 +21,6 @@ class Seq2SeqPolicy(ILPolicy):
             action_space.n,
         )
 
-    @classmethod
-    def from_config(cls, config, observation_space, action_space):
-        config.defrost()
-        config.MODEL.TORCH_GPU_ID = config.TORCH_GPU_ID
-        config.freeze()
-        return cls(observation_space=observation_space, action_space=action_space,
-                   model_config=config.MODEL)
-
 
 class Seq2SeqNet(Net):
     """instruction final state || depth fc || rgb fc (|| prev action) -> GRU/LSTM."""
