@@ -78,23 +78,27 @@ class WaypointPredictionNet(Net):
         self.stop_linear = nn.Linear(hs, 1)
         nn.init.constant_(self.stop_linear.bias, 0)
         self.compress_x_linear = relu_fc(hs, pano_width)
-        self._init_distance_linear(hs + pano_width, pano_width)
-        self._init_offset_linear(hs + pano_width, pano_width)
+        self._build_component_heads(hs + pano_width)
         self.train()
 
-    # ---- reference helpers (waypoint_predictors.py:184-264)
+    # ---- class index -> metres / radians (waypoint_predictors.py:184-215)
+    @staticmethod
+    def _bin_centre(index, low, high, bins):
+        """value of class `index` when [low, high] is divided into `bins` classes, ends included"""
+        return low + index * ((high - low) / (bins - 1))
+
     def distance_to_continuous(self, distance):
-        if self.wypt_cfg.continuous_distance:
+        wc = self.wypt_cfg
+        if wc.continuous_distance:
             return distance
-        rng = self.wypt_cfg.max_distance_prediction - self.wypt_cfg.min_distance_prediction
-        return self.wypt_cfg.min_distance_prediction + distance * (
-            rng / (self.wypt_cfg.discrete_distances - 1))
+        return self._bin_centre(distance, wc.min_distance_prediction, wc.max_distance_prediction,
+                                wc.discrete_distances)
 
     def offset_to_continuous(self, offset):
         if self.wypt_cfg.continuous_offset:
             return offset
-        per_pano = 2 * np.pi / self._num_panos
-        return (-per_pano / 2) + offset * (per_pano / (self.wypt_cfg.discrete_offsets - 1))
+        half_slot = np.pi / self._num_panos
+        return self._bin_centre(offset, -half_slot, half_slot, self.wypt_cfg.discrete_offsets)
 
     @property
     def num_recurrent_layers(self):
@@ -109,23 +113,26 @@ class WaypointPredictionNet(Net):
     def output_size(self):
         return self._hidden_size
 
-    def _init_distance_linear(self, in_dim, final_feature_size):
-        if self.wypt_cfg.continuous_distance:
-            self.distance_linear = nn.Sequential(nn.Linear(in_dim, 1), nn.Sigmoid())
-            self.distance_var_linear = nn.Sequential(
-                nn.Linear(self._hidden_size + final_feature_size, 1), nn.Sigmoid())
-        else:
-            self.distance_linear = nn.Linear(in_dim, self.wypt_cfg.discrete_distances)
+    def _build_component_heads(self, width):
+        """distance / offset heads over [panorama slot feature, recurrent state] rows of `width`
+        (waypoint_predictors.py:217-264): a continuous component has a squashed mean head and a
+        sigmoid variance head, a discrete one a single classifier."""
+        wc = self.wypt_cfg
 
-    def _init_offset_linear(self, in_dim, final_feature_size):
-        if self.wypt_cfg.continuous_offset:
-            self.offset_linear = nn.Sequential(
-                nn.Linear(in_dim, 1), TemperatureTanh(temperature=self.wypt_cfg.offset_temperature))
-            self.offset_scale = np.pi / self._num_panos
-            self.offset_var_linear = nn.Sequential(
-                nn.Linear(self._hidden_size + final_feature_size, 1), nn.Sigmoid())
+        def squashed(activation):
+            return nn.Sequential(nn.Linear(width, 1), activation)
+
+        if wc.continuous_distance:
+            self.distance_linear = squashed(nn.Sigmoid())
+            self.distance_var_linear = squashed(nn.Sigmoid())
         else:
-            self.offset_linear = nn.Linear(in_dim, self.wypt_cfg.discrete_offsets)
+            self.distance_linear = nn.Linear(width, wc.discrete_distances)
+        if wc.continuous_offset:
+            self.offset_linear = squashed(TemperatureTanh(temperature=wc.offset_temperature))
+            self.offset_scale = np.pi / self._num_panos
+            self.offset_var_linear = squashed(nn.Sigmoid())
+        else:
+            self.offset_linear = nn.Linear(width, wc.discrete_offsets)
 
     def _encode_frames(self, encoder, key, frames, history, masks):
         """12 pano frames + the (done-masked) history frame as one batch of B*13 images
