@@ -58,47 +58,90 @@ def synth_batch(N, hw, L, device, seed=1):
     return ({k: mv(v) for k, v in obs.items()}, mv(prev), mv(masks), mv(targets), mv(weights))
 
 
+def host_cpu_facts():
+    """CPU model, sockets, physical cores and logical CPUs of this host (/proc/cpuinfo), plus
+    the logical CPUs this process may run on."""
+    model, phys, logical = "unknown", set(), 0
+    try:
+        pid = cid = None
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "model name":
+                model = v
+            elif k == "processor":
+                logical += 1
+            elif k == "physical id":
+                pid = v
+            elif k == "core id":
+                cid = v
+                phys.add((pid, cid))
+    except OSError:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count() or 1
+    return {"model": model, "sockets": len({p for p, _ in phys}) or None,
+            "physical_cores": len(phys) or None, "logical_cpus": logical or None,
+            "usable_logical_cpus": usable}
+
+
 def cpu_baseline_worker(num_envs, hw, L, threads):
-    """Runs in a child process: CPU oracle (port of the reference policy) timed on
-    `threads` host threads on a bounded sample of the bench workload."""
+    """Runs in a child process: CPU oracle (port of the reference policy) timed on the host
+    cores on a bounded sample of the bench workload.  `threads` is a comma list: each count
+    gets 1 warm-up + 2 timed iterations and the best count is reported (oneDNN/OpenMP on a
+    many-core shared host is not monotone in the thread count)."""
     from oracle import policy_cpu as oc
     from oracle import thirdparty as tp
 
-    torch.set_num_threads(threads)
     pol = oc.CMAPolicy.from_config(tp.make_config("CMAPolicy"), *tp.make_spaces(hw, hw))
     opt = torch.optim.Adam(pol.parameters(), lr=2.5e-4)
     n = min(num_envs, 8)
     obs, prev, masks, tgt, w = synth_batch(n, hw, L, "cpu")
     oc.AuxLosses.activate()
-    times = []
-    for i in range(4):
-        t0 = time.time()
-        oc.il_update(pol, opt, obs, prev, masks, tgt, w, 512)
-        dt = time.time() - t0
-        log(f"cpu_baseline iter {i}: {dt:.2f}s")
-        if i > 0:
-            times.append(dt)
-    best = min(times)
+    sweep = {}
+    t_start = time.time()
+    for th in [int(t) for t in str(threads).split(",")]:
+        if time.time() - t_start > 45:  # bounded: the default bench run finishes within minutes
+            break
+        torch.set_num_threads(th)
+        times = []
+        for i in range(3):
+            t0 = time.time()
+            oc.il_update(pol, opt, obs, prev, masks, tgt, w, 512)
+            dt = time.time() - t0
+            log(f"cpu_baseline {th} threads iter {i}: {dt:.2f}s")
+            if i > 0:
+                times.append(dt)
+        sweep[th] = min(times)
+    best_th = min(sweep, key=sweep.get)
+    facts = host_cpu_facts()
     print(json.dumps({
-        "value": round(n / best, 2), "unit": "policy-steps/sec", "cores": threads, "kind": "port",
+        "value": round(n / sweep[best_th], 2), "unit": "policy-steps/sec", "cores": best_th,
+        "kind": "port",
         "sample": f"CMA fwd+bwd+Adam (oracle/policy_cpu.py), {n} envs x {hw}x{hw} RGB-D, L={L}, "
-                  f"min of {len(times)} iters after 1 warm-up, torch CPU fp32, {threads} threads"}))
+                  f"min of 2 iters after 1 warm-up, torch CPU fp32, best of thread counts "
+                  f"{sorted(sweep)} = {best_th} threads",
+        "host_cpu": facts,
+        "steps_per_sec_by_threads": {str(k): round(n / v, 2) for k, v in sorted(sweep.items())}}))
 
 
 def cpu_baseline(num_envs, hw, L, timeout_s=100):
-    """Bounded: the child is killed after `timeout_s` (the default bench run must
-    finish within minutes).  Thread count: MKL-DNN/OpenMP degrade badly when
-    oversubscribed on a many-core shared host, so at most 32 threads are used and
-    that number is what `cores` reports."""
+    """Bounded: the child is killed after `timeout_s` (the default bench run must finish within
+    minutes).  The child sweeps a few thread counts up to the host's physical cores and reports
+    the best one as `cores`; the host's CPU model / socket / core counts ride along in
+    `host_cpu` (north_star: "core count stated")."""
     import subprocess
 
-    try:
-        usable = len(os.sched_getaffinity(0))
-    except AttributeError:
-        usable = os.cpu_count() or 1
-    threads = min(usable, 32)
+    facts = host_cpu_facts()
+    usable = facts["usable_logical_cpus"]
+    phys = min(facts["physical_cores"] or usable, usable)
+    counts = sorted({min(c, usable) for c in (16, 32, 64, phys)})
+    threads = max(counts)
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--num-envs",
-           str(num_envs), "--hw", str(hw), "--tokens", str(L), "--threads", str(threads)]
+           str(num_envs), "--hw", str(hw), "--tokens", str(L), "--threads",
+           ",".join(str(c) for c in counts)]
     env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads))
     try:
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, env=env)
@@ -106,7 +149,8 @@ def cpu_baseline(num_envs, hw, L, timeout_s=100):
         return json.loads(r.stdout.strip().splitlines()[-1])
     except Exception as e:  # timeout / parse error: report, never block the GPU line
         return {"value": None, "unit": "policy-steps/sec", "cores": threads, "kind": "port",
-                "sample": f"cpu baseline did not finish within {timeout_s}s ({type(e).__name__})"}
+                "sample": f"cpu baseline did not finish within {timeout_s}s ({type(e).__name__})",
+                "host_cpu": facts}
 
 
 def pmc_traffic(n_conv):
@@ -123,6 +167,122 @@ def pmc_traffic(n_conv):
     if rec.get("igemm_launches_per_step") != n_conv:
         return None
     return rec.get("hbm_bytes_per_launch")
+
+
+def conv_kernel_time(policy, obs, dev, repeats=3):
+    """GPU-paced duration of every convolution launch of the two visual trunks' forward
+    (the 107 igemm launches of a step).
+
+    The trunks run eagerly on ONE stream (graph replay hides the individual launches from
+    the host; concurrent branches would stretch each other's kernels) with a HIP event
+    before and after each conv launch.  Events are device-side timestamps, but an event
+    pair also contains whatever time the stream sat idle waiting for the HOST to issue the
+    launch -- on a slow host that idle time used to be booked as kernel time.  So the pass is
+    issued behind a spin kernel that keeps the stream busy until the host has queued
+    everything: all launches then execute back to back and the pairs measure device time
+    only.  The marker cost of an empty event pair (measured in the same backlog) is
+    subtracted per launch.  Checks: every per-launch time is the minimum over `repeats`
+    passes; the sum must not exceed the single-stream duration of the whole eager pass
+    (one event pair around everything) -- otherwise None is returned with the reason."""
+    import vlnce_amd.encoders.resnet_encoders as enc
+    from vlnce_amd import ops
+
+    saved = {k: os.environ.get(k) for k in ("VLNCE_HIP_GRAPHS", "VLNCE_SIDE_STREAMS")}
+    os.environ["VLNCE_HIP_GRAPHS"] = "0"
+    os.environ["VLNCE_SIDE_STREAMS"] = "0"
+    orig_conv = ops.conv2d_nhwc
+    events = []
+
+    def timed_conv(*a, **k):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = orig_conv(*a, **k)
+        e1.record()
+        events.append((e0, e1))
+        return out
+
+    def trunks():
+        with torch.no_grad():
+            policy.net.rgb_encoder.trunk_features(obs)
+            policy.net.depth_encoder.trunk_features(obs)
+
+    def ev():
+        return torch.cuda.Event(enable_timing=True)
+
+    try:
+        trunks()  # eager warm-up of this mode
+        torch.cuda.synchronize()
+        # host issue time of one eager pass and the spin kernel's rate
+        t0 = time.perf_counter()
+        trunks()
+        host_ms = 1e3 * (time.perf_counter() - t0)
+        torch.cuda.synchronize()
+        a, b = ev(), ev()
+        a.record()
+        torch.cuda._sleep(2_000_000)
+        b.record()
+        torch.cuda.synchronize()
+        cyc_per_ms = 2_000_000 / max(a.elapsed_time(b), 1e-3)
+        backlog_ms = min(3.0 * host_ms + 30.0, 2000.0)
+        per_launch, totals, empties = None, [], []
+        enc.ops.conv2d_nhwc = timed_conv
+        for _ in range(repeats):
+            events.clear()
+            torch.cuda._sleep(int(backlog_ms * cyc_per_ms))
+            nul = [(ev(), ev()) for _ in range(8)]
+            for e0, e1 in nul:
+                e0.record()
+                e1.record()
+            w0, w1 = ev(), ev()
+            w0.record()
+            trunks()
+            w1.record()
+            torch.cuda.synchronize()
+            empties.append(sorted(e0.elapsed_time(e1) for e0, e1 in nul)[len(nul) // 2])
+            cur = [e0.elapsed_time(e1) for e0, e1 in events]
+            per_launch = cur if per_launch is None else [min(x, y) for x, y in zip(per_launch, cur)]
+            totals.append(w0.elapsed_time(w1))
+    finally:
+        enc.ops.conv2d_nhwc = orig_conv
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    empty = min(empties)
+    n = len(per_launch)
+    conv_ms = sum(max(t - empty, 0.0) for t in per_launch)
+    whole = min(totals)
+    log(f"conv attribution: {n} launches, {conv_ms:.3f} ms of a {whole:.3f} ms eager single-stream "
+        f"trunk pair (empty event pair {1e3 * empty:.1f} us, host issue {host_ms:.1f} ms)")
+    res = {"n": n, "conv_ms": conv_ms, "eager_trunks_ms": whole, "empty_pair_us": 1e3 * empty,
+           "host_issue_ms": host_ms, "reason": None}
+    if not (0.0 < conv_ms <= whole * 1.001):
+        res["reason"] = (f"per-launch event sum {conv_ms:.3f} ms is not inside the eager "
+                         f"single-stream pass {whole:.3f} ms")
+    return res
+
+
+def act_latency(policy, batch, dev, sizes=(1, 4, 8), iters=20):
+    """forward-only act() (eval, no_grad) at the small batches of the eval / inference loops
+    (base_il_trainer.py:284-331): mean wall time per call in ms, graphs as the policy uses them."""
+    obs, prev, masks = batch[0], batch[1], batch[2]
+    out = {}
+    with torch.no_grad():
+        for n in sizes:
+            if n > prev.size(0):
+                continue
+            o = {k: v[:n].contiguous() for k, v in obs.items()}
+            h0 = torch.zeros(n, policy.net.num_recurrent_layers, 512, device=dev)
+            for _ in range(4):  # eager pass, capturing pass, replays
+                policy.act(o, h0, prev[:n], masks[:n], deterministic=True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                policy.act(o, h0, prev[:n], masks[:n], deterministic=True)
+            torch.cuda.synchronize()
+            out[str(n)] = round(1e3 * (time.perf_counter() - t0) / iters, 3)
+    return out
 
 
 def main():
@@ -142,7 +302,7 @@ def main():
                     help="for rocprofv3 --pmc passes: 1 warm-up + 1 eager single-stream step, "
                          "nothing else")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
-    ap.add_argument("--threads", type=int, default=8, help=argparse.SUPPRESS)
+    ap.add_argument("--threads", default="8", help=argparse.SUPPRESS)
     ap.add_argument("--no-pipeline", action="store_true",
                     help="do not start the next step's frozen visual trunks (encode_ahead) "
                          "before enqueuing the current step's update")
@@ -248,18 +408,6 @@ def main():
         torch.cuda.synchronize()
         log(f"warm-up step {i}: {1e3 * (time.perf_counter() - t0):.1f} ms")
 
-    # conv-kernel time: HIP events around every conv launch on the launch stream
-    conv_events = []
-    orig_conv = ops.conv2d_nhwc
-
-    def timed_conv(*a, **k):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        out = orig_conv(*a, **k)
-        e1.record()
-        conv_events.append((e0, e1))
-        return out
-
     def sync():
         if use_dist:
             dist.barrier()
@@ -283,21 +431,25 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = tmax.item()
 
-    # separate, untimed-for-throughput pass to attribute time to the dominant kernel
-    # (graph replay hides the individual launches from the host, so this pass runs eagerly)
-    import vlnce_amd.encoders.resnet_encoders as enc
-    # and on ONE stream, so concurrent branches do not stretch each other's kernel durations
-    os.environ["VLNCE_HIP_GRAPHS"] = "0"
-    os.environ["VLNCE_SIDE_STREAMS"] = "0"
-    enc.ops.conv2d_nhwc = timed_conv
-    step()
-    torch.cuda.synchronize()
-    enc.ops.conv2d_nhwc = orig_conv
-    os.environ.pop("VLNCE_HIP_GRAPHS")
-    os.environ.pop("VLNCE_SIDE_STREAMS")
-    conv_ms = sum(a.elapsed_time(b) for a, b in conv_events)
-    n_conv = len(conv_events)
+    # ---- plain loop (what the unchanged trainers issue: no encode_ahead), same step count
+    no_pipe_ms = None
+    if pipeline:
+        for _ in range(2):
+            step()
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        sync()
+        no_pipe_ms = 1e3 * (time.perf_counter() - t1) / args.steps
+        if use_dist:
+            tm = torch.tensor([no_pipe_ms], device=dev)
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            no_pipe_ms = tm.item()
+        log(f"plain loop (no encode_ahead): {no_pipe_ms:.3f} ms/step")
 
+    # ---- dominant-kernel attribution: separate, untimed-for-throughput pass
+    conv = conv_kernel_time(policy, batch[0], dev)
     # secondary figure: forward-only act() under no_grad in eval mode
     policy.eval()
     h0 = torch.zeros(args.num_envs, 2, 512, device=dev)
@@ -310,19 +462,21 @@ def main():
             policy.act(batch[0], h0, batch[1], batch[2], deterministic=True)
         sync()
         act_s = (time.perf_counter() - ta) / args.steps
+    act_small = act_latency(policy, batch, dev) if rank == 0 else {}
     policy.train()
 
     if rank == 0:
         ms = 1e3 * elapsed / args.steps
         value = args.num_envs * world * args.steps / elapsed
+        # the attributed launches are the forward convolutions of the two trunks (in the
+        # trainable-encoder variant the data-gradient launches are the same kernel again)
         conv_flop = CONV_GFLOP_PER_ENV * 1e9 * args.num_envs
         step_gflop = CMA_FWD_BWD_FROZEN_GFLOP
         if args.trainable_encoders:
-            # the timed launches are forward + data-gradient convs (algorithmic flops; the
-            # stems need no dX); the weight-gradient kernel adds another forward's worth
-            conv_flop = (2 * CONV_GFLOP_PER_ENV - STEM_GFLOP_PER_ENV) * 1e9 * args.num_envs
             step_gflop += 2 * CONV_GFLOP_PER_ENV - STEM_GFLOP_PER_ENV
-        achieved = conv_flop / (conv_ms * 1e-3) / 1e12
+        conv_ms, n_conv = conv["conv_ms"], conv["n"]
+        ok = conv["reason"] is None
+        achieved = conv_flop / (conv_ms * 1e-3) / 1e12 if ok else None
         line = {
             "metric": "policy-steps/sec (fwd+bwd)", "value": round(value, 1),
             "unit": "policy-steps/sec", "n_gpus": world, "steps": args.steps,
@@ -337,13 +491,23 @@ def main():
                                    f"{args.hw}x{args.hw} RGB-D, {args.tokens}-token instruction",
                        "global_batch": args.num_envs * world, "parallelism": f"dp{world}",
                        "whole_step_tflops": round(step_gflop * value / 1e3, 2),
-                       "act_fwd_only_eval_steps_per_sec_per_gpu": round(args.num_envs / act_s, 1)},
-            "roofline": {"bound": "mfma", "kernel": "igemm_kernel (conv2d fwd, fp32 32x32x2 MFMA)",
-                         "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+                       "no_pipeline_ms_per_step": round(no_pipe_ms, 3) if no_pipe_ms else None,
+                       "no_pipeline_steps_per_sec": (
+                           round(1e3 * args.num_envs * world / no_pipe_ms, 1) if no_pipe_ms
+                           else round(value, 1)),
+                       "act_fwd_only_eval_steps_per_sec_per_gpu": round(args.num_envs / act_s, 1),
+                       "act_latency_ms_by_num_envs": act_small},
+            "roofline": {"bound": "mfma", "kernel": "igemm conv2d fwd (fp32 32x32x2 MFMA)",
+                         "achieved": round(achieved, 2) if ok else None,
+                         "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4) if ok else None,
                          "launches_per_step": n_conv,
                          "avg_launch_ms": round(conv_ms / max(n_conv, 1), 4),
                          "kernel_ms_per_step": round(conv_ms, 3),
+                         "eager_single_stream_trunks_ms": round(conv["eager_trunks_ms"], 3),
+                         "timing": "HIP events per launch behind a device-side backlog "
+                                   "(GPU-paced), empty-pair cost subtracted, min of 3 passes",
+                         "invalid_reason": conv["reason"],
                          "traffic": pmc_traffic(n_conv)},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -11,6 +11,8 @@ for p in (REPO, os.path.join(REPO, "tests", "golden")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # synthetic-weight tests build frozen trunks without ImageNet files on purpose
+    config.addinivalue_line("filterwarnings", "ignore:TorchVisionResNet.*RANDOMLY initialised")
 
 
 def pytest_collection_modifyitems(config, items):

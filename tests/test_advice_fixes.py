@@ -1,0 +1,140 @@
+"""Host-side fixes from the round-1 review: ImageNet-weights path of the frozen RGB trunk,
+DD-PPO checkpoint files with a pickled config next to the state_dict, kernel launches on the
+tensors' device rather than the process's current device, LRU graph cache, length buckets."""
+import types
+import warnings
+
+import pytest
+import torch
+
+import vlnce_amd
+from vlnce_amd import _lib, streams
+from vlnce_amd.encoders import resnet_encoders as enc
+
+
+def _torchvision_named(trunk):
+    """the trunk's parameters / buffers under torchvision's own resnet key names"""
+    inv = {v: k for k, v in enc._TV_CHILD_INDEX.items()}
+    out = {}
+    for k, v in trunk.state_dict().items():
+        head, _, rest = k.partition(".")
+        out[inv[head] + "." + rest] = torch.randn_like(v) if v.is_floating_point() else v.clone()
+    out["fc.weight"] = torch.randn(1000, trunk.final_channels)
+    out["fc.bias"] = torch.randn(1000)
+    return out
+
+
+@pytest.mark.parametrize("cls", [enc.TorchVisionResNet18, enc.TorchVisionResNet50])
+def test_torchvision_state_dict_loads_strictly(cls, tmp_path):
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        probe = cls(128, spatial_output=True)
+    sd = _torchvision_named(probe.cnn)
+    path = tmp_path / "resnet.pth"
+    torch.save(sd, path)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")  # a trunk with weights must not warn
+        m = cls(128, spatial_output=True, pretrained_weights=str(path))
+    assert torch.equal(m.cnn[0].weight, sd["conv1.weight"])
+    assert torch.equal(m.cnn[7][0].conv1.weight, sd["layer4.0.conv1.weight"])
+    assert torch.equal(m.cnn[1].running_var, sd["bn1.running_var"])
+    assert not any(p.requires_grad for p in m.cnn.parameters())
+    bad = dict(sd)
+    bad.pop("layer2.0.conv1.weight")
+    with pytest.raises(RuntimeError):
+        m.load_torchvision_weights(bad)
+
+
+def test_frozen_random_trunk_warns_loudly():
+    with pytest.warns(UserWarning, match="RANDOMLY initialised"):
+        enc.TorchVisionResNet18(128)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        enc.TorchVisionResNet18(128, trainable=True)
+
+
+def test_config_key_reaches_the_encoder(tmp_path):
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        probe = enc.TorchVisionResNet50(256, spatial_output=True)
+    sd = _torchvision_named(probe.cnn)
+    path = tmp_path / "r50.pth"
+    torch.save(sd, path)
+    cfg = vlnce_amd.make_config("CMAPolicy", **{"RGB_ENCODER.pretrained_weights": str(path)})
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        pol = vlnce_amd.build_model(cfg, *vlnce_amd.make_spaces(64, 64))
+    assert torch.equal(pol.net.rgb_encoder.cnn[0].weight, sd["conv1.weight"])
+
+
+class _PickledConfig:  # stands in for the yacs node the published DD-PPO files carry
+    def __init__(self):
+        self.RL = types.SimpleNamespace(PPO=types.SimpleNamespace(hidden_size=512))
+
+
+def test_ddppo_checkpoint_with_pickled_config_loads(tmp_path):
+    spaces = vlnce_amd.make_spaces(64, 64)[0]
+    src = enc.VlnResnetDepthEncoder(spaces, output_size=128)
+    sd = {"actor_critic.net.visual_encoder." + k: torch.randn_like(v)
+          for k, v in src.visual_encoder.state_dict().items()}
+    sd["actor_critic.net.state_encoder.rnn.weight_ih_l0"] = torch.zeros(3)  # ignored prefix
+    path = tmp_path / "gibson-2plus-resnet50.pth"
+    torch.save({"state_dict": sd, "config": _PickledConfig()}, path)
+    dst = enc.VlnResnetDepthEncoder(spaces, output_size=128, checkpoint=str(path))
+    k0 = "backbone.conv1.0.weight"
+    assert torch.equal(dst.visual_encoder.state_dict()[k0],
+                       sd["actor_critic.net.visual_encoder." + k0])
+
+
+class _FakeTensor:
+    def __init__(self, idx):
+        self.is_cuda = True
+        self.device = types.SimpleNamespace(index=idx)
+
+    def data_ptr(self):
+        return 0x1000
+
+
+def test_launch_device_follows_the_tensors(monkeypatch):
+    """policy on cuda:1 while the process's current device is 0 (TORCH_GPU_ID != 0 and no
+    torch.cuda.set_device, as the reference trainers run): the stream must be cuda:1's and the
+    current device must be 1 for the launch and 0 again afterwards."""
+    state = {"cur": 0, "log": []}
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: state["cur"])
+    monkeypatch.setattr(torch.cuda, "set_device",
+                        lambda d: (state["log"].append(d), state.__setitem__("cur", d)))
+    monkeypatch.setattr(torch.cuda, "current_stream",
+                        lambda dev=None: types.SimpleNamespace(
+                            cuda_stream=1000 + (state["cur"] if dev is None else dev)))
+    _lib._ptr(_FakeTensor(1))
+    _lib._ptr(None)
+    _lib._ptr(_FakeTensor(1))
+    assert _lib._stream() == 1001 and state["cur"] == 1
+    _lib._leave_device()
+    assert state["cur"] == 0 and state["log"] == [1, 0]
+    # same device as current: nothing switches
+    _lib._ptr(_FakeTensor(0))
+    assert _lib._stream() == 1000 and state["log"] == [1, 0]
+    _lib._leave_device()
+    # tensors of two devices in one call are refused
+    _lib._ptr(_FakeTensor(0))
+    with pytest.raises(RuntimeError, match="cuda:0 and cuda:1"):
+        _lib._ptr(_FakeTensor(1))
+    assert _lib._CALL.dev is None
+
+
+def test_bucket_rows():
+    assert [streams.bucket_rows(n) for n in (1, 8, 9, 80, 81, 200)] == [8, 8, 16, 80, 88, 200]
+
+
+def test_graphed_tail_cache_is_lru():
+    class Tail(streams.GraphedTail):
+        MAX_GRAPHS = 2
+
+    t = Tail(lambda: (lambda *a: a[0]))
+    t.entries["a"] = 1
+    t.entries["b"] = 1
+    t.entries.move_to_end("a")          # "a" was used last -> "b" is the eviction victim
+    while len(t.entries) >= t.MAX_GRAPHS:
+        t.entries.popitem(last=False)
+    assert list(t.entries) == ["a"]

@@ -9,6 +9,7 @@ lives under tests/ and is never importable from the product.)
 """
 import ctypes as C
 import os
+import threading
 
 import torch
 
@@ -106,16 +107,51 @@ def load_cdll(path=LIB_PATH):
     return dll
 
 
+class _CallState(threading.local):
+    """device of the tensors of the call being assembled + the device to switch back to"""
+    dev = None
+    restore = None
+
+
+_CALL = _CallState()
+
+
 def _ptr(t):
     if t is None:
         return None
     if not t.is_cuda:
         raise RuntimeError("libvlnce_hip: tensor is not on a GPU (no CPU fallback)")
+    idx = t.device.index
+    if _CALL.dev is None:
+        _CALL.dev = idx
+    elif _CALL.dev != idx:
+        first, _CALL.dev = _CALL.dev, None
+        raise RuntimeError(f"libvlnce_hip: tensors of one call live on cuda:{first} and "
+                           f"cuda:{idx}")
     return t.data_ptr()
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    """HIP stream for the call whose pointer arguments were just converted by _ptr(): torch's
+    current stream OF THE TENSORS' DEVICE.  The reference trainers put the policy on
+    torch.device("cuda", TORCH_GPU_ID) without ever calling torch.cuda.set_device
+    (base_il_trainer.py:58-66), so the process's current device need not be the policy's; a
+    kernel must be launched with its own device current, so the device is switched here and
+    switched back by HipLib._check right after the launch."""
+    dev, _CALL.dev = _CALL.dev, None
+    if dev is None:
+        return torch.cuda.current_stream().cuda_stream
+    cur = torch.cuda.current_device()
+    if dev != cur:
+        _CALL.restore = cur
+        torch.cuda.set_device(dev)
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+def _leave_device():
+    if _CALL.restore is not None:
+        cur, _CALL.restore = _CALL.restore, None
+        torch.cuda.set_device(cur)
 
 
 class HipLib:
@@ -133,6 +169,7 @@ class HipLib:
                                "rebuild it (python __graft_entry__.py)")
 
     def _check(self, rc, what):
+        _leave_device()
         if rc != 0:
             raise RuntimeError(f"{what} failed (rc={rc}): {self.dll.vlnce_last_error().decode()}")
 

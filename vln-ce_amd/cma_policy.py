@@ -14,7 +14,7 @@ from .net_parts import (apply_ablations, build_depth_encoder, build_rgb_encoder,
 from .policy import ILPolicy, Net
 from .registry import baseline_registry
 from .rnn_state_encoder import build_rnn_state_encoder
-from .streams import BranchStreams, GraphedTail
+from .streams import BranchStreams, GraphedTail, bucket_rows
 
 
 @baseline_registry.register_policy
@@ -164,6 +164,13 @@ class CMANet(Net):
         act = F.embedding(prev_action_index(prev_actions, masks),
                           self.prev_action_embedding.weight)
         masks_u8 = masks.reshape(-1).to(torch.uint8)
+        if ins.is_cuda:
+            # Lmax is batch-dependent (App. B-8): pad it to a bucket so that the captured tail
+            # graphs are shared across batches.  All-zero rows are exactly what rowzero_mask /
+            # the additive -1e8 text-attention mask already treat as padding (weight exp(-inf)=0).
+            pad = bucket_rows(ins.size(1)) - ins.size(1)
+            if pad:
+                ins = F.pad(ins, (0, 0, 0, pad))
         x, rnn_states_out = self._tail(ins.contiguous(), dep.contiguous(), rgb.contiguous(), act,
                                        rnn_states.contiguous(), masks_u8)
         register_progress_loss(self, x, observations)

@@ -16,6 +16,7 @@ NHWC (a permuted view), so forward hooks on `.cnn` / `.visual_encoder`
 ops get channels-last rows without a copy.
 """
 import os
+import warnings
 from collections import OrderedDict
 
 import numpy as np
@@ -467,11 +468,39 @@ class HipResNetTrunk(nn.Sequential):
         return grads
 
 
+_TV_CHILD_INDEX = {"conv1": "0", "bn1": "1", "layer1": "4", "layer2": "5", "layer3": "6",
+                   "layer4": "7"}
+
+
+def torchvision_trunk_state_dict(sd):
+    """torchvision `resnet18/50().state_dict()` (keys conv1.*, bn1.*, layer1.0.conv1.* ..., fc.*)
+    -> the keys of `nn.Sequential(*children[:-1])` that the reference stores the trunk under
+    (resnet_encoders.py:136-139): conv1 -> 0, bn1 -> 1, layer1..4 -> 4..7; the
+    classifier `fc.*` is dropped.  A dict that already uses the Sequential keys passes through."""
+    out = {}
+    for k, v in sd.items():
+        head, _, rest = k.partition(".")
+        if head == "fc":
+            continue
+        out[(_TV_CHILD_INDEX.get(head, head) + "." + rest) if rest else k] = v
+    return out
+
+
 class TorchVisionResNet(nn.Module):
-    """resnet_encoders.py:118-219."""
+    """resnet_encoders.py:118-219.
+
+    The reference builds `models.resnet18/50(pretrained=True)`, i.e. an ImageNet-initialised
+    trunk that is frozen by default.  There is no network here, so the ImageNet weights come
+    from a local file: `pretrained_weights` (config key MODEL.RGB_ENCODER.pretrained_weights,
+    or the VLNCE_TORCHVISION_WEIGHTS environment variable) names a torchvision resnet
+    state_dict (`resnet50-*.pth`); it is loaded strictly.  Without it the trunk keeps its
+    random initialisation -- fine when a full policy checkpoint is restored afterwards or for
+    synthetic benchmarks, WRONG for training from scratch with a frozen trunk, hence the
+    warning."""
 
     def __init__(self, output_size, resnet_version="resnet50", normalize_visual_inputs=False,
-                 trainable=False, spatial_output=False, single_spatial_filter=True):
+                 trainable=False, spatial_output=False, single_spatial_filter=True,
+                 pretrained_weights=None):
         super().__init__()
         self.normalize_visual_inputs = normalize_visual_inputs
         self.spatial_output = spatial_output
@@ -482,6 +511,15 @@ class TorchVisionResNet(nn.Module):
         else:
             raise ValueError(resnet_version)
         self.resnet_layer_size = self.cnn.final_channels
+        pretrained_weights = pretrained_weights or os.environ.get("VLNCE_TORCHVISION_WEIGHTS")
+        if pretrained_weights and pretrained_weights != "NONE":
+            self.load_torchvision_weights(pretrained_weights)
+        elif not trainable:
+            warnings.warn(
+                f"TorchVisionResNet({resnet_version}): the frozen RGB trunk is RANDOMLY initialised "
+                "(the reference uses ImageNet weights, pretrained=True).  Set "
+                "MODEL.RGB_ENCODER.pretrained_weights / VLNCE_TORCHVISION_WEIGHTS to a torchvision "
+                "state_dict, or restore a full policy checkpoint before training.", stacklevel=2)
         for p in self.cnn.parameters():
             p.requires_grad_(trainable)
         self.cnn.train(trainable)
@@ -496,6 +534,15 @@ class TorchVisionResNet(nn.Module):
             self.spatial_embeddings = nn.Embedding(4 * 4, 64)
             self.output_shape = (self.resnet_layer_size + 64, 4, 4)
         self._in_cache = None
+
+    def load_torchvision_weights(self, path_or_state_dict):
+        """strict load of a torchvision resnet state_dict into the trunk (before `del cnn[8]`
+        or after: the pools hold no parameters)."""
+        sd = path_or_state_dict
+        if not isinstance(sd, dict):
+            sd = torch.load(sd, map_location="cpu", weights_only=True)
+        sd = sd.get("state_dict", sd)
+        self.cnn.load_state_dict(torchvision_trunk_state_dict(sd), strict=True)
 
     def _input_transform(self, device):
         # /255 then optional ImageNet mean/std (:171-192), fused into the stem's loader
@@ -526,7 +573,7 @@ class TorchVisionResNet(nn.Module):
 
     def forward(self, observations):
         if "rgb_features" in observations:
-            feats = wait_ready(observations["rgb_features"])
+            feats = wait_ready(observations["rgb_features"], observations, "rgb_features")
         else:
             feats = self.trunk_features(observations)
         if not self.spatial_output:
@@ -808,7 +855,9 @@ class VlnResnetDepthEncoder(nn.Module):
         for p in self.visual_encoder.parameters():
             p.requires_grad_(trainable)
         if checkpoint != "NONE":
-            ddppo_weights = torch.load(checkpoint, map_location="cpu")
+            # the published DD-PPO files (gibson-2plus-resnet50.pth ...) carry a pickled config
+            # object next to "state_dict": a trusted local file, loaded as upstream does
+            ddppo_weights = torch.load(checkpoint, map_location="cpu", weights_only=False)
             prefix = "actor_critic.net.visual_encoder."
             sd = {k[len(prefix):]: v for k, v in ddppo_weights["state_dict"].items()
                   if k.startswith(prefix)}
@@ -844,7 +893,7 @@ class VlnResnetDepthEncoder(nn.Module):
 
     def forward(self, observations):
         if "depth_features" in observations:
-            x = wait_ready(observations["depth_features"])
+            x = wait_ready(observations["depth_features"], observations, "depth_features")
         else:
             x = self.trunk_features(observations)
         b, c, h, w = x.shape

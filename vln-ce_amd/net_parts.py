@@ -31,7 +31,8 @@ def build_rgb_encoder(model_config, **extra):
     cls = getattr(resnet_encoders, cfg.cnn_type)
     trainable = extra.pop("trainable", cfg.trainable)
     return cls(cfg.output_size, normalize_visual_inputs=model_config.normalize_rgb,
-               trainable=trainable, **extra)
+               trainable=trainable, pretrained_weights=cfg.get("pretrained_weights", None)
+               if hasattr(cfg, "get") else getattr(cfg, "pretrained_weights", None), **extra)
 
 
 def relu_fc(n_in, n_out, *front):

@@ -10,14 +10,14 @@ used, so the BPTT kernel overlaps the tail's backward as well.
 Set VLNCE_SIDE_STREAMS=0 to serialise everything on the current stream."""
 import gc
 import os
-import weakref
+from collections import OrderedDict
 
 import torch
 
 
 TIMING = [] if os.environ.get("VLNCE_STREAM_TIMING") else None  # (idx, start, end) events
 _SIDE_STREAMS = {}  # (idx, device index) -> stream; one set per process, shared by all policies
-_READY = {}  # id(tensor) -> (weakref, event): tensors produced ahead of time on a side stream
+_READY = {}  # storage address -> completion event of tensors produced ahead on a side stream
 
 
 class capture_guard:
@@ -38,19 +38,31 @@ class capture_guard:
         return False
 
 
+READY_KEY = "_vlnce_ready"  # observation-dict entry: {feature key: completion event}
+_READY_MAX = 64
+
+
 def mark_ready(t, event):
-    """remember that `t` is complete once `event` has fired (see wait_ready)."""
-    key = id(t)
-    _READY[key] = (weakref.ref(t, lambda _r, k=key: _READY.pop(k, None)), event)
+    """remember that the memory of `t` is complete once `event` has fired (see wait_ready).
+    Keyed on the STORAGE address, so any view of `t` (slice, index, permute, reshape) finds the
+    event; a stale entry whose storage was freed and re-used only costs a wait on an event that
+    has long fired.  Copies made on another stream (`.to(dtype)`, `.clone()`) before wait_ready
+    are not covered -- the event also rides in the observation dict (READY_KEY) for consumers
+    that rebuild tensors from the dict."""
+    _READY[t.untyped_storage().data_ptr()] = event
+    while len(_READY) > _READY_MAX:
+        _READY.pop(next(iter(_READY)))
 
 
-def wait_ready(t):
+def wait_ready(t, observations=None, key=None):
     """orders the current stream after the side-stream producer of `t` (no-op for ordinary
     tensors); every consumer of a tensor handed out by encode_ahead() calls this."""
-    ent = _READY.get(id(t))
-    if ent is not None and ent[0]() is t:
+    ev = _READY.get(t.untyped_storage().data_ptr()) if t.is_cuda else None
+    if ev is None and observations is not None:
+        ev = (observations.get(READY_KEY) or {}).get(key)
+    if ev is not None:
         cur = torch.cuda.current_stream(t.device)
-        cur.wait_event(ent[1])
+        cur.wait_event(ev)
         t.record_stream(cur)
     return t
 
@@ -205,6 +217,7 @@ class BranchStreams:
             feats, done = self.launch(fork, idx, dev, lambda e=enc: e.trunk_features(observations))
             mark_ready(feats, done)
             out[key] = feats
+            out[READY_KEY] = {**(out.get(READY_KEY) or {}), key: done}
         return out
 
 
@@ -217,13 +230,14 @@ class GraphedTail:
     Set VLNCE_HIP_GRAPHS=0 to disable."""
 
     MAX_GRAPHS = 8
+    CAPTURE_AFTER = 2  # sightings of a signature before it is captured (1 eager pass first)
 
     def __init__(self, make_module):
         # make_graphed_callables patches the module's forward in place, so every captured
         # signature gets its own (cheap: it only references the shared sub-modules) instance
         self.make_module = make_module
         self.module = make_module()
-        self.entries = {}
+        self.entries = OrderedDict()  # signature -> sightings (int) | graphed callable; LRU
 
     def __call__(self, *tensors):
         t0 = tensors[0]
@@ -233,15 +247,25 @@ class GraphedTail:
         key = tuple((tuple(t.shape), t.dtype, t.requires_grad) for t in tensors) + (
             torch.is_grad_enabled(),)
         ent = self.entries.get(key)
-        if ent is None:
-            if len(self.entries) >= self.MAX_GRAPHS:
-                self.entries.pop(next(iter(self.entries)))
-            self.entries[key] = "seen"
-            return self.module(*tensors)
-        if ent == "seen":
+        if ent is None or isinstance(ent, int):
+            seen = (ent or 0) + 1
+            if seen < self.CAPTURE_AFTER:
+                while len(self.entries) >= self.MAX_GRAPHS:
+                    self.entries.popitem(last=False)  # least recently used
+                self.entries[key] = seen
+                self.entries.move_to_end(key)
+                return self.module(*tensors)
             sample = tuple(t.detach().clone().requires_grad_(t.requires_grad) for t in tensors)
             with capture_guard():
                 ent = torch.cuda.make_graphed_callables(self.make_module(), sample,
                                                         allow_unused_input=True)
             self.entries[key] = ent
+        self.entries.move_to_end(key)
         return ent(*tensors)
+
+
+def bucket_rows(n, step=8):
+    """smallest multiple of `step` >= n: instruction lengths are padded to buckets before a
+    graphed tail so that batches whose longest instruction differs by a few tokens share one
+    captured graph (the pad rows are all-zero, which the text attention masks out exactly)."""
+    return ((int(n) + step - 1) // step) * step
