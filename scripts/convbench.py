@@ -53,7 +53,7 @@ def main():
     tot_t = tot_f = 0.0
     print(f"{'layer':22s} {'M':>8s} {'K':>6s} {'N':>5s} {'us':>9s} {'TF/s':>7s} x cnt")
     for name, hw, cin, cout, k, s, cnt in R50:
-        if args.only and args.only not in name:
+        if args.only and not any(o in name for o in args.only.split(",")):
             continue
         x = torch.randn(args.n, hw, hw, cin, device=dev)
         w = torch.randn(cout, k, k, cin, device=dev) * (cin * k * k) ** -0.5

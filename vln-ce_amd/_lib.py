@@ -14,7 +14,8 @@ import threading
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvlnce_hip.so")
+# VLNCE_HIP_LIB: load another build of the library (bisection / tuning builds, scripts/build_variants.sh)
+LIB_PATH = os.environ.get("VLNCE_HIP_LIB") or os.path.join(_HERE, "libvlnce_hip.so")
 
 _P = C.c_void_p
 _I = C.c_int

@@ -62,10 +62,51 @@ struct IgemmParams {
   float* stat_partial;
   int tiles_m, tiles_n;
   int splitk;  // > 1: blockIdx.y owns a K range and atomically adds into a pre-zeroed C
+  int pk_tiles;  // conv_pk_kernel: tiles one workgroup walks before it retires
   long a_bytes, b_bytes;  // extents of A / B for the buffer-descriptor loaders
 };
 
 __device__ __forceinline__ f32x4 ldg4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+
+// BatchNorm / GroupNorm partial statistics of one wave's accumulator sub-tile (rows x NT*32
+// columns).  Lane (half, l31) holds, per 32x32 MFMA tile, column l31 and rows
+// (r&3) + 8*(r>>2) + 4*half.  Two passes over the registers: column sums -> sub-tile mean ->
+// sum of squared deviations (Chan/Welford form, merged later in fp64).
+template <int MT, int NT>
+__device__ __forceinline__ void wave_stats(const f32x16 (&acc)[MT][NT], float* stat_partial,
+                                           int part_row, int rows_left, int rows_full, int col0,
+                                           int N, int half, int l31) {
+  const int rows_valid = min(rows_full, rows_left);
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (row < rows_valid) s += acc[i][j][r];
+      }
+    s += __shfl_xor(s, 32, 64);
+    const float mean = rows_valid > 0 ? s / (float)rows_valid : 0.f;
+    float m2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const float d = acc[i][j][r] - mean;
+        if (row < rows_valid) m2 += d * d;
+      }
+    m2 += __shfl_xor(m2, 32, 64);
+    const int col = col0 + j * 32 + l31;
+    if (half == 0 && col < N && rows_left > 0) {
+      float* dst = stat_partial + ((long)part_row * N + col) * 2;
+      dst[0] = s;
+      dst[1] = m2;
+    }
+  }
+}
 
 // CIN_C / KW_C: compile-time Cin and KW for the scalar im2col loader (0 = runtime values);
 // the 7x7 stems (Cin 3 / 1) use them so k -> (r, q, ci) is multiply-shift, not a division.
@@ -598,68 +639,16 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
   }
 
   // ------------------------------------------------------------------ BN statistics of the raw tile
+  // one partial per WAVE sub-tile (WTM rows x WTN columns): {sum, M2 about the sub-tile mean},
+  // index (tile_m * WM + wm).  No cross-wave reduction and no barrier here; the finalize
+  // kernels merge the partials in fp64.
 #ifdef IGEMM_DBG_NOSTATS  // bisection builds: -DIGEMM_DBG_NOSTATS / _NOSTORE / _NOMFMA
   if (false) {
 #else
   if (p.stat_partial != nullptr) {
 #endif
-    float* red = smem;  // [WM][BN] floats, reused twice; all MFMA reads are behind the last barrier
-    const int rows_valid = min(BM, p.M - m0);
-    float csum[NT];
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      float s = 0.f;
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          if (row < rows_valid) s += acc[i][j][r];
-        }
-      s += __shfl_xor(s, 32, 64);
-      csum[j] = s;
-      if (half == 0) red[wm * BN + wn * WTN + j * 32 + l31] = s;
-    }
-    __syncthreads();
-    float cmean[NT];
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      float s = 0.f;
-#pragma unroll
-      for (int w = 0; w < WM; ++w) s += red[w * BN + wn * WTN + j * 32 + l31];
-      csum[j] = s;
-      cmean[j] = s / (float)rows_valid;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      float s = 0.f;
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          const float d = acc[i][j][r] - cmean[j];
-          if (row < rows_valid) s += d * d;
-        }
-      s += __shfl_xor(s, 32, 64);
-      if (half == 0) red[wm * BN + wn * WTN + j * 32 + l31] = s;
-    }
-    __syncthreads();
-    if (wm == 0 && half == 0) {
-#pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        float m2 = 0.f;
-#pragma unroll
-        for (int w = 0; w < WM; ++w) m2 += red[w * BN + wn * WTN + j * 32 + l31];
-        const int col = n0 + wn * WTN + j * 32 + l31;
-        if (col < p.N) {
-          float* dst = p.stat_partial + ((long)tile_m * p.N + col) * 2;
-          dst[0] = csum[j];
-          dst[1] = m2;
-        }
-      }
-    }
+    wave_stats<MT, NT>(acc, p.stat_partial, tile_m * WM + wm, p.M - (m0 + wm * WTM), WTM,
+                       n0 + wn * WTN, p.N, half, l31);
   }
 
   // ------------------------------------------------------------------ epilogue
@@ -749,6 +738,334 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
         }
       }
     }
+  }
+}
+
+// ====================================================================================
+// Persistent convolution kernel (the hot path: channels-last conv with Cin % 32 == 0 through
+// the buffer-descriptor loaders, [N,K] weights).
+//
+// Why: the one-tile-per-workgroup kernel above pays, per output tile, a cold prologue (index
+// math + a fully exposed first operand load), and an epilogue whose stores must DRAIN before
+// the workgroup can retire and a new one can start.  On the short-K / store-heavy layers
+// (ResNet layer1/2 1x1 expansions: K = 64..128, 64 KB of output per tile) that fixed cost is
+// several times the tile's MFMA time and the whole chip runs load -> compute -> store in
+// lock-step.  Here 2 workgroups per CU stay resident and walk a strided list of tiles with ONE
+// flattened (tile, k-tile) pipeline:
+//   * the operand loads of the NEXT tile's first K-tile are issued before the MFMAs of the
+//     current tile's last K-tile, so no tile but the first sees load latency;
+//   * the epilogue's global stores are fire-and-forget: the wave goes straight on to the next
+//     tile's MFMAs while they drain;
+//   * statistics are per-wave partials (no barrier); the LDS transpose of the accumulator
+//     tile goes through the one stage buffer that is free at that point, in two halves.
+// The tile list of a workgroup is a stride through an XCD-contiguous range (N-tile fastest),
+// so the 64 workgroups of an XCD work on neighbouring tiles and share A row-panels in its L2.
+template <int BM, int BN, int DUAL>
+__global__ __launch_bounds__(256, 2) void conv_pk_kernel(IgemmParams p) {
+  constexpr int WM = 2, WN = 2;
+  constexpr int WTM = BM / WM, WTN = BN / WN;
+  constexpr int MT = WTM / 32, NT = WTN / 32;
+  constexpr int A_TILE = BM * LDP, B_TILE = BN * LDP;
+  constexpr int STAGE = A_TILE + B_TILE;
+  constexpr int A_ROWS = BM / 32, B_ROWS = BN / 32;
+  constexpr int LDC = BN + 4;
+  // the accumulator tile is transposed through ONE stage buffer: whole or in two halves
+  constexpr int EP_PASSES = (BM * LDC <= STAGE) ? 1 : 2;
+  constexpr int EP_ROWS = BM / EP_PASSES;
+  static_assert(EP_ROWS * LDC <= STAGE, "epilogue staging must fit one stage buffer");
+  static_assert(EP_PASSES == 1 || EP_ROWS == WTM, "two passes = one per wave row");
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int lrow = tid >> 3, lk4 = (tid & 7) * 4;
+
+  // ---- this workgroup's tile list.  XCD x owns tiles [x*per_xcd, (x+1)*per_xcd).  Its
+  // workgroups are dispatched in slot order, PK_RES (= 2 per CU) at a time; "round" r of
+  // PK_RES workgroups covers PK_RES * pk_tiles consecutive tiles, each workgroup taking every
+  // PK_RES-th of them, so the resident workgroups always work on neighbouring tiles.  A
+  // workgroup retires after pk_tiles tiles: bounded lifetime, so kernels of other (side)
+  // streams get CU slots every few tiles instead of only at the end of the launch.
+  constexpr int PK_RES = 64;
+  const int ntiles = p.tiles_m * p.tiles_n;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int per_xcd = (ntiles + 7) >> 3;
+  const int round = slot / PK_RES;
+  const int x0 = xcd * per_xcd + round * (PK_RES * p.pk_tiles);
+  const int t_end = min(min(ntiles, (xcd + 1) * per_xcd), x0 + PK_RES * p.pk_tiles);
+  constexpr int wg_per_xcd = PK_RES;  // stride of this workgroup's tile list
+  int tile = x0 + (slot - round * PK_RES);
+  if (tile >= t_end) return;
+  const int KT = p.K / BK;
+  const int HoWo = p.Ho * p.Wo;
+
+  // ---- buffer descriptors (wave-uniform, built from kernel arguments only)
+  const long bias = ((long)p.pad * p.W + p.pad) * p.lda * 4;  // keeps voffsets non-negative
+  const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char*>(reinterpret_cast<const char*>(p.A)) - bias, 0, (int)(p.a_bytes + bias),
+      0x00020000);
+  __amdgpu_buffer_rsrc_t rsrc_a2 = rsrc_a;
+  if constexpr (DUAL)
+    rsrc_a2 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(p.A2)) - bias, 0, (int)(p.a_bytes + bias),
+        0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char*>(reinterpret_cast<const char*>(p.B)), 0, (int)p.b_bytes, 0x00020000);
+
+  // ---- loader state: belongs to the tile whose K-tiles are being FETCHED (one K-tile ahead of
+  // the MFMAs, i.e. it moves on to the next tile while the current one is still computing)
+  int ld_m0 = 0, ld_n0 = 0;
+  int a_voff[A_ROWS];
+  unsigned a_taps[A_ROWS];
+  int b_voff[B_ROWS];
+  int u_r = 0, u_q = 0, u_ci = 0;
+  f32x4 a_reg[A_ROWS], b_reg[B_ROWS];
+  f32x4 a2_reg[DUAL ? A_ROWS : 1];
+  f32x4 pro_s = {1.f, 1.f, 1.f, 1.f}, pro_t = {0.f, 0.f, 0.f, 0.f}, pro_c = {0.f, 0.f, 0.f, 0.f};
+  f32x4 pro2_s = {1.f, 1.f, 1.f, 1.f}, pro2_t = {0.f, 0.f, 0.f, 0.f}, pro2_c = {0.f, 0.f, 0.f, 0.f};
+  unsigned a_okmask = 0;
+  int a_kcur = 0;
+
+  auto setup_loader = [&](int t) {
+    const int tm = t / p.tiles_n;
+    ld_m0 = tm * BM;
+    ld_n0 = (t - tm * p.tiles_n) * BN;
+#pragma unroll
+    for (int i = 0; i < A_ROWS; ++i) {
+      const int m = ld_m0 + i * 32 + lrow;
+      a_voff[i] = BUF_OOB;
+      a_taps[i] = 0;
+      if (m < p.M) {
+        const int img = m / HoWo;
+        const int rem = m - img * HoWo;
+        const int ho = rem / p.Wo;
+        const int wo = rem - ho * p.Wo;
+        const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
+        a_voff[i] =
+            (int)((((long)(img * p.H + hi0 + p.pad) * p.W + wi0 + p.pad) * p.lda + lk4) * 4);
+        unsigned mask = 0;
+        for (int r = 0; r < p.KH; ++r)
+          for (int q = 0; q < p.KW; ++q)
+            if ((unsigned)(hi0 + r) < (unsigned)p.H && (unsigned)(wi0 + q) < (unsigned)p.W)
+              mask |= 1u << (r * p.KW + q);
+        a_taps[i] = mask;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < B_ROWS; ++i) {
+      const int n = ld_n0 + i * 32 + lrow;
+      b_voff[i] = n < p.N ? (int)(((long)n * p.ldb + lk4) * 4) : BUF_OOB;
+    }
+    u_r = u_q = u_ci = 0;
+  };
+
+  // fetch the next K-tile of the loader's tile into registers (A rows through the tap mask,
+  // B rows straight), and the per-channel prologue vectors that belong to it
+  auto fetch = [&]() {
+    const int tap = u_r * p.KW + u_q;
+    const int soff = ((u_r * p.W + u_q) * p.lda + u_ci) * 4;
+    const int koff = (tap * p.Cin + u_ci) * 4;
+    if (p.in_scale != nullptr) {
+      pro_s = ldg4(p.in_scale + u_ci + lk4);
+      pro_t = ldg4(p.in_shift + u_ci + lk4);
+      if (p.in_center) pro_c = ldg4(p.in_center + u_ci + lk4);
+    }
+    if constexpr (DUAL) {
+      a_kcur = u_ci;
+      if (p.in2_scale != nullptr) {
+        pro2_s = ldg4(p.in2_scale + u_ci + lk4);
+        pro2_t = ldg4(p.in2_shift + u_ci + lk4);
+        if (p.in2_center) pro2_c = ldg4(p.in2_center + u_ci + lk4);
+      }
+    }
+    a_okmask = 0;
+#pragma unroll
+    for (int i = 0; i < A_ROWS; ++i) {
+      const unsigned ok = (a_taps[i] >> tap) & 1u;
+      a_okmask |= ok << i;
+      a_reg[i] = __builtin_bit_cast(
+          f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, ok ? a_voff[i] : BUF_OOB, soff, 0));
+      if constexpr (DUAL)
+        a2_reg[i] = __builtin_bit_cast(
+            f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a2, ok ? a_voff[i] : BUF_OOB, soff, 0));
+    }
+#pragma unroll
+    for (int i = 0; i < B_ROWS; ++i)
+      b_reg[i] = __builtin_bit_cast(
+          f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, b_voff[i], koff, 0));
+    u_ci += BK;
+    if (u_ci >= p.Cin) {
+      u_ci = 0;
+      if (++u_q == p.KW) {
+        u_q = 0;
+        ++u_r;
+      }
+    }
+  };
+
+  // registers -> LDS stage, applying the operand prologue (and writing the materialised
+  // dual-input value once, from the workgroups of N-tile 0)
+  auto stash = [&](float* stage) {
+    float* As = stage;
+    float* Bs = stage + A_TILE;
+    if (p.in_scale != nullptr) {
+#pragma unroll
+      for (int i = 0; i < A_ROWS; ++i) {
+        f32x4 v = (a_reg[i] - pro_c) * pro_s + pro_t;
+        if constexpr (DUAL) v += (a2_reg[i] - pro2_c) * pro2_s + pro2_t;
+        if (p.in_relu) {
+          v.x = fmaxf(v.x, 0.f);
+          v.y = fmaxf(v.y, 0.f);
+          v.z = fmaxf(v.z, 0.f);
+          v.w = fmaxf(v.w, 0.f);
+        }
+        const bool ok = (a_okmask >> i) & 1u;
+        if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (DUAL) {
+          if (p.side_out != nullptr && ld_n0 == 0 && ok)
+            *reinterpret_cast<f32x4*>(p.side_out + (long)(ld_m0 + i * 32 + lrow) * p.lda + a_kcur +
+                                      lk4) = v;
+        }
+        a_reg[i] = v;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < A_ROWS; ++i)
+      *reinterpret_cast<f32x4*>(As + (i * 32 + lrow) * LDP + lk4) = a_reg[i];
+#pragma unroll
+    for (int i = 0; i < B_ROWS; ++i)
+      *reinterpret_cast<f32x4*>(Bs + (i * 32 + lrow) * LDP + lk4) = b_reg[i];
+  };
+
+  const bool has_res = p.residual != nullptr;
+
+  setup_loader(tile);
+  fetch();
+  stash(smem);
+  __syncthreads();
+  int par = 0;
+
+  while (true) {
+    const int tile_m = tile / p.tiles_n;
+    const int m0 = tile_m * BM;
+    const int n0 = (tile - tile_m * p.tiles_n) * BN;
+    const int next_tile = tile + wg_per_xcd;
+    const bool more_tiles = next_tile < t_end;
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    for (int kt = 0; kt < KT; ++kt) {
+      const float* cur = smem + par * STAGE;
+      bool staged = true;
+      if (kt + 1 < KT) {
+        fetch();
+      } else if (more_tiles) {
+        setup_loader(next_tile);
+        fetch();
+      } else {
+        staged = false;
+      }
+      const float* Aw = cur + (wm * WTM + l31) * LDP + 4 * half;
+      const float* Bw = cur + A_TILE + (wn * WTN + l31) * LDP + 4 * half;
+#pragma unroll
+      for (int g = 0; g < BK / 8; ++g) {
+        f32x4 af[MT], bf[NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const f32x4*>(Aw + i * 32 * LDP + 8 * g);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) bf[j] = *reinterpret_cast<const f32x4*>(Bw + j * 32 * LDP + 8 * g);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#ifdef IGEMM_DBG_NOMFMA
+              acc[i][j][0] += af[i][e] * bf[j][e];
+#else
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
+#endif
+      }
+      if (staged) stash(smem + (par ^ 1) * STAGE);
+      __syncthreads();
+      par ^= 1;
+    }
+
+    // ---- statistics of the raw tile: per-wave partials, no barrier
+#ifndef IGEMM_DBG_NOSTATS
+    if (p.stat_partial != nullptr)
+#else
+    if (false)
+#endif
+      wave_stats<MT, NT>(acc, p.stat_partial, tile_m * WM + wm, p.M - (m0 + wm * WTM), WTM,
+                         n0 + wn * WTN, p.N, half, l31);
+
+    // ---- epilogue: transpose through the free stage buffer (smem + (par^1)*STAGE: the one the
+    // last K-tile was read from; stage `par` already holds the next tile's first K-tile),
+    // then 16-byte row stores that drain while the next tile computes
+    float* Ct = smem + (par ^ 1) * STAGE;
+    constexpr int TPR = BN / 4;     // threads per output row
+    constexpr int RPP = 256 / TPR;  // rows per pass
+    const int c4 = (tid % TPR) * 4;
+    const int col = n0 + c4;
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (col < p.N) {
+      if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + col);
+      if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + col);
+    }
+#pragma unroll
+    for (int ep = 0; ep < EP_PASSES; ++ep) {
+      if (EP_PASSES == 1 || wm == ep) {
+        const int rbase = EP_PASSES == 1 ? wm * WTM : 0;
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int row = rbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+              Ct[row * LDC + wn * WTN + j * 32 + l31] = acc[i][j][r];
+            }
+      }
+      __syncthreads();
+      if (col < p.N) {
+#pragma unroll 4
+        for (int rr = tid / TPR; rr < EP_ROWS; rr += RPP) {
+          const int row = m0 + ep * EP_ROWS + rr;
+          if (row >= p.M) break;
+          f32x4 v = *reinterpret_cast<const f32x4*>(Ct + rr * LDC + c4);
+          v = v * sc + sh;
+          if (has_res) v += *reinterpret_cast<const f32x4*>(p.residual + (long)row * p.ldr + col);
+          v.x = apply_act(v.x, p.act);
+          v.y = apply_act(v.y, p.act);
+          v.z = apply_act(v.z, p.act);
+          v.w = apply_act(v.w, p.act);
+          float* dst = p.C + (long)row * p.ldc + col;
+          if (p.accumulate) v += *reinterpret_cast<const f32x4*>(dst);
+#if defined(IGEMM_DBG_NOSTORE)
+          if (v.x == 123456.f) *reinterpret_cast<f32x4*>(dst) = v;  // keeps the value alive
+#elif defined(IGEMM_DBG_NTSTORE)
+          __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(dst));
+#else
+          *reinterpret_cast<f32x4*>(dst) = v;
+#endif
+        }
+      }
+      __syncthreads();  // Ct is overwritten by the next pass / the next tile's second K-tile
+    }
+
+    if (!more_tiles) break;
+    tile = next_tile;
   }
 }
 
@@ -872,16 +1189,70 @@ void fill_epilogue(IgemmParams& p, const vlnce_epilogue* e) {
 
 bool aligned16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
+// multi-tile launch: 64 workgroups per XCD per round (2 per CU), each walking pk_tiles tiles
+template <int BM, int BN, int DUAL>
+int launch_pk(const IgemmParams& p, hipStream_t stream) {
+  constexpr int smem_bytes = 2 * (BM + BN) * LDP * (int)sizeof(float);
+  auto kern = conv_pk_kernel<BM, BN, DUAL>;
+  static bool attr_set = false;  // per instantiation
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
+    if (e != hipSuccess) {
+      vlnce_set_error("conv_pk: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      return 2;
+    }
+    attr_set = true;
+  }
+  IgemmParams q = p;
+  q.tiles_m = ceil_div(p.M, BM);
+  q.tiles_n = ceil_div(p.N, BN);
+  q.splitk = 1;
+  const long ntiles = (long)q.tiles_m * q.tiles_n;
+  if (ntiles <= 0 || ntiles > 0x7fffffffL) {
+    vlnce_set_error("conv_pk: bad tile count %ld", ntiles);
+    return 1;
+  }
+  // tiles per workgroup (tuning knob; 1 = one tile per workgroup, large = fully persistent)
+  static const int pk_tiles = getenv("VLNCE_PK_TILES") ? atoi(getenv("VLNCE_PK_TILES")) : 8;
+  q.pk_tiles = pk_tiles < 1 ? 1 : pk_tiles;
+  const long per_xcd = (ntiles + 7) / 8;
+  const long rounds = (per_xcd + 64L * q.pk_tiles - 1) / (64L * q.pk_tiles);
+  // the last round of an XCD may be short: only as many workgroups as it has tiles
+  const long last = per_xcd - (rounds - 1) * 64L * q.pk_tiles;
+  const long slots = (rounds - 1) * 64 + (last < 64 ? last : 64);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(8 * slots)), dim3(256), smem_bytes, stream, q);
+  VLNCE_CHECK_LAUNCH("conv_pk");
+  return 0;
+}
+
+template <int DUAL>
+int dispatch_pk(const IgemmParams& p, hipStream_t s) {
+  const TileChoice t = choose_tile(p.M, p.N);
+  if (t.bm == 128 && t.bn == 128) return launch_pk<128, 128, DUAL>(p, s);
+  if (t.bm == 128 && t.bn == 64) return launch_pk<128, 64, DUAL>(p, s);
+  return launch_pk<64, 64, DUAL>(p, s);
+}
+
+// the persistent kernel covers the 16-byte store epilogue only
+bool pk_ok(const IgemmParams& p) {
+  static const bool off = getenv("VLNCE_IGEMM_NO_PERSIST") != nullptr;
+  return !off && ((p.N & 3) == 0) && ((p.ldc & 3) == 0) && aligned16(p.C) &&
+         (!p.residual || (((p.ldr & 3) == 0) && aligned16(p.residual))) &&
+         (!p.scale || aligned16(p.scale)) && (!p.shift || aligned16(p.shift));
+}
+
 }  // namespace
 
+// rows per statistics partial = the M extent of one wave's sub-tile (BM / 2)
 extern "C" int vlnce_conv2d_tile_rows(const vlnce_conv_desc* d) {
   const long M = (long)d->N * d->Ho * d->Wo;
-  return choose_tile(M, d->Cout).bm;
+  return choose_tile(M, d->Cout).bm / 2;
 }
 
 extern "C" int vlnce_conv2d_tiles_m(const vlnce_conv_desc* d) {
   const long M = (long)d->N * d->Ho * d->Wo;
-  return ceil_div(M, choose_tile(M, d->Cout).bm);
+  return ceil_div(M, choose_tile(M, d->Cout).bm / 2);
 }
 
 extern "C" int vlnce_conv2d_fwd(const float* x, const float* w, float* y, const vlnce_conv_desc* d,
@@ -945,9 +1316,9 @@ extern "C" int vlnce_conv2d_fwd(const float* x, const float* w, float* y, const 
                         (!p.in2_center || (p.in2_scale && aligned16(p.in2_center))),
                     "conv2d_fwd: the dual-input prologue needs x2 + in_scale on a 1x1/stride-1/"
                     "pad-0 convolution with Cin %% 32 == 0 and 16-byte aligned operands");
-    return dispatch_dual(p, s);
+    return pk_ok(p) ? dispatch_pk<1>(p, s) : dispatch_dual(p, s);
   }
-  if (v4 && buf_ok(p)) return dispatch_tiles<A_BUF, B_BUF>(p, s);
+  if (v4 && buf_ok(p)) return pk_ok(p) ? dispatch_pk<0>(p, s) : dispatch_tiles<A_BUF, B_BUF>(p, s);
   if (v4) return dispatch_tiles<A_IM2COL_V4, B_NK_V4>(p, s);
   if (d->KW == 7 && d->Cin == 3) return dispatch_stem<3>(p, s);
   if (d->KW == 7 && d->Cin == 1) return dispatch_stem<1>(p, s);
