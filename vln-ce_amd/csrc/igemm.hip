@@ -22,6 +22,7 @@
 //     share an A row-panel hit the same L2.
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -62,8 +63,9 @@ struct IgemmParams {
   float* stat_partial;
   int tiles_m, tiles_n;
   int splitk;  // > 1: blockIdx.y owns a K range and atomically adds into a pre-zeroed C
-  int pk_tiles;  // conv_pk_kernel: tiles one workgroup walks before it retires
-  long a_bytes, b_bytes;  // extents of A / B for the buffer-descriptor loaders
+  int pk_tiles;  // conv_dma_kernel: tiles one workgroup walks before it retires
+  int stat_rows;  // conv_dma_kernel: rows per statistics partial (vlnce_conv2d_tile_rows)
+  long a_bytes, b_bytes, c_bytes;  // extents of A / B / C for the buffer descriptors
 };
 
 __device__ __forceinline__ f32x4 ldg4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
@@ -98,6 +100,36 @@ __device__ __forceinline__ void wave_stats(const f32x16 (&acc)[MT][NT], float* s
         const float d = acc[i][j][r] - mean;
         if (row < rows_valid) m2 += d * d;
       }
+    m2 += __shfl_xor(m2, 32, 64);
+    const int col = col0 + j * 32 + l31;
+    if (half == 0 && col < N && rows_left > 0) {
+      float* dst = stat_partial + ((long)part_row * N + col) * 2;
+      dst[0] = s;
+      dst[1] = m2;
+    }
+  }
+}
+
+// the same for ONE 32-row MFMA block (NT 32x32 tiles side by side)
+template <int NT>
+__device__ __forceinline__ void wave_stats_block(const f32x16 (&acc)[NT], float* stat_partial,
+                                                 int part_row, int rows_left, int col0, int N,
+                                                 int half, int l31) {
+  const int rows_valid = min(32, rows_left);
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      if ((r & 3) + 8 * (r >> 2) + 4 * half < rows_valid) s += acc[j][r];
+    s += __shfl_xor(s, 32, 64);
+    const float mean = rows_valid > 0 ? s / (float)rows_valid : 0.f;
+    float m2 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float d = acc[j][r] - mean;
+      if ((r & 3) + 8 * (r >> 2) + 4 * half < rows_valid) m2 += d * d;
+    }
     m2 += __shfl_xor(m2, 32, 64);
     const int col = col0 + j * 32 + l31;
     if (half == 0 && col < N && rows_left > 0) {
@@ -742,54 +774,54 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
 }
 
 // ====================================================================================
-// Persistent convolution kernel (the hot path: channels-last conv with Cin % 32 == 0 through
-// the buffer-descriptor loaders, [N,K] weights).
+// conv_dma_kernel: the hot convolution path (channels-last, Cin % 16 == 0, [N,K] weights).
 //
-// Why: the one-tile-per-workgroup kernel above pays, per output tile, a cold prologue (index
-// math + a fully exposed first operand load), and an epilogue whose stores must DRAIN before
-// the workgroup can retire and a new one can start.  On the short-K / store-heavy layers
-// (ResNet layer1/2 1x1 expansions: K = 64..128, 64 KB of output per tile) that fixed cost is
-// several times the tile's MFMA time and the whole chip runs load -> compute -> store in
-// lock-step.  Here 2 workgroups per CU stay resident and walk a strided list of tiles with ONE
-// flattened (tile, k-tile) pipeline:
-//   * the operand loads of the NEXT tile's first K-tile are issued before the MFMAs of the
-//     current tile's last K-tile, so no tile but the first sees load latency;
-//   * the epilogue's global stores are fire-and-forget: the wave goes straight on to the next
-//     tile's MFMAs while they drain;
-//   * statistics are per-wave partials (no barrier); the LDS transpose of the accumulator
-//     tile goes through the one stage buffer that is free at that point, in two halves.
-// The tile list of a workgroup is a stride through an XCD-contiguous range (N-tile fastest),
-// so the 64 workgroups of an XCD work on neighbouring tiles and share A row-panels in its L2.
-template <int BM, int BN, int DUAL>
-__global__ __launch_bounds__(256, 2) void conv_pk_kernel(IgemmParams p) {
-  constexpr int WM = 2, WN = 2;
-  constexpr int WTM = BM / WM, WTN = BN / WN;
-  constexpr int MT = WTM / 32, NT = WTN / 32;
-  constexpr int A_TILE = BM * LDP, B_TILE = BN * LDP;
-  constexpr int STAGE = A_TILE + B_TILE;
-  constexpr int A_ROWS = BM / 32, B_ROWS = BN / 32;
-  constexpr int LDC = BN + 4;
-  // the accumulator tile is transposed through ONE stage buffer: whole or in two halves
-  constexpr int EP_PASSES = (BM * LDC <= STAGE) ? 1 : 2;
-  constexpr int EP_ROWS = BM / EP_PASSES;
-  static_assert(EP_ROWS * LDC <= STAGE, "epilogue staging must fit one stage buffer");
-  static_assert(EP_PASSES == 1 || EP_ROWS == WTM, "two passes = one per wave row");
+// Measured on the one-tile-per-workgroup kernel above (profiles/r02_c_*): layer time ~= time of
+// the data movement alone + time of the MFMAs alone, i.e. the two never overlapped -- every
+// K-tile pays "wait for the staged loads, write LDS, barrier, read fragments" with the matrix
+// pipe idle (~400-600 cycles per K-tile), and every tile pays a cold prologue and an epilogue
+// whose stores must drain before the workgroup can retire.  This kernel removes those seams:
+//   * operands go global -> LDS by DMA (buffer_load ... lds): no staging registers, no LDS
+//     write pass, and a ring of 3 K-tiles of 32 channels in flight.  LDS rows are the
+//     unpadded 128-byte K-runs the DMA writes (wave-linear), chunk-swizzled on the SOURCE
+//     address ((row/2)&7 xor chunk) so that the ds_read_b128 fragment reads are conflict-free;
+//   * the K loop is rotated: the MFMA operands of the next group (also across K-tiles and
+//     across output tiles) are read while the current group's MFMAs issue, and the ONE barrier
+//     per K-tile sits in the middle of the MFMA stream ("stage t+1 has landed for everybody,
+//     stage t-1 is free") -- nothing but barrier skew is left between MFMAs;
+//   * the prologue of the A operand (previous layer's BatchNorm + ReLU, zero padding AFTER it)
+//     is applied to the fragments in registers; its per-channel vectors ride in the stage;
+//   * a workgroup walks a strided list of output tiles (bounded: it retires after pk_tiles so
+//     that kernels of side streams get CU slots); the DMA ring runs across tile boundaries;
+//   * epilogue straight from the accumulator registers, no LDS, no barrier: statistics partials
+//     per wave, then scale/shift/activation into a register copy whose 4-byte row-segment
+//     stores (2 full 128-byte lines per instruction) are issued ONE PER MFMA during the next
+//     tile's first K-tile (counted vmcnt: the ring never waits for a store).
+template <int BM, int BN, int PRO>
+__global__ __launch_bounds__(256, 2) void conv_dma_kernel(IgemmParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int NSTAGE = 3;
+  constexpr int DBK = 32;                   // channels per K-tile (one 128-byte LDS row)
+  constexpr int NG = DBK / 8;               // MFMA operand groups (8 channels) per K-tile
+  constexpr int WTM = BM / 2, WTN = BN / 2, MT = WTM / 32, NT = WTN / 32;
+  constexpr int RB = 128, RPI = 8;          // row bytes; rows per wave-wide DMA instruction
+  constexpr int A_BYTES = BM * RB, B_BYTES = BN * RB, PV_BYTES = PRO ? 384 : 0;
+  constexpr int STAGE_BYTES = A_BYTES + B_BYTES + PV_BYTES;
+  constexpr int A_INSTR = BM / RPI / 4, B_INSTR = BN / RPI / 4;  // DMA instructions per wave
+  constexpr int GM = 4 * MT * NT;           // MFMAs (= deferred stores) per operand group
+  constexpr int H2 = 2 * GM;                // ... per half K-tile
+  constexpr int NS = 16 * MT * NT;          // accumulator registers = stores per wave per tile
+  static_assert(NS == NG * GM, "a tile's stores cover exactly one K-tile of MFMAs");
+  typedef __attribute__((address_space(3))) void lds_void;
 
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+  extern __shared__ __attribute__((aligned(16))) char dsm[];
 
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int half = lane >> 5, l31 = lane & 31;
-  const int lrow = tid >> 3, lk4 = (tid & 7) * 4;
 
-  // ---- this workgroup's tile list.  XCD x owns tiles [x*per_xcd, (x+1)*per_xcd).  Its
-  // workgroups are dispatched in slot order, PK_RES (= 2 per CU) at a time; "round" r of
-  // PK_RES workgroups covers PK_RES * pk_tiles consecutive tiles, each workgroup taking every
-  // PK_RES-th of them, so the resident workgroups always work on neighbouring tiles.  A
-  // workgroup retires after pk_tiles tiles: bounded lifetime, so kernels of other (side)
-  // streams get CU slots every few tiles instead of only at the end of the launch.
+  // ---- this workgroup's tile list (see launch_dma): XCD-contiguous, stride 64, pk_tiles long
   constexpr int PK_RES = 64;
   const int ntiles = p.tiles_m * p.tiles_n;
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -797,107 +829,101 @@ __global__ __launch_bounds__(256, 2) void conv_pk_kernel(IgemmParams p) {
   const int round = slot / PK_RES;
   const int x0 = xcd * per_xcd + round * (PK_RES * p.pk_tiles);
   const int t_end = min(min(ntiles, (xcd + 1) * per_xcd), x0 + PK_RES * p.pk_tiles);
-  constexpr int wg_per_xcd = PK_RES;  // stride of this workgroup's tile list
-  int tile = x0 + (slot - round * PK_RES);
-  if (tile >= t_end) return;
-  const int KT = p.K / BK;
+  const int first_tile = x0 + (slot - round * PK_RES);
+  if (first_tile >= t_end) return;
+  const int KT = p.K / DBK;
   const int HoWo = p.Ho * p.Wo;
+  const bool taps_matter = PRO && (p.KH * p.KW > 1);
 
-  // ---- buffer descriptors (wave-uniform, built from kernel arguments only)
+  // ---- buffer descriptors (wave-uniform: kernel arguments only)
   const long bias = ((long)p.pad * p.W + p.pad) * p.lda * 4;  // keeps voffsets non-negative
   const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<char*>(reinterpret_cast<const char*>(p.A)) - bias, 0, (int)(p.a_bytes + bias),
       0x00020000);
-  __amdgpu_buffer_rsrc_t rsrc_a2 = rsrc_a;
-  if constexpr (DUAL)
-    rsrc_a2 = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char*>(reinterpret_cast<const char*>(p.A2)) - bias, 0, (int)(p.a_bytes + bias),
-        0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<char*>(reinterpret_cast<const char*>(p.B)), 0, (int)p.b_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_c = __builtin_amdgcn_make_buffer_rsrc(
+      reinterpret_cast<char*>(p.C), 0, (int)p.c_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rsrc_ps = rsrc_b, rsrc_pt = rsrc_b, rsrc_pc = rsrc_b;
+  if constexpr (PRO) {
+    rsrc_ps = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in_scale), 0, p.Cin * 4, 0x00020000);
+    rsrc_pt = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in_shift), 0, p.Cin * 4, 0x00020000);
+    rsrc_pc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in_center), 0, p.Cin * 4, 0x00020000);
+  }
 
-  // ---- loader state: belongs to the tile whose K-tiles are being FETCHED (one K-tile ahead of
-  // the MFMAs, i.e. it moves on to the next tile while the current one is still computing)
-  int ld_m0 = 0, ld_n0 = 0;
-  int a_voff[A_ROWS];
-  unsigned a_taps[A_ROWS];
-  int b_voff[B_ROWS];
-  int u_r = 0, u_q = 0, u_ci = 0;
-  f32x4 a_reg[A_ROWS], b_reg[B_ROWS];
-  f32x4 a2_reg[DUAL ? A_ROWS : 1];
-  f32x4 pro_s = {1.f, 1.f, 1.f, 1.f}, pro_t = {0.f, 0.f, 0.f, 0.f}, pro_c = {0.f, 0.f, 0.f, 0.f};
-  f32x4 pro2_s = {1.f, 1.f, 1.f, 1.f}, pro2_t = {0.f, 0.f, 0.f, 0.f}, pro2_c = {0.f, 0.f, 0.f, 0.f};
-  unsigned a_okmask = 0;
-  int a_kcur = 0;
+  // ------------------------------------------------------------------ loader (DMA) side
+  // instruction j of this wave fills LDS rows [(j*4 + wave)*8, +8): lane -> row lane/8,
+  // PHYSICAL 16-byte chunk lane%8, which holds LOGICAL chunk (lane%8) ^ ((row/2)&7)
+  const int drow = lane >> 3, dchunk = lane & 7;
+  int a_voff[A_INSTR], b_voff[B_INSTR];
+  unsigned a_taps[A_INSTR];
+  int u_r = 0, u_q = 0, u_ci = 0;  // filter tap / channel of the next K-tile to fetch
+  int l_tile = first_tile, l_kt = 0;
+  bool l_more = true;
 
-  auto setup_loader = [&](int t) {
+  auto tap_mask = [&](int m, int& voff_out, int chunk) -> unsigned {
+    // pixel of output row m: byte offset of its (tap 0, channel chunk) and the valid-tap bits
+    voff_out = BUF_OOB;
+    if (m >= p.M) return 0u;
+    const int img = m / HoWo;
+    const int rem = m - img * HoWo;
+    const int ho = rem / p.Wo;
+    const int wo = rem - ho * p.Wo;
+    const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
+    voff_out = (int)((((long)(img * p.H + hi0 + p.pad) * p.W + wi0 + p.pad) * p.lda + chunk * 4) * 4);
+    unsigned mask = 0;
+    for (int r = 0; r < p.KH; ++r)
+      for (int q = 0; q < p.KW; ++q)
+        if ((unsigned)(hi0 + r) < (unsigned)p.H && (unsigned)(wi0 + q) < (unsigned)p.W)
+          mask |= 1u << (r * p.KW + q);
+    return mask;
+  };
+
+  auto loader_setup = [&](int t) {
     const int tm = t / p.tiles_n;
-    ld_m0 = tm * BM;
-    ld_n0 = (t - tm * p.tiles_n) * BN;
+    const int lm0 = tm * BM, ln0 = (t - tm * p.tiles_n) * BN;
 #pragma unroll
-    for (int i = 0; i < A_ROWS; ++i) {
-      const int m = ld_m0 + i * 32 + lrow;
-      a_voff[i] = BUF_OOB;
-      a_taps[i] = 0;
-      if (m < p.M) {
-        const int img = m / HoWo;
-        const int rem = m - img * HoWo;
-        const int ho = rem / p.Wo;
-        const int wo = rem - ho * p.Wo;
-        const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
-        a_voff[i] =
-            (int)((((long)(img * p.H + hi0 + p.pad) * p.W + wi0 + p.pad) * p.lda + lk4) * 4);
-        unsigned mask = 0;
-        for (int r = 0; r < p.KH; ++r)
-          for (int q = 0; q < p.KW; ++q)
-            if ((unsigned)(hi0 + r) < (unsigned)p.H && (unsigned)(wi0 + q) < (unsigned)p.W)
-              mask |= 1u << (r * p.KW + q);
-        a_taps[i] = mask;
-      }
+    for (int j = 0; j < A_INSTR; ++j) {
+      const int row = (j * 4 + wave) * RPI + drow;
+      a_taps[j] = tap_mask(lm0 + row, a_voff[j], dchunk ^ ((row >> 1) & 7));
     }
 #pragma unroll
-    for (int i = 0; i < B_ROWS; ++i) {
-      const int n = ld_n0 + i * 32 + lrow;
-      b_voff[i] = n < p.N ? (int)(((long)n * p.ldb + lk4) * 4) : BUF_OOB;
+    for (int j = 0; j < B_INSTR; ++j) {
+      const int row = (j * 4 + wave) * RPI + drow;
+      const int n = ln0 + row;
+      b_voff[j] = n < p.N ? (int)(((long)n * p.ldb + (dchunk ^ ((row >> 1) & 7)) * 4) * 4) : BUF_OOB;
     }
     u_r = u_q = u_ci = 0;
   };
 
-  // fetch the next K-tile of the loader's tile into registers (A rows through the tap mask,
-  // B rows straight), and the per-channel prologue vectors that belong to it
-  auto fetch = [&]() {
+  // DMA of the loader's next K-tile into ring slot `buf`; moves on to the next tile of the
+  // list when the current one is exhausted
+  auto issue = [&](int buf) {
+    char* base = dsm + buf * STAGE_BYTES;
     const int tap = u_r * p.KW + u_q;
     const int soff = ((u_r * p.W + u_q) * p.lda + u_ci) * 4;
     const int koff = (tap * p.Cin + u_ci) * 4;
-    if (p.in_scale != nullptr) {
-      pro_s = ldg4(p.in_scale + u_ci + lk4);
-      pro_t = ldg4(p.in_shift + u_ci + lk4);
-      if (p.in_center) pro_c = ldg4(p.in_center + u_ci + lk4);
+#pragma unroll
+    for (int j = 0; j < A_INSTR; ++j) {
+      const bool ok = (a_taps[j] >> tap) & 1u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_void*)(base + (j * 4 + wave) * 1024), 16,
+                                               ok ? a_voff[j] : BUF_OOB, soff, 0, 0);
     }
-    if constexpr (DUAL) {
-      a_kcur = u_ci;
-      if (p.in2_scale != nullptr) {
-        pro2_s = ldg4(p.in2_scale + u_ci + lk4);
-        pro2_t = ldg4(p.in2_shift + u_ci + lk4);
-        if (p.in2_center) pro2_c = ldg4(p.in2_center + u_ci + lk4);
+#pragma unroll
+    for (int j = 0; j < B_INSTR; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(
+          rsrc_b, (lds_void*)(base + A_BYTES + (j * 4 + wave) * 1024), 16, b_voff[j], koff, 0, 0);
+    if constexpr (PRO) {
+      // the 32 channels' scale | shift | center (128 bytes each) ride in the stage; every wave
+      // writes the same bytes (keeps the per-wave DMA count uniform for the counted waits)
+      if (lane < 8) {
+        const int po = u_ci * 4 + lane * 16;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_ps, (lds_void*)(base + A_BYTES + B_BYTES), 16, po, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_pt, (lds_void*)(base + A_BYTES + B_BYTES + 128), 16, po, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_pc, (lds_void*)(base + A_BYTES + B_BYTES + 256), 16, po, 0, 0, 0);
       }
     }
-    a_okmask = 0;
-#pragma unroll
-    for (int i = 0; i < A_ROWS; ++i) {
-      const unsigned ok = (a_taps[i] >> tap) & 1u;
-      a_okmask |= ok << i;
-      a_reg[i] = __builtin_bit_cast(
-          f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, ok ? a_voff[i] : BUF_OOB, soff, 0));
-      if constexpr (DUAL)
-        a2_reg[i] = __builtin_bit_cast(
-            f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a2, ok ? a_voff[i] : BUF_OOB, soff, 0));
-    }
-#pragma unroll
-    for (int i = 0; i < B_ROWS; ++i)
-      b_reg[i] = __builtin_bit_cast(
-          f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, b_voff[i], koff, 0));
-    u_ci += BK;
+    u_ci += DBK;
     if (u_ci >= p.Cin) {
       u_ci = 0;
       if (++u_q == p.KW) {
@@ -905,58 +931,170 @@ __global__ __launch_bounds__(256, 2) void conv_pk_kernel(IgemmParams p) {
         ++u_r;
       }
     }
+    if (++l_kt == KT) {
+      l_kt = 0;
+      l_tile += PK_RES;
+      if (l_tile < t_end) loader_setup(l_tile);
+      else l_more = false;
+    }
   };
 
-  // registers -> LDS stage, applying the operand prologue (and writing the materialised
-  // dual-input value once, from the workgroups of N-tile 0)
-  auto stash = [&](float* stage) {
-    float* As = stage;
-    float* Bs = stage + A_TILE;
-    if (p.in_scale != nullptr) {
+  // ------------------------------------------------------------------ compute side
+  // fragment byte offsets inside a stage, per operand group (chunk swizzle folded in)
+  int a_rd[NG][MT], b_rd[NG][NT];
 #pragma unroll
-      for (int i = 0; i < A_ROWS; ++i) {
-        f32x4 v = (a_reg[i] - pro_c) * pro_s + pro_t;
-        if constexpr (DUAL) v += (a2_reg[i] - pro2_c) * pro2_s + pro2_t;
-        if (p.in_relu) {
-          v.x = fmaxf(v.x, 0.f);
-          v.y = fmaxf(v.y, 0.f);
-          v.z = fmaxf(v.z, 0.f);
-          v.w = fmaxf(v.w, 0.f);
-        }
-        const bool ok = (a_okmask >> i) & 1u;
-        if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
-        if constexpr (DUAL) {
-          if (p.side_out != nullptr && ld_n0 == 0 && ok)
-            *reinterpret_cast<f32x4*>(p.side_out + (long)(ld_m0 + i * 32 + lrow) * p.lda + a_kcur +
-                                      lk4) = v;
-        }
-        a_reg[i] = v;
-      }
+  for (int g = 0; g < NG; ++g) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int row = wm * WTM + i * 32 + l31;
+      a_rd[g][i] = row * RB + (((2 * g + half) ^ ((row >> 1) & 7)) << 4);
     }
 #pragma unroll
-    for (int i = 0; i < A_ROWS; ++i)
-      *reinterpret_cast<f32x4*>(As + (i * 32 + lrow) * LDP + lk4) = a_reg[i];
+    for (int j = 0; j < NT; ++j) {
+      const int row = wn * WTN + j * 32 + l31;
+      b_rd[g][j] = A_BYTES + row * RB + (((2 * g + half) ^ ((row >> 1) & 7)) << 4);
+    }
+  }
+  const float relu_floor = p.in_relu ? 0.f : -INFINITY;
+
+  f32x4 fa[2][MT], fb[2][NT];       // operand fragments: [group parity]
+  f32x4 pvs[2], pvt[2], pvc[2];     // prologue vectors of the group (PRO)
+  unsigned f_taps[MT], nf_taps[MT]; // valid-tap bits of this lane's fragment rows (this / next tile)
 #pragma unroll
-    for (int i = 0; i < B_ROWS; ++i)
-      *reinterpret_cast<f32x4*>(Bs + (i * 32 + lrow) * LDP + lk4) = b_reg[i];
+  for (int i = 0; i < MT; ++i) f_taps[i] = nf_taps[i] = 0xffffffffu;
+
+  auto frag_taps = [&](int t, unsigned (&out)[MT]) {
+    const int tm = t / p.tiles_n;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      int dummy;
+      out[i] = tap_mask(tm * BM + wm * WTM + i * 32 + l31, dummy, 0);
+    }
   };
 
-  const bool has_res = p.residual != nullptr;
+  auto read_frags = [&](const char* stage, int g, int slot_) {  // g, slot_: compile-time
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+      fa[slot_][i] = *reinterpret_cast<const f32x4*>(stage + a_rd[g][i]);
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+      fb[slot_][j] = *reinterpret_cast<const f32x4*>(stage + b_rd[g][j]);
+    if constexpr (PRO) {
+      const char* pv = stage + A_BYTES + B_BYTES + ((2 * g + half) << 4);
+      pvs[slot_] = *reinterpret_cast<const f32x4*>(pv);
+      pvt[slot_] = *reinterpret_cast<const f32x4*>(pv + 128);
+      pvc[slot_] = *reinterpret_cast<const f32x4*>(pv + 256);
+    }
+  };
 
-  setup_loader(tile);
-  fetch();
-  stash(smem);
-  __syncthreads();
-  int par = 0;
+  // x' = max((x - c) * s + t, floor), zero where the filter tap reads padding
+  auto transform = [&](int slot_, int tap, const unsigned (&taps)[MT]) {
+    if constexpr (PRO) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        f32x4 v = (fa[slot_][i] - pvc[slot_]) * pvs[slot_] + pvt[slot_];
+        v.x = fmaxf(v.x, relu_floor);
+        v.y = fmaxf(v.y, relu_floor);
+        v.z = fmaxf(v.z, relu_floor);
+        v.w = fmaxf(v.w, relu_floor);
+        if (taps_matter && !((taps[i] >> tap) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+        fa[slot_][i] = v;
+      }
+    }
+  };
 
+  f32x16 acc[MT][NT];
+  float pend[NS];     // the previous tile's epilogue values, stored one per MFMA
+  int st_voff[NT];        // this lane's byte offset inside 32-column block j of a row (or OOB)
+#pragma unroll
+  for (int j = 0; j < NT; ++j) st_voff[j] = BUF_OOB;
+  int st_soff = 0;        // scalar byte offset of the pending tile's wave sub-tile origin
+  const int ldc4 = p.ldc * 4;
+
+  auto store_one = [&](int s) {  // s: compile-time index into pend[] = (j, i, r)
+    const int r = s & 15, i = (s >> 4) % MT, j = (s >> 4) / MT;
+    const int soff = st_soff + (i * 32 + (r & 3) + 8 * (r >> 2)) * ldc4 + j * 128;
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pend[s]), rsrc_c, st_voff[j], soff, 0);
+  };
+
+  // one K-tile.  PHASE: 0 nothing pending | 1 the K-tile after a tile end: the pending tile's NS
+  // stores ride on its NS MFMAs | 2 the K-tile after that: no stores, but H2 of them are younger
+  // than the DMA it waits for
+  int buf = 0;            // ring slot of the current K-tile
+  int c_tap = 0, c_ci = 0;
+  bool have_next;         // a K-tile follows this one (in this or the next tile)
+
+#define VLNCE_MFMA_GROUP(SLOT, STORE_BASE, WITH_STORES)                                          \
+  _Pragma("unroll") for (int e = 0; e < 4; ++e) _Pragma("unroll") for (int i = 0; i < MT; ++i)   \
+      _Pragma("unroll") for (int j = 0; j < NT; ++j) {                                           \
+    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[SLOT][i][e], fb[SLOT][j][e], acc[i][j],  \
+                                                     0, 0, 0);                                   \
+    if constexpr (WITH_STORES) store_one((STORE_BASE) + (e * MT + i) * NT + j);                  \
+  }
+
+  auto ktile = [&](auto phase_tag, bool last_of_tile) {
+    constexpr int PHASE = decltype(phase_tag)::value;
+    constexpr bool ST = PHASE == 1;
+    const char* cur = dsm + buf * STAGE_BYTES;
+    const int nbuf = buf + 1 == NSTAGE ? 0 : buf + 1;
+    const int pbuf = buf == 0 ? NSTAGE - 1 : buf - 1;
+    // ---- groups 0 and 1 (group 0's operands are already in slot 0)
+    read_frags(cur, 1, 1);
+    VLNCE_MFMA_GROUP(0, 0, ST)
+    transform(1, c_tap, f_taps);
+    read_frags(cur, 2, 0);
+    VLNCE_MFMA_GROUP(1, GM, ST)
+    transform(0, c_tap, f_taps);
+    // ---- the stage after this one has landed (mine), then everybody's; stage t-1 is free
+    if (have_next) {
+      if constexpr (PHASE != 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(H2) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    if (l_more) issue(pbuf);
+    // ---- groups 2 and 3; group 0 of the next K-tile is fetched behind group 3's MFMAs
+    read_frags(cur, 3, 1);
+    VLNCE_MFMA_GROUP(0, 2 * GM, ST)
+    transform(1, c_tap, f_taps);
+    int n_tap = c_tap, n_ci = c_ci + DBK;
+    if (n_ci >= p.Cin) {
+      n_ci = 0;
+      ++n_tap;
+    }
+    if (last_of_tile) n_tap = 0;
+    if (have_next) read_frags(dsm + nbuf * STAGE_BYTES, 0, 0);
+    VLNCE_MFMA_GROUP(1, 3 * GM, ST)
+    if (have_next) {
+      if (last_of_tile) transform(0, 0, nf_taps);
+      else transform(0, n_tap, f_taps);
+    }
+    c_tap = n_tap;
+    c_ci = last_of_tile ? 0 : n_ci;
+    buf = nbuf;
+  };
+
+  // ------------------------------------------------------------------ fill the ring
+  loader_setup(first_tile);
+  if (taps_matter) frag_taps(first_tile, f_taps);
+#pragma unroll
+  for (int s = 0; s < NSTAGE - 1; ++s)
+    if (l_more) issue(s);
+  // stage 0 (the older of the two in flight) has landed
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_INSTR + B_INSTR + (PRO ? 3 : 0)) : "memory");
+  __builtin_amdgcn_s_barrier();
+  read_frags(dsm, 0, 0);
+  transform(0, 0, f_taps);
+
+  bool pending = false;
+  int tile = first_tile;
   while (true) {
     const int tile_m = tile / p.tiles_n;
     const int m0 = tile_m * BM;
     const int n0 = (tile - tile_m * p.tiles_n) * BN;
-    const int next_tile = tile + wg_per_xcd;
+    const int next_tile = tile + PK_RES;
     const bool more_tiles = next_tile < t_end;
+    if (taps_matter && more_tiles) frag_taps(next_tile, nf_taps);
 
-    f32x16 acc[MT][NT];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -965,108 +1103,59 @@ __global__ __launch_bounds__(256, 2) void conv_pk_kernel(IgemmParams p) {
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     for (int kt = 0; kt < KT; ++kt) {
-      const float* cur = smem + par * STAGE;
-      bool staged = true;
-      if (kt + 1 < KT) {
-        fetch();
-      } else if (more_tiles) {
-        setup_loader(next_tile);
-        fetch();
+      const bool last = kt + 1 == KT;
+      have_next = !last || more_tiles;
+      if (pending && kt == 0) ktile(std::integral_constant<int, 1>{}, last);
+      else if (pending && kt == 1) ktile(std::integral_constant<int, 2>{}, last);
+      else ktile(std::integral_constant<int, 0>{}, last);
+    }
+
+    // ---- statistics of the raw tile: per-wave partials (rows of p.stat_rows), no barrier
+    if (p.stat_partial != nullptr) {
+      if (MT == 2 && p.stat_rows == 32) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+          wave_stats_block<NT>(acc[i], p.stat_partial, (m0 + wm * WTM) / 32 + i,
+                               p.M - (m0 + wm * WTM + i * 32), n0 + wn * WTN, p.N, half, l31);
       } else {
-        staged = false;
+        wave_stats<MT, NT>(acc, p.stat_partial, tile_m * 2 + wm, p.M - (m0 + wm * WTM), WTM,
+                           n0 + wn * WTN, p.N, half, l31);
       }
-      const float* Aw = cur + (wm * WTM + l31) * LDP + 4 * half;
-      const float* Bw = cur + A_TILE + (wn * WTN + l31) * LDP + 4 * half;
-#pragma unroll
-      for (int g = 0; g < BK / 8; ++g) {
-        f32x4 af[MT], bf[NT];
-#pragma unroll
-        for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const f32x4*>(Aw + i * 32 * LDP + 8 * g);
-#pragma unroll
-        for (int j = 0; j < NT; ++j) bf[j] = *reinterpret_cast<const f32x4*>(Bw + j * 32 * LDP + 8 * g);
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-          for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
-#ifdef IGEMM_DBG_NOMFMA
-              acc[i][j][0] += af[i][e] * bf[j][e];
-#else
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
-#endif
-      }
-      if (staged) stash(smem + (par ^ 1) * STAGE);
-      __syncthreads();
-      par ^= 1;
     }
 
-    // ---- statistics of the raw tile: per-wave partials, no barrier
-#ifndef IGEMM_DBG_NOSTATS
-    if (p.stat_partial != nullptr)
-#else
-    if (false)
-#endif
-      wave_stats<MT, NT>(acc, p.stat_partial, tile_m * WM + wm, p.M - (m0 + wm * WTM), WTM,
-                         n0 + wn * WTN, p.N, half, l31);
-
-    // ---- epilogue: transpose through the free stage buffer (smem + (par^1)*STAGE: the one the
-    // last K-tile was read from; stage `par` already holds the next tile's first K-tile),
-    // then 16-byte row stores that drain while the next tile computes
-    float* Ct = smem + (par ^ 1) * STAGE;
-    constexpr int TPR = BN / 4;     // threads per output row
-    constexpr int RPP = 256 / TPR;  // rows per pass
-    const int c4 = (tid % TPR) * 4;
-    const int col = n0 + c4;
-    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-    if (col < p.N) {
-      if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + col);
-      if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + col);
+    // ---- epilogue values into the pending registers; their stores ride on the next tile
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int col = n0 + wn * WTN + j * 32 + l31;
+      const bool cok = col < p.N;
+      const float sc = (p.scale && cok) ? p.scale[col] : 1.f;
+      const float sh = (p.shift && cok) ? p.shift[col] : 0.f;
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          pend[(j * MT + i) * 16 + r] = apply_act(acc[i][j][r] * sc + sh, p.act);
     }
+    // rows >= M fall outside the output's buffer descriptor and are dropped by the hardware
+    // bounds check; a 32-column block at or beyond N (N % 32 == 0, host-checked) is masked here
 #pragma unroll
-    for (int ep = 0; ep < EP_PASSES; ++ep) {
-      if (EP_PASSES == 1 || wm == ep) {
-        const int rbase = EP_PASSES == 1 ? wm * WTM : 0;
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-          for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const int row = rbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-              Ct[row * LDC + wn * WTN + j * 32 + l31] = acc[i][j][r];
-            }
-      }
-      __syncthreads();
-      if (col < p.N) {
-#pragma unroll 4
-        for (int rr = tid / TPR; rr < EP_ROWS; rr += RPP) {
-          const int row = m0 + ep * EP_ROWS + rr;
-          if (row >= p.M) break;
-          f32x4 v = *reinterpret_cast<const f32x4*>(Ct + rr * LDC + c4);
-          v = v * sc + sh;
-          if (has_res) v += *reinterpret_cast<const f32x4*>(p.residual + (long)row * p.ldr + col);
-          v.x = apply_act(v.x, p.act);
-          v.y = apply_act(v.y, p.act);
-          v.z = apply_act(v.z, p.act);
-          v.w = apply_act(v.w, p.act);
-          float* dst = p.C + (long)row * p.ldc + col;
-          if (p.accumulate) v += *reinterpret_cast<const f32x4*>(dst);
-#if defined(IGEMM_DBG_NOSTORE)
-          if (v.x == 123456.f) *reinterpret_cast<f32x4*>(dst) = v;  // keeps the value alive
-#elif defined(IGEMM_DBG_NTSTORE)
-          __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(dst));
-#else
-          *reinterpret_cast<f32x4*>(dst) = v;
-#endif
-        }
-      }
-      __syncthreads();  // Ct is overwritten by the next pass / the next tile's second K-tile
-    }
+    for (int j = 0; j < NT; ++j)
+      st_voff[j] = (n0 + wn * WTN + j * 32 + l31) < p.N ? (4 * half * p.ldc + l31) * 4 : BUF_OOB;
+    st_soff = __builtin_amdgcn_readfirstlane(((m0 + wm * WTM) * p.ldc + n0 + wn * WTN) * 4);
+    pending = true;
 
     if (!more_tiles) break;
     tile = next_tile;
+    if (taps_matter) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i) f_taps[i] = nf_taps[i];
+    }
   }
+  // the last tile's stores
+#pragma unroll
+  for (int s = 0; s < NS; ++s) store_one(s);
+#undef VLNCE_MFMA_GROUP
+#endif
 }
 
 // y = act(y + shift): second pass of a split-K GEMM that has a bias / activation
@@ -1189,17 +1278,19 @@ void fill_epilogue(IgemmParams& p, const vlnce_epilogue* e) {
 
 bool aligned16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
-// multi-tile launch: 64 workgroups per XCD per round (2 per CU), each walking pk_tiles tiles
-template <int BM, int BN, int DUAL>
-int launch_pk(const IgemmParams& p, hipStream_t stream) {
-  constexpr int smem_bytes = 2 * (BM + BN) * LDP * (int)sizeof(float);
-  auto kern = conv_pk_kernel<BM, BN, DUAL>;
+// conv_dma launch: 64 workgroups per XCD per round (2 per CU), each walking pk_tiles tiles
+__device__ float vlnce_zero_vec[4096];
+
+template <int BM, int BN, int PRO>
+int launch_dma(const IgemmParams& p, hipStream_t stream) {
+  constexpr int smem_bytes = 3 * ((BM + BN) * 128 + (PRO ? 384 : 0));
+  auto kern = conv_dma_kernel<BM, BN, PRO>;
   static bool attr_set = false;  // per instantiation
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
     if (e != hipSuccess) {
-      vlnce_set_error("conv_pk: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      vlnce_set_error("conv_dma: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
       return 2;
     }
     attr_set = true;
@@ -1210,7 +1301,7 @@ int launch_pk(const IgemmParams& p, hipStream_t stream) {
   q.splitk = 1;
   const long ntiles = (long)q.tiles_m * q.tiles_n;
   if (ntiles <= 0 || ntiles > 0x7fffffffL) {
-    vlnce_set_error("conv_pk: bad tile count %ld", ntiles);
+    vlnce_set_error("conv_dma: bad tile count %ld", ntiles);
     return 1;
   }
   // tiles per workgroup (tuning knob; 1 = one tile per workgroup, large = fully persistent)
@@ -1222,24 +1313,36 @@ int launch_pk(const IgemmParams& p, hipStream_t stream) {
   const long last = per_xcd - (rounds - 1) * 64L * q.pk_tiles;
   const long slots = (rounds - 1) * 64 + (last < 64 ? last : 64);
   hipLaunchKernelGGL(kern, dim3((unsigned)(8 * slots)), dim3(256), smem_bytes, stream, q);
-  VLNCE_CHECK_LAUNCH("conv_pk");
+  VLNCE_CHECK_LAUNCH("conv_dma");
   return 0;
 }
 
-template <int DUAL>
-int dispatch_pk(const IgemmParams& p, hipStream_t s) {
-  const TileChoice t = choose_tile(p.M, p.N);
-  if (t.bm == 128 && t.bn == 128) return launch_pk<128, 128, DUAL>(p, s);
-  if (t.bm == 128 && t.bn == 64) return launch_pk<128, 64, DUAL>(p, s);
-  return launch_pk<64, 64, DUAL>(p, s);
+template <int PRO>
+int dispatch_dma(const IgemmParams& p, hipStream_t s) {
+  // 128x64 is the largest tile: 128x128 would need accumulators + the deferred-store copy +
+  // double-buffered fragments = more than the 256 registers two waves per SIMD leave each.
+  // The M extent (hence the statistics granularity, vlnce_conv2d_tile_rows) is choose_tile's.
+  IgemmParams q = p;
+  q.stat_rows = choose_tile(p.M, p.N).bm / 2;  // what vlnce_conv2d_tile_rows told the caller
+  if ((long)ceil_div(p.M, 128) * ceil_div(p.N, 64) >= 512) return launch_dma<128, 64, PRO>(q, s);
+  q.stat_rows = 32;
+  if (choose_tile(p.M, p.N).bm != 64) {  // cannot happen: fewer than 512 128x64 tiles => 64x64
+    vlnce_set_error("conv_dma: inconsistent statistics granularity");
+    return 1;
+  }
+  return launch_dma<64, 64, PRO>(q, s);
 }
 
-// the persistent kernel covers the 16-byte store epilogue only
-bool pk_ok(const IgemmParams& p) {
-  static const bool off = getenv("VLNCE_IGEMM_NO_PERSIST") != nullptr;
-  return !off && ((p.N & 3) == 0) && ((p.ldc & 3) == 0) && aligned16(p.C) &&
-         (!p.residual || (((p.ldr & 3) == 0) && aligned16(p.residual))) &&
-         (!p.scale || aligned16(p.scale)) && (!p.shift || aligned16(p.shift));
+// what conv_dma_kernel covers: 32-channel K-tiles inside one filter tap, at least 2 of them,
+// 32-column output blocks, plain epilogue (scale / shift / activation, statistics)
+bool dma_ok(const IgemmParams& p) {
+  // opt-in while it is slower than the register-staged kernel (profiles/r02_e_*)
+  static const bool off = getenv("VLNCE_IGEMM_DMA") == nullptr;
+  const long bias = ((long)p.pad * p.W + p.pad) * p.lda * 4;
+  return !off && (p.Cin % 32 == 0) && p.K >= 64 && (p.lda % 4 == 0) && (p.ldb % 4 == 0) &&
+         (p.N % 32 == 0) && p.KH * p.KW <= 32 && p.a_bytes + bias < 0x7fffffffL &&
+         p.b_bytes < 0x7fffffffL && p.c_bytes < 0x7fffffffL && !p.residual && !p.accumulate &&
+         !p.A2 && !p.side_out && p.Cin <= 4096;
 }
 
 }  // namespace
@@ -1306,6 +1409,7 @@ extern "C" int vlnce_conv2d_fwd(const float* x, const float* w, float* y, const 
   p.splitk = 1;
   p.a_bytes = (((long)d->N * d->H * d->W - 1) * p.lda + d->Cin) * 4;
   p.b_bytes = (long)d->Cout * p.K * 4;
+  p.c_bytes = ((M - 1) * p.ldc + d->Cout) * 4;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (p.A2 != nullptr || p.side_out != nullptr) {
     VLNCE_CHECK_ARG(p.A2 && p.in_scale && d->KH == 1 && d->KW == 1 && d->stride == 1 &&
@@ -1316,9 +1420,21 @@ extern "C" int vlnce_conv2d_fwd(const float* x, const float* w, float* y, const 
                         (!p.in2_center || (p.in2_scale && aligned16(p.in2_center))),
                     "conv2d_fwd: the dual-input prologue needs x2 + in_scale on a 1x1/stride-1/"
                     "pad-0 convolution with Cin %% 32 == 0 and 16-byte aligned operands");
-    return pk_ok(p) ? dispatch_pk<1>(p, s) : dispatch_dual(p, s);
+    return dispatch_dual(p, s);
   }
-  if (v4 && buf_ok(p)) return pk_ok(p) ? dispatch_pk<0>(p, s) : dispatch_tiles<A_BUF, B_BUF>(p, s);
+  if (v4 && dma_ok(p)) {
+    if (p.in_scale == nullptr) return dispatch_dma<0>(p, s);
+    if (p.in_center == nullptr) {  // the kernel always subtracts a centre: hand it zeros
+      static float* zeros = nullptr;
+      if (!zeros && hipGetSymbolAddress(reinterpret_cast<void**>(&zeros), HIP_SYMBOL(vlnce_zero_vec)) != hipSuccess) {
+        vlnce_set_error("conv2d_fwd: no zero vector");
+        return 2;
+      }
+      p.in_center = zeros;
+    }
+    return dispatch_dma<1>(p, s);
+  }
+  if (v4 && buf_ok(p)) return dispatch_tiles<A_BUF, B_BUF>(p, s);
   if (v4) return dispatch_tiles<A_IM2COL_V4, B_NK_V4>(p, s);
   if (d->KW == 7 && d->Cin == 3) return dispatch_stem<3>(p, s);
   if (d->KW == 7 && d->Cin == 1) return dispatch_stem<1>(p, s);
