@@ -28,7 +28,7 @@ typedef void* vlnce_stream_t;
 
 enum { VLNCE_ACT_NONE = 0, VLNCE_ACT_RELU = 1, VLNCE_ACT_SIGMOID = 2, VLNCE_ACT_TANH = 3 };
 
-int vlnce_version(void); /* major*100 + minor; 110 = this header */
+int vlnce_version(void); /* major*100 + minor; 120 = this header */
 const char* vlnce_last_error(void);
 
 /* ---------------------------------------------------------------- conv / GEMM
@@ -181,6 +181,39 @@ int vlnce_avgpool2x2(const float* x, float* y, int N, int H, int W, int C, vlnce
 int vlnce_space_to_depth2(const float* x, float* y, int N, int H, int W, int C, int pad_lo,
                           int pad_hi, const float* scale, const float* shift,
                           vlnce_stream_t stream);
+/* ------------------------------------------------------------- observation ingest
+ * What habitat's batch_obs (fp32 cast), CenterCropperPerSensor / ObsStack
+ * (habitat_extensions/obs_transformers.py:21-145), the waypoint net's concatenation of 12
+ * panorama frames with the done-masked history frame (waypoint_predictors.py:330-375) and the
+ * encoders' own input handling (/255, avg_pool2d(2): resnet_encoders.py:95,198-199) do in four
+ * passes over fp32 frames, in one pass over the frames in their STORAGE type (uint8 RGB). */
+#define VLNCE_DT_F32 0
+#define VLNCE_DT_U8 1
+typedef struct {
+  const void* x;              /* [N, F, Hs, Ws, C] frames (F = 1: a plain [N, Hs, Ws, C] sensor)      */
+  const void* x2;             /* optional extra frame per env [N, Hs, Ws, C], appended as frame F      */
+  const unsigned char* mask2; /* optional [N]: the extra frame is multiplied by it (not-done mask)     */
+  int dtype;                  /* VLNCE_DT_F32 | VLNCE_DT_U8: element type of x and x2                  */
+  int N, F, Hs, Ws, C;
+  int y0, x0, H, W;           /* centre-crop window: rows [y0, y0+H), columns [x0, x0+W) of each frame */
+} vlnce_frames;
+/* RGB stem input: 2x2 space-to-depth of every (cropped) frame with the per-channel input
+ * transform, y [N*(F + (x2 != NULL)), H/2+pad_lo+pad_hi, W/2+pad_lo+pad_hi, 4C] fp32; image index
+ * n*(F+1) + f as torch.cat([frames, history.unsqueeze(1)], 1).flatten(0, 1) orders them. */
+int vlnce_frames_s2d(const vlnce_frames* frames, float* y, int pad_lo, int pad_hi,
+                     const float* scale, const float* shift, vlnce_stream_t stream);
+/* depth stem input: F.avg_pool2d(x, 2) of every frame, y [N*(F+..), H/2, W/2, C] fp32 */
+int vlnce_frames_avgpool2(const vlnce_frames* frames, float* y, vlnce_stream_t stream);
+/* the frames as fp32 [N*(F+..), H, W, C] (x*scale+shift when given): stems that cannot take the
+ * space-to-depth form, trainable encoders */
+int vlnce_frames_f32(const vlnce_frames* frames, float* y, const float* scale, const float* shift,
+                     vlnce_stream_t stream);
+/* eager ObsStack + CenterCropperPerSensor: out[n, f, h, w, :] = srcs[f][n, y0+h, x0+w, :] for F
+ * (<= 16) source sensors [N, Hs, Ws, C] of elem_bytes-wide elements; `srcs` is a HOST array of
+ * device pointers; out [N, F, H, W, C] in the source element type (bytes are moved as they are). */
+int vlnce_frames_gather(const void* const* srcs, int F, int elem_bytes, int N, int Hs, int Ws,
+                        int C, int y0, int x0, int H, int W, void* out, vlnce_stream_t stream);
+
 int vlnce_adaptive_avgpool(const float* x, float* y, int N, int H, int W, int C, int OH, int OW,
                            int ldy, vlnce_stream_t stream);
 
@@ -288,6 +321,22 @@ int vlnce_rnn_seq_bwd(int kind, int dirs, const float* const* w_hh_t, const int*
 /* y[b, c] = mean_p x[b, p, c]   (AdaptiveAvgPool1d(1) of rgb_linear, cma_policy.py:104) */
 int vlnce_mean_rows(const float* x, float* y, int B, int P, int C, vlnce_stream_t stream);
 /* x[b, :] *= mask[b]  (done-mask zeroing of the recurrent state; out may alias x) */
+/* One step of a T-step state-encoder rollout over N <= 16 episodes, fused (habitat
+ * RNNStateEncoder.seq_forward, call sites cma_policy.py:249-256,287-294; rollout_storage.py:154-276):
+ *   fwd: hp = mask * h_prev; gates(gi + hp W_hh^T + b_hh); h (, c)          -- one launch
+ *   bwd: dh = dout + carry; gate gradients (dgi, dgh);
+ *        carry <- mask * (dh*z + dgh W_hh)  (GRU) | mask * (dgates W_hh)  (LSTM) -- two launches
+ * w_hh_t is W_hh^T [H, G*H]; carry is read and overwritten; acc0 is [N,H] scratch.
+ * aux = W_hn h + b_hn (GRU) | c_t (LSTM); gates = post-activation gates, torch order. */
+int vlnce_rnn_step_supported(int N, int H, int lstm);
+int vlnce_rnn_step_fwd(int lstm, const float* gi, const float* h_prev, const float* c_prev,
+                       const uint8_t* mask, const float* w_hh, const float* b_hh, float* hp_out,
+                       float* h_out, float* aux_out, float* gates_out, int N, int H,
+                       vlnce_stream_t stream);
+int vlnce_rnn_step_bwd(int lstm, const float* dout, float* carry, const float* dc,
+                       const float* gates, const float* aux, const float* hp, const float* c_prev,
+                       const uint8_t* mask, const float* w_hh_t, float* dgi, float* dgh,
+                       float* acc0, float* dc_prev, int N, int H, vlnce_stream_t stream);
 int vlnce_mask_rows(const float* x, const uint8_t* mask, float* out, int B, int H,
                     vlnce_stream_t stream);
 

@@ -276,6 +276,38 @@ class HostSim:
     def avgpool2x2(self, x, y, N, H, W, Cc):
         y.copy_(F.avg_pool2d(x.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1))
 
+    def rnn_step_supported(self, N, H, lstm):
+        return False  # the fused steps are a launch-count optimisation of the same arithmetic
+
+    # ---- observation ingest (contract of include/vlnce_hip.h, vlnce_frames_*)
+    @staticmethod
+    def _frames_f32(fr):
+        """the descriptor's frames as fp32 [N*(F+extra), H, W, C] (crop, stack, masked extra frame)"""
+        N, F_, Hs, Ws, Cc = fr["N"], fr["F"], fr["Hs"], fr["Ws"], fr["C"]
+        y0, x0, H, W = fr["y0"], fr["x0"], fr["H"], fr["W"]
+        v = fr["x"].reshape(N, F_, Hs, Ws, Cc)[:, :, y0:y0 + H, x0:x0 + W].float()
+        if fr.get("x2") is not None:
+            e = fr["x2"].reshape(N, 1, Hs, Ws, Cc)[:, :, y0:y0 + H, x0:x0 + W].float()
+            if fr.get("mask2") is not None:
+                e = e * fr["mask2"].reshape(N, 1, 1, 1, 1).float()
+            v = torch.cat([v, e], dim=1)
+        return v.reshape(-1, H, W, Cc)
+
+    def frames_s2d(self, fr, y, pad_lo, pad_hi, scale=None, shift=None):
+        v = self._frames_f32(fr)
+        self.space_to_depth2(v, y, v.size(0), fr["H"], fr["W"], fr["C"], pad_lo, pad_hi, scale, shift)
+
+    def frames_avgpool2(self, fr, y):
+        v = self._frames_f32(fr)
+        y.copy_(F.avg_pool2d(v.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1))
+
+    def frames_f32(self, fr, y, scale=None, shift=None):
+        v = self._frames_f32(fr)
+        y.copy_(v * scale + shift if scale is not None else v)
+
+    def frames_gather(self, srcs, elem_bytes, N, Hs, Ws, Cc, y0, x0, H, W, out):
+        out.copy_(torch.stack([t[:, y0:y0 + H, x0:x0 + W] for t in srcs], dim=1))
+
     def adaptive_avgpool(self, x, y, N, H, W, Cc, OH, OW, ldy):
         v = F.adaptive_avg_pool2d(x.permute(0, 3, 1, 2), (OH, OW)).permute(0, 2, 3, 1)
         _mat(y, N * OH * OW, Cc, ldy).copy_(v.reshape(-1, Cc))

@@ -147,3 +147,189 @@ def test_sharded_policy_update_equals_full_batch(tmp_path, monkeypatch):
     gmax = max(v.abs().max().item() for v in want.values())
     for n in want:
         assert torch.allclose(got[n], want[n], rtol=1e-4, atol=1e-6 * max(gmax, 1.0)), n
+
+
+# ------------------------------------------------------------------ progress monitor under DP
+def _pm_policy_and_batch():
+    import cases
+    import vlnce_amd
+    from oracle import thirdparty as tp
+
+    case = dict(cases.CASES["cma_update_64"], N=4, T=3, lengths=[6, 10, 3, 8], mode="eval",
+                overrides={"PROGRESS_MONITOR.use": True})
+    policy, _ = cases.build_policy(vlnce_amd, case, vlnce_amd.make_config, vlnce_amd.make_spaces,
+                                   tp.synth_state_dict)
+    policy.train()
+    policy.net.rgb_encoder.eval()
+    policy.net.depth_encoder.eval()
+    obs, prev, masks, extra = cases.build_inputs(case)
+    w = extra["weights"].clone()
+    w[1:, 0] = 0.0  # unbalanced: rank 0's shard has fewer unmasked rows than rank 1's
+    w[2, 1] = 0.0
+    extra["weights"] = w
+    return policy, obs, prev, masks, extra, case
+
+
+def pm_worker(rank, world, port, out, exact):
+    import hostsim
+    import vlnce_amd
+    from vlnce_amd import _lib
+    from vlnce_amd.il_harness import update_agent
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    _lib._LIB = hostsim.HostSim()
+    policy, obs, prev, masks, extra, case = _pm_policy_and_batch()
+    T, N = case["T"], case["N"]
+    sl = shard_rows(N, rank, world)
+    red = GradientAllReducer(policy, bucket_bytes=1 << 18)
+    vlnce_amd.AuxLosses.activate()
+    vlnce_amd.AuxLosses.set_data_parallel(exact)
+    update_agent(policy, None, {k: _shard(v, T, N, sl) for k, v in obs.items()},
+                 _shard(prev, T, N, sl), _shard(masks, T, N, sl), extra["targets"][:, sl],
+                 extra["weights"][:, sl], 512, step_grad=False, grad_hook=red.finish)
+    if rank == 0:
+        torch.save({n: p.grad for n, p in policy.named_parameters() if p.grad is not None}, out)
+    dist.destroy_process_group()
+
+
+def test_progress_monitor_loss_is_a_global_masked_mean_under_data_parallelism(tmp_path, monkeypatch):
+    """aux_losses.py:24-32 averages the progress loss over ALL unmasked rows (and, through the
+    [B] x [B,1] broadcast of App. B-2, over the progress targets of the whole batch).  With
+    unbalanced masks the mean of per-rank means differs; AuxLosses.set_data_parallel() restores
+    the single-process gradient exactly."""
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (os.path.dirname(here), here, os.path.join(here, "golden")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import hostsim
+    import vlnce_amd
+    from vlnce_amd import _lib
+    from vlnce_amd.il_harness import update_agent
+
+    def spawn(exact):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        out = str(tmp_path / f"pm_{int(exact)}.pt")
+        mp.spawn(pm_worker, args=(2, port, out, exact), nprocs=2, join=True)
+        return torch.load(out)
+
+    monkeypatch.setattr(_lib, "_LIB", hostsim.HostSim())
+    policy, obs, prev, masks, extra, case = _pm_policy_and_batch()
+    vlnce_amd.AuxLosses.activate()
+    update_agent(policy, None, obs, prev, masks, extra["targets"], extra["weights"], 512,
+                 step_grad=False)
+    vlnce_amd.AuxLosses.deactivate()
+    want = {n: p.grad for n, p in policy.named_parameters() if p.grad is not None}
+    key = "net.progress_monitor.weight"
+    assert key in want
+    gmax = max(v.abs().max().item() for v in want.values())
+
+    def worst(got):
+        return max((got[n] - want[n]).abs().max().item() for n in want)
+
+    exact, naive = spawn(True), spawn(False)
+    assert worst(exact) < 1e-5 * max(gmax, 1.0), worst(exact)
+    # the documented deviation of the plain per-rank mean is real on this batch
+    assert worst(naive) > 1e-3 * want[key].abs().max().item()
+
+
+# ------------------------------------------------------------------ torch DDP + WaypointPolicy
+def _wp_policy_and_sample():
+    import cases
+    import vlnce_amd
+    from oracle import thirdparty as tp
+
+    # equal instruction lengths: the waypoint net's instruction attention keeps PAD keys in its
+    # softmax (App. B-3), so its output depends on the batch's longest instruction (App. B-8) --
+    # upstream's DDP shards differ from the unsharded batch in exactly the same way
+    case = dict(cases.CASES["waypoint_ppo_update_64"], N=4, T=2, lengths=[9, 9, 9, 9])
+    policy, _ = cases.build_policy(vlnce_amd, case, vlnce_amd.make_config, vlnce_amd.make_spaces,
+                                   tp.synth_state_dict)
+    obs, prev, masks, extra = cases.build_inputs(case)
+    with torch.no_grad():
+        B = obs["rgb"].size(0)
+        out = policy.act(obs, torch.zeros(B, policy.net.num_recurrent_layers, 256),
+                         {k: v.clone() for k, v in prev.items()}, masks, deterministic=True)
+    for k, v in out[2].items():
+        extra["act_" + k] = v.detach().clone()
+    return policy, obs, prev, masks, extra, case
+
+
+def _wp_loss(policy, obs, prev, masks, extra, h0):
+    """the actor-critic terms of WDDPPO.update (ddppo_alg.py:65-132) -- plain means over rows"""
+    import cases
+
+    actions = {k[4:]: v for k, v in extra.items() if k.startswith("act_")}
+    values, logp, entropy, _ = policy.evaluate_actions(obs, h0, prev, masks, actions)
+    ratio = torch.exp(logp - extra["old_logp"])
+    adv = extra["adv"]
+    action_loss = -torch.min(ratio * adv, ratio.clamp(0.8, 1.2) * adv).mean()
+    value_loss = 0.5 * ((extra["returns"] - values) ** 2).mean()
+    return value_loss * cases.PPO["value_loss_coef"] + action_loss \
+        - cases.PPO["entropy_coef"] * entropy["pano"].mean()
+
+
+def ddp_worker(rank, world, port, out):
+    import hostsim
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    from vlnce_amd import _lib
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    _lib._LIB = hostsim.HostSim()
+    policy, obs, prev, masks, extra, case = _wp_policy_and_sample()
+    T, N = case["T"], case["N"]
+    sl = shard_rows(N, rank, world)
+    sh = lambda t: _shard(t, T, N, sl)  # noqa: E731
+    # habitat-lab v0.1.7 DecentralizedDistributedMixin.init_distributed: the policy is wrapped
+    # only to obtain DDP's reducer; forward goes through evaluate_actions on the bare module and
+    # reducer.prepare_for_backward([loss]) marks the unused action_distribution.* parameters
+    # (ddppo_waypoint_trainer.py:370: find_unused_params=True)
+    ddp = DDP(policy, find_unused_parameters=True)
+    for _ in range(2):
+        policy.zero_grad()
+        ex = {k: (sh(v) if isinstance(v, torch.Tensor) and v.dim() > 0 and v.size(0) == T * N else v)
+              for k, v in extra.items()}
+        loss = _wp_loss(policy, {k: sh(v) for k, v in obs.items()}, {k: sh(v) for k, v in prev.items()},
+                        sh(masks), ex, extra["h0"][sl])
+        ddp.reducer.prepare_for_backward([loss])
+        loss.backward()
+    if rank == 0:
+        torch.save({n: p.grad for n, p in policy.named_parameters() if p.grad is not None}, out)
+    dist.destroy_process_group()
+
+
+def test_waypoint_policy_under_torch_ddp_reducer(tmp_path, monkeypatch):
+    """The reference's only distributed path: WaypointPolicy inside torch DDP with
+    find_unused_parameters=True.  The custom autograd Functions of the HIP host path (here on the
+    ABI simulator) must coexist with DDP's reducer hooks: 2 gloo ranks x 2 envs == 4 envs."""
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (os.path.dirname(here), here, os.path.join(here, "golden")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import hostsim
+    from vlnce_amd import _lib
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "ddp_grads.pt")
+    mp.spawn(ddp_worker, args=(2, port, out), nprocs=2, join=True)
+    got = torch.load(out)
+    monkeypatch.setattr(_lib, "_LIB", hostsim.HostSim())
+    policy, obs, prev, masks, extra, case = _wp_policy_and_sample()
+    _wp_loss(policy, obs, prev, masks, extra, extra["h0"]).backward()
+    want = {n: p.grad for n, p in policy.named_parameters() if p.grad is not None}
+    assert "action_distribution.linear.weight" not in want  # the unused head
+    assert set(want) <= set(got) and len(want) > 20
+    gmax = max(v.abs().max().item() for v in want.values())
+    for n in want:
+        assert torch.allclose(got[n], want[n], rtol=1e-4, atol=1e-6 * max(gmax, 1.0)), n

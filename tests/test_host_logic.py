@@ -250,3 +250,38 @@ def test_truncated_normal_matches_oracle_including_sampling():
     assert torch.equal(sa, sb) and bool(((sa >= lo) & (sa <= hi)).all())
     with pytest.raises(AssertionError):
         a.log_prob(torch.full((64, 1), 0.3))
+
+
+@pytest.mark.parametrize("policy_name,final_only", [("CMAPolicy", False), ("Seq2SeqPolicy", True)])
+def test_instruction_dedup_equals_row_by_row_encoding(sim, policy_name, final_only):
+    """A sequence-mode batch repeats each episode's token row T times; encoding the distinct rows
+    once and gathering must equal encoding every row (values and parameter gradients)."""
+    from vlnce_amd.encoders.instruction_encoder import InstructionEncoder
+
+    torch.manual_seed(3)
+    cfg = vlnce_amd.make_config(policy_name).MODEL.INSTRUCTION_ENCODER
+    cfg.final_state_only = final_only
+    enc = InstructionEncoder(cfg)
+    g = torch.Generator().manual_seed(4)
+    eps = torch.zeros(3, 200, dtype=torch.long)
+    for i, L in enumerate((5, 9, 7)):
+        eps[i, :L] = torch.randint(1, 2504, (L,), generator=g)
+    pad = torch.ones(1, 200, dtype=torch.long)            # collate_fn pads with 1.0 (App. B-7)
+    tokens = torch.cat([eps, eps, eps[:2], pad, eps, pad, pad, eps, eps[1:]], dim=0)  # 20 rows
+    assert tokens.size(0) >= enc.DEDUP_MIN_ROWS
+    w = torch.randn(1)
+
+    def run(min_rows):
+        enc.DEDUP_MIN_ROWS = min_rows
+        enc.zero_grad()
+        out = enc({"instruction": tokens})
+        (out * torch.linspace(0.5, 1.5, out.numel()).view_as(out) * w).sum().backward()
+        return out.detach(), [p.grad.clone() for p in enc.parameters() if p.grad is not None]
+
+    ref, gref = run(10 ** 9)
+    got, ggot = run(16)
+    assert got.shape == ref.shape
+    assert torch.allclose(got, ref, atol=1e-6, rtol=1e-6)
+    assert len(ggot) == len(gref) > 0
+    for a, b in zip(ggot, gref):
+        assert torch.allclose(a, b, atol=1e-5, rtol=1e-4)

@@ -658,7 +658,7 @@ def test_conv_group_norm_from_epilogue_stats(hip, N, hw, Cin, Cout, k, groups):
 
 
 @pytest.mark.parametrize("lstm", [False, True])
-@pytest.mark.parametrize("T,N,H", [(40, 5, 512), (7, 64, 256)])
+@pytest.mark.parametrize("T,N,H", [(40, 5, 512), (7, 64, 256), (9, 16, 256), (5, 3, 24)])
 def test_masked_rnn_rollout_vs_torch_cells(hip, lstm, T, N, H):
     """ops.MaskedRNNSeqFn on the GPU (the T-step state-encoder rollout of a cached-feature DAgger
     batch / DD-PPO minibatch) against torch cells stepped on the CPU, forward and all gradients."""

@@ -1,0 +1,166 @@
+"""Observation transforms: oracle and product against the goldens produced by
+the reference's own CenterCropperPerSensor / ObsStack (tests/golden/make_goldens_obs.py), the
+uint8 ingest kernels against their contract, and end-to-end equality of the policy on uint8
+frames / centre-crop views with the fp32 path."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import hostsim
+import make_goldens_obs as mg
+import vlnce_amd
+from oracle import policy_cpu as oc
+from vlnce_amd import obs_transforms as ot
+from vlnce_amd import ops
+
+GOLD = os.path.dirname(os.path.abspath(mg.__file__))
+DEV = "cuda:0"
+
+
+def gold(name):
+    return {k[4:]: torch.from_numpy(v) for k, v in np.load(os.path.join(GOLD, name)).items()}
+
+
+def same(a, b):
+    assert set(a) == set(b), (sorted(a), sorted(b))
+    for k in a:
+        assert a[k].dtype == b[k].dtype and a[k].shape == b[k].shape, k
+        assert torch.equal(a[k].cpu(), b[k].cpu()), k
+
+
+def single_cam():
+    return {k: v for k, v in mg.inputs().items() if k in ("rgb", "depth", "instruction")}
+
+
+# ------------------------------------------------------------------ CPU tier
+def test_oracle_matches_reference_goldens():
+    same(oc.center_cropper_per_sensor(single_cam(), mg.CROPS), gold("obs_center_crop.npz"))
+    same(oc.obs_stack(mg.inputs(), mg.STACK), gold("obs_stack.npz"))
+    same(oc.center_cropper_per_sensor(oc.obs_stack(mg.inputs(), mg.STACK), mg.CROPS),
+         gold("obs_stack_crop.npz"))
+
+
+def test_product_transforms_match_reference_goldens_on_cpu():
+    same(ot.CenterCropperPerSensor(mg.CROPS)(single_cam()), gold("obs_center_crop.npz"))
+    same(ot.ObsStack(mg.STACK)(mg.inputs()), gold("obs_stack.npz"))
+    both = ot.apply_obs_transforms_batch(mg.inputs(), [ot.ObsStack(mg.STACK),
+                                                       ot.CenterCropperPerSensor(mg.CROPS)])
+    same(both, gold("obs_stack_crop.npz"))
+
+
+def test_observation_space_rewrites():
+    spaces, _ = vlnce_amd.make_spaces(20, 26)
+    sp = {f"rgb{'' if i == 0 else '_' + str(i)}": spaces.spaces["rgb"] for i in range(12)}
+    sp.update({f"depth{'' if i == 0 else '_' + str(i)}": spaces.spaces["depth"] for i in range(12)})
+    space = vlnce_amd.config.Dict(sp)
+    out = ot.ObsStack(mg.STACK).transform_observation_space(space)
+    assert set(out.spaces) == {"rgb", "depth"}
+    assert out.spaces["rgb"].shape == (12, 20, 26, 3) and out.spaces["depth"].shape == (12, 20, 26, 1)
+    out = ot.CenterCropperPerSensor(mg.CROPS).transform_observation_space(out)
+    assert out.spaces["rgb"].shape == (12, 14, 16, 3) and out.spaces["depth"].shape == (12, 16, 18, 1)
+    assert set(space.spaces) == set(sp)  # the input space is not modified
+
+
+def test_batch_obs_keeps_storage_dtypes():
+    envs = [{"rgb": np.full((4, 5, 3), i, np.uint8), "depth": np.full((4, 5, 1), i / 4, np.float32),
+             "instruction": np.arange(6) + i} for i in range(3)]
+    b = ot.batch_obs(envs, "cpu")
+    assert b["rgb"].dtype == torch.uint8 and b["rgb"].shape == (3, 4, 5, 3)
+    assert b["depth"].dtype == torch.float32 and b["instruction"].dtype == torch.int64
+    assert torch.equal(b["rgb"][2], torch.full((4, 5, 3), 2, dtype=torch.uint8))
+
+
+def test_frame_descriptor_reads_crop_views_without_a_copy():
+    base = torch.randint(0, 256, (3, 4, 10, 12, 3), dtype=torch.uint8)
+    view = base[:, :, 2:8, 1:11, :]
+    fr = ops.frames(view)
+    assert fr["x"].data_ptr() == base.data_ptr() and (fr["Hs"], fr["Ws"]) == (10, 12)
+    assert (fr["y0"], fr["x0"], fr["H"], fr["W"], fr["F"], fr["images"]) == (2, 1, 6, 10, 4, 12)
+    want = view.float().reshape(12, 6, 10, 3)
+    assert torch.equal(hostsim.HostSim._frames_f32(fr), want)
+    # frame stack + masked extra frame (the waypoint net's 12 + 1 frames)
+    hist = torch.randint(0, 256, (3, 6, 10, 3), dtype=torch.uint8)
+    mask = torch.tensor([1, 0, 1])
+    fr = ops.frames((view, hist, mask))
+    got = hostsim.HostSim._frames_f32(fr).reshape(3, 5, 6, 10, 3)
+    assert fr["images"] == 15 and torch.equal(got[:, :4], view.float())
+    assert torch.equal(got[:, 4], hist.float() * mask.view(3, 1, 1, 1).float())
+
+
+# ------------------------------------------------------------------ GPU tier
+@pytest.mark.gpu
+def test_obs_stack_and_crop_kernels_match_reference_goldens():
+    dev_in = {k: v.to(DEV) for k, v in mg.inputs().items()}
+    same(ot.ObsStack(mg.STACK)(dict(dev_in)), gold("obs_stack.npz"))
+    both = ot.apply_obs_transforms_batch(dict(dev_in), [ot.ObsStack(mg.STACK),
+                                                        ot.CenterCropperPerSensor(mg.CROPS)])
+    same({k: v.contiguous() for k, v in both.items()}, gold("obs_stack_crop.npz"))
+    # stack + crop fused in the gather kernel
+    srcs = [dev_in["rgb" + ("" if i == 0 else f"_{i}")] for i in range(12)]
+    y0, x0, h, w = ot.center_crop_window(20, 26, (14, 16))
+    assert torch.equal(ops.frames_gather(srcs, (y0, x0, h, w)).cpu(), gold("obs_stack_crop.npz")["rgb"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.uint8, torch.float32])
+def test_ingest_kernels_match_their_contract(dtype):
+    sim = hostsim.HostSim()
+    g = torch.Generator().manual_seed(3)
+    mk = (lambda *s: torch.randint(0, 256, s, generator=g, dtype=torch.uint8)) if dtype == torch.uint8 \
+        else (lambda *s: torch.rand(*s, generator=g) * 255)
+    base = mk(3, 4, 12, 14, 3)
+    view = base[:, :, 1:11, 2:12, :]                     # centre-crop view of a frame stack
+    hist, mask = mk(3, 10, 10, 3), torch.tensor([1, 0, 1], dtype=torch.uint8)
+    sc, sh = torch.rand(3) + 0.5, torch.randn(3)
+    for cpu_in in (base[:, 0], view, (view, hist, mask)):
+        dev_in = tuple(t.to(DEV) for t in cpu_in) if isinstance(cpu_in, tuple) else cpu_in.to(DEV)
+        if not isinstance(cpu_in, tuple) and cpu_in is view:  # keep it a VIEW on the device too
+            dev_in = base.to(DEV)[:, :, 1:11, 2:12, :]
+        fc, fd = ops.frames(cpu_in), ops.frames(dev_in)
+        assert fd["x"].is_cuda and (fd["y0"], fd["x0"]) == (fc["y0"], fc["x0"])
+        n, H, W = fc["images"], fc["H"], fc["W"]
+        want = torch.empty(n, H // 2 + 3, W // 2 + 3, 12)
+        sim.frames_s2d(fc, want, 2, 1, sc, sh)
+        assert torch.equal(ops.frames_s2d(fd, 2, 1, sc.to(DEV), sh.to(DEV)).cpu(), want)
+        want = torch.empty(n, H, W, 3)
+        sim.frames_f32(fc, want, sc, sh)
+        assert torch.equal(ops.frames_f32(fd, sc.to(DEV), sh.to(DEV)).cpu(), want)
+        want = torch.empty(n, H // 2, W // 2, 3)
+        sim.frames_avgpool2(fc, want)
+        assert (ops.frames_avgpool2(fd).cpu() - want).abs().max() <= 1e-4 * 255
+
+
+@pytest.mark.gpu
+def test_policy_on_uint8_frames_and_crop_views_equals_fp32_frames():
+    """CMA act() on uint8 RGB (a quarter of the H2D bytes) and on a centre-crop VIEW of larger
+    frames gives bit-identical logits to the reference-style fp32 contiguous input."""
+    torch.manual_seed(0)
+    pol = vlnce_amd.build_model(vlnce_amd.make_config("CMAPolicy"), *vlnce_amd.make_spaces(64, 64))
+    pol.to(DEV).eval()
+    g = torch.Generator().manual_seed(5)
+    N = 3
+    big_rgb = torch.randint(0, 256, (N, 80, 72, 3), generator=g, dtype=torch.uint8).to(DEV)
+    big_d = torch.rand(N, 70, 76, 1, generator=g).to(DEV)
+    cropped = ot.CenterCropperPerSensor([("rgb", (64, 64)), ("depth", (64, 64))])(
+        {"rgb": big_rgb, "depth": big_d})
+    assert not cropped["rgb"].is_contiguous() and cropped["rgb"].dtype == torch.uint8
+    ins = torch.zeros(N, 200, dtype=torch.long)
+    ins[:, :11] = torch.randint(1, 2504, (N, 11), generator=g)
+    common = dict(instruction=ins.to(DEV))
+    h0 = torch.zeros(N, pol.net.num_recurrent_layers, 512, device=DEV)
+    prev = torch.zeros(N, 1, dtype=torch.long, device=DEV)
+    masks = torch.ones(N, 1, dtype=torch.uint8, device=DEV)
+
+    def logits(obs):
+        with torch.no_grad():
+            out = [pol.build_distribution(obs, h0, prev, masks).logits.clone() for _ in range(3)]
+        assert torch.equal(out[0], out[1]) and torch.equal(out[1], out[2])  # eager = graph replay
+        return out[0]
+
+    ref = logits(dict(common, rgb=cropped["rgb"].float().contiguous(),
+                      depth=cropped["depth"].contiguous()))
+    assert torch.equal(logits(dict(common, rgb=cropped["rgb"].contiguous(),
+                                   depth=cropped["depth"].contiguous())), ref)   # uint8
+    assert torch.equal(logits(dict(common, **cropped)), ref)                      # uint8 views

@@ -1,0 +1,116 @@
+"""GPU tier, policy parity at the BASELINE.json geometries the small goldens do not reach:
+
+* configs[4] -- WaypointPolicy, 12+1 frames of 256x256 RGB-D per env, 200-token instructions:
+  act / evaluate_actions / get_value and one WDDPPO minibatch update (loss terms + every
+  parameter-gradient norm) against the CPU oracle at a batch it finishes in seconds, plus
+  size-independent properties at the full num_envs=32 (416 frames);
+* configs[2] -- the benchmarked thing itself, `_update_agent` (base_il_trainer.py:134-180) of the
+  CMA policy at 256x256 / 80 tokens with batch-statistics BatchNorm: loss and every trainable
+  gradient against the oracle.
+Tolerance: 1e-4 (north_star), relative for quantities whose magnitude exceeds 1."""
+import copy
+
+import pytest
+import torch
+
+import cases
+import vlnce_amd
+from oracle import policy_cpu as oc
+from oracle import thirdparty as tp
+from test_oracle_golden import compare
+from test_policy_gpu import DEV, hip_ppo, hip_update, to_dev
+
+pytestmark = pytest.mark.gpu
+torch.distributions.Distribution.set_default_validate_args(False)
+
+
+def _oracle_update(policy, obs, prev, masks, targets, weights):
+    hs = policy.net.model_config.STATE_ENCODER.hidden_size
+    return oc.il_update(policy, None, obs, prev, masks, targets, weights, hs, step_grad=False)
+
+
+def _oracle_ppo(policy, sample):
+    return oc.ppo_update(policy, None, sample, step_grad=False, **cases.PPO)
+
+
+def _pair(case):
+    ref, _ = cases.build_policy(oc, case, tp.make_config, tp.make_spaces, tp.synth_state_dict)
+    hip, _ = cases.build_policy(vlnce_amd, case, vlnce_amd.make_config, vlnce_amd.make_spaces,
+                                tp.synth_state_dict)
+    return ref, hip.to(DEV)
+
+
+WP_ACT = dict(policy="WaypointPolicy", hw=256, N=2, T=1, lengths=[200, 173], mode="eval",
+              call="waypoint")
+WP_PPO = dict(policy="WaypointPolicy", hw=256, N=2, T=2, lengths=[200, 173], mode="ppo",
+              call="ppo_update")
+
+
+def test_waypoint_config5_act_and_evaluate_vs_oracle():
+    ref, hip = _pair(WP_ACT)
+    obs, prev, masks, extra = cases.build_inputs(WP_ACT)
+    want = cases.run_case(ref, WP_ACT, obs, copy.deepcopy(prev), masks, extra)
+    got = cases.run_case(hip, WP_ACT, to_dev(obs), to_dev(prev), to_dev(masks), to_dev(extra))
+    compare(got, want, atol=1e-4, rtol=1e-4)
+
+
+def test_waypoint_config5_ppo_update_vs_oracle():
+    ref, hip = _pair(WP_PPO)
+    obs, prev, masks, extra = cases.build_inputs(WP_PPO)
+    # the action components of the rollout come from the (oracle) policy's own act(), so that they
+    # lie inside the truncated-normal supports
+    with torch.no_grad():
+        B = obs["rgb"].size(0)
+        out = ref.act(obs, torch.zeros(B, ref.net.num_recurrent_layers, 256), copy.deepcopy(prev),
+                      masks, deterministic=True)
+    for k, v in out[2].items():
+        extra["act_" + k] = v.detach().clone()
+    want = cases.run_case(ref, WP_PPO, obs, copy.deepcopy(prev), masks, extra, ppo_fn=_oracle_ppo)
+    got = cases.run_case(hip, WP_PPO, to_dev(obs), to_dev(prev), to_dev(masks), to_dev(extra),
+                         ppo_fn=hip_ppo)
+    compare(got, want, atol=1e-4, rtol=1e-4)
+
+
+def test_waypoint_num_envs_32_properties():
+    """416 frames of 256x256 through the ResNet-18 / depth trunks: rows are independent of the
+    batch they ride in (eval encoders), outputs finite, shapes as the reference's."""
+    N = 32
+    case = dict(WP_ACT, N=N, lengths=[200 - 3 * (i % 11) for i in range(N)])
+    _, hip = _pair(dict(case, N=2, lengths=[200, 173]))
+    obs, prev, masks, extra = cases.build_inputs(case)
+    obs, prev, masks = to_dev(obs), to_dev(prev), to_dev(masks)
+    h0 = torch.zeros(N, hip.net.num_recurrent_layers, 256, device=DEV)
+    idx = torch.tensor([0, 5, 17, 31], device=DEV)
+    with torch.no_grad():
+        out = hip.act(obs, h0, {k: v.clone() for k, v in prev.items()}, masks, deterministic=True)
+        value, elems, logp, h1, pdist = out[0], out[2], out[5], out[6], out[7]
+        sub = hip.act({k: v[idx] for k, v in obs.items()}, h0[idx],
+                      {k: v[idx].clone() for k, v in prev.items()}, masks[idx], deterministic=True)
+        v2, lp2, ent, _ = hip.evaluate_actions(obs, h0, {k: v.clone() for k, v in prev.items()},
+                                               masks, elems)
+    assert value.shape == (N, 1) and h1.shape == (N, 2, 256) and pdist.logits.shape == (N, 13)
+    for t in (value, logp, h1, pdist.logits, v2, lp2, *ent.values()):
+        assert torch.isfinite(t).all()
+    # the sub-batch has a different Lmax (key count of the multiplicative-mask attention is the
+    # batch's longest instruction, App. B-3/B-8): compare rows whose Lmax is shared -- row 0 is
+    # the longest instruction of both batches
+    assert (sub[7].logits - pdist.logits[idx]).abs().max().item() < 1e-4
+    assert (sub[0] - value[idx]).abs().max().item() < 1e-4
+    assert (v2 - value).abs().max().item() < 1e-5  # evaluate_actions == act on the same inputs
+
+
+CMA_UPDATE = dict(policy="CMAPolicy", hw=256, N=4, T=1, lengths=[80, 74, 80, 61], mode="train",
+                  call="update", overrides={"PROGRESS_MONITOR.use": True})
+
+
+def test_cma_update_at_baseline_geometry_vs_oracle():
+    """BaseVLNCETrainer._update_agent at 256x256 / 80 tokens, batch-statistics BatchNorm as the
+    policy is constructed: loss, action / aux loss, the norm of EVERY trainable gradient, three
+    full gradient tensors and the BatchNorm running statistics."""
+    ref, hip = _pair(CMA_UPDATE)
+    obs, prev, masks, extra = cases.build_inputs(CMA_UPDATE)
+    want = cases.run_case(ref, CMA_UPDATE, obs, prev, masks, extra, _oracle_update, oc.AuxLosses)
+    got = cases.run_case(hip, CMA_UPDATE, to_dev(obs), to_dev(prev), to_dev(masks), to_dev(extra),
+                         hip_update, vlnce_amd.AuxLosses)
+    assert len(want["grad_names"]) > 30
+    compare(got, want, atol=1e-4, rtol=2e-4)

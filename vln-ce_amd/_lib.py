@@ -34,6 +34,11 @@ class Prologue(C.Structure):
                 ("side_out", _P)]
 
 
+class Frames(C.Structure):
+    _fields_ = [("x", _P), ("x2", _P), ("mask2", _P), ("dtype", _I), ("N", _I), ("F", _I),
+                ("Hs", _I), ("Ws", _I), ("C", _I), ("y0", _I), ("x0", _I), ("H", _I), ("W", _I)]
+
+
 class Epilogue(C.Structure):
     _fields_ = [("scale", _P), ("shift", _P), ("residual", _P), ("ldr", _I), ("act", _I),
                 ("accumulate", _I), ("stat_partial", _P)]
@@ -64,6 +69,10 @@ _SIGNATURES = {
     "vlnce_dagger_targets": (_I, [_P, _P, _I, _I, _F, _P, _P, _P, _P]),
     "vlnce_ppo_returns": (_I, [_P, _P, _P, _P, _P, _I, _I, _F, _F, _I, _P]),
     "vlnce_space_to_depth2": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "vlnce_frames_s2d": (_I, [C.POINTER(Frames), _P, _I, _I, _P, _P, _P]),
+    "vlnce_frames_avgpool2": (_I, [C.POINTER(Frames), _P, _P]),
+    "vlnce_frames_f32": (_I, [C.POINTER(Frames), _P, _P, _P, _P]),
+    "vlnce_frames_gather": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "vlnce_adaptive_avgpool": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "vlnce_attn_fwd": (_I, [_P, _P, _I, _P, _I, _P, _I, _F, _P, _P, _I, _I, _I, _I, _P]),
     "vlnce_attn_bwd": (_I, [_P, _P, _P, _I, _P, _I, _P, _I, _F, _P, _P, _P, _I, _P, _I,
@@ -85,6 +94,9 @@ _SIGNATURES = {
     "vlnce_rnn_seq_supported": (_I, [_I, _I]),
     "vlnce_rnn_seq_fwd": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "vlnce_rnn_seq_bwd": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "vlnce_rnn_step_supported": (_I, [_I, _I, _I]),
+    "vlnce_rnn_step_fwd": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
+    "vlnce_rnn_step_bwd": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "vlnce_select_rows": (_I, [_P, _P, _P, _P, _I, _I, _P]),
     "vlnce_act_bwd": (_I, [_P, _P, _P, _L, _I, _P]),
 }
@@ -160,7 +172,7 @@ class HipLib:
 
     name = "hip"
 
-    ABI = 110  # include/vlnce_hip.h
+    ABI = 120  # include/vlnce_hip.h
 
     def __init__(self, path=LIB_PATH):
         self.dll = load_cdll(path)
@@ -290,6 +302,37 @@ class HipLib:
                                                    _ptr(scale), _ptr(shift), _stream()),
                     "vlnce_space_to_depth2")
 
+    # ---- observation ingest
+    _DT = {torch.float32: 0, torch.uint8: 1}
+
+    def _frames(self, fr):
+        """fr: dict(x, x2, mask2, N, F, Hs, Ws, C, y0, x0, H, W) with tensors for x / x2 / mask2"""
+        x = fr["x"]
+        if fr.get("x2") is not None and fr["x2"].dtype != x.dtype:
+            raise RuntimeError("libvlnce_hip: frames and the extra frame differ in dtype")
+        return Frames(_ptr(x), _ptr(fr.get("x2")), _ptr(fr.get("mask2")), self._DT[x.dtype],
+                      *[int(fr[k]) for k in ("N", "F", "Hs", "Ws", "C", "y0", "x0", "H", "W")])
+
+    def frames_s2d(self, fr, y, pad_lo, pad_hi, scale=None, shift=None):
+        d = self._frames(fr)
+        self._check(self.dll.vlnce_frames_s2d(C.byref(d), _ptr(y), pad_lo, pad_hi, _ptr(scale),
+                                              _ptr(shift), _stream()), "vlnce_frames_s2d")
+
+    def frames_avgpool2(self, fr, y):
+        d = self._frames(fr)
+        self._check(self.dll.vlnce_frames_avgpool2(C.byref(d), _ptr(y), _stream()),
+                    "vlnce_frames_avgpool2")
+
+    def frames_f32(self, fr, y, scale=None, shift=None):
+        d = self._frames(fr)
+        self._check(self.dll.vlnce_frames_f32(C.byref(d), _ptr(y), _ptr(scale), _ptr(shift),
+                                              _stream()), "vlnce_frames_f32")
+
+    def frames_gather(self, srcs, elem_bytes, N, Hs, Ws, Cc, y0, x0, H, W, out):
+        arr = (C.c_void_p * len(srcs))(*[_ptr(t) for t in srcs])
+        self._check(self.dll.vlnce_frames_gather(arr, len(srcs), elem_bytes, N, Hs, Ws, Cc, y0, x0,
+                                                 H, W, _ptr(out), _stream()), "vlnce_frames_gather")
+
     def avgpool2x2(self, x, y, N, H, W, Cc):
         self._check(self.dll.vlnce_avgpool2x2(_ptr(x), _ptr(y), N, H, W, Cc, _stream()),
                     "vlnce_avgpool2x2")
@@ -409,6 +452,23 @@ class HipLib:
             kind, dirs, pa(w_hh_t, dirs), _ptr(lengths), pa(out, dirs), pa(gates_save, dirs),
             pa(aux_save, dirs), pa(dout, dirs), pa(dh_final, dirs), pa(dgi, dirs), pa(dgh, dirs),
             B, Lm, H, _stream()), "vlnce_rnn_seq_bwd")
+
+    def rnn_step_supported(self, N, H, lstm):
+        return bool(self.dll.vlnce_rnn_step_supported(N, H, int(lstm)))
+
+    def rnn_step_fwd(self, lstm, gi, h_prev, c_prev, mask, w_hh, b_hh, hp_out, h_out, aux_out,
+                     gates_out, N, H):
+        self._check(self.dll.vlnce_rnn_step_fwd(
+            int(lstm), _ptr(gi), _ptr(h_prev), _ptr(c_prev), _ptr(mask), _ptr(w_hh), _ptr(b_hh),
+            _ptr(hp_out), _ptr(h_out), _ptr(aux_out), _ptr(gates_out), N, H, _stream()),
+            "vlnce_rnn_step_fwd")
+
+    def rnn_step_bwd(self, lstm, dout, carry, dc, gates, aux, hp, c_prev, mask, w_hh_t, dgi, dgh,
+                     acc0, dc_prev, N, H):
+        self._check(self.dll.vlnce_rnn_step_bwd(
+            int(lstm), _ptr(dout), _ptr(carry), _ptr(dc), _ptr(gates), _ptr(aux), _ptr(hp),
+            _ptr(c_prev), _ptr(mask), _ptr(w_hh_t), _ptr(dgi), _ptr(dgh), _ptr(acc0),
+            _ptr(dc_prev), N, H, _stream()), "vlnce_rnn_step_bwd")
 
     def select_rows(self, mask, a, b, out, B, H):
         self._check(self.dll.vlnce_select_rows(_ptr(mask), _ptr(a), _ptr(b), _ptr(out), B, H,

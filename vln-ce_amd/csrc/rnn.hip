@@ -185,6 +185,176 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
   }
 }
 
+// ------------------------------------------------------------------ fused rollout steps
+// One step of a masked GRU / LSTM state encoder over N <= 16 episodes is a GEMV-sized product
+// (h W_hh^T: N x H x G*H) between two pointwise stages; as three launches forward and six backward
+// it is pure launch latency (a cached-feature DAgger update is ~2700 dependent launches).
+// Fused: forward = ONE launch per step, backward = TWO.
+//
+// rows_dot: res[r][n] = sum_k X[n][k] * Wrows[r][k] for the R weight rows of this workgroup.
+// X (N rows of K floats) sits in LDS; each wave takes rows r = wave, wave+4, ..., reads them with
+// coalesced float4 loads (lane l: k = 4l + 256 i) and reduces the N dot products by shuffles.
+template <int MAXN>
+__device__ __forceinline__ void rows_dot(const float* __restrict__ Xs, int N, int K,
+                                         const float* __restrict__ W, long ldw, int r0, int R,
+                                         float* __restrict__ res /* [R][MAXN] in LDS */) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int r = wave; r < R; r += 4) {
+    const float* wrow = W + (long)(r0 + r) * ldw;
+    float acc[MAXN];
+#pragma unroll
+    for (int n = 0; n < MAXN; ++n) acc[n] = 0.f;
+    for (int k = lane * 4; k < K; k += 256) {
+      const f32x4 w = *reinterpret_cast<const f32x4*>(wrow + k);
+#pragma unroll
+      for (int n = 0; n < MAXN; ++n)
+        if (n < N) {
+          const f32x4 x = *reinterpret_cast<const f32x4*>(Xs + n * K + k);
+          acc[n] += w.x * x.x + w.y * x.y + w.z * x.z + w.w * x.w;
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < MAXN; ++n)
+      if (n < N) {
+        const float v = wave_sum(acc[n]);
+        if (lane == 0) res[r * MAXN + n] = v;
+      }
+  }
+}
+
+constexpr int STEP_MAXN = 16;   // episodes per fused step
+constexpr int STEP_UNITS = 8;   // hidden units per workgroup (forward)
+constexpr int STEP_COLS = 16;   // carry columns per workgroup (backward)
+
+// forward step: hp = mask * h_prev (stored for backward); gh = hp W_hh^T + b_hh for this
+// workgroup's hidden units; gates; h (and c).  LSTM: c_prev masked too.
+template <bool LSTM>
+__global__ __launch_bounds__(256) void rnn_step_fwd_kernel(
+    const float* __restrict__ gi, const float* __restrict__ h_prev, const float* __restrict__ c_prev,
+    const uint8_t* __restrict__ mask, const float* __restrict__ w_hh,
+    const float* __restrict__ b_hh, float* __restrict__ hp_out, float* __restrict__ h_out,
+    float* __restrict__ aux_out, float* __restrict__ gates_out, int N, int H) {
+  constexpr int G = LSTM ? 4 : 3;
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* Xs = sm;                       // [N][H] masked previous state
+  float* res = sm + STEP_MAXN * H;      // [G*UNITS][MAXN]
+  const int j0 = blockIdx.x * STEP_UNITS;
+  for (int i = threadIdx.x; i < N * H; i += 256) {
+    const int n = i / H;
+    const float v = h_prev[i] * (mask ? (float)mask[n] : 1.f);
+    Xs[i] = v;
+    if (blockIdx.x == 0 && hp_out) hp_out[i] = v;
+  }
+  __syncthreads();
+  // weight rows of unit j: j, H+j, 2H+j(, 3H+j): gather them as G groups of UNITS rows
+  for (int g = 0; g < G; ++g)
+    rows_dot<STEP_MAXN>(Xs, N, H, w_hh, H, g * H + j0, STEP_UNITS, res + g * STEP_UNITS * STEP_MAXN);
+  __syncthreads();
+  for (int i = threadIdx.x; i < N * STEP_UNITS; i += 256) {
+    const int n = i / STEP_UNITS, u = i - n * STEP_UNITS, j = j0 + u;
+    if (j >= H) continue;
+    const float* gib = gi + (long)n * G * H;
+    float gh[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) gh[g] = res[(g * STEP_UNITS + u) * STEP_MAXN + n] + b_hh[g * H + j];
+    const long o = (long)n * H + j;
+    float* gs = gates_out + (long)n * G * H;
+    if constexpr (LSTM) {
+      const float cp = c_prev[o] * (mask ? (float)mask[n] : 1.f);
+      const float ig = sigm(gib[j] + gh[0]);
+      const float fg = sigm(gib[H + j] + gh[1]);
+      const float gg = tanhf(gib[2 * H + j] + gh[2]);
+      const float og = sigm(gib[3 * H + j] + gh[3]);
+      const float cn = fg * cp + ig * gg;
+      aux_out[o] = cn;
+      h_out[o] = og * tanhf(cn);
+      gs[j] = ig;
+      gs[H + j] = fg;
+      gs[2 * H + j] = gg;
+      gs[3 * H + j] = og;
+    } else {
+      const float hp = Xs[n * H + j];
+      const float r = sigm(gib[j] + gh[0]);
+      const float z = sigm(gib[H + j] + gh[1]);
+      const float n_ = tanhf(gib[2 * H + j] + r * gh[2]);
+      h_out[o] = (1.f - z) * n_ + z * hp;
+      aux_out[o] = gh[2];
+      gs[j] = r;
+      gs[H + j] = z;
+      gs[2 * H + j] = n_;
+    }
+  }
+}
+
+// backward step, part 1 (pointwise): dh = dout + carry; gate gradients; acc0 = dh * z (GRU) |
+// dc_prev (LSTM).  Part 2 below turns dgh into the recurrent data gradient.
+template <bool LSTM>
+__global__ __launch_bounds__(256) void rnn_step_bwd_gates_kernel(
+    const float* __restrict__ dout, const float* __restrict__ carry, const float* __restrict__ dc,
+    const float* __restrict__ gates, const float* __restrict__ aux, const float* __restrict__ hp,
+    const float* __restrict__ c_prev, const uint8_t* __restrict__ mask, float* __restrict__ dgi,
+    float* __restrict__ dgh, float* __restrict__ acc0, float* __restrict__ dc_prev, int N, int H) {
+  constexpr int G = LSTM ? 4 : 3;
+  const long total = (long)N * H;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long n = i / H;
+    const int j = (int)(i - n * H);
+    const float* g = gates + n * G * H;
+    const float d = dout[i] + carry[i];
+    float* a = dgi + n * G * H;
+    if constexpr (LSTM) {
+      const float ig = g[j], fg = g[H + j], gg = g[2 * H + j], og = g[3 * H + j];
+      const float mk = mask ? (float)mask[n] : 1.f;
+      const float cp = c_prev[i] * mk;
+      const float tc = tanhf(aux[i]);
+      const float dcc = dc[i] + d * og * (1.f - tc * tc);
+      a[j] = dcc * gg * ig * (1.f - ig);
+      a[H + j] = dcc * cp * fg * (1.f - fg);
+      a[2 * H + j] = dcc * ig * (1.f - gg * gg);
+      a[3 * H + j] = d * tc * og * (1.f - og);
+      dc_prev[i] = dcc * fg * mk;
+      acc0[i] = 0.f;
+    } else {
+      const float r = g[j], z = g[H + j], nn = g[2 * H + j];
+      const float dn = d * (1.f - z);
+      const float dz = d * (hp[i] - nn);
+      const float dnp = dn * (1.f - nn * nn);
+      const float dr = dnp * aux[i];
+      const float drp = dr * r * (1.f - r);
+      const float dzp = dz * z * (1.f - z);
+      a[j] = drp;
+      a[H + j] = dzp;
+      a[2 * H + j] = dnp;
+      float* c = dgh + n * G * H;
+      c[j] = drp;
+      c[H + j] = dzp;
+      c[2 * H + j] = dnp * r;
+      acc0[i] = d * z;
+    }
+  }
+}
+
+// backward step, part 2: carry[n, k] = mask[n] * (acc0[n, k] + sum_w dgh[n, w] * W_hh[w, k]),
+// with W_hh^T rows (wt [H][G*H]) so the reduction runs along contiguous memory
+__global__ __launch_bounds__(256) void rnn_step_bwd_carry_kernel(
+    const float* __restrict__ dgh, const float* __restrict__ wt, const float* __restrict__ acc0,
+    const uint8_t* __restrict__ mask, float* __restrict__ carry, int N, int H, int GH) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* Xs = sm;                     // [N][GH]
+  float* res = sm + (long)N * GH;     // [COLS][MAXN]
+  for (int i = threadIdx.x; i < N * GH; i += 256) Xs[i] = dgh[i];
+  __syncthreads();
+  const int k0 = blockIdx.x * STEP_COLS;
+  rows_dot<STEP_MAXN>(Xs, N, GH, wt, GH, k0, min(STEP_COLS, H - k0), res);
+  __syncthreads();
+  for (int i = threadIdx.x; i < N * STEP_COLS; i += 256) {
+    const int n = i / STEP_COLS, u = i - n * STEP_COLS, k = k0 + u;
+    if (k >= H) continue;
+    const long o = (long)n * H + k;
+    carry[o] = (acc0[o] + res[u * STEP_MAXN + n]) * (mask ? (float)mask[n] : 1.f);
+  }
+}
+
 inline int grid_for(long work) {
   long g = (work + 255) / 256;
   if (g < 1) g = 1;
@@ -287,5 +457,73 @@ extern "C" int vlnce_act_bwd(const float* dy, const float* y, float* dz, long n,
   hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(n)), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), dy, y, dz, n, act);
   VLNCE_CHECK_LAUNCH("act_bwd");
+  return 0;
+}
+
+extern "C" int vlnce_rnn_step_supported(int N, int H, int lstm) {
+  const int G = lstm ? 4 : 3;
+  return N > 0 && N <= STEP_MAXN && H % STEP_UNITS == 0 && H % 4 == 0 &&
+         ((long)N * G * H + STEP_COLS * STEP_MAXN) * 4 <= 150 * 1024;
+}
+
+extern "C" int vlnce_rnn_step_fwd(int lstm, const float* gi, const float* h_prev,
+                                  const float* c_prev, const uint8_t* mask, const float* w_hh,
+                                  const float* b_hh, float* hp_out, float* h_out, float* aux_out,
+                                  float* gates_out, int N, int H, vlnce_stream_t stream) {
+  VLNCE_CHECK_ARG(gi && h_prev && w_hh && b_hh && h_out && aux_out && gates_out && (!lstm || c_prev),
+                  "rnn_step_fwd: null argument");
+  VLNCE_CHECK_ARG(vlnce_rnn_step_supported(N, H, lstm), "rnn_step_fwd: N=%d H=%d not supported", N, H);
+  const int G = lstm ? 4 : 3;
+  const int smem = (STEP_MAXN * H + G * STEP_UNITS * STEP_MAXN) * 4;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  static bool attr[2] = {false, false};
+  auto k0 = rnn_step_fwd_kernel<false>;
+  auto k1 = rnn_step_fwd_kernel<true>;
+  if (!attr[lstm ? 1 : 0]) {
+    (void)hipFuncSetAttribute(lstm ? reinterpret_cast<const void*>(k1) : reinterpret_cast<const void*>(k0),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    attr[lstm ? 1 : 0] = true;
+  }
+  VLNCE_CHECK_ARG(smem <= 64 * 1024, "rnn_step_fwd: H too large");
+  if (lstm)
+    hipLaunchKernelGGL(k1, dim3(H / STEP_UNITS), dim3(256), smem, s, gi, h_prev, c_prev, mask, w_hh,
+                       b_hh, hp_out, h_out, aux_out, gates_out, N, H);
+  else
+    hipLaunchKernelGGL(k0, dim3(H / STEP_UNITS), dim3(256), smem, s, gi, h_prev, c_prev, mask, w_hh,
+                       b_hh, hp_out, h_out, aux_out, gates_out, N, H);
+  VLNCE_CHECK_LAUNCH("rnn_step_fwd");
+  return 0;
+}
+
+extern "C" int vlnce_rnn_step_bwd(int lstm, const float* dout, float* carry, const float* dc,
+                                  const float* gates, const float* aux, const float* hp,
+                                  const float* c_prev, const uint8_t* mask, const float* w_hh_t,
+                                  float* dgi, float* dgh, float* acc0, float* dc_prev, int N, int H,
+                                  vlnce_stream_t stream) {
+  VLNCE_CHECK_ARG(dout && carry && gates && aux && w_hh_t && dgi && dgh && acc0,
+                  "rnn_step_bwd: null argument");
+  VLNCE_CHECK_ARG(!lstm || (dc && c_prev && dc_prev), "rnn_step_bwd: LSTM needs dc / c_prev / dc_prev");
+  VLNCE_CHECK_ARG(lstm || hp, "rnn_step_bwd: GRU needs the masked previous state");
+  VLNCE_CHECK_ARG(vlnce_rnn_step_supported(N, H, lstm), "rnn_step_bwd: N=%d H=%d not supported", N, H);
+  const int G = lstm ? 4 : 3, GH = G * H;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (lstm)
+    hipLaunchKernelGGL(rnn_step_bwd_gates_kernel<true>, dim3(grid_for((long)N * H)), dim3(256), 0, s,
+                       dout, carry, dc, gates, aux, hp, c_prev, mask, dgi, dgh, acc0, dc_prev, N, H);
+  else
+    hipLaunchKernelGGL(rnn_step_bwd_gates_kernel<false>, dim3(grid_for((long)N * H)), dim3(256), 0, s,
+                       dout, carry, dc, gates, aux, hp, c_prev, mask, dgi, dgh, acc0, dc_prev, N, H);
+  VLNCE_CHECK_LAUNCH("rnn_step_bwd (gates)");
+  const int smem = (N * GH + STEP_COLS * STEP_MAXN) * 4;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rnn_step_bwd_carry_kernel),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+    attr = true;
+  }
+  // the LSTM's recurrent pre-activation gradient is dgi itself (dgh aliases it at the call site)
+  hipLaunchKernelGGL(rnn_step_bwd_carry_kernel, dim3(ceil_div(H, STEP_COLS)), dim3(256), smem, s,
+                     lstm ? dgi : dgh, w_hh_t, acc0, mask, carry, N, H, GH);
+  VLNCE_CHECK_LAUNCH("rnn_step_bwd (carry)");
   return 0;
 }

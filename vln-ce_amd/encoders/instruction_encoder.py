@@ -69,14 +69,33 @@ class InstructionEncoder(nn.Module):
                     c = ops.select_rows(m, c_new, c)
         return outs, h
 
+    DEDUP_MIN_ROWS = 16  # below this a batch is one step of distinct environments
+
     def forward(self, observations):
+        """Sequence-mode batches ([T*N, 200] tokens: a cached-feature DAgger batch,
+        dagger_trainer.py:39-114, or a DD-PPO minibatch, rollout_storage.py:154-276) repeat every
+        episode's instruction T times (and pad with all-ones rows); the recurrence is run once per
+        DISTINCT token row and the result gathered back -- same values, T-fold less LSTM work.
+        The gather's autograd adds the T gradients of a row before they enter BPTT."""
         cfg = self.config
         if cfg.sensor_uuid == "instruction":
             tokens = observations["instruction"].long()
+            if tokens.size(0) >= self.DEDUP_MIN_ROWS:
+                uniq, inverse = torch.unique(tokens, dim=0, return_inverse=True)
+                if uniq.size(0) < tokens.size(0):
+                    out = self._encode(F.embedding(uniq, self.embedding_layer.weight,
+                                                   padding_idx=self.embedding_layer.padding_idx))
+                    # [U, C, L] / [U, H] -> rows; the stacked bidirectional final state is [2, U, H]
+                    dim = 1 if (cfg.final_state_only and out.dim() == 3) else 0
+                    return out.index_select(dim, inverse)
             feats = F.embedding(tokens, self.embedding_layer.weight,
                                 padding_idx=self.embedding_layer.padding_idx)
         else:
             feats = observations["rxr_instruction"]
+        return self._encode(feats)
+
+    def _encode(self, feats):
+        cfg = self.config
         # :77-78 a step counts iff its feature vector is not all-zero; pack_padded_sequence
         # then keeps the first `length` steps of each sample.  One host sync, as upstream (.cpu()).
         lengths = (feats != 0.0).any(dim=2).sum(dim=1)

@@ -97,8 +97,15 @@ class _GraphRunner:
     def captured(self, key):
         return not self.enabled() or isinstance(self.entries.get(key), list)
 
+    @staticmethod
+    def _parts(x):
+        return tuple(x) if isinstance(x, (tuple, list)) else (x,)
+
     def __call__(self, x, key):
-        if (not self.enabled() or not x.is_cuda or torch.cuda.is_current_stream_capturing()):
+        """x: a tensor or a tuple of tensors / None (frame stack, extra frame, mask)."""
+        parts = self._parts(x)
+        probe = parts[0]
+        if (not self.enabled() or not probe.is_cuda or torch.cuda.is_current_stream_capturing()):
             return self.fn(x)
         ent = self.entries.get(key)
         if ent is None:
@@ -107,12 +114,14 @@ class _GraphRunner:
             self.entries[key] = "seen"
             return self.fn(x)
         self.entries.move_to_end(key)
-        cur = torch.cuda.current_stream(x.device)
+        cur = torch.cuda.current_stream(probe.device)
         if ent == "seen":
-            static_in = x.clone()
+            # static inputs keep the STORAGE dtype (uint8 frames stay uint8); clone() densifies
+            # a centre-crop view, so inside the graph the crop is part of this copy
+            static_in = tuple(None if t is None else t.clone() for t in parts)
             graph = torch.cuda.CUDAGraph()
             with capture_guard(), torch.cuda.graph(graph):
-                static_out = self.fn(static_in)
+                static_out = self.fn(static_in if isinstance(x, (tuple, list)) else static_in[0])
             ent = [graph, static_in, static_out, None]
             self.entries[key] = ent
         else:
@@ -121,7 +130,9 @@ class _GraphRunner:
             # done with them
             if ent[3] is not None:
                 cur.wait_event(ent[3])
-            ent[1].copy_(x)
+            for dst, src in zip(ent[1], parts):
+                if dst is not None:
+                    dst.copy_(src)
         ent[0].replay()
         out = ent[2].clone()
         ent[3] = torch.cuda.Event()
@@ -129,12 +140,14 @@ class _GraphRunner:
         return out
 
 
-def _stem_is_s2d(conv, x):
+def _stem_is_s2d(conv, H, W=None):
     """the frozen trunks run a 7x7/stride-2/pad-3 stem as a 4x4 convolution over 2x2
-    space-to-depth blocks (contiguous 16-byte operand loads instead of a 3- or 1-channel gather)."""
+    space-to-depth blocks (contiguous 16-byte operand loads instead of a 3- or 1-channel gather).
+    `H` may be a [N,H,W,C] tensor."""
+    if W is None:
+        H, W = H.size(1), H.size(2)
     return (conv.kernel_size == (7, 7) and conv.stride == (2, 2) and conv.padding == (3, 3)
-            and x.size(1) % 2 == 0 and x.size(2) % 2 == 0
-            and os.environ.get("VLNCE_STEM_S2D", "1") != "0")
+            and H % 2 == 0 and W % 2 == 0 and os.environ.get("VLNCE_STEM_S2D", "1") != "0")
 
 
 def _as_nhwc(t_nchw_logical):
@@ -314,41 +327,46 @@ class HipResNetTrunk(nn.Sequential):
         return self._conv_bn_eval(x, st[-1][0], st[-1][1], True, residual=identity)
 
     def forward(self, x_nhwc_raw):
-        """x: [B,H,W,3] pixel values 0..255 (channels-last as the simulator
-        delivers them); returns logical NCHW features."""
-        x = ops._f32c(x_nhwc_raw)
+        """x: [B,H,W,3] pixel values 0..255 -- uint8 as the simulator delivers them or fp32 as
+        habitat's batch_obs casts them -- channels-last, possibly a centre-crop view; or the
+        tuple (frames [B,F,H,W,3], extra frame [B,H,W,3], mask [B]) of ops.frames.  Returns
+        logical NCHW features."""
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             # trainable encoder: layer-by-layer forward that records what backward needs
+            x = ops.frames_f32(ops.frames(x_nhwc_raw))
             return tb.TrunkFn.apply(self, x, *self.trainable_params()).permute(0, 3, 1, 2)
-        key, train = self._graph_key(x.shape)
-        y = self._graphs(x, key)
+        key, train = self._graph_key(ops.frames_signature(x_nhwc_raw))
+        y = self._graphs(x_nhwc_raw, key)
         if train:
             self._bn_gen += 1
         return y.permute(0, 3, 1, 2)
 
-    def _graph_key(self, shape):
+    def _graph_key(self, signature):
         modes = tuple(m.training for m in self._norms)
         if any(modes) and not all(modes):
             raise NotImplementedError("mixed train/eval BatchNorm modes inside one trunk")
-        key = (tuple(shape), modes[0], tuple(p._version for p in self.parameters()),
+        key = (signature, modes[0], tuple(p._version for p in self.parameters()),
                id(self.input_scale[0]), len(list(self.children())),
                0 if modes[0] else self._bn_gen)
         return key, modes[0]
 
-    def graph_ready(self, shape):
-        """True when a forward with this input shape would only replay a captured graph."""
-        return self._graphs.captured(self._graph_key(shape)[0])
+    def graph_ready(self, x):
+        """True when a forward with this input would only replay a captured graph."""
+        return self._graphs.captured(self._graph_key(ops.frames_signature(x))[0])
 
     def _forward_impl(self, x):
         with torch.no_grad():
             kids = list(self.children())
             train = kids[1].training
             touched = []
-            s2d = _stem_is_s2d(kids[0], x)
+            fr = ops.frames(x)  # crop window / frame stack / uint8 -> read by the ingest kernel
+            s2d = _stem_is_s2d(kids[0], fr["H"], fr["W"])
             pro = self.input_scale
             if s2d:  # /255 (+mean/std) applied while regrouping, before the zero border
-                x = ops.space_to_depth2(x, 2, 1, self.input_scale[0], self.input_scale[1])
+                x = ops.frames_s2d(fr, 2, 1, self.input_scale[0], self.input_scale[1])
                 pro = None
+            else:
+                x = ops.frames_f32(fr)
             if train:
                 raw, pend = self._conv_stats(x, kids[0], kids[1], touched, prologue=pro, s2d=s2d)
                 x = ops.maxpool3x3s2(raw, pend[0], pend[1], in_relu=True, in_center=pend[2])
@@ -561,15 +579,15 @@ class TorchVisionResNet(nn.Module):
         """output of the torchvision trunk (what dagger_trainer.py:300-314 caches as
         `rgb_features`): logical [B, C, h, w]."""
         rgb = observations["rgb"]
-        self.cnn.input_scale = self._input_transform(rgb.device)
+        self.cnn.input_scale = self._input_transform(_GraphRunner._parts(rgb)[0].device)
         return self.cnn(rgb)
 
     def trunk_parameters(self):
         return self.cnn.parameters()
 
     def trunk_ready(self, observations):
-        self.cnn.input_scale = self._input_transform(observations["rgb"].device)
-        return self.cnn.graph_ready(observations["rgb"].shape)
+        self.cnn.input_scale = self._input_transform(_GraphRunner._parts(observations["rgb"])[0].device)
+        return self.cnn.graph_ready(observations["rgb"])
 
     def forward(self, observations):
         if "rgb_features" in observations:
@@ -713,20 +731,21 @@ class HipResNetEncoder(nn.Module):
         return x
 
     def forward(self, observations):
-        x = ops._f32c(observations["depth"])  # [B,H,W,1] is already channels-last
+        x = observations["depth"]  # [B,H,W,1] channels-last already; or the ops.frames tuple
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            x = ops.frames_f32(ops.frames(x))
             return tb.TrunkFn.apply(self, x, *self.trainable_params()).permute(0, 3, 1, 2)
-        return self._graphs(x, self._graph_key(x.shape)).permute(0, 3, 1, 2)
+        return self._graphs(x, self._graph_key(ops.frames_signature(x))).permute(0, 3, 1, 2)
 
-    def _graph_key(self, shape):
-        return (tuple(shape), tuple(p._version for p in self.parameters()))
+    def _graph_key(self, signature):
+        return (signature, tuple(p._version for p in self.parameters()))
 
-    def graph_ready(self, shape):
-        return self._graphs.captured(self._graph_key(shape))
+    def graph_ready(self, x):
+        return self._graphs.captured(self._graph_key(ops.frames_signature(x)))
 
     def _forward_impl(self, x):
         with torch.no_grad():
-            x = ops.avgpool2x2(x)
+            x = ops.frames_avgpool2(ops.frames(x))
             bb = self.backbone
             x = self._conv_gn(x, bb.conv1[0], bb.conv1[1], True)
             x = ops.maxpool3x3s2(x)
@@ -889,7 +908,7 @@ class VlnResnetDepthEncoder(nn.Module):
         return self.visual_encoder.parameters()
 
     def trunk_ready(self, observations):
-        return self.visual_encoder.graph_ready(observations["depth"].shape)
+        return self.visual_encoder.graph_ready(observations["depth"])
 
     def forward(self, observations):
         if "depth_features" in observations:

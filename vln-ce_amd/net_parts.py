@@ -79,5 +79,8 @@ def register_progress_loss(net, features, observations):
         return
     head = net.progress_monitor
     estimate = ops.linear(features, head.weight, head.bias, ops.ACT_TANH).squeeze(1)
-    estimate, target = torch.broadcast_tensors(estimate, observations["progress"])
+    # rows i of the [B, B] loss matrix range over the progress targets of the WHOLE batch: under
+    # data parallelism they are gathered from all ranks (AuxLosses.set_data_parallel)
+    estimate, target = torch.broadcast_tensors(estimate,
+                                               AuxLosses.gather_rows(observations["progress"]))
     AuxLosses.register_loss("progress_monitor", (estimate - target) ** 2, cfg.alpha)

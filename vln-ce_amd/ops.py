@@ -181,6 +181,107 @@ def stem_weight_s2d(w_ohwi):
             .reshape(Cout, 4, 4, 4 * Cc).contiguous())
 
 
+# ----------------------------------------------------------------- observation ingest
+def _frame_view(t):
+    """[..., H, W, C] frames tensor (uint8 or fp32) -> (base, Hs, Ws, y0, x0): `base` is a
+    contiguous-layout [images, Hs, Ws, C] tensor over the same memory and (y0, x0) the window
+    `t` occupies in each image.  A contiguous tensor is its own base; a centre-crop VIEW
+    (habitat's center_crop returns a slice, obs_transformers.py:69-79) is decoded from its strides
+    so that the crop costs nothing; any other layout is materialised."""
+    if t.dtype not in (torch.uint8, torch.float32):
+        t = t.float()
+    imgs = t.numel() // (t.size(-3) * t.size(-2) * t.size(-1)) if t.numel() else 0
+    H, W, Cc = t.shape[-3:]
+    if t.is_contiguous():
+        return t.reshape(imgs, H, W, Cc), H, W, 0, 0
+    t4 = None
+    if t.dim() == 4:
+        t4 = t
+    elif t.dim() == 5 and t.stride(0) == t.size(1) * t.stride(1):  # [N, F] merges without a copy
+        t4 = torch.as_strided(t, (imgs, H, W, Cc), t.stride()[1:], t.storage_offset())
+    if t4 is not None and imgs > 1 and t4.stride(3) == 1 and t4.stride(2) == Cc:
+        sN, sH = t4.stride(0), t4.stride(1)
+        if sH % Cc == 0 and sH > 0 and sN % sH == 0:
+            Ws, Hs = sH // Cc, sN // sH
+            off = t4.storage_offset() % sN
+            y0, rem = divmod(off, sH)
+            if rem % Cc == 0 and y0 + H <= Hs and rem // Cc + W <= Ws:
+                x0 = rem // Cc
+                base = torch.as_strided(t4, (imgs, Hs, Ws, Cc), (sN, sH, Cc, 1),
+                                        t4.storage_offset() - off)
+                return base, Hs, Ws, y0, x0
+    return t.contiguous().reshape(imgs, H, W, Cc), H, W, 0, 0
+
+
+def frames(x):
+    """Frame descriptor of an encoder input: a [N,H,W,C] sensor, a [N,F,H,W,C] frame stack, or the
+    tuple (stack [N,F,H,W,C], extra [N,H,W,C], mask [N] | None) the waypoint net feeds (12
+    panorama frames + the done-masked history frame, waypoint_predictors.py:330-375)."""
+    x2 = mask2 = None
+    if isinstance(x, (tuple, list)):
+        x, x2, mask2 = x
+    F_ = x.size(1) if x.dim() == 5 else 1
+    N = x.size(0)
+    base, Hs, Ws, y0, x0 = _frame_view(x)
+    H, W, Cc = x.shape[-3:]
+    fr = dict(x=base, x2=None, mask2=None, N=N, F=F_, Hs=Hs, Ws=Ws, C=Cc, y0=y0, x0=x0, H=H, W=W)
+    if x2 is not None:
+        assert x2.shape == (N, H, W, Cc), (x2.shape, x.shape)
+        if x2.dtype != base.dtype:
+            x2 = x2.to(base.dtype)
+        b2, Hs2, Ws2, y2, x2o = _frame_view(x2)
+        if (Hs2, Ws2, y2, x2o) != (Hs, Ws, y0, x0):  # the extra frame shares the window geometry
+            b2 = x2.contiguous()
+            if (Hs, Ws, y0, x0) != (H, W, 0, 0):
+                base = x.contiguous().reshape(N * F_, H, W, Cc)
+                fr.update(x=base, Hs=H, Ws=W, y0=0, x0=0)
+        fr["x2"] = b2
+        if mask2 is not None:
+            fr["mask2"] = mask2.reshape(-1).to(torch.uint8).contiguous()
+    fr["images"] = N * (F_ + (x2 is not None))
+    return fr
+
+
+def frames_signature(x):
+    parts = x if isinstance(x, (tuple, list)) else (x,)
+    return tuple((tuple(t.shape), t.dtype) if t is not None else None for t in parts)
+
+
+def frames_s2d(fr, pad_lo, pad_hi, scale=None, shift=None):
+    """space_to_depth2 of every frame of the descriptor (+ per-channel input transform)."""
+    y = torch.empty((fr["images"], fr["H"] // 2 + pad_lo + pad_hi, fr["W"] // 2 + pad_lo + pad_hi,
+                     4 * fr["C"]), device=fr["x"].device, dtype=torch.float32)
+    L().frames_s2d(fr, y, pad_lo, pad_hi, scale, shift)
+    return y
+
+
+def frames_avgpool2(fr):
+    y = torch.empty((fr["images"], fr["H"] // 2, fr["W"] // 2, fr["C"]), device=fr["x"].device,
+                    dtype=torch.float32)
+    L().frames_avgpool2(fr, y)
+    return y
+
+
+def frames_f32(fr, scale=None, shift=None):
+    y = torch.empty((fr["images"], fr["H"], fr["W"], fr["C"]), device=fr["x"].device,
+                    dtype=torch.float32)
+    L().frames_f32(fr, y, scale, shift)
+    return y
+
+
+def frames_gather(srcs, crop=None):
+    """out[n, f] = crop(srcs[f][n]): ObsStack (+ CenterCropperPerSensor) of F same-shaped sensors
+    [N, Hs, Ws, C] in one pass, element type preserved.  crop = (y0, x0, H, W) | None."""
+    s0 = srcs[0]
+    N, Hs, Ws, Cc = s0.shape
+    srcs = [t if t.is_contiguous() else t.contiguous() for t in srcs]
+    assert all(t.shape == s0.shape and t.dtype == s0.dtype for t in srcs)
+    y0, x0, H, W = crop if crop is not None else (0, 0, Hs, Ws)
+    out = torch.empty((N, len(srcs), H, W, Cc), device=s0.device, dtype=s0.dtype)
+    L().frames_gather(srcs, s0.element_size(), N, Hs, Ws, Cc, y0, x0, H, W, out)
+    return out
+
+
 def avgpool2x2(x):
     N, H, W, Cc = x.shape
     y = torch.empty((N, H // 2, W // 2, Cc), device=x.device, dtype=torch.float32)
@@ -465,7 +566,16 @@ class MaskedRNNSeqFn(Function):
         gh = torch.empty((N, GH), device=dev, dtype=torch.float32)
         gi3, m2 = gi.view(T, N, GH), mask.view(T, N)
         h, c = h0, (_f32c(c0) if lstm else None)
+        b_hh = _f32c(b_hh)
+        fused = lib.rnn_step_supported(N, H, lstm)
         for t in range(T):
+            if fused:  # mask, h W_hh^T and the gates of this step in ONE launch
+                lib.rnn_step_fwd(lstm, gi3[t], h, c, m2[t], w_hh, b_hh, hp[t], out[t], aux[t],
+                                 gates[t], N, H)
+                if lstm:
+                    c = aux[t]
+                h = out[t]
+                continue
             lib.mask_rows(h, m2[t], hp[t], N, H)
             lib.gemm(hp[t], H, 0, w_hh, H, 0, gh, GH, N, GH, H, shift=b_hh)
             if lstm:
@@ -500,7 +610,16 @@ class MaskedRNNSeqFn(Function):
         dh_t = torch.empty((N, H), device=dev, dtype=torch.float32)
         acc = torch.empty((N, H), device=dev, dtype=torch.float32)
         dc_prev = torch.empty((N, H), device=dev, dtype=torch.float32) if lstm else None
+        fused = lib.rnn_step_supported(N, H, lstm)
+        w_hh_t = w_hh.t().contiguous() if fused else None
         for t in range(T - 1, -1, -1):
+            if fused:  # gate gradients, then carry <- mask * (dh*z + dgh W_hh): two launches
+                c_prev = (aux[t - 1] if t > 0 else c0) if lstm else None
+                lib.rnn_step_bwd(lstm, dout[t], carry, dc, gates[t], aux[t], hp[t], c_prev, m2[t],
+                                 w_hh_t, dgi[t], dgh[t], acc, dc_prev, N, H)
+                if lstm:
+                    dc, dc_prev = dc_prev, dc
+                continue
             torch.add(dout[t], carry, out=dh_t)
             if lstm:
                 c_prev = aux[t - 1] if t > 0 else c0

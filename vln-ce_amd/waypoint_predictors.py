@@ -137,10 +137,10 @@ class WaypointPredictionNet(Net):
     def _encode_frames(self, encoder, key, frames, history, masks):
         """12 pano frames + the (done-masked) history frame as one batch of B*13 images
         (:330-375).  Returns rows [B, 12, P, C] and [B, P, C]."""
-        hist = history * masks.view(-1, 1, 1, 1).to(history.dtype)
-        allf = torch.cat([frames, hist.unsqueeze(1)], dim=1)
-        b, n = allf.shape[:2]
-        emb = rows_of(encoder({key: allf.reshape(b * n, *allf.shape[2:])}))  # [B*13, P, C]
+        # the ingest kernel reads the 12 frames and the history frame in place (times its
+        # not-done mask) -- no concatenated fp32 copy of B*13 frames (ops.frames)
+        b, n = frames.size(0), frames.size(1) + 1
+        emb = rows_of(encoder({key: (frames, history, masks.reshape(-1))}))  # [B*13, P, C]
         emb = emb.reshape(b, n, *emb.shape[1:])
         return emb[:, : self._num_panos], emb[:, self._num_panos]
 
