@@ -29,6 +29,8 @@ def main():
     ap.add_argument("--episodes", type=int, default=5)   # IL.batch_size
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--update-only", action="store_true",
+                    help="only the CMA update on the collated batch (for rocprofv3 runs)")
     a = ap.parse_args()
     dev = "cuda:0"
     rng = np.random.RandomState(0)
@@ -53,6 +55,25 @@ def main():
         out = data_path.collate_trajectories(trajs, dev, inflection_coef=3.2)
     torch.cuda.synchronize()
     e2e = (time.perf_counter() - t0) / a.iters
+
+    if a.update_only:
+        torch.manual_seed(0)
+        policy = vlnce_amd.build_model(vlnce_amd.make_config("CMAPolicy"),
+                                       *vlnce_amd.make_spaces(256, 256)).to(dev)
+        opt = torch.optim.Adam(policy.parameters(), lr=2.5e-4)
+        obs_b, prev_b, masks_b, corr_b, w_b = out
+        for _ in range(4):
+            update_agent(policy, opt, obs_b, prev_b, masks_b, corr_b, w_b, 512)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.iters):
+            update_agent(policy, opt, obs_b, prev_b, masks_b, corr_b, w_b, 512)
+        torch.cuda.synchronize()
+        upd = (time.perf_counter() - t0) / a.iters
+        print(json.dumps({"cma_update_ms": round(upd * 1e3, 3), "rows": Tmax * B,
+                          "fused_steps": os.environ.get("VLNCE_RNN_STEP_FUSED", "1"),
+                          "instr_dedup": os.environ.get("VLNCE_INSTR_DEDUP", "1")}))
+        return
 
     # kernels alone: rows already on the device
     lib = vlnce_amd.ops.L()

@@ -454,6 +454,8 @@ class HipLib:
             B, Lm, H, _stream()), "vlnce_rnn_seq_bwd")
 
     def rnn_step_supported(self, N, H, lstm):
+        if os.environ.get("VLNCE_RNN_STEP_FUSED", "1") == "0":  # A/B switch (scripts/bench_data_path.py)
+            return False
         return bool(self.dll.vlnce_rnn_step_supported(N, H, int(lstm)))
 
     def rnn_step_fwd(self, lstm, gi, h_prev, c_prev, mask, w_hh, b_hh, hp_out, h_out, aux_out,

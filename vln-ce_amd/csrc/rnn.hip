@@ -191,40 +191,77 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
 // it is pure launch latency (a cached-feature DAgger update is ~2700 dependent launches).
 // Fused: forward = ONE launch per step, backward = TWO.
 //
-// rows_dot: res[r][n] = sum_k X[n][k] * Wrows[r][k] for the R weight rows of this workgroup.
-// X (N rows of K floats) sits in LDS; each wave takes rows r = wave, wave+4, ..., reads them with
-// coalesced float4 loads (lane l: k = 4l + 256 i) and reduces the N dot products by shuffles.
-template <int MAXN>
-__device__ __forceinline__ void rows_dot(const float* __restrict__ Xs, int N, int K,
-                                         const float* __restrict__ W, long ldw, int r0, int R,
-                                         float* __restrict__ res /* [R][MAXN] in LDS */) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int r = wave; r < R; r += 4) {
-    const float* wrow = W + (long)(r0 + r) * ldw;
-    float acc[MAXN];
+// rows_dot: res[r * MAXN + n] = sum_k X[n][k] * Wrows[r][k] for the R weight rows of this
+// workgroup.  Both operands sit in LDS (row pitch K + 4 floats: neighbouring rows land on
+// different banks): the weight rows are fetched with coalesced, independent float4 loads -- one
+// memory latency for the whole panel -- and every (row, episode) pair is a private dot product
+// of a K-slice in one thread, so there is no cross-lane reduction chain (a first version reduced
+// 64-lane partials with six dependent ds_bpermute per value: 19 us per step).
+__device__ __forceinline__ void stage_rows(float* __restrict__ dst, const float* __restrict__ src,
+                                           long ld, int r0, int R, int K) {
+  // 8 independent 16-byte loads in flight per thread before the first LDS write: the panel costs
+  // ~2 memory latencies, not one per element
+  const int Kp = K + 4, k4 = K >> 2, total = R * k4;
+  for (int base = threadIdx.x; base < total; base += 256 * 8) {
+    f32x4 v[8];
 #pragma unroll
-    for (int n = 0; n < MAXN; ++n) acc[n] = 0.f;
-    for (int k = lane * 4; k < K; k += 256) {
-      const f32x4 w = *reinterpret_cast<const f32x4*>(wrow + k);
-#pragma unroll
-      for (int n = 0; n < MAXN; ++n)
-        if (n < N) {
-          const f32x4 x = *reinterpret_cast<const f32x4*>(Xs + n * K + k);
-          acc[n] += w.x * x.x + w.y * x.y + w.z * x.z + w.w * x.w;
-        }
+    for (int u = 0; u < 8; ++u) {
+      const int i = base + u * 256;
+      if (i < total) {
+        const int r = i / k4, c = (i - r * k4) * 4;
+        v[u] = *reinterpret_cast<const f32x4*>(src + (long)(r0 + r) * ld + c);
+      }
     }
 #pragma unroll
-    for (int n = 0; n < MAXN; ++n)
-      if (n < N) {
-        const float v = wave_sum(acc[n]);
-        if (lane == 0) res[r * MAXN + n] = v;
+    for (int u = 0; u < 8; ++u) {
+      const int i = base + u * 256;
+      if (i < total) {
+        const int r = i / k4, c = (i - r * k4) * 4;
+        *reinterpret_cast<f32x4*>(dst + r * Kp + c) = v[u];
       }
+    }
   }
+}
+
+template <int MAXN>
+__device__ __forceinline__ void rows_dot(const float* __restrict__ Xs, const float* __restrict__ Ws,
+                                         int N, int K, int R, float* __restrict__ part,
+                                         float* __restrict__ res) {
+  // pairs (r, n) x K-slices over the 256 threads; slice partials meet in `part`
+  const int Kp = K + 4;
+  const int P = R * N;
+  int KS = 256 / P;
+  KS = KS >= 4 ? 4 : (KS >= 2 ? 2 : 1);
+  const int len = K / KS;  // multiple of 4 (K % 16 == 0)
+  for (int t = threadIdx.x; t < P * KS; t += 256) {
+    const int pair = t % P, ks = t / P;
+    const int r = pair / N, n = pair - r * N;
+    const float* w = Ws + r * Kp + ks * len;
+    const float* x = Xs + n * Kp + ks * len;
+    float a0 = 0.f, a1 = 0.f;
+    for (int k = 0; k < len; k += 8) {
+      const f32x4 w0 = *reinterpret_cast<const f32x4*>(w + k);
+      const f32x4 x0 = *reinterpret_cast<const f32x4*>(x + k);
+      const f32x4 w1 = *reinterpret_cast<const f32x4*>(w + k + 4);
+      const f32x4 x1 = *reinterpret_cast<const f32x4*>(x + k + 4);
+      a0 += w0.x * x0.x + w0.y * x0.y + w0.z * x0.z + w0.w * x0.w;
+      a1 += w1.x * x1.x + w1.y * x1.y + w1.z * x1.z + w1.w * x1.w;
+    }
+    part[ks * P + pair] = a0 + a1;
+  }
+  __syncthreads();
+  for (int pair = threadIdx.x; pair < P; pair += 256) {
+    float v = part[pair];
+    for (int ks = 1; ks < KS; ++ks) v += part[ks * P + pair];
+    const int r = pair / N, n = pair - r * N;
+    res[r * MAXN + n] = v;
+  }
+  __syncthreads();
 }
 
 constexpr int STEP_MAXN = 16;   // episodes per fused step
 constexpr int STEP_UNITS = 8;   // hidden units per workgroup (forward)
-constexpr int STEP_COLS = 16;   // carry columns per workgroup (backward)
+constexpr int STEP_COLS = 8;    // carry columns per workgroup (backward)
 
 // forward step: hp = mask * h_prev (stored for backward); gh = hp W_hh^T + b_hh for this
 // workgroup's hidden units; gates; h (and c).  LSTM: c_prev masked too.
@@ -235,21 +272,25 @@ __global__ __launch_bounds__(256) void rnn_step_fwd_kernel(
     const float* __restrict__ b_hh, float* __restrict__ hp_out, float* __restrict__ h_out,
     float* __restrict__ aux_out, float* __restrict__ gates_out, int N, int H) {
   constexpr int G = LSTM ? 4 : 3;
+  constexpr int R = G * STEP_UNITS;
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  float* Xs = sm;                       // [N][H] masked previous state
-  float* res = sm + STEP_MAXN * H;      // [G*UNITS][MAXN]
+  const int Hp = H + 4;
+  float* Xs = sm;                          // [N][Hp] masked previous state
+  float* Ws = Xs + N * Hp;                 // [R][Hp] weight rows of this workgroup's units
+  float* part = Ws + R * Hp;               // [4][R*N]
+  float* res = part + 4 * R * STEP_MAXN;   // [R][MAXN]
   const int j0 = blockIdx.x * STEP_UNITS;
-  for (int i = threadIdx.x; i < N * H; i += 256) {
-    const int n = i / H;
-    const float v = h_prev[i] * (mask ? (float)mask[n] : 1.f);
-    Xs[i] = v;
-    if (blockIdx.x == 0 && hp_out) hp_out[i] = v;
+  // weight rows of unit j: j, H+j, 2H+j(, 3H+j), staged as G groups of UNITS consecutive rows
+  for (int g = 0; g < G; ++g) stage_rows(Ws + g * STEP_UNITS * Hp, w_hh, H, g * H + j0, STEP_UNITS, H);
+  for (int i = threadIdx.x; i < N * (H >> 2); i += 256) {
+    const int n = i / (H >> 2), k = (i - n * (H >> 2)) * 4;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(h_prev + (long)n * H + k) *
+                    (mask ? (float)mask[n] : 1.f);
+    *reinterpret_cast<f32x4*>(Xs + n * Hp + k) = v;
+    if (blockIdx.x == 0 && hp_out) *reinterpret_cast<f32x4*>(hp_out + (long)n * H + k) = v;
   }
   __syncthreads();
-  // weight rows of unit j: j, H+j, 2H+j(, 3H+j): gather them as G groups of UNITS rows
-  for (int g = 0; g < G; ++g)
-    rows_dot<STEP_MAXN>(Xs, N, H, w_hh, H, g * H + j0, STEP_UNITS, res + g * STEP_UNITS * STEP_MAXN);
-  __syncthreads();
+  rows_dot<STEP_MAXN>(Xs, Ws, N, H, R, part, res);
   for (int i = threadIdx.x; i < N * STEP_UNITS; i += 256) {
     const int n = i / STEP_UNITS, u = i - n * STEP_UNITS, j = j0 + u;
     if (j >= H) continue;
@@ -273,7 +314,7 @@ __global__ __launch_bounds__(256) void rnn_step_fwd_kernel(
       gs[2 * H + j] = gg;
       gs[3 * H + j] = og;
     } else {
-      const float hp = Xs[n * H + j];
+      const float hp = Xs[n * Hp + j];
       const float r = sigm(gib[j] + gh[0]);
       const float z = sigm(gib[H + j] + gh[1]);
       const float n_ = tanhf(gib[2 * H + j] + r * gh[2]);
@@ -340,13 +381,20 @@ __global__ __launch_bounds__(256) void rnn_step_bwd_carry_kernel(
     const float* __restrict__ dgh, const float* __restrict__ wt, const float* __restrict__ acc0,
     const uint8_t* __restrict__ mask, float* __restrict__ carry, int N, int H, int GH) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  float* Xs = sm;                     // [N][GH]
-  float* res = sm + (long)N * GH;     // [COLS][MAXN]
-  for (int i = threadIdx.x; i < N * GH; i += 256) Xs[i] = dgh[i];
-  __syncthreads();
+  const int Kp = GH + 4;
+  float* Xs = sm;                           // [N][Kp] gate gradients of this step
+  float* Ws = Xs + N * Kp;                  // [COLS][Kp] rows of W_hh^T
+  float* part = Ws + STEP_COLS * Kp;        // [4][COLS*N]
+  float* res = part + 4 * STEP_COLS * STEP_MAXN;
   const int k0 = blockIdx.x * STEP_COLS;
-  rows_dot<STEP_MAXN>(Xs, N, GH, wt, GH, k0, min(STEP_COLS, H - k0), res);
+  const int R = min(STEP_COLS, H - k0);
+  stage_rows(Ws, wt, GH, k0, R, GH);
+  for (int i = threadIdx.x; i < N * (GH >> 2); i += 256) {
+    const int n = i / (GH >> 2), c = (i - n * (GH >> 2)) * 4;
+    *reinterpret_cast<f32x4*>(Xs + n * Kp + c) = *reinterpret_cast<const f32x4*>(dgh + (long)n * GH + c);
+  }
   __syncthreads();
+  rows_dot<STEP_MAXN>(Xs, Ws, N, GH, R, part, res);
   for (int i = threadIdx.x; i < N * STEP_COLS; i += 256) {
     const int n = i / STEP_COLS, u = i - n * STEP_COLS, k = k0 + u;
     if (k >= H) continue;
@@ -462,8 +510,9 @@ extern "C" int vlnce_act_bwd(const float* dy, const float* y, float* dz, long n,
 
 extern "C" int vlnce_rnn_step_supported(int N, int H, int lstm) {
   const int G = lstm ? 4 : 3;
-  return N > 0 && N <= STEP_MAXN && H % STEP_UNITS == 0 && H % 4 == 0 &&
-         ((long)N * G * H + STEP_COLS * STEP_MAXN) * 4 <= 150 * 1024;
+  return N > 0 && N <= STEP_MAXN && H % 32 == 0 &&
+         ((long)(N + STEP_COLS) * (G * H + 4) + 5 * STEP_COLS * STEP_MAXN) * 4 <= 152 * 1024 &&
+         ((long)(N + G * STEP_UNITS) * (H + 4) + 5 * G * STEP_UNITS * STEP_MAXN) * 4 <= 152 * 1024;
 }
 
 extern "C" int vlnce_rnn_step_fwd(int lstm, const float* gi, const float* h_prev,
@@ -474,17 +523,16 @@ extern "C" int vlnce_rnn_step_fwd(int lstm, const float* gi, const float* h_prev
                   "rnn_step_fwd: null argument");
   VLNCE_CHECK_ARG(vlnce_rnn_step_supported(N, H, lstm), "rnn_step_fwd: N=%d H=%d not supported", N, H);
   const int G = lstm ? 4 : 3;
-  const int smem = (STEP_MAXN * H + G * STEP_UNITS * STEP_MAXN) * 4;
+  const int smem = ((N + G * STEP_UNITS) * (H + 4) + 5 * G * STEP_UNITS * STEP_MAXN) * 4;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   static bool attr[2] = {false, false};
   auto k0 = rnn_step_fwd_kernel<false>;
   auto k1 = rnn_step_fwd_kernel<true>;
   if (!attr[lstm ? 1 : 0]) {
     (void)hipFuncSetAttribute(lstm ? reinterpret_cast<const void*>(k1) : reinterpret_cast<const void*>(k0),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+                        hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
     attr[lstm ? 1 : 0] = true;
   }
-  VLNCE_CHECK_ARG(smem <= 64 * 1024, "rnn_step_fwd: H too large");
   if (lstm)
     hipLaunchKernelGGL(k1, dim3(H / STEP_UNITS), dim3(256), smem, s, gi, h_prev, c_prev, mask, w_hh,
                        b_hh, hp_out, h_out, aux_out, gates_out, N, H);
@@ -514,7 +562,7 @@ extern "C" int vlnce_rnn_step_bwd(int lstm, const float* dout, float* carry, con
     hipLaunchKernelGGL(rnn_step_bwd_gates_kernel<false>, dim3(grid_for((long)N * H)), dim3(256), 0, s,
                        dout, carry, dc, gates, aux, hp, c_prev, mask, dgi, dgh, acc0, dc_prev, N, H);
   VLNCE_CHECK_LAUNCH("rnn_step_bwd (gates)");
-  const int smem = (N * GH + STEP_COLS * STEP_MAXN) * 4;
+  const int smem = ((N + STEP_COLS) * (GH + 4) + 5 * STEP_COLS * STEP_MAXN) * 4;
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rnn_step_bwd_carry_kernel),
