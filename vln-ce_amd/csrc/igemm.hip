@@ -110,6 +110,50 @@ __device__ __forceinline__ void wave_stats(const f32x16 (&acc)[MT][NT], float* s
   }
 }
 
+// per-wave partials at a granularity of `rows` = 16 or 32 pixels (GroupNorm over samples of 16 /
+// 32 / ... pixels: partial tiles must not straddle samples).  Block b of 16 rows lives in MFMA
+// tile i = b / 2, accumulator registers [8 * (b % 2), +8) of both half-waves.
+template <int MT, int NT>
+__device__ __forceinline__ void wave_stats_fine(const f32x16 (&acc)[MT][NT], float* stat_partial,
+                                                int rows, int row0, int M, int col0, int N,
+                                                int half, int l31) {
+  const int nblk = MT * 32 / rows;
+  for (int b = 0; b < nblk; ++b) {
+    const int r_first = b * rows;                  // first row of the block inside the wave tile
+    const int left = M - (row0 + r_first);
+    const int valid = min(rows, left);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          if (row >= r_first && row < r_first + valid) s += acc[i][j][r];
+        }
+      s += __shfl_xor(s, 32, 64);
+      const float mean = valid > 0 ? s / (float)valid : 0.f;
+      float m2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          const float d = acc[i][j][r] - mean;
+          if (row >= r_first && row < r_first + valid) m2 += d * d;
+        }
+      m2 += __shfl_xor(m2, 32, 64);
+      const int col = col0 + j * 32 + l31;
+      if (half == 0 && col < N && left > 0) {
+        float* dst = stat_partial + ((long)((row0 + r_first) / rows) * N + col) * 2;
+        dst[0] = s;
+        dst[1] = m2;
+      }
+    }
+  }
+}
+
 // the same for ONE 32-row MFMA block (NT 32x32 tiles side by side)
 template <int NT>
 __device__ __forceinline__ void wave_stats_block(const f32x16 (&acc)[NT], float* stat_partial,
@@ -679,8 +723,12 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
 #else
   if (p.stat_partial != nullptr) {
 #endif
-    wave_stats<MT, NT>(acc, p.stat_partial, tile_m * WM + wm, p.M - (m0 + wm * WTM), WTM,
-                       n0 + wn * WTN, p.N, half, l31);
+    if (p.stat_rows > 0 && p.stat_rows < WTM)
+      wave_stats_fine<MT, NT>(acc, p.stat_partial, p.stat_rows, m0 + wm * WTM, p.M, n0 + wn * WTN,
+                              p.N, half, l31);
+    else
+      wave_stats<MT, NT>(acc, p.stat_partial, tile_m * WM + wm, p.M - (m0 + wm * WTM), WTM,
+                         n0 + wn * WTN, p.N, half, l31);
   }
 
   // ------------------------------------------------------------------ epilogue
@@ -1322,15 +1370,13 @@ int dispatch_dma(const IgemmParams& p, hipStream_t s) {
   // 128x64 is the largest tile: 128x128 would need accumulators + the deferred-store copy +
   // double-buffered fragments = more than the 256 registers two waves per SIMD leave each.
   // The M extent (hence the statistics granularity, vlnce_conv2d_tile_rows) is choose_tile's.
-  IgemmParams q = p;
-  q.stat_rows = choose_tile(p.M, p.N).bm / 2;  // what vlnce_conv2d_tile_rows told the caller
-  if ((long)ceil_div(p.M, 128) * ceil_div(p.N, 64) >= 512) return launch_dma<128, 64, PRO>(q, s);
-  q.stat_rows = 32;
-  if (choose_tile(p.M, p.N).bm != 64) {  // cannot happen: fewer than 512 128x64 tiles => 64x64
+  // p.stat_rows (what vlnce_conv2d_tile_rows told the caller) is 64 or 32 here (dma_ok)
+  if ((long)ceil_div(p.M, 128) * ceil_div(p.N, 64) >= 512) return launch_dma<128, 64, PRO>(p, s);
+  if (p.stat_partial && p.stat_rows != 32) {
     vlnce_set_error("conv_dma: inconsistent statistics granularity");
     return 1;
   }
-  return launch_dma<64, 64, PRO>(q, s);
+  return launch_dma<64, 64, PRO>(p, s);
 }
 
 // what conv_dma_kernel covers: 32-channel K-tiles inside one filter tap, at least 2 of them,
@@ -1342,20 +1388,27 @@ bool dma_ok(const IgemmParams& p) {
   return !off && (p.Cin % 32 == 0) && p.K >= 64 && (p.lda % 4 == 0) && (p.ldb % 4 == 0) &&
          (p.N % 32 == 0) && p.KH * p.KW <= 32 && p.a_bytes + bias < 0x7fffffffL &&
          p.b_bytes < 0x7fffffffL && p.c_bytes < 0x7fffffffL && !p.residual && !p.accumulate &&
-         !p.A2 && !p.side_out && p.Cin <= 4096;
+         !p.A2 && !p.side_out && p.Cin <= 4096 && !(p.stat_partial && p.stat_rows < 32);
 }
 
 }  // namespace
 
-// rows per statistics partial = the M extent of one wave's sub-tile (BM / 2)
-extern "C" int vlnce_conv2d_tile_rows(const vlnce_conv_desc* d) {
+// rows per statistics partial: the M extent of one wave's sub-tile (BM / 2 = 64 or 32), halved
+// down to 16 while it does not divide a sample's pixel count (GroupNorm needs partials that do
+// not straddle samples; habitat's depth trunk ends at 4x4 = 16 pixels per sample)
+static int stat_rows_for(const vlnce_conv_desc* d) {
   const long M = (long)d->N * d->Ho * d->Wo;
-  return choose_tile(M, d->Cout).bm / 2;
+  int r = choose_tile(M, d->Cout).bm / 2;
+  const int hw = d->Ho * d->Wo;
+  while (r > 16 && hw % r != 0) r /= 2;
+  return r;
 }
+
+extern "C" int vlnce_conv2d_tile_rows(const vlnce_conv_desc* d) { return stat_rows_for(d); }
 
 extern "C" int vlnce_conv2d_tiles_m(const vlnce_conv_desc* d) {
   const long M = (long)d->N * d->Ho * d->Wo;
-  return ceil_div(M, choose_tile(M, d->Cout).bm / 2);
+  return ceil_div(M, stat_rows_for(d));
 }
 
 extern "C" int vlnce_conv2d_fwd(const float* x, const float* w, float* y, const vlnce_conv_desc* d,
@@ -1410,6 +1463,7 @@ extern "C" int vlnce_conv2d_fwd(const float* x, const float* w, float* y, const 
   p.a_bytes = (((long)d->N * d->H * d->W - 1) * p.lda + d->Cin) * 4;
   p.b_bytes = (long)d->Cout * p.K * 4;
   p.c_bytes = ((M - 1) * p.ldc + d->Cout) * 4;
+  p.stat_rows = stat_rows_for(d);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (p.A2 != nullptr || p.side_out != nullptr) {
     VLNCE_CHECK_ARG(p.A2 && p.in_scale && d->KH == 1 && d->KW == 1 && d->stride == 1 &&
