@@ -112,7 +112,7 @@ int vlnce_colsum(const float* x, int ldx, int M, int N, float* out, int accumula
  * vlnce_bn_finalize reduces the conv epilogue's partials (Chan's parallel
  * variance, fp64 combine) into per-channel scale/shift and updates the running
  * statistics exactly like torch (unbiased running_var). */
-size_t vlnce_bn_finalize_workspace_bytes(int tiles_m, int C); /* currently always 0 */
+size_t vlnce_bn_finalize_workspace_bytes(int tiles_m, int C); /* 0 unless tiles_m > 4096 */
 int vlnce_bn_finalize(const float* stat_partial, int tiles_m, int tile_rows, int M, int C,
                       const float* gamma, const float* beta, float eps, float momentum,
                       float* running_mean, float* running_var, /* may be NULL */

@@ -193,18 +193,20 @@ def test_gemm_accumulate_and_strided_views(hip):
 
 
 # ------------------------------------------------------------------ norms / pools
-@pytest.mark.parametrize("tiles,Cc", [(7, 96), (256, 64), (700, 64), (8192, 64), (300, 200)])
+@pytest.mark.parametrize("tiles,Cc", [(7, 96), (256, 64), (700, 64), (8192, 64), (300, 200),
+                                      (16389, 64), (4099, 32)])
 def test_bn_finalize_contract(hip, tiles, Cc):
-    rows = 128
+    rows = 64
     M = tiles * rows - 40
     part = rnd(tiles, Cc, 2, seed=1).abs()
     t = dict(partial=part, gamma=rnd(Cc, seed=2), beta=rnd(Cc, seed=3),
              running_mean=rnd(Cc, seed=4), running_var=rnd(Cc, seed=5).abs(),
              scale_out=torch.zeros(Cc), shift_out=torch.zeros(Cc), mean_out=torch.zeros(Cc),
              rstd_out=torch.zeros(Cc))
+    # more than 4096 tiles: the finalize first coarsens the partials into caller-provided scratch
     wb = _lib.get_lib().bn_finalize_workspace_bytes(tiles, Cc)
-    assert wb == 0  # the single-launch finalize needs no scratch
-    t["workspace"] = None
+    assert (wb > 0) == (tiles > 4096)
+    t["workspace"] = torch.zeros(wb // 8, dtype=torch.float64) if wb else None
     sc = dict(tiles_m=tiles, tile_rows=rows, M=M, Cc=Cc, eps=1e-5, momentum=0.1)
     cpu, gpu = both("bn_finalize", t, sc)
     for k in ("scale_out", "shift_out", "mean_out", "rstd_out", "running_mean", "running_var"):

@@ -140,7 +140,8 @@ def test_ingest_kernels_match_their_contract(dtype):
 @pytest.mark.gpu
 def test_policy_on_uint8_frames_and_crop_views_equals_fp32_frames():
     """CMA act() on uint8 RGB (a quarter of the H2D bytes) and on a centre-crop VIEW of larger
-    frames gives bit-identical logits to the reference-style fp32 contiguous input."""
+    frames gives the logits of the reference-style fp32 contiguous input (the ingest itself is
+    bit-exact, test_ingest_kernels_match_their_contract; downstream split-K atomics round)."""
     torch.manual_seed(0)
     pol = vlnce_amd.build_model(vlnce_amd.make_config("CMAPolicy"), *vlnce_amd.make_spaces(64, 64))
     pol.to(DEV).eval()
@@ -161,11 +162,13 @@ def test_policy_on_uint8_frames_and_crop_views_equals_fp32_frames():
     def logits(obs):
         with torch.no_grad():
             out = [pol.build_distribution(obs, h0, prev, masks).logits.clone() for _ in range(3)]
-        assert torch.equal(out[0], out[1]) and torch.equal(out[1], out[2])  # eager = graph replay
+        # eager = capturing call = graph replay (to rounding: small-batch convolutions and tail
+        # GEMMs combine split-K partial sums with fp32 atomics)
+        assert (out[0] - out[1]).abs().max() < 1e-5 and (out[1] - out[2]).abs().max() < 1e-5
         return out[0]
 
     ref = logits(dict(common, rgb=cropped["rgb"].float().contiguous(),
                       depth=cropped["depth"].contiguous()))
-    assert torch.equal(logits(dict(common, rgb=cropped["rgb"].contiguous(),
-                                   depth=cropped["depth"].contiguous())), ref)   # uint8
-    assert torch.equal(logits(dict(common, **cropped)), ref)                      # uint8 views
+    u8 = logits(dict(common, rgb=cropped["rgb"].contiguous(), depth=cropped["depth"].contiguous()))
+    assert (u8 - ref).abs().max() < 1e-5                                          # uint8
+    assert (logits(dict(common, **cropped)) - ref).abs().max() < 1e-5            # uint8 views

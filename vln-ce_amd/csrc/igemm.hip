@@ -1488,7 +1488,40 @@ extern "C" int vlnce_conv2d_fwd(const float* x, const float* w, float* y, const 
     }
     return dispatch_dma<1>(p, s);
   }
-  if (v4 && buf_ok(p)) return dispatch_tiles<A_BUF, B_BUF>(p, s);
+  if (v4 && buf_ok(p)) {
+    // Small batches (act() at num_envs 1..8, eval BatchNorm folded into scale/shift): a late
+    // ResNet layer is a handful of 64x64 tiles with a reduction of up to 144 K-tiles -- one
+    // workgroup walking them alone is pure latency (20-50 us per layer).  Split the reduction
+    // over blockIdx.y with atomic accumulation into a zeroed output and apply the epilogue
+    // (scale/shift/residual/activation) in a second, row-wise pass.
+    const int sk = (!p.stat_partial && !p.accumulate && p.ldc == p.N &&
+                    ((p.scale && p.shift) || (!p.scale && !p.residual)))
+                       ? choose_splitk(p)
+                       : 1;
+    if (sk > 1) {
+      const float* scale = p.scale;
+      const float* shift = p.shift;
+      const float* residual = p.residual;
+      const int act = p.act, ldr = p.ldr;
+      p.scale = p.shift = p.residual = nullptr;
+      p.act = 0;
+      p.splitk = sk;
+      vlnce_zero(y, M, p.N, p.ldc, s);
+      if (int rc = dispatch_small<A_BUF, B_BUF>(p, s)) return rc;
+      if (scale) {
+        VLNCE_CHECK_ARG(!residual || ldr == p.N, "conv2d_fwd: split-K needs a contiguous residual");
+        return vlnce_scale_shift_act(y, scale, shift, nullptr, 0, residual, y, M, p.N, act, stream);
+      }
+      if (shift || act) {
+        const long work = M * p.N;
+        const int grid = (int)((work + 255) / 256 > 2048 ? 2048 : (work + 255) / 256);
+        hipLaunchKernelGGL(bias_act_kernel, dim3(grid), dim3(256), 0, s, y, p.ldc, (int)M, p.N, shift, act);
+        VLNCE_CHECK_LAUNCH("conv2d_fwd bias/act");
+      }
+      return 0;
+    }
+    return dispatch_tiles<A_BUF, B_BUF>(p, s);
+  }
   if (v4) return dispatch_tiles<A_IM2COL_V4, B_NK_V4>(p, s);
   if (d->KW == 7 && d->Cin == 3) return dispatch_stem<3>(p, s);
   if (d->KW == 7 && d->Cin == 1) return dispatch_stem<1>(p, s);

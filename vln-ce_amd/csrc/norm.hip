@@ -98,6 +98,46 @@ __global__ __launch_bounds__(BNF_CH* BNF_SL) void bn_finalize_kernel(
   }
 }
 
+// Layers with very many statistics partials (the 7x7 stem at num_envs=64: 16384 tiles of 64
+// rows) first merge groups of BN_COARSEN consecutive tiles -- Chan's update, one thread per (coarse
+// tile, channel), all loads independent -- so that the finalize keeps its tiles in registers.
+constexpr int BN_COARSEN = 16;
+__global__ __launch_bounds__(256) void bn_coarsen_kernel(const float* __restrict__ partial,
+                                                         int tiles_m, int tile_rows, int M, int C,
+                                                         float* __restrict__ coarse) {
+  const int ctiles = (tiles_m + BN_COARSEN - 1) / BN_COARSEN;
+  const long total = (long)ctiles * C;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int ct = (int)(i / C), c = (int)(i - (long)ct * C);
+    const int t0 = ct * BN_COARSEN;
+    float2 v[BN_COARSEN];
+#pragma unroll
+    for (int k = 0; k < BN_COARSEN; ++k) {
+      v[k] = float2{0.f, 0.f};
+      if (t0 + k < tiles_m) v[k] = *reinterpret_cast<const float2*>(partial + ((long)(t0 + k) * C + c) * 2);
+    }
+    double s = 0.0;
+    long rows = 0;
+#pragma unroll
+    for (int k = 0; k < BN_COARSEN; ++k)
+      if (t0 + k < tiles_m) {
+        s += (double)v[k].x;
+        rows += min(tile_rows, M - (t0 + k) * tile_rows);
+      }
+    const double mean = s / (double)rows;
+    double m2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < BN_COARSEN; ++k)
+      if (t0 + k < tiles_m) {
+        const int nt = min(tile_rows, M - (t0 + k) * tile_rows);
+        const double d = (double)v[k].x / (double)nt - mean;
+        m2 += (double)v[k].y + (double)nt * d * d;
+      }
+    coarse[i * 2] = (float)s;
+    coarse[i * 2 + 1] = (float)m2;
+  }
+}
+
 // ---------------------------------------------------------------- scale/shift/act apply
 template <bool VEC>
 __global__ __launch_bounds__(256) void scale_shift_act_kernel(
@@ -278,9 +318,9 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(
 }  // namespace
 
 extern "C" size_t vlnce_bn_finalize_workspace_bytes(int tiles_m, int C) {
-  (void)tiles_m;
-  (void)C;
-  return 0;  // the single-launch finalize needs no scratch (kept in the ABI for callers)
+  // more tiles than the finalize holds in registers: room for the coarsened partials
+  if (tiles_m <= 4096) return 0;
+  return (size_t)ceil_div(tiles_m, BN_COARSEN) * C * 2 * sizeof(float);
 }
 
 extern "C" int vlnce_bn_finalize(const float* stat_partial, int tiles_m, int tile_rows, int M,
@@ -289,8 +329,6 @@ extern "C" int vlnce_bn_finalize(const float* stat_partial, int tiles_m, int til
                                  float* scale_out, float* shift_out, float* mean_out,
                                  float* rstd_out, void* workspace, size_t workspace_bytes,
                                  vlnce_stream_t stream) {
-  (void)workspace;
-  (void)workspace_bytes;
   VLNCE_CHECK_ARG(stat_partial && scale_out && shift_out, "bn_finalize: null argument");
   VLNCE_CHECK_ARG(tiles_m > 0 && tile_rows > 0 && M > 0 && C > 0, "bn_finalize: bad shape");
   VLNCE_CHECK_ARG((long)(tiles_m - 1) * tile_rows < M && (long)tiles_m * tile_rows >= M,
@@ -298,6 +336,18 @@ extern "C" int vlnce_bn_finalize(const float* stat_partial, int tiles_m, int til
   VLNCE_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr),
                   "bn_finalize: running stats must come together");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const size_t need = vlnce_bn_finalize_workspace_bytes(tiles_m, C);
+  if (need > 0 && workspace != nullptr && workspace_bytes >= need) {
+    float* coarse = static_cast<float*>(workspace);
+    const int ctiles = ceil_div(tiles_m, BN_COARSEN);
+    long g = ((long)ctiles * C + 255) / 256;
+    hipLaunchKernelGGL(bn_coarsen_kernel, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0, s,
+                       stat_partial, tiles_m, tile_rows, M, C, coarse);
+    VLNCE_CHECK_LAUNCH("bn_coarsen");
+    stat_partial = coarse;
+    tiles_m = ctiles;
+    tile_rows *= BN_COARSEN;
+  }
   if (tiles_m > 256)
     hipLaunchKernelGGL((bn_finalize_kernel<4, 256>), dim3(ceil_div(C, 4)), dim3(1024), 0, s,
                        stat_partial, tiles_m, tile_rows, M, C, gamma, beta, eps, momentum,
