@@ -63,8 +63,7 @@ struct IgemmParams {
   float* stat_partial;
   int tiles_m, tiles_n;
   int splitk;  // > 1: blockIdx.y owns a K range and atomically adds into a pre-zeroed C
-  int pk_tiles;  // conv_dma_kernel: tiles one workgroup walks before it retires
-  int stat_rows;  // conv_dma_kernel: rows per statistics partial (vlnce_conv2d_tile_rows)
+  int stat_rows;  // rows per statistics partial (vlnce_conv2d_tile_rows)
   long a_bytes, b_bytes, c_bytes;  // extents of A / B / C for the buffer descriptors
 };
 
@@ -822,387 +821,442 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
 }
 
 // ====================================================================================
-// conv_dma_kernel: the hot convolution path (channels-last, Cin % 16 == 0, [N,K] weights).
+// conv_x3_kernel: the hot convolution path (channels-last, Cin % 32 == 0, [N,K] weights).
 //
-// Measured on the one-tile-per-workgroup kernel above (profiles/r02_c_*): layer time ~= time of
-// the data movement alone + time of the MFMAs alone, i.e. the two never overlapped -- every
-// K-tile pays "wait for the staged loads, write LDS, barrier, read fragments" with the matrix
-// pipe idle (~400-600 cycles per K-tile), and every tile pays a cold prologue and an epilogue
-// whose stores must drain before the workgroup can retire.  This kernel removes those seams:
-//   * operands go global -> LDS by DMA (buffer_load ... lds): no staging registers, no LDS
-//     write pass, and a ring of 3 K-tiles of 32 channels in flight.  LDS rows are the
-//     unpadded 128-byte K-runs the DMA writes (wave-linear), chunk-swizzled on the SOURCE
-//     address ((row/2)&7 xor chunk) so that the ds_read_b128 fragment reads are conflict-free;
-//   * the K loop is rotated: the MFMA operands of the next group (also across K-tiles and
-//     across output tiles) are read while the current group's MFMAs issue, and the ONE barrier
-//     per K-tile sits in the middle of the MFMA stream ("stage t+1 has landed for everybody,
-//     stage t-1 is free") -- nothing but barrier skew is left between MFMAs;
-//   * the prologue of the A operand (previous layer's BatchNorm + ReLU, zero padding AFTER it)
-//     is applied to the fragments in registers; its per-channel vectors ride in the stage;
-//   * a workgroup walks a strided list of output tiles (bounded: it retires after pk_tiles so
-//     that kernels of side streams get CU slots); the DMA ring runs across tile boundaries;
-//   * epilogue straight from the accumulator registers, no LDS, no barrier: statistics partials
-//     per wave, then scale/shift/activation into a register copy whose 4-byte row-segment
-//     stores (2 full 128-byte lines per instruction) are issued ONE PER MFMA during the next
-//     tile's first K-tile (counted vmcnt: the ring never waits for a store).
-template <int BM, int BN, int PRO>
-__global__ __launch_bounds__(256, 2) void conv_dma_kernel(IgemmParams p) {
+// fp32 convolution on the bf16 matrix pipe.  gfx950 has no fp32-rate matrix instruction beyond
+// v_mfma_f32_32x32x2_f32 (157 TF/s, = the vector rate); v_mfma_f32_32x32x16_bf16 is 16x faster.
+// Every fp32 operand is split EXACTLY into three bf16 planes by truncation,
+//     x = x1 + x2 + x3   (8 + 8 + 8 mantissa bits, same exponent range as fp32),
+// and a product a*b is the six plane products of order <= 2^-16,
+//     a1 b1 + (a1 b2 + a2 b1) + (a2 b2 + a1 b3 + a3 b1),
+// each exact in the fp32 accumulator; the dropped terms are O(2^-24) relative, the size of an
+// fp32 rounding.  Measured against fp64 the result error is 1.1-1.2x that of the fp32-MFMA
+// kernel above and the same as rocBLAS/MIOpen fp32 (profiles/r02_o_conv_accuracy_*.txt).  Six
+// bf16 MFMAs of 32 cycles replace eight fp32 MFMAs of 64 cycles per 32x32x16 block: 2.7x less
+// matrix-pipe time.
+//
+// What the fp32-MFMA kernel taught (profiles/r02_c_*): with every wave doing "load, transform,
+// write LDS, barrier, read fragments, MFMA", the matrix pipe idles while the wave does anything
+// else, and the co-resident workgroup runs in lock-step, so nothing covers it.  Here the roles
+// are split.  A workgroup is 16 waves, four per SIMD, one workgroup per CU:
+//   * waves 8-15, the PRODUCERS (two per SIMD: one wave alone issues one instruction per ~4
+//     cycles, not enough for ~400 instructions per K-tile): buffer-load the A (im2col) and B
+//     (weight) K-tiles into a register ring several tiles ahead, apply the operand prologue
+//     (previous layer's BatchNorm + ReLU, the dual-input block end, zero padding after it),
+//     split to bf16 planes and write them to LDS;
+//   * waves 0-7, the MATRIX waves (two per SIMD, taking turns on the matrix pipe: while one
+//     waits for LDS or a counter the other issues): ds_read_b128 fragments, MFMAs, and the
+//     epilogue of their 64x32 sub-tile straight from the accumulator registers.
+// The SIMD's matrix pipe (matrix wave) and its VALU / memory pipes (producer waves) run side by
+// side by hardware arbitration, not by compiler scheduling.
+// LDS: two stages of {A, B} x 3 planes x rows x 80 bytes (32 bf16 + 16 bytes pad: the
+// ds_read_b128 fragment reads are conflict-free).  The hand-over is two LDS counters instead of
+// s_barrier (measured: a barrier per K-tile costs the matrix pipe ~200 idle cycles of skew):
+// per stage, `full` counts its writes (8 per K-tile), `empty` the matrix waves done reading it
+// (8 per K-tile); whoever is ahead never waits.  The LDS unit executes one wave's operations in
+// order, so "data writes, then counter add" needs no wait in between.
+// A workgroup walks a strided list of output tiles; the K-tile stream (and the producers'
+// register ring) runs across tile boundaries, so the prologue of a tile (addresses, first loads)
+// and its epilogue are covered by the neighbours' MFMAs.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int X3_PITCH = 80;      // bytes per LDS row of one plane
+constexpr int X3_PRODUCERS = 8;  // producer waves; the matrix waves are WM x WN = 8 (or 4)
+
+template <int ROWS, int DUAL>
+struct X3Staged {
+  f32x4 a[ROWS];
+  f32x4 a2[DUAL ? ROWS : 1];
+  f32x4 ps, pt, pc, p2s, p2t, p2c;
+  unsigned ok;
+  int kcur, m0;
+};
+
+// x (4 consecutive k of one row) -> the three planes' 8-byte LDS words
+__device__ __forceinline__ void x3_split_store(f32x4 x, char* row_ptr, int plane_bytes) {
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+#ifdef X3_DBG_NOSPLIT  // ceiling probe: what the kernel does when the split costs nothing
+  const f32x4 r = x, s = x;
+#else
+  const u32x4 xm = __builtin_bit_cast(u32x4, x) & 0xffff0000u;
+  const f32x4 r = x - __builtin_bit_cast(f32x4, xm);
+  const u32x4 rm = __builtin_bit_cast(u32x4, r) & 0xffff0000u;
+  const f32x4 s = r - __builtin_bit_cast(f32x4, rm);
+#endif
+  const u32x4 xb = __builtin_bit_cast(u32x4, x), rb = __builtin_bit_cast(u32x4, r),
+              sb = __builtin_bit_cast(u32x4, s);
+  const u32x2 h = {__builtin_amdgcn_perm(xb[1], xb[0], 0x07060302u),
+                   __builtin_amdgcn_perm(xb[3], xb[2], 0x07060302u)};
+  const u32x2 m = {__builtin_amdgcn_perm(rb[1], rb[0], 0x07060302u),
+                   __builtin_amdgcn_perm(rb[3], rb[2], 0x07060302u)};
+  const u32x2 l = {__builtin_amdgcn_perm(sb[1], sb[0], 0x07060302u),
+                   __builtin_amdgcn_perm(sb[3], sb[2], 0x07060302u)};
+  *reinterpret_cast<u32x2*>(row_ptr) = h;
+  *reinterpret_cast<u32x2*>(row_ptr + plane_bytes) = m;
+  *reinterpret_cast<u32x2*>(row_ptr + 2 * plane_bytes) = l;
+}
+
+__device__ __forceinline__ int x3_peek(const int* flag) {
+  return __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void x3_wait(const int* flag, int seen, int need) {
+  while (seen < need) {
+    __builtin_amdgcn_s_sleep(1);
+    seen = x3_peek(flag);
+  }
+  asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void x3_signal(int* flag) {
+  asm volatile("" ::: "memory");
+  __hip_atomic_fetch_add(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+template <int BM, int BN, int WM, int WN, int DUAL>
+__global__ __launch_bounds__((WM * WN + X3_PRODUCERS) * 64) void conv_x3_kernel(IgemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  constexpr int NSTAGE = 3;
-  constexpr int DBK = 32;                   // channels per K-tile (one 128-byte LDS row)
-  constexpr int NG = DBK / 8;               // MFMA operand groups (8 channels) per K-tile
-  constexpr int WTM = BM / 2, WTN = BN / 2, MT = WTM / 32, NT = WTN / 32;
-  constexpr int RB = 128, RPI = 8;          // row bytes; rows per wave-wide DMA instruction
-  constexpr int A_BYTES = BM * RB, B_BYTES = BN * RB, PV_BYTES = PRO ? 384 : 0;
-  constexpr int STAGE_BYTES = A_BYTES + B_BYTES + PV_BYTES;
-  constexpr int A_INSTR = BM / RPI / 4, B_INSTR = BN / RPI / 4;  // DMA instructions per wave
-  constexpr int GM = 4 * MT * NT;           // MFMAs (= deferred stores) per operand group
-  constexpr int H2 = 2 * GM;                // ... per half K-tile
-  constexpr int NS = 16 * MT * NT;          // accumulator registers = stores per wave per tile
-  static_assert(NS == NG * GM, "a tile's stores cover exactly one K-tile of MFMAs");
-  typedef __attribute__((address_space(3))) void lds_void;
+  constexpr int X3_MATRIX = WM * WN;  // matrix waves (8: two per SIMD take turns on the pipe)
+  constexpr int WTM = BM / WM, WTN = BN / WN, MT = WTM / 32, NT = WTN / 32;
+  constexpr int A_PLANE = BM * X3_PITCH, B_PLANE = BN * X3_PITCH;
+  constexpr int A_BYTES = 3 * A_PLANE, B_BYTES = 3 * B_PLANE;
+  constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
+  constexpr int PR = X3_PRODUCERS * 64 / 8;          // rows per producer pass (8 float4 each)
+  constexpr int A_ROWS = BM / PR, B_ROWS = BN / PR;  // producer passes
+  static_assert(MT >= 1 && NT >= 1 && A_ROWS >= 1 && B_ROWS >= 1, "tile");
 
-  extern __shared__ __attribute__((aligned(16))) char dsm[];
+  extern __shared__ __attribute__((aligned(16))) char xsm[];
+  // counters per STAGE: waves are at most one K-tile apart, so a single running count could be
+  // reached by fast waves' next-K-tile adds while a slow wave's are missing; a stage's count
+  // cannot (its next use waits for everybody's current one)
+  int* const full = reinterpret_cast<int*>(xsm + 2 * STAGE_BYTES);  // [2]
+  int* const empty = full + 2;                                       // [2]
 
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-  const int half = lane >> 5, l31 = lane & 31;
+  const int half = lane >> 5;
+  const int l31 = lane & 31;
+  const int KT = p.K / BK;
 
-  // ---- this workgroup's tile list (see launch_dma): XCD-contiguous, stride 64, pk_tiles long
-  constexpr int PK_RES = 64;
+  // ---- this workgroup's tiles: virtual block ids blockIdx.x + r * gridDim.x through the
+  // XCD-aware map of igemm_kernel (gridDim.x is a multiple of 8 or the whole tile count)
   const int ntiles = p.tiles_m * p.tiles_n;
-  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int per_xcd = (ntiles + 7) >> 3;
-  const int round = slot / PK_RES;
-  const int x0 = xcd * per_xcd + round * (PK_RES * p.pk_tiles);
-  const int t_end = min(min(ntiles, (xcd + 1) * per_xcd), x0 + PK_RES * p.pk_tiles);
-  const int first_tile = x0 + (slot - round * PK_RES);
-  if (first_tile >= t_end) return;
-  const int KT = p.K / DBK;
-  const int HoWo = p.Ho * p.Wo;
-  const bool taps_matter = PRO && (p.KH * p.KW > 1);
-
-  // ---- buffer descriptors (wave-uniform: kernel arguments only)
-  const long bias = ((long)p.pad * p.W + p.pad) * p.lda * 4;  // keeps voffsets non-negative
-  const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<char*>(reinterpret_cast<const char*>(p.A)) - bias, 0, (int)(p.a_bytes + bias),
-      0x00020000);
-  const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<char*>(reinterpret_cast<const char*>(p.B)), 0, (int)p.b_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsrc_c = __builtin_amdgcn_make_buffer_rsrc(
-      reinterpret_cast<char*>(p.C), 0, (int)p.c_bytes, 0x00020000);
-  __amdgpu_buffer_rsrc_t rsrc_ps = rsrc_b, rsrc_pt = rsrc_b, rsrc_pc = rsrc_b;
-  if constexpr (PRO) {
-    rsrc_ps = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in_scale), 0, p.Cin * 4, 0x00020000);
-    rsrc_pt = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in_shift), 0, p.Cin * 4, 0x00020000);
-    rsrc_pc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in_center), 0, p.Cin * 4, 0x00020000);
-  }
-
-  // ------------------------------------------------------------------ loader (DMA) side
-  // instruction j of this wave fills LDS rows [(j*4 + wave)*8, +8): lane -> row lane/8,
-  // PHYSICAL 16-byte chunk lane%8, which holds LOGICAL chunk (lane%8) ^ ((row/2)&7)
-  const int drow = lane >> 3, dchunk = lane & 7;
-  int a_voff[A_INSTR], b_voff[B_INSTR];
-  unsigned a_taps[A_INSTR];
-  int u_r = 0, u_q = 0, u_ci = 0;  // filter tap / channel of the next K-tile to fetch
-  int l_tile = first_tile, l_kt = 0;
-  bool l_more = true;
-
-  auto tap_mask = [&](int m, int& voff_out, int chunk) -> unsigned {
-    // pixel of output row m: byte offset of its (tap 0, channel chunk) and the valid-tap bits
-    voff_out = BUF_OOB;
-    if (m >= p.M) return 0u;
-    const int img = m / HoWo;
-    const int rem = m - img * HoWo;
-    const int ho = rem / p.Wo;
-    const int wo = rem - ho * p.Wo;
-    const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
-    voff_out = (int)((((long)(img * p.H + hi0 + p.pad) * p.W + wi0 + p.pad) * p.lda + chunk * 4) * 4);
-    unsigned mask = 0;
-    for (int r = 0; r < p.KH; ++r)
-      for (int q = 0; q < p.KW; ++q)
-        if ((unsigned)(hi0 + r) < (unsigned)p.H && (unsigned)(wi0 + q) < (unsigned)p.W)
-          mask |= 1u << (r * p.KW + q);
-    return mask;
+  const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int G_total = my_tiles * KT;  // K-tiles this workgroup streams
+  auto tile_of = [&](int round, int& m0, int& n0) {
+    const int v = blockIdx.x + round * gridDim.x;
+    const int q = ntiles >> 3, r = ntiles & 7, xcd = v & 7, idx = v >> 3;
+    const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int tm = tile / p.tiles_n;
+    m0 = tm * BM;
+    n0 = (tile - tm * p.tiles_n) * BN;
   };
 
-  auto loader_setup = [&](int t) {
-    const int tm = t / p.tiles_n;
-    const int lm0 = tm * BM, ln0 = (t - tm * p.tiles_n) * BN;
-#pragma unroll
-    for (int j = 0; j < A_INSTR; ++j) {
-      const int row = (j * 4 + wave) * RPI + drow;
-      a_taps[j] = tap_mask(lm0 + row, a_voff[j], dchunk ^ ((row >> 1) & 7));
-    }
-#pragma unroll
-    for (int j = 0; j < B_INSTR; ++j) {
-      const int row = (j * 4 + wave) * RPI + drow;
-      const int n = ln0 + row;
-      b_voff[j] = n < p.N ? (int)(((long)n * p.ldb + (dchunk ^ ((row >> 1) & 7)) * 4) * 4) : BUF_OOB;
-    }
-    u_r = u_q = u_ci = 0;
-  };
+  if (tid < 4) full[tid] = 0;
+  __syncthreads();
 
-  // DMA of the loader's next K-tile into ring slot `buf`; moves on to the next tile of the
-  // list when the current one is exhausted
-  auto issue = [&](int buf) {
-    char* base = dsm + buf * STAGE_BYTES;
-    const int tap = u_r * p.KW + u_q;
-    const int soff = ((u_r * p.W + u_q) * p.lda + u_ci) * 4;
-    const int koff = (tap * p.Cin + u_ci) * 4;
+  if (wave >= X3_MATRIX) {
+    // ================================================================ producer waves
+    const int ptid = tid - X3_MATRIX * 64;
+    const int lrow = ptid >> 3;
+    const int lk4 = (ptid & 7) * 4;
+    const long bias = ((long)p.pad * p.W + p.pad) * p.lda * 4;  // keeps voffsets non-negative
+    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(p.A)) - bias, 0, (int)(p.a_bytes + bias),
+        0x00020000);
+    __amdgpu_buffer_rsrc_t rsrc_a2 = rsrc_a;
+    if constexpr (DUAL)
+      rsrc_a2 = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<char*>(reinterpret_cast<const char*>(p.A2)) - bias, 0,
+          (int)(p.a_bytes + bias), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(p.B)), 0, (int)p.b_bytes, 0x00020000);
+    const bool has_pro = p.in_scale != nullptr;
+    const bool pad_matters = p.pad > 0;
+    const int HoWo = p.Ho * p.Wo;
+
+    // ---- load cursor: the tile whose K-tiles are being fetched
+    int a_voff[A_ROWS], b_voff[B_ROWS];
+    unsigned a_taps[A_ROWS];  // bit t: filter tap t of this output pixel reads inside the image
+    int l_round = 0, l_m0 = 0, l_n0 = 0, l_kt = 0;
+    int u_r = 0, u_q = 0, u_ci = 0, u_k = 0;  // wave-uniform (tap, channel, k) of the next fetch
+    auto setup_tile = [&](int round) {
+      int m0, n0;
+      tile_of(round, m0, n0);
+      l_m0 = m0;
+      l_n0 = n0;
 #pragma unroll
-    for (int j = 0; j < A_INSTR; ++j) {
-      const bool ok = (a_taps[j] >> tap) & 1u;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_void*)(base + (j * 4 + wave) * 1024), 16,
-                                               ok ? a_voff[j] : BUF_OOB, soff, 0, 0);
-    }
+      for (int i = 0; i < A_ROWS; ++i) {
+        const int m = m0 + i * PR + lrow;
+        a_voff[i] = BUF_OOB;
+        a_taps[i] = 0;
+        if (m < p.M) {
+          const int img = m / HoWo;
+          const int rem = m - img * HoWo;
+          const int ho = rem / p.Wo;
+          const int wo = rem - ho * p.Wo;
+          const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
+          a_voff[i] =
+              (int)((((long)(img * p.H + hi0 + p.pad) * p.W + wi0 + p.pad) * p.lda + lk4) * 4);
+          unsigned mask = 0;
+          for (int r = 0; r < p.KH; ++r)
+            for (int q = 0; q < p.KW; ++q)
+              if ((unsigned)(hi0 + r) < (unsigned)p.H && (unsigned)(wi0 + q) < (unsigned)p.W)
+                mask |= 1u << (r * p.KW + q);
+          a_taps[i] = mask;
+        }
+      }
 #pragma unroll
-    for (int j = 0; j < B_INSTR; ++j)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(
-          rsrc_b, (lds_void*)(base + A_BYTES + (j * 4 + wave) * 1024), 16, b_voff[j], koff, 0, 0);
-    if constexpr (PRO) {
-      // the 32 channels' scale | shift | center (128 bytes each) ride in the stage; every wave
-      // writes the same bytes (keeps the per-wave DMA count uniform for the counted waits)
-      if (lane < 8) {
-        const int po = u_ci * 4 + lane * 16;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_ps, (lds_void*)(base + A_BYTES + B_BYTES), 16, po, 0, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_pt, (lds_void*)(base + A_BYTES + B_BYTES + 128), 16, po, 0, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_pc, (lds_void*)(base + A_BYTES + B_BYTES + 256), 16, po, 0, 0, 0);
+      for (int i = 0; i < B_ROWS; ++i) {
+        const int n = n0 + i * PR + lrow;
+        b_voff[i] = n < p.N ? (int)(((long)n * p.ldb + lk4) * 4) : BUF_OOB;
+      }
+      u_r = u_q = u_ci = u_k = 0;
+    };
+
+    // Register ring of NSET staged K-tiles: NSET-1 tiles of loads are in flight while one is
+    // transformed and written to LDS.  Loads past the last K-tile are issued out of range (the
+    // hardware returns zeros, no traffic).
+    constexpr int NSET = DUAL ? 2 : 3;
+    typedef X3Staged<A_ROWS, DUAL> Staged;
+    Staged st[NSET];
+    f32x4 sb[NSET][B_ROWS];
+#pragma unroll
+    for (int j = 0; j < NSET; ++j)
+      st[j].ps = st[j].pt = st[j].pc = st[j].p2s = st[j].p2t = st[j].p2c = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto load = [&](Staged& s, f32x4 (&b)[B_ROWS], bool live) {
+      const int tap = u_r * p.KW + u_q;
+      const int soff = ((u_r * p.W + u_q) * p.lda + u_ci) * 4;
+      if (has_pro && live) {
+        s.ps = ldg4(p.in_scale + u_ci + lk4);
+        s.pt = ldg4(p.in_shift + u_ci + lk4);
+        if (p.in_center) s.pc = ldg4(p.in_center + u_ci + lk4);
+      }
+      if constexpr (DUAL) {
+        s.kcur = u_ci;
+        s.m0 = l_n0 == 0 ? l_m0 : -1;  // side_out rows, or -1: not this tile's job
+        s.p2s = f32x4{1.f, 1.f, 1.f, 1.f};
+        if (p.in2_scale != nullptr && live) {
+          s.p2s = ldg4(p.in2_scale + u_ci + lk4);
+          s.p2t = ldg4(p.in2_shift + u_ci + lk4);
+          if (p.in2_center) s.p2c = ldg4(p.in2_center + u_ci + lk4);
+        }
+      }
+      s.ok = 0;
+#pragma unroll
+      for (int i = 0; i < A_ROWS; ++i) {
+        const unsigned ok = live ? ((a_taps[i] >> tap) & 1u) : 0u;
+        s.ok |= ok << i;
+        s.a[i] = __builtin_bit_cast(
+            f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, ok ? a_voff[i] : BUF_OOB, soff, 0));
+        if constexpr (DUAL)
+          s.a2[i] = __builtin_bit_cast(
+              f32x4,
+              __builtin_amdgcn_raw_buffer_load_b128(rsrc_a2, ok ? a_voff[i] : BUF_OOB, soff, 0));
+      }
+#pragma unroll
+      for (int i = 0; i < B_ROWS; ++i)
+        b[i] = __builtin_bit_cast(
+            f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, live ? b_voff[i] : BUF_OOB,
+                                                         u_k * 4, 0));
+      // advance the cursor by one K-tile; past the tile's last one, move to the next tile
+      u_k += BK;
+      u_ci += BK;
+      if (u_ci >= p.Cin) {
+        u_ci = 0;
+        if (++u_q == p.KW) {
+          u_q = 0;
+          ++u_r;
+        }
+      }
+      if (++l_kt == KT) {
+        l_kt = 0;
+        if (++l_round < my_tiles) setup_tile(l_round);
+      }
+    };
+
+    auto stash = [&](const Staged& s, const f32x4 (&b)[B_ROWS], char* stage) {
+      char* arow = stage + lrow * X3_PITCH + lk4 * 2;
+      char* brow = stage + A_BYTES + lrow * X3_PITCH + lk4 * 2;
+#pragma unroll
+      for (int i = 0; i < A_ROWS; ++i) {
+        f32x4 v = s.a[i];
+        if (has_pro) {
+          v = __builtin_elementwise_fma(v - s.pc, s.ps, s.pt);
+          if constexpr (DUAL) v += __builtin_elementwise_fma(s.a2[i] - s.p2c, s.p2s, s.p2t);
+          if (p.in_relu) v = __builtin_elementwise_max(v, f32x4{0.f, 0.f, 0.f, 0.f});
+          // zero padding comes AFTER the transform (rows past M are never stored or counted)
+          if (pad_matters && !((s.ok >> i) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+          if constexpr (DUAL) {
+            // the materialised block output: written once, by the workgroups of n-tile 0
+            // (1x1 convolution: every tile of one tile_m row has the same rows)
+            if (p.side_out != nullptr && s.m0 >= 0 && ((s.ok >> i) & 1u))
+              *reinterpret_cast<f32x4*>(p.side_out + (long)(s.m0 + i * PR + lrow) * p.lda +
+                                        s.kcur + lk4) = v;
+          }
+        }
+        x3_split_store(v, arow + i * PR * X3_PITCH, A_PLANE);
+      }
+#pragma unroll
+      for (int i = 0; i < B_ROWS; ++i) x3_split_store(b[i], brow + i * PR * X3_PITCH, B_PLANE);
+    };
+
+    // K-tile g of the stream goes to stage g & 1 once the matrix waves are done with K-tile
+    // g - 2; iteration g: issue the loads of K-tile g + NSET - 1, write K-tile g
+    setup_tile(0);
+#pragma unroll
+    for (int j = 0; j < NSET - 1; ++j) load(st[j], sb[j], j < G_total);
+    for (int g0 = 0; g0 < G_total; g0 += NSET) {
+#pragma unroll
+      for (int j = 0; j < NSET; ++j) {
+        const int g = g0 + j;
+        if (g < G_total) {
+          const int seen = x3_peek(empty + (g & 1));
+          load(st[(j + NSET - 1) % NSET], sb[(j + NSET - 1) % NSET], g + NSET - 1 < G_total);
+          x3_wait(empty + (g & 1), seen, X3_MATRIX * (g >> 1));  // K-tile g-2 has been read
+          stash(st[j], sb[j], xsm + (g & 1) * STAGE_BYTES);
+          if (lane == 0) x3_signal(full + (g & 1));  // (in LDS order behind this wave's stage writes)
+        }
       }
     }
-    u_ci += DBK;
-    if (u_ci >= p.Cin) {
-      u_ci = 0;
-      if (++u_q == p.KW) {
-        u_q = 0;
-        ++u_r;
-      }
-    }
-    if (++l_kt == KT) {
-      l_kt = 0;
-      l_tile += PK_RES;
-      if (l_tile < t_end) loader_setup(l_tile);
-      else l_more = false;
-    }
-  };
-
-  // ------------------------------------------------------------------ compute side
-  // fragment byte offsets inside a stage, per operand group (chunk swizzle folded in)
-  int a_rd[NG][MT], b_rd[NG][NT];
-#pragma unroll
-  for (int g = 0; g < NG; ++g) {
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      const int row = wm * WTM + i * 32 + l31;
-      a_rd[g][i] = row * RB + (((2 * g + half) ^ ((row >> 1) & 7)) << 4);
-    }
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int row = wn * WTN + j * 32 + l31;
-      b_rd[g][j] = A_BYTES + row * RB + (((2 * g + half) ^ ((row >> 1) & 7)) << 4);
-    }
-  }
-  const float relu_floor = p.in_relu ? 0.f : -INFINITY;
-
-  f32x4 fa[2][MT], fb[2][NT];       // operand fragments: [group parity]
-  f32x4 pvs[2], pvt[2], pvc[2];     // prologue vectors of the group (PRO)
-  unsigned f_taps[MT], nf_taps[MT]; // valid-tap bits of this lane's fragment rows (this / next tile)
-#pragma unroll
-  for (int i = 0; i < MT; ++i) f_taps[i] = nf_taps[i] = 0xffffffffu;
-
-  auto frag_taps = [&](int t, unsigned (&out)[MT]) {
-    const int tm = t / p.tiles_n;
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      int dummy;
-      out[i] = tap_mask(tm * BM + wm * WTM + i * 32 + l31, dummy, 0);
-    }
-  };
-
-  auto read_frags = [&](const char* stage, int g, int slot_) {  // g, slot_: compile-time
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-      fa[slot_][i] = *reinterpret_cast<const f32x4*>(stage + a_rd[g][i]);
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-      fb[slot_][j] = *reinterpret_cast<const f32x4*>(stage + b_rd[g][j]);
-    if constexpr (PRO) {
-      const char* pv = stage + A_BYTES + B_BYTES + ((2 * g + half) << 4);
-      pvs[slot_] = *reinterpret_cast<const f32x4*>(pv);
-      pvt[slot_] = *reinterpret_cast<const f32x4*>(pv + 128);
-      pvc[slot_] = *reinterpret_cast<const f32x4*>(pv + 256);
-    }
-  };
-
-  // x' = max((x - c) * s + t, floor), zero where the filter tap reads padding
-  auto transform = [&](int slot_, int tap, const unsigned (&taps)[MT]) {
-    if constexpr (PRO) {
-#pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        f32x4 v = (fa[slot_][i] - pvc[slot_]) * pvs[slot_] + pvt[slot_];
-        v.x = fmaxf(v.x, relu_floor);
-        v.y = fmaxf(v.y, relu_floor);
-        v.z = fmaxf(v.z, relu_floor);
-        v.w = fmaxf(v.w, relu_floor);
-        if (taps_matter && !((taps[i] >> tap) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
-        fa[slot_][i] = v;
-      }
-    }
-  };
-
-  f32x16 acc[MT][NT];
-  float pend[NS];     // the previous tile's epilogue values, stored one per MFMA
-  int st_voff[NT];        // this lane's byte offset inside 32-column block j of a row (or OOB)
-#pragma unroll
-  for (int j = 0; j < NT; ++j) st_voff[j] = BUF_OOB;
-  int st_soff = 0;        // scalar byte offset of the pending tile's wave sub-tile origin
-  const int ldc4 = p.ldc * 4;
-
-  auto store_one = [&](int s) {  // s: compile-time index into pend[] = (j, i, r)
-    const int r = s & 15, i = (s >> 4) % MT, j = (s >> 4) / MT;
-    const int soff = st_soff + (i * 32 + (r & 3) + 8 * (r >> 2)) * ldc4 + j * 128;
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pend[s]), rsrc_c, st_voff[j], soff, 0);
-  };
-
-  // one K-tile.  PHASE: 0 nothing pending | 1 the K-tile after a tile end: the pending tile's NS
-  // stores ride on its NS MFMAs | 2 the K-tile after that: no stores, but H2 of them are younger
-  // than the DMA it waits for
-  int buf = 0;            // ring slot of the current K-tile
-  int c_tap = 0, c_ci = 0;
-  bool have_next;         // a K-tile follows this one (in this or the next tile)
-
-#define VLNCE_MFMA_GROUP(SLOT, STORE_BASE, WITH_STORES)                                          \
-  _Pragma("unroll") for (int e = 0; e < 4; ++e) _Pragma("unroll") for (int i = 0; i < MT; ++i)   \
-      _Pragma("unroll") for (int j = 0; j < NT; ++j) {                                           \
-    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[SLOT][i][e], fb[SLOT][j][e], acc[i][j],  \
-                                                     0, 0, 0);                                   \
-    if constexpr (WITH_STORES) store_one((STORE_BASE) + (e * MT + i) * NT + j);                  \
-  }
-
-  auto ktile = [&](auto phase_tag, bool last_of_tile) {
-    constexpr int PHASE = decltype(phase_tag)::value;
-    constexpr bool ST = PHASE == 1;
-    const char* cur = dsm + buf * STAGE_BYTES;
-    const int nbuf = buf + 1 == NSTAGE ? 0 : buf + 1;
-    const int pbuf = buf == 0 ? NSTAGE - 1 : buf - 1;
-    // ---- groups 0 and 1 (group 0's operands are already in slot 0)
-    read_frags(cur, 1, 1);
-    VLNCE_MFMA_GROUP(0, 0, ST)
-    transform(1, c_tap, f_taps);
-    read_frags(cur, 2, 0);
-    VLNCE_MFMA_GROUP(1, GM, ST)
-    transform(0, c_tap, f_taps);
-    // ---- the stage after this one has landed (mine), then everybody's; stage t-1 is free
-    if (have_next) {
-      if constexpr (PHASE != 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(H2) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();
-    if (l_more) issue(pbuf);
-    // ---- groups 2 and 3; group 0 of the next K-tile is fetched behind group 3's MFMAs
-    read_frags(cur, 3, 1);
-    VLNCE_MFMA_GROUP(0, 2 * GM, ST)
-    transform(1, c_tap, f_taps);
-    int n_tap = c_tap, n_ci = c_ci + DBK;
-    if (n_ci >= p.Cin) {
-      n_ci = 0;
-      ++n_tap;
-    }
-    if (last_of_tile) n_tap = 0;
-    if (have_next) read_frags(dsm + nbuf * STAGE_BYTES, 0, 0);
-    VLNCE_MFMA_GROUP(1, 3 * GM, ST)
-    if (have_next) {
-      if (last_of_tile) transform(0, 0, nf_taps);
-      else transform(0, n_tap, f_taps);
-    }
-    c_tap = n_tap;
-    c_ci = last_of_tile ? 0 : n_ci;
-    buf = nbuf;
-  };
-
-  // ------------------------------------------------------------------ fill the ring
-  loader_setup(first_tile);
-  if (taps_matter) frag_taps(first_tile, f_taps);
-#pragma unroll
-  for (int s = 0; s < NSTAGE - 1; ++s)
-    if (l_more) issue(s);
-  // stage 0 (the older of the two in flight) has landed
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_INSTR + B_INSTR + (PRO ? 3 : 0)) : "memory");
-  __builtin_amdgcn_s_barrier();
-  read_frags(dsm, 0, 0);
-  transform(0, 0, f_taps);
-
-  bool pending = false;
-  int tile = first_tile;
-  while (true) {
-    const int tile_m = tile / p.tiles_n;
-    const int m0 = tile_m * BM;
-    const int n0 = (tile - tile_m * p.tiles_n) * BN;
-    const int next_tile = tile + PK_RES;
-    const bool more_tiles = next_tile < t_end;
-    if (taps_matter && more_tiles) frag_taps(next_tile, nf_taps);
-
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-      for (int j = 0; j < NT; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    for (int kt = 0; kt < KT; ++kt) {
-      const bool last = kt + 1 == KT;
-      have_next = !last || more_tiles;
-      if (pending && kt == 0) ktile(std::integral_constant<int, 1>{}, last);
-      else if (pending && kt == 1) ktile(std::integral_constant<int, 2>{}, last);
-      else ktile(std::integral_constant<int, 0>{}, last);
-    }
-
-    // ---- statistics of the raw tile: per-wave partials (rows of p.stat_rows), no barrier
-    if (p.stat_partial != nullptr) {
-      if (MT == 2 && p.stat_rows == 32) {
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-          wave_stats_block<NT>(acc[i], p.stat_partial, (m0 + wm * WTM) / 32 + i,
-                               p.M - (m0 + wm * WTM + i * 32), n0 + wn * WTN, p.N, half, l31);
-      } else {
-        wave_stats<MT, NT>(acc, p.stat_partial, tile_m * 2 + wm, p.M - (m0 + wm * WTM), WTM,
-                           n0 + wn * WTN, p.N, half, l31);
-      }
-    }
-
-    // ---- epilogue values into the pending registers; their stores ride on the next tile
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int col = n0 + wn * WTN + j * 32 + l31;
-      const bool cok = col < p.N;
-      const float sc = (p.scale && cok) ? p.scale[col] : 1.f;
-      const float sh = (p.shift && cok) ? p.shift[col] : 0.f;
+  } else {
+    // ================================================================ matrix waves
+    const int wm = wave / WN, wn = wave % WN;
+    struct Frag {
+      bf16x8 a[MT][3];
+      bf16x8 b[NT][3];
+    };
+    const char* abase = xsm + (wm * WTM + l31) * X3_PITCH + half * 16;
+    const char* bbase = xsm + A_BYTES + (wn * WTN + l31) * X3_PITCH + half * 16;
+    auto read = [&](Frag& f, int stage, int slab) {
+      const int off = stage * STAGE_BYTES + slab * 32;
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          pend[(j * MT + i) * 16 + r] = apply_act(acc[i][j][r] * sc + sh, p.act);
-    }
-    // rows >= M fall outside the output's buffer descriptor and are dropped by the hardware
-    // bounds check; a 32-column block at or beyond N (N % 32 == 0, host-checked) is masked here
+        for (int q = 0; q < 3; ++q)
+          f.a[i][q] = *reinterpret_cast<const bf16x8*>(abase + off + q * A_PLANE + i * 32 * X3_PITCH);
 #pragma unroll
-    for (int j = 0; j < NT; ++j)
-      st_voff[j] = (n0 + wn * WTN + j * 32 + l31) < p.N ? (4 * half * p.ldc + l31) * 4 : BUF_OOB;
-    st_soff = __builtin_amdgcn_readfirstlane(((m0 + wm * WTM) * p.ldc + n0 + wn * WTN) * 4);
-    pending = true;
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+          f.b[j][q] = *reinterpret_cast<const bf16x8*>(bbase + off + q * B_PLANE + j * 32 * X3_PITCH);
+    };
+    f32x16 acc[MT][NT];
+    auto mma = [&](const Frag& f) {
+      constexpr int PA[6] = {2, 0, 1, 1, 0, 0};  // smallest products first
+      constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+      for (int q = 0; q < 6; ++q)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][PA[q]], f.b[j][PB[q]],
+                                                                acc[i][j], 0, 0, 0);
+    };
+    const __amdgpu_buffer_rsrc_t rsrc_c = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<char*>(p.C), 0, (int)p.c_bytes, 0x00020000);
 
-    if (!more_tiles) break;
-    tile = next_tile;
-    if (taps_matter) {
+#ifdef X3_DBG_TIME
+    const long long d_c0 = clock64(), d_w0 = wall_clock64();
+    long long d_wait = 0;
+#endif
+    Frag fa, fb;
+    // the SIMD's VALU issue port is shared with the producer waves: the MFMAs must win it the
+    // moment the matrix pipe frees up, the producers take the slots in between
+    __builtin_amdgcn_s_setprio(3);
+    x3_wait(full, x3_peek(full), X3_PRODUCERS);  // K-tile 0 is written (stage 0's first)
+    read(fa, 0, 0);
+    int g = 0;
+#ifdef X3_DBG_TIME
+    const long long d_c1 = clock64();
+#endif
+    for (int round = 0; round < my_tiles; ++round) {
+      int m0, n0;
+      tile_of(round, m0, n0);
+      // epilogue vectors of this wave's columns (loaded now, used after the K loop)
+      float e_sc[NT], e_sh[NT];
+      int e_voff[NT];
 #pragma unroll
-      for (int i = 0; i < MT; ++i) f_taps[i] = nf_taps[i];
+      for (int j = 0; j < NT; ++j) {
+        const int col = n0 + wn * WTN + j * 32 + l31;
+        const bool ok = col < p.N;
+        e_sc[j] = (ok && p.scale) ? p.scale[col] : 1.f;
+        e_sh[j] = (ok && p.shift) ? p.shift[col] : 0.f;
+        e_voff[j] = ok ? (int)((((long)(m0 + wm * WTM + 4 * half)) * p.ldc + col) * 4) : BUF_OOB;
+      }
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+      for (int t = 0; t < KT; ++t, ++g) {
+        // (the scheduling fences keep the LDS reads of the NEXT slab in front of the current
+        // slab's MFMAs; left alone the compiler sinks them behind and the pipe waits on LDS)
+        const int seen = x3_peek(full + ((g + 1) & 1));
+        read(fb, g & 1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(fa);
+        __builtin_amdgcn_sched_barrier(0);
+        if (g + 1 < G_total) {
+#ifdef X3_DBG_TIME
+          const long long d_a = clock64();
+#endif
+          x3_wait(full + ((g + 1) & 1), seen, X3_PRODUCERS * (((g + 1) >> 1) + 1));  // K-tile g+1 is written
+#ifdef X3_DBG_TIME
+          d_wait += clock64() - d_a;
+#endif
+          read(fa, (g + 1) & 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // this wave's reads of K-tile g are complete once fb has arrived (LDS returns in order)
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(3 * (MT + NT)) : "memory");
+        if (lane == 0) x3_signal(empty + (g & 1));
+        __builtin_amdgcn_sched_barrier(0);
+        mma(fb);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+
+      // -------------------------------------------------------------- statistics partials
+      if (p.stat_partial != nullptr) {
+        const int tile_m = m0 / BM;
+        if (p.stat_rows > 0 && p.stat_rows < WTM)
+          wave_stats_fine<MT, NT>(acc, p.stat_partial, p.stat_rows, m0 + wm * WTM, p.M,
+                                  n0 + wn * WTN, p.N, half, l31);
+        else
+          wave_stats<MT, NT>(acc, p.stat_partial, tile_m * WM + wm, p.M - (m0 + wm * WTM), WTM,
+                             n0 + wn * WTN, p.N, half, l31);
+      }
+      // -------------------------------------------------------------- epilogue from registers
+      // one store = 2 rows x 32 columns = two full 128-byte lines; rows past M fall outside
+      // the buffer (the row bound is folded into the descriptor's extent) only for the last
+      // tile row, where the lane offset is sent out of range instead
+      const int rows_left = p.M - (m0 + wm * WTM + 4 * half);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int rw = i * 32 + (r & 3) + 8 * (r >> 2);
+          const int soff = rw * p.ldc * 4;
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            const float v = apply_act(acc[i][j][r] * e_sc[j] + e_sh[j], p.act);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc_c,
+                                                  rw < rows_left ? e_voff[j] : BUF_OOB, soff, 0);
+          }
+        }
     }
+    __builtin_amdgcn_s_setprio(0);
+#ifdef X3_DBG_TIME
+    if (blockIdx.x == 8 && tid == 0) {
+      const long long c = clock64() - d_c0, w = wall_clock64() - d_w0;
+      printf("x3 tiles %d KT %d: first K-tile after %lld cycles; total %lld cycles = %lld ticks of 100 MHz "
+             "(%.2f GHz); waiting for producers %lld\n", my_tiles, KT, d_c1 - d_c0, c, w,
+             (double)c / (double)w * 0.1, d_wait);
+    }
+#endif
   }
-  // the last tile's stores
-#pragma unroll
-  for (int s = 0; s < NS; ++s) store_one(s);
-#undef VLNCE_MFMA_GROUP
 #endif
 }
 
@@ -1326,19 +1380,29 @@ void fill_epilogue(IgemmParams& p, const vlnce_epilogue* e) {
 
 bool aligned16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
-// conv_dma launch: 64 workgroups per XCD per round (2 per CU), each walking pk_tiles tiles
-__device__ float vlnce_zero_vec[4096];
+// CUs of the device, rounded down to a multiple of 8 (one conv_x3 workgroup per CU)
+int x3_cus() {
+  static const int cus = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess)
+      hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return n >= 8 ? (n / 8) * 8 : 8;
+  }();
+  return cus;
+}
 
-template <int BM, int BN, int PRO>
-int launch_dma(const IgemmParams& p, hipStream_t stream) {
-  constexpr int smem_bytes = 3 * ((BM + BN) * 128 + (PRO ? 384 : 0));
-  auto kern = conv_dma_kernel<BM, BN, PRO>;
+// conv_x3_kernel launch: one workgroup (16 or 12 waves) per CU, walking tiles
+template <int BM, int BN, int WM, int WN, int DUAL>
+int launch_x3(const IgemmParams& p, hipStream_t stream) {
+  constexpr int smem_bytes = 2 * 3 * (BM + BN) * X3_PITCH + 16;  // two stages + 4 counters
+  constexpr int threads = (WM * WN + X3_PRODUCERS) * 64;
+  auto kern = conv_x3_kernel<BM, BN, WM, WN, DUAL>;
   static bool attr_set = false;  // per instantiation
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
     if (e != hipSuccess) {
-      vlnce_set_error("conv_dma: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      vlnce_set_error("conv_x3: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
       return 2;
     }
     attr_set = true;
@@ -1347,61 +1411,82 @@ int launch_dma(const IgemmParams& p, hipStream_t stream) {
   q.tiles_m = ceil_div(p.M, BM);
   q.tiles_n = ceil_div(p.N, BN);
   q.splitk = 1;
-  const long ntiles = (long)q.tiles_m * q.tiles_n;
-  if (ntiles <= 0 || ntiles > 0x7fffffffL) {
-    vlnce_set_error("conv_dma: bad tile count %ld", ntiles);
+  const long nwg = (long)q.tiles_m * q.tiles_n;
+  if (nwg <= 0 || nwg > 0x7fffffffL) {
+    vlnce_set_error("conv_x3: bad grid %ld", nwg);
     return 1;
   }
-  // tiles per workgroup (tuning knob; 1 = one tile per workgroup, large = fully persistent)
-  static const int pk_tiles = getenv("VLNCE_PK_TILES") ? atoi(getenv("VLNCE_PK_TILES")) : 8;
-  q.pk_tiles = pk_tiles < 1 ? 1 : pk_tiles;
-  const long per_xcd = (ntiles + 7) / 8;
-  const long rounds = (per_xcd + 64L * q.pk_tiles - 1) / (64L * q.pk_tiles);
-  // the last round of an XCD may be short: only as many workgroups as it has tiles
-  const long last = per_xcd - (rounds - 1) * 64L * q.pk_tiles;
-  const long slots = (rounds - 1) * 64 + (last < 64 ? last : 64);
-  hipLaunchKernelGGL(kern, dim3((unsigned)(8 * slots)), dim3(256), smem_bytes, stream, q);
-  VLNCE_CHECK_LAUNCH("conv_dma");
+  // one workgroup per CU walks tiles a grid apart (a multiple of 8: the XCD of a tile is fixed)
+  const int cus = x3_cus();
+  const unsigned grid = nwg <= cus ? (unsigned)nwg : (unsigned)cus;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), smem_bytes, stream, q);
+  VLNCE_CHECK_LAUNCH("conv_x3");
   return 0;
 }
 
-template <int PRO>
-int dispatch_dma(const IgemmParams& p, hipStream_t s) {
-  // 128x64 is the largest tile: 128x128 would need accumulators + the deferred-store copy +
-  // double-buffered fragments = more than the 256 registers two waves per SIMD leave each.
-  // The M extent (hence the statistics granularity, vlnce_conv2d_tile_rows) is choose_tile's.
-  // p.stat_rows (what vlnce_conv2d_tile_rows told the caller) is 64 or 32 here (dma_ok)
-  if ((long)ceil_div(p.M, 128) * ceil_div(p.N, 64) >= 512) return launch_dma<128, 64, PRO>(p, s);
-  if (p.stat_partial && p.stat_rows != 32) {
-    vlnce_set_error("conv_dma: inconsistent statistics granularity");
-    return 1;
-  }
-  return launch_dma<64, 64, PRO>(p, s);
+// convolution arithmetic: 1 = fp32 operands split into three bf16 planes, six products on the
+// bf16 matrix pipe (conv_x3_kernel; fp32-equivalent result, see the kernel's header);
+// 0 = v_mfma_f32_32x32x2_f32 everywhere (igemm_kernel).  VLNCE_CONV_MATH=f32 selects 0.
+int conv_math() {
+  static const int m = [] {
+    const char* e = getenv("VLNCE_CONV_MATH");
+    return (e && (e[0] == 'f' || e[0] == '0')) ? 0 : 1;
+  }();
+  return m;
 }
 
-// what conv_dma_kernel covers: 32-channel K-tiles inside one filter tap, at least 2 of them,
-// 32-column output blocks, plain epilogue (scale / shift / activation, statistics)
-bool dma_ok(const IgemmParams& p) {
-  // opt-in while it is slower than the register-staged kernel (profiles/r02_e_*)
-  static const bool off = getenv("VLNCE_IGEMM_DMA") == nullptr;
-  const long bias = ((long)p.pad * p.W + p.pad) * p.lda * 4;
-  return !off && (p.Cin % 32 == 0) && p.K >= 64 && (p.lda % 4 == 0) && (p.ldb % 4 == 0) &&
-         (p.N % 32 == 0) && p.KH * p.KW <= 32 && p.a_bytes + bias < 0x7fffffffL &&
-         p.b_bytes < 0x7fffffffL && p.c_bytes < 0x7fffffffL && !p.residual && !p.accumulate &&
-         !p.A2 && !p.side_out && p.Cin <= 4096 && !(p.stat_partial && p.stat_rows < 32);
+// what conv_x3_kernel covers: the buffer-descriptor hot path (buf_ok) with whole 32-channel
+// K-tiles and a plain epilogue (scale / shift / activation, statistics).  Tile: the largest of
+// 128x128, 64x128, 128x64, 64x64 that keeps >= 80 % of the CUs busy over the rounds a workgroup
+// per CU needs (tiles / (rounds * CUs)).
+struct X3Plan {
+  int bm, bn;
+};
+bool x3_plan(const IgemmParams& p, X3Plan* out) {
+  if (!conv_math() || !buf_ok(p) || p.splitk > 1) return false;
+  if (p.residual || p.accumulate || p.c_bytes >= 0x7fffffffL) return false;
+  static const int force = getenv("VLNCE_X3_TILE") ? atoi(getenv("VLNCE_X3_TILE")) : 0;  // tuning
+  const X3Plan cand[4] = {{128, 128}, {64, 128}, {128, 64}, {64, 64}};
+  if (force >= 1 && force <= 4) {
+    *out = cand[force - 1];
+    return true;
+  }
+  const int cus = x3_cus();
+  double best = 0.0;
+  for (const X3Plan& c : cand) {
+    if (c.bn == 128 && p.N <= 64) continue;
+    const long tiles = (long)ceil_div(p.M, c.bm) * ceil_div(p.N, c.bn);
+    const long rounds = (tiles + cus - 1) / cus;
+    const double eff = (double)tiles / (double)(rounds * cus);
+    if (eff >= 0.8) {
+      *out = c;
+      return true;
+    }
+    if (eff > best) {
+      best = eff;
+      *out = c;
+    }
+  }
+  return best >= 0.4;  // below that the problem is a handful of tiles: split-K / small-tile path
+}
+template <int DUAL>
+int dispatch_x3(const IgemmParams& p, const X3Plan& t, hipStream_t s) {
+  if (t.bm == 128 && t.bn == 128) return launch_x3<128, 128, 2, 4, DUAL>(p, s);
+  if (t.bm == 64 && t.bn == 128) return launch_x3<64, 128, 2, 4, DUAL>(p, s);
+  if (t.bm == 128 && t.bn == 64) return launch_x3<128, 64, 4, 2, DUAL>(p, s);
+  return launch_x3<64, 64, 2, 2, DUAL>(p, s);
 }
 
 }  // namespace
 
-// rows per statistics partial: the M extent of one wave's sub-tile (BM / 2 = 64 or 32), halved
-// down to 16 while it does not divide a sample's pixel count (GroupNorm needs partials that do
-// not straddle samples; habitat's depth trunk ends at 4x4 = 16 pixels per sample)
+// rows per statistics partial: 32 output pixels (the M extent of the smallest wave sub-tile of
+// any convolution kernel here), 16 when a sample's pixel count is not a multiple of 32
+// (GroupNorm needs partials that do not straddle samples; habitat's depth trunk ends at 4x4 = 16
+// pixels per sample).  A function of the descriptor only: the caller sizes the partial buffer
+// before it knows which kernel runs.
 static int stat_rows_for(const vlnce_conv_desc* d) {
-  const long M = (long)d->N * d->Ho * d->Wo;
-  int r = choose_tile(M, d->Cout).bm / 2;
   const int hw = d->Ho * d->Wo;
-  while (r > 16 && hw % r != 0) r /= 2;
-  return r;
+  return hw % 32 == 0 ? 32 : 16;
 }
 
 extern "C" int vlnce_conv2d_tile_rows(const vlnce_conv_desc* d) { return stat_rows_for(d); }
@@ -1474,19 +1559,8 @@ extern "C" int vlnce_conv2d_fwd(const float* x, const float* w, float* y, const 
                         (!p.in2_center || (p.in2_scale && aligned16(p.in2_center))),
                     "conv2d_fwd: the dual-input prologue needs x2 + in_scale on a 1x1/stride-1/"
                     "pad-0 convolution with Cin %% 32 == 0 and 16-byte aligned operands");
+    if (X3Plan t; x3_plan(p, &t)) return dispatch_x3<1>(p, t, s);
     return dispatch_dual(p, s);
-  }
-  if (v4 && dma_ok(p)) {
-    if (p.in_scale == nullptr) return dispatch_dma<0>(p, s);
-    if (p.in_center == nullptr) {  // the kernel always subtracts a centre: hand it zeros
-      static float* zeros = nullptr;
-      if (!zeros && hipGetSymbolAddress(reinterpret_cast<void**>(&zeros), HIP_SYMBOL(vlnce_zero_vec)) != hipSuccess) {
-        vlnce_set_error("conv2d_fwd: no zero vector");
-        return 2;
-      }
-      p.in_center = zeros;
-    }
-    return dispatch_dma<1>(p, s);
   }
   if (v4 && buf_ok(p)) {
     // Small batches (act() at num_envs 1..8, eval BatchNorm folded into scale/shift): a late
@@ -1520,6 +1594,7 @@ extern "C" int vlnce_conv2d_fwd(const float* x, const float* w, float* y, const 
       }
       return 0;
     }
+    if (X3Plan t; x3_plan(p, &t)) return dispatch_x3<0>(p, t, s);
     return dispatch_tiles<A_BUF, B_BUF>(p, s);
   }
   if (v4) return dispatch_tiles<A_IM2COL_V4, B_NK_V4>(p, s);
