@@ -15,8 +15,11 @@ its own trunk passes, tail forward, backward and Adam; the frozen trunks of step
 issued (policy.encode_ahead, side HIP streams) before step k's update is enqueued so that
 they overlap its latency-bound tail -- `--no-pipeline` times the plain loop.
 
-The JSON line also carries `roofline` (dominant kernel = the fp32-MFMA
-implicit-GEMM convolution, timed with HIP events on the launch stream) and,
+The JSON line also carries `roofline` (dominant kernel = the implicit-GEMM
+convolution: conv_x3_kernel, fp32 operands split exactly into three bf16 planes and multiplied
+as six plane products on the bf16 matrix pipe, plus the fp32-MFMA igemm_kernel for the stems
+and the small layers; timed with HIP events on the launch stream; priced against the fp32
+MFMA peak, the roofline of the arithmetic the reference asks for) and,
 on rank 0 at N=1, `cpu_baseline` (the CPU oracle restatement of the reference
 policy timed on the host cores on a bounded sample of the same workload).
 """
@@ -33,6 +36,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense
 # algorithmic FLOPs per policy-step (one env), CMA 256x256 L=80
 CMA_FWD_GFLOP = 11.461
 CMA_FWD_BWD_FROZEN_GFLOP = 11.630
@@ -153,25 +157,45 @@ def cpu_baseline(num_envs, hw, L, timeout_s=100):
                 "host_cpu": facts}
 
 
+def f32_mfma_compare(args):
+    """The same bench with every convolution on v_mfma_f32_32x32x2_f32 (VLNCE_CONV_MATH=f32; the
+    switch is read once per process, hence a child process): what the step costs without the
+    bf16-plane kernel.  Reported beside `value`, never as `value`."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(args.steps), "--warmup",
+           str(args.warmup), "--num-envs", str(args.num_envs), "--no-cpu-baseline",
+           "--no-f32-compare"]
+    try:
+        out = subprocess.run(cmd, env=dict(os.environ, VLNCE_CONV_MATH="f32"), capture_output=True,
+                             text=True, timeout=600).stdout.strip().splitlines()
+        d = json.loads(out[-1])
+        return {"value": d["value"], "ms_per_step": d["ms_per_step"],
+                "no_pipeline_ms_per_step": d["config"]["no_pipeline_ms_per_step"],
+                "roofline_frac": d["roofline"]["frac"],
+                "conv_kernel_ms_per_step": d["roofline"]["kernel_ms_per_step"]}
+    except Exception as e:  # never block the main line
+        return {"value": None, "error": type(e).__name__}
+
+
 def pmc_traffic(n_conv):
     """HBM bytes per conv launch from the committed rocprofv3 PMC passes of this same
-    workload (profiles/r01_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate
+    workload (profiles/r02_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate
     passes of `bench.py --pmc-step`, gfx950 corrections applied as MI355X_MICROARCH.md
     prescribes).  None when the file is absent or was taken for a different launch count."""
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
-                        "r01_pmc_traffic.json")
+                        "r02_pmc_traffic.json")
     try:
         rec = json.load(open(path))
     except OSError:
         return None
-    if rec.get("igemm_launches_per_step") != n_conv:
+    if rec.get("conv_launches_per_step") != n_conv:
         return None
     return rec.get("hbm_bytes_per_launch")
 
 
 def conv_kernel_time(policy, obs, dev, repeats=3):
     """GPU-paced duration of every convolution launch of the two visual trunks' forward
-    (the 107 igemm launches of a step).
+    (the 107 convolution launches of a step).
 
     The trunks run eagerly on ONE stream (graph replay hides the individual launches from
     the host; concurrent branches would stretch each other's kernels) with a HIP event
@@ -296,6 +320,8 @@ def main():
     ap.add_argument("--bn", choices=["train", "eval"], default="train",
                     help="train = as constructed by the reference (batch statistics)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-f32-compare", action="store_true",
+                    help="skip the child run with every convolution on the fp32 MFMA instruction")
     ap.add_argument("--trainable-encoders", action="store_true",
                     help="MODEL.{RGB,DEPTH}_ENCODER.trainable=True: trunks get dgrad/wgrad too")
     ap.add_argument("--pmc-step", action="store_true",
@@ -497,10 +523,28 @@ def main():
                            else round(value, 1)),
                        "act_fwd_only_eval_steps_per_sec_per_gpu": round(args.num_envs / act_s, 1),
                        "act_latency_ms_by_num_envs": act_small},
-            "roofline": {"bound": "mfma", "kernel": "igemm conv2d fwd (fp32 32x32x2 MFMA)",
+            "roofline": {"bound": "mfma",
+                         "kernel": "conv2d fwd: conv_x3_kernel (fp32 operands split exactly into "
+                                   "3 bf16 planes, 6 x v_mfma_f32_32x32x16_bf16 per 32x32x16 "
+                                   "block, fp32 accumulate) + igemm_kernel (v_mfma_f32_32x32x2_f32: "
+                                   "stems, small layers)",
                          "achieved": round(achieved, 2) if ok else None,
                          "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4) if ok else None,
+                         "peak_is": "the fp32 MFMA peak: `achieved` counts ALGORITHMIC fp32 FLOPs, "
+                                    "so frac can exceed what v_mfma_f32_32x32x2_f32 could deliver; "
+                                    "on the bf16 pipe the same work is 6 plane products per "
+                                    "multiply",
+                         "bf16_pipe": {"instruction": "v_mfma_f32_32x32x16_bf16",
+                                       "hw_flops_per_algorithmic_flop": 6,
+                                       "peak": BF16_MFMA_PEAK_TFLOPS,
+                                       "frac_if_all_launches_were_x3": (
+                                           round(6 * achieved / BF16_MFMA_PEAK_TFLOPS, 4) if ok
+                                           else None)},
+                         "arithmetic": "fp32-equivalent: max error vs fp64 is 1.1-1.2x the "
+                                       "fp32-MFMA kernel's and equal to rocBLAS/MIOpen fp32 "
+                                       "(profiles/r02_o_conv_accuracy_*.txt); VLNCE_CONV_MATH=f32 "
+                                       "selects the fp32-MFMA kernel everywhere",
                          "launches_per_step": n_conv,
                          "avg_launch_ms": round(conv_ms / max(n_conv, 1), 4),
                          "kernel_ms_per_step": round(conv_ms, 3),
@@ -510,6 +554,8 @@ def main():
                          "invalid_reason": conv["reason"],
                          "traffic": pmc_traffic(n_conv)},
         }
+        if world == 1 and not args.no_f32_compare and "VLNCE_CONV_MATH" not in os.environ:
+            line["config"]["fp32_mfma_only"] = f32_mfma_compare(args)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.num_envs, args.hw, args.tokens)
         print(json.dumps(line))

@@ -28,7 +28,7 @@ typedef void* vlnce_stream_t;
 
 enum { VLNCE_ACT_NONE = 0, VLNCE_ACT_RELU = 1, VLNCE_ACT_SIGMOID = 2, VLNCE_ACT_TANH = 3 };
 
-int vlnce_version(void); /* major*100 + minor; 120 = this header */
+int vlnce_version(void); /* major*100 + minor; 130 = this header */
 const char* vlnce_last_error(void);
 
 /* ---------------------------------------------------------------- conv / GEMM
@@ -68,6 +68,12 @@ typedef struct {
   const float* in2_shift;
   const float* in2_center;
   float* side_out;
+  /* Optional: the weights w_ohwi pre-split into three bf16 planes by
+   * vlnce_conv2d_split_weights() (layout [3][Cout*KH*KW*Cin] of 16-bit words).  With it,
+   * convolutions on the buffer-descriptor hot path (Cin % 32 == 0) run as six bf16 plane
+   * products on the bf16 matrix pipe (conv_x3_kernel: fp32-equivalent result, DESIGN.md
+   * section 6); without it (NULL) they run on v_mfma_f32_32x32x2_f32. */
+  const void* w_split;
 } vlnce_prologue;
 
 typedef struct {
@@ -85,6 +91,10 @@ typedef struct {
 
 int vlnce_conv2d_tiles_m(const vlnce_conv_desc* d);   /* rows of stat_partial  */
 int vlnce_conv2d_tile_rows(const vlnce_conv_desc* d); /* BM chosen for `d`      */
+
+/* planes[q][i], q = 0..2: bf16 words with w[i] == planes[0][i] + planes[1][i] + planes[2][i]
+ * exactly (truncation split, 8 + 8 + 8 mantissa bits).  `planes` holds 3 * count 16-bit words. */
+int vlnce_conv2d_split_weights(const float* w, void* planes, long count, vlnce_stream_t stream);
 
 int vlnce_conv2d_fwd(const float* x, const float* w_ohwi, float* y,
                      const vlnce_conv_desc* d, const vlnce_prologue* pro,

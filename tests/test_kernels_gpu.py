@@ -4,6 +4,8 @@ random inputs.  Tolerance: 1e-4 relative to the output scale (fp32; the MFMA
 is an exact-fp32 fmaf chain, differences are summation order only).
 Shapes are the ones the policies issue scaled to a small
 batch, plus ragged edges (rows / channels / K not multiples of the tile)."""
+import os
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -40,6 +42,8 @@ def both(method, tensors, scalars):
     cpu = {k: (v.clone() if v is not None else None) for k, v in tensors.items()}
     gpu = {k: (v.to(DEV) if v is not None else None) for k, v in tensors.items()}
     getattr(SIM, method)(**cpu, **scalars)
+    if method == "conv2d_fwd":  # the pre-split weights select the bf16-plane kernel where it applies
+        gpu["w_split"] = ops.split_weights(gpu["w"])
     getattr(_lib.get_lib(), method)(**gpu, **scalars)
     torch.cuda.synchronize()
     return cpu, gpu
@@ -708,3 +712,39 @@ def test_masked_rnn_rollout_vs_torch_cells(hip, lstm, T, N, H):
     close(y_hip, y_ref, what="rollout outputs")
     for i, (a, b) in enumerate(zip(g_hip, g_ref)):
         close(a, b, 3e-4, what=f"rollout grad {i}")
+
+
+# ------------------------------------------------------------------ bf16-plane convolution kernel
+def test_split_weights_is_exact(hip):
+    """w == plane0 + plane1 + plane2 bit for bit (truncation split: 8 + 8 + 8 mantissa bits),
+    including huge, tiny and negative values.  (Only where a residual would be an fp32 denormal,
+    |w| < ~2^-110, the GPU flushes it: absolute error below 2^-126, checked separately.)"""
+    torch.manual_seed(3)
+    w = torch.randn(64, 3, 3, 32) * torch.exp(8 * torch.randn(64, 1, 1, 1))
+    w.view(-1)[:6] = torch.tensor([0.0, -0.0, 1e-30, -3e38, 1.0, -1.0 + 2.0 ** -23])
+    wg = w.to(DEV)
+    planes = ops.split_weights(wg)
+    assert planes is not None and planes.shape == (3, w.numel())
+    assert ops.split_weights(wg) is planes  # cached on the tensor
+    p = (planes.cpu().to(torch.int32) & 0xFFFF) << 16
+    f = p.view(torch.float32).double()
+    assert torch.equal((f[0] + f[1] + f[2]).float(), w.view(-1))
+    wg.mul_(2.0)  # written in place: split again
+    assert ops.split_weights(wg) is not planes
+    tiny = torch.full((1, 1, 1, 32), 1e-38, device=DEV)
+    q = (ops.split_weights(tiny).cpu().to(torch.int32) & 0xFFFF) << 16
+    assert (q.view(torch.float32).double().sum(0) - 1e-38).abs().max().item() < 2.0 ** -126
+
+
+@pytest.mark.parametrize("tile", [1, 2, 3, 4])
+def test_conv_x3_every_tile_shape(tile):
+    """conv_x3_kernel has four tile shapes chosen by problem size; force each one (VLNCE_X3_TILE,
+    read once per process) over the conv / block cases, including several tiles per workgroup,
+    ragged M, N below the tile width, the dual-input prologue and statistics partials."""
+    import subprocess
+    import sys
+    env = dict(os.environ, VLNCE_X3_TILE=str(tile))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu",
+                        "-k", "conv2d_fwd or bottleneck or block", "-p", "no:cacheprovider"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:]

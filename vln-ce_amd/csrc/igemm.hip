@@ -54,6 +54,7 @@ struct IgemmParams {
   const float* in2_shift;
   const float* in2_center;
   float* side_out;
+  const void* Bsplit;  // conv_x3_kernel: the weights as three bf16 planes [3][N*K]
   const float* scale;
   const float* shift;
   const float* residual;
@@ -866,9 +867,8 @@ template <int ROWS, int DUAL>
 struct X3Staged {
   f32x4 a[ROWS];
   f32x4 a2[DUAL ? ROWS : 1];
-  f32x4 ps, pt, pc, p2s, p2t, p2c;
   unsigned ok;
-  int kcur, m0;
+  int m0;
 };
 
 // x (4 consecutive k of one row) -> the three planes' 8-byte LDS words
@@ -919,8 +919,8 @@ __global__ __launch_bounds__((WM * WN + X3_PRODUCERS) * 64) void conv_x3_kernel(
   constexpr int A_BYTES = 3 * A_PLANE, B_BYTES = 3 * B_PLANE;
   constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
   constexpr int PR = X3_PRODUCERS * 64 / 8;          // rows per producer pass (8 float4 each)
-  constexpr int A_ROWS = BM / PR, B_ROWS = BN / PR;  // producer passes
-  static_assert(MT >= 1 && NT >= 1 && A_ROWS >= 1 && B_ROWS >= 1, "tile");
+  constexpr int A_ROWS = BM / PR;                    // producer passes over the A tile
+  static_assert(MT >= 1 && NT >= 1 && A_ROWS >= 1 && BN <= X3_PRODUCERS * 16, "tile");
 
   extern __shared__ __attribute__((aligned(16))) char xsm[];
   // counters per STAGE: waves are at most one K-tile apart, so a single running count could be
@@ -967,14 +967,18 @@ __global__ __launch_bounds__((WM * WN + X3_PRODUCERS) * 64) void conv_x3_kernel(
       rsrc_a2 = __builtin_amdgcn_make_buffer_rsrc(
           const_cast<char*>(reinterpret_cast<const char*>(p.A2)) - bias, 0,
           (int)(p.a_bytes + bias), 0x00020000);
+    // B comes pre-split (vlnce_conv2d_split_weights): three planes of N*K bf16, row n = K
+    // contiguous; thread -> (row ptid / 4, 16-byte chunk ptid % 4 of the K-tile's 64 bytes)
+    const int plane_b = (int)(p.b_bytes >> 1);  // bytes of one plane
     const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char*>(reinterpret_cast<const char*>(p.B)), 0, (int)p.b_bytes, 0x00020000);
+        const_cast<char*>(reinterpret_cast<const char*>(p.Bsplit)), 0, 3 * plane_b, 0x00020000);
+    const int brow = ptid >> 2, bchunk = ptid & 3;
     const bool has_pro = p.in_scale != nullptr;
     const bool pad_matters = p.pad > 0;
     const int HoWo = p.Ho * p.Wo;
 
     // ---- load cursor: the tile whose K-tiles are being fetched
-    int a_voff[A_ROWS], b_voff[B_ROWS];
+    int a_voff[A_ROWS], b_voff;
     unsigned a_taps[A_ROWS];  // bit t: filter tap t of this output pixel reads inside the image
     int l_round = 0, l_m0 = 0, l_n0 = 0, l_kt = 0;
     int u_r = 0, u_q = 0, u_ci = 0, u_k = 0;  // wave-uniform (tap, channel, k) of the next fetch
@@ -1004,43 +1008,41 @@ __global__ __launch_bounds__((WM * WN + X3_PRODUCERS) * 64) void conv_x3_kernel(
           a_taps[i] = mask;
         }
       }
-#pragma unroll
-      for (int i = 0; i < B_ROWS; ++i) {
-        const int n = n0 + i * PR + lrow;
-        b_voff[i] = n < p.N ? (int)(((long)n * p.ldb + lk4) * 4) : BUF_OOB;
-      }
+      b_voff = (brow < BN && n0 + brow < p.N) ? ((n0 + brow) * p.ldb + bchunk * 8) * 2 : BUF_OOB;
       u_r = u_q = u_ci = u_k = 0;
     };
 
     // Register ring of NSET staged K-tiles: NSET-1 tiles of loads are in flight while one is
     // transformed and written to LDS.  Loads past the last K-tile are issued out of range (the
     // hardware returns zeros, no traffic).
-    constexpr int NSET = DUAL ? 2 : 3;
+    constexpr int NSET = (DUAL && A_ROWS > 1) ? 2 : 3;
     typedef X3Staged<A_ROWS, DUAL> Staged;
     Staged st[NSET];
-    f32x4 sb[NSET][B_ROWS];
-#pragma unroll
-    for (int j = 0; j < NSET; ++j)
-      st[j].ps = st[j].pt = st[j].pc = st[j].p2s = st[j].p2t = st[j].p2c = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    auto load = [&](Staged& s, f32x4 (&b)[B_ROWS], bool live) {
-      const int tap = u_r * p.KW + u_q;
-      const int soff = ((u_r * p.W + u_q) * p.lda + u_ci) * 4;
-      if (has_pro && live) {
-        s.ps = ldg4(p.in_scale + u_ci + lk4);
-        s.pt = ldg4(p.in_shift + u_ci + lk4);
-        if (p.in_center) s.pc = ldg4(p.in_center + u_ci + lk4);
-      }
-      if constexpr (DUAL) {
-        s.kcur = u_ci;
-        s.m0 = l_n0 == 0 ? l_m0 : -1;  // side_out rows, or -1: not this tile's job
-        s.p2s = f32x4{1.f, 1.f, 1.f, 1.f};
-        if (p.in2_scale != nullptr && live) {
-          s.p2s = ldg4(p.in2_scale + u_ci + lk4);
-          s.p2t = ldg4(p.in2_shift + u_ci + lk4);
-          if (p.in2_center) s.p2c = ldg4(p.in2_center + u_ci + lk4);
+    u32x4 sb[NSET][3];
+    // The prologue vectors of a K-tile (its 32 input channels) are not part of the ring: one copy,
+    // fetched right after the previous K-tile was written (they are L1/L2 hits: every row of
+    // every workgroup reads the same few KB), a K-tile time before they are used.
+    f32x4 ps = {0.f, 0.f, 0.f, 0.f}, pt = ps, pc = ps, p2s = {1.f, 1.f, 1.f, 1.f}, p2t = ps, p2c = ps;
+    int s_ci = 0;  // first input channel of the K-tile to be written next
+    auto load_vec = [&]() {
+      if (has_pro) {
+        ps = ldg4(p.in_scale + s_ci + lk4);
+        pt = ldg4(p.in_shift + s_ci + lk4);
+        if (p.in_center) pc = ldg4(p.in_center + s_ci + lk4);
+        if constexpr (DUAL) {
+          if (p.in2_scale != nullptr) {
+            p2s = ldg4(p.in2_scale + s_ci + lk4);
+            p2t = ldg4(p.in2_shift + s_ci + lk4);
+            if (p.in2_center) p2c = ldg4(p.in2_center + s_ci + lk4);
+          }
         }
       }
+    };
+
+    auto load = [&](Staged& s, u32x4 (&b)[3], bool live) {
+      const int tap = u_r * p.KW + u_q;
+      const int soff = ((u_r * p.W + u_q) * p.lda + u_ci) * 4;
+      if constexpr (DUAL) s.m0 = l_n0 == 0 ? l_m0 : -1;  // side_out rows, or -1: not this tile's job
       s.ok = 0;
 #pragma unroll
       for (int i = 0; i < A_ROWS; ++i) {
@@ -1054,10 +1056,9 @@ __global__ __launch_bounds__((WM * WN + X3_PRODUCERS) * 64) void conv_x3_kernel(
               __builtin_amdgcn_raw_buffer_load_b128(rsrc_a2, ok ? a_voff[i] : BUF_OOB, soff, 0));
       }
 #pragma unroll
-      for (int i = 0; i < B_ROWS; ++i)
-        b[i] = __builtin_bit_cast(
-            f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, live ? b_voff[i] : BUF_OOB,
-                                                         u_k * 4, 0));
+      for (int q = 0; q < 3; ++q)
+        b[q] = __builtin_amdgcn_raw_buffer_load_b128(
+            rsrc_b, (live && b_voff != BUF_OOB) ? b_voff + q * plane_b : BUF_OOB, u_k * 2, 0);
       // advance the cursor by one K-tile; past the tile's last one, move to the next tile
       u_k += BK;
       u_ci += BK;
@@ -1074,15 +1075,14 @@ __global__ __launch_bounds__((WM * WN + X3_PRODUCERS) * 64) void conv_x3_kernel(
       }
     };
 
-    auto stash = [&](const Staged& s, const f32x4 (&b)[B_ROWS], char* stage) {
+    auto stash = [&](const Staged& s, const u32x4 (&b)[3], char* stage) {
       char* arow = stage + lrow * X3_PITCH + lk4 * 2;
-      char* brow = stage + A_BYTES + lrow * X3_PITCH + lk4 * 2;
 #pragma unroll
       for (int i = 0; i < A_ROWS; ++i) {
         f32x4 v = s.a[i];
         if (has_pro) {
-          v = __builtin_elementwise_fma(v - s.pc, s.ps, s.pt);
-          if constexpr (DUAL) v += __builtin_elementwise_fma(s.a2[i] - s.p2c, s.p2s, s.p2t);
+          v = __builtin_elementwise_fma(v - pc, ps, pt);
+          if constexpr (DUAL) v += __builtin_elementwise_fma(s.a2[i] - p2c, p2s, p2t);
           if (p.in_relu) v = __builtin_elementwise_max(v, f32x4{0.f, 0.f, 0.f, 0.f});
           // zero padding comes AFTER the transform (rows past M are never stored or counted)
           if (pad_matters && !((s.ok >> i) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1090,19 +1090,27 @@ __global__ __launch_bounds__((WM * WN + X3_PRODUCERS) * 64) void conv_x3_kernel(
             // the materialised block output: written once, by the workgroups of n-tile 0
             // (1x1 convolution: every tile of one tile_m row has the same rows)
             if (p.side_out != nullptr && s.m0 >= 0 && ((s.ok >> i) & 1u))
-              *reinterpret_cast<f32x4*>(p.side_out + (long)(s.m0 + i * PR + lrow) * p.lda +
-                                        s.kcur + lk4) = v;
+              *reinterpret_cast<f32x4*>(p.side_out + (long)(s.m0 + i * PR + lrow) * p.lda + s_ci +
+                                        lk4) = v;
           }
         }
         x3_split_store(v, arow + i * PR * X3_PITCH, A_PLANE);
       }
+      if (brow < BN) {
+        char* bdst = stage + A_BYTES + brow * X3_PITCH + bchunk * 16;
 #pragma unroll
-      for (int i = 0; i < B_ROWS; ++i) x3_split_store(b[i], brow + i * PR * X3_PITCH, B_PLANE);
+        for (int q = 0; q < 3; ++q) *reinterpret_cast<u32x4*>(bdst + q * B_PLANE) = b[q];
+      }
     };
 
     // K-tile g of the stream goes to stage g & 1 once the matrix waves are done with K-tile
     // g - 2; iteration g: issue the loads of K-tile g + NSET - 1, write K-tile g
+#ifdef X3_DBG_TIME
+    long long d_pl = 0, d_pw = 0, d_pm = 0, d_ps = 0;
+    const long long d_p0 = clock64();
+#endif
     setup_tile(0);
+    load_vec();
 #pragma unroll
     for (int j = 0; j < NSET - 1; ++j) load(st[j], sb[j], j < G_total);
     for (int g0 = 0; g0 < G_total; g0 += NSET) {
@@ -1110,14 +1118,38 @@ __global__ __launch_bounds__((WM * WN + X3_PRODUCERS) * 64) void conv_x3_kernel(
       for (int j = 0; j < NSET; ++j) {
         const int g = g0 + j;
         if (g < G_total) {
+#ifdef X3_DBG_TIME
+          const long long d_0 = clock64();
+#endif
           const int seen = x3_peek(empty + (g & 1));
           load(st[(j + NSET - 1) % NSET], sb[(j + NSET - 1) % NSET], g + NSET - 1 < G_total);
+#ifdef X3_DBG_TIME
+          const long long d_1 = clock64();
+#endif
           x3_wait(empty + (g & 1), seen, X3_MATRIX * (g >> 1));  // K-tile g-2 has been read
+#ifdef X3_DBG_TIME
+          const long long d_2 = clock64();
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSET - 1) * (A_ROWS * (1 + DUAL) + 3)) : "memory");
+          const long long d_3 = clock64();
+#endif
           stash(st[j], sb[j], xsm + (g & 1) * STAGE_BYTES);
           if (lane == 0) x3_signal(full + (g & 1));  // (in LDS order behind this wave's stage writes)
+          s_ci += BK;
+          if (s_ci >= p.Cin) s_ci = 0;
+          if (g + 1 < G_total) load_vec();
+#ifdef X3_DBG_TIME
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          const long long d_4 = clock64();
+          d_pl += d_1 - d_0; d_pw += d_2 - d_1; d_pm += d_3 - d_2; d_ps += d_4 - d_3;
+#endif
         }
       }
     }
+#ifdef X3_DBG_TIME
+    if (blockIdx.x == 8 && (tid == X3_MATRIX * 64 || tid == X3_MATRIX * 64 + 448))
+      printf("x3 producer wave %d: total %lld: issue loads %lld, wait for matrix waves %lld, wait for "
+             "data %lld, transform+write %lld\n", wave, (long long)(clock64() - d_p0), d_pl, d_pw, d_pm, d_ps);
+#endif
   } else {
     // ================================================================ matrix waves
     const int wm = wave / WN, wn = wave % WN;
@@ -1443,7 +1475,7 @@ struct X3Plan {
   int bm, bn;
 };
 bool x3_plan(const IgemmParams& p, X3Plan* out) {
-  if (!conv_math() || !buf_ok(p) || p.splitk > 1) return false;
+  if (!conv_math() || !p.Bsplit || !buf_ok(p) || p.splitk > 1) return false;
   if (p.residual || p.accumulate || p.c_bytes >= 0x7fffffffL) return false;
   static const int force = getenv("VLNCE_X3_TILE") ? atoi(getenv("VLNCE_X3_TILE")) : 0;  // tuning
   const X3Plan cand[4] = {{128, 128}, {64, 128}, {128, 64}, {64, 64}};
@@ -1496,6 +1528,33 @@ extern "C" int vlnce_conv2d_tiles_m(const vlnce_conv_desc* d) {
   return ceil_div(M, stat_rows_for(d));
 }
 
+// w[i] -> planes[q][i], q = 0..2: the exact three-way bf16 split of conv_x3_kernel's B operand
+__global__ __launch_bounds__(256) void split_weights_kernel(const float* __restrict__ w,
+                                                            unsigned short* __restrict__ planes,
+                                                            long count) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < count; i += gridDim.x * 256L) {
+    const float x = w[i];
+    const unsigned xb = __float_as_uint(x);
+    const float r = x - __uint_as_float(xb & 0xffff0000u);
+    const unsigned rb = __float_as_uint(r);
+    const float t = r - __uint_as_float(rb & 0xffff0000u);
+    planes[i] = (unsigned short)(xb >> 16);
+    planes[count + i] = (unsigned short)(rb >> 16);
+    planes[2 * count + i] = (unsigned short)(__float_as_uint(t) >> 16);
+  }
+}
+
+extern "C" int vlnce_conv2d_split_weights(const float* w, void* planes, long count,
+                                          vlnce_stream_t stream) {
+  VLNCE_CHECK_ARG(w && planes && count > 0, "conv2d_split_weights: bad argument");
+  const long blocks = (count + 255) / 256;
+  hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)),
+                     dim3(256), 0, reinterpret_cast<hipStream_t>(stream), w,
+                     reinterpret_cast<unsigned short*>(planes), count);
+  VLNCE_CHECK_LAUNCH("conv2d_split_weights");
+  return 0;
+}
+
 extern "C" int vlnce_conv2d_fwd(const float* x, const float* w, float* y, const vlnce_conv_desc* d,
                                 const vlnce_prologue* pro, const vlnce_epilogue* epi,
                                 vlnce_stream_t stream) {
@@ -1538,6 +1597,7 @@ extern "C" int vlnce_conv2d_fwd(const float* x, const float* w, float* y, const 
   p.in2_shift = pro ? pro->in2_shift : nullptr;
   p.in2_center = pro ? pro->in2_center : nullptr;
   p.side_out = pro ? pro->side_out : nullptr;
+  p.Bsplit = pro ? pro->w_split : nullptr;
   VLNCE_CHECK_ARG((p.in_scale == nullptr) == (p.in_shift == nullptr),
                   "conv2d_fwd: in_scale and in_shift must come together");
   fill_epilogue(p, epi);

@@ -33,6 +33,22 @@ def _rows2d(t):
 
 
 # ----------------------------------------------------------------- conv (forward only)
+def split_weights(w_ohwi):
+    """The weights as three bf16 planes (vlnce_conv2d_split_weights) for the bf16-matrix-pipe
+    convolution kernel, or None where that kernel does not apply (Cin % 32 != 0).  Cached on
+    the weight tensor itself and redone when the tensor is written in place; the encoders pass
+    their packed OHWI tensors (one object per parameter version), so a frozen trunk splits once."""
+    if not w_ohwi.is_cuda or w_ohwi.shape[-1] % 32 != 0 or w_ohwi.dtype != torch.float32:
+        return None
+    hit = getattr(w_ohwi, "_vlnce_split", None)
+    if hit is None or hit[0] != w_ohwi._version:
+        planes = torch.empty((3, w_ohwi.numel()), device=w_ohwi.device, dtype=torch.int16)
+        L().conv2d_split_weights(w_ohwi, planes)
+        hit = (w_ohwi._version, planes)
+        w_ohwi._vlnce_split = hit
+    return hit[1]
+
+
 def conv_geometry(x, w, stride, pad, ldx=None):
     N, H, W, Cin = x.shape
     Cout, KH, KW, Cin2 = w.shape
@@ -70,7 +86,7 @@ def conv2d_nhwc(x, w_ohwi, stride, pad, *, in_scale=None, in_shift=None, in_cent
                     side_out=side_out)
     L().conv2d_fwd(x, w_ohwi, y, g, in_scale=in_scale, in_shift=in_shift, in_center=in_center,
                    in_relu=int(in_relu), **dual, scale=scale, shift=shift, residual=residual, ldr=g["Cout"], act=act,
-                   stat_partial=partial)
+                   stat_partial=partial, w_split=split_weights(w_ohwi))
     return (y, stats) if want_stats else y
 
 
