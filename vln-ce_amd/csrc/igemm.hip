@@ -906,8 +906,11 @@ __device__ __forceinline__ void x3_wait(const int* flag, int seen, int need) {
   asm volatile("" ::: "memory");
 }
 __device__ __forceinline__ void x3_signal(int* flag) {
-  asm volatile("" ::: "memory");
-  __hip_atomic_fetch_add(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  // one lane's ds_add_u32 (the caller masks to lane 0); written out because the compiler's
+  // atomic optimiser wraps a wave-uniform add in a ballot / mbcnt sequence
+  typedef __attribute__((address_space(3))) int lds_int;
+  const unsigned addr = (unsigned)(__UINTPTR_TYPE__)(lds_int*)flag;
+  asm volatile("ds_add_u32 %0, %1" ::"v"(addr), "v"(1) : "memory");
 }
 
 template <int BM, int BN, int WM, int WN, int DUAL>
@@ -975,6 +978,7 @@ __global__ __launch_bounds__((WM * WN + X3_PRODUCERS) * 64) void conv_x3_kernel(
     const int brow = ptid >> 2, bchunk = ptid & 3;
     const bool has_pro = p.in_scale != nullptr;
     const bool pad_matters = p.pad > 0;
+    const float relu_floor = p.in_relu ? 0.f : -__builtin_huge_valf();  // max(x, -inf) = x
     const int HoWo = p.Ho * p.Wo;
 
     // ---- load cursor: the tile whose K-tiles are being fetched
@@ -1022,7 +1026,7 @@ __global__ __launch_bounds__((WM * WN + X3_PRODUCERS) * 64) void conv_x3_kernel(
     // The prologue vectors of a K-tile (its 32 input channels) are not part of the ring: one copy,
     // fetched right after the previous K-tile was written (they are L1/L2 hits: every row of
     // every workgroup reads the same few KB), a K-tile time before they are used.
-    f32x4 ps = {0.f, 0.f, 0.f, 0.f}, pt = ps, pc = ps, p2s = {1.f, 1.f, 1.f, 1.f}, p2t = ps, p2c = ps;
+    f32x4 ps = {0.f, 0.f, 0.f, 0.f}, pt = ps, pc = ps, p2s = {1.f, 1.f, 1.f, 1.f}, pt2 = ps, p2c = ps;
     int s_ci = 0;  // first input channel of the K-tile to be written next
     auto load_vec = [&]() {
       if (has_pro) {
@@ -1032,7 +1036,7 @@ __global__ __launch_bounds__((WM * WN + X3_PRODUCERS) * 64) void conv_x3_kernel(
         if constexpr (DUAL) {
           if (p.in2_scale != nullptr) {
             p2s = ldg4(p.in2_scale + s_ci + lk4);
-            p2t = ldg4(p.in2_shift + s_ci + lk4);
+            pt2 = pt + ldg4(p.in2_shift + s_ci + lk4);
             if (p.in2_center) p2c = ldg4(p.in2_center + s_ci + lk4);
           }
         }
@@ -1081,9 +1085,23 @@ __global__ __launch_bounds__((WM * WN + X3_PRODUCERS) * 64) void conv_x3_kernel(
       for (int i = 0; i < A_ROWS; ++i) {
         f32x4 v = s.a[i];
         if (has_pro) {
-          v = __builtin_elementwise_fma(v - pc, ps, pt);
-          if constexpr (DUAL) v += __builtin_elementwise_fma(s.a2[i] - p2c, p2s, p2t);
-          if (p.in_relu) v = __builtin_elementwise_max(v, f32x4{0.f, 0.f, 0.f, 0.f});
+          // (scalar fma / max per element: packed fp32 VALU beside MFMAs costs more issue time
+          // than the two plain instructions it replaces -- MI355X_MICROARCH.md)
+          if constexpr (DUAL) {
+            if (p.in2_scale != nullptr) {  // downsample branch: its own BatchNorm (pt2 = pt + p2t)
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                v[e] = fmaxf(fmaf(v[e] - pc[e], ps[e], fmaf(s.a2[i][e] - p2c[e], p2s[e], pt2[e])),
+                             relu_floor);
+            } else {  // identity skip: added as is
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                v[e] = fmaxf(fmaf(v[e] - pc[e], ps[e], pt[e]) + s.a2[i][e], relu_floor);
+            }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(v[e] - pc[e], ps[e], pt[e]), relu_floor);
+          }
           // zero padding comes AFTER the transform (rows past M are never stored or counted)
           if (pad_matters && !((s.ok >> i) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
           if constexpr (DUAL) {
@@ -1292,6 +1310,37 @@ __global__ __launch_bounds__((WM * WN + X3_PRODUCERS) * 64) void conv_x3_kernel(
 #endif
 }
 
+// statistics partials {sum, M2 about the block mean} of a finished [M, N] output, per block of
+// `rows` output pixels and column: the second pass of a split-K convolution that feeds a
+// BatchNorm / GroupNorm (same layout as the convolution kernels' epilogue partials)
+__global__ __launch_bounds__(256) void rows_stats_kernel(const float* __restrict__ y, int ldc, int M,
+                                                         int N, int rows,
+                                                         float* __restrict__ partial) {
+  const int col = blockIdx.y * 64 + (threadIdx.x & 63);
+  const int blk = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int r0 = blk * rows;
+  if (col >= N || r0 >= M) return;
+  const int n = min(rows, M - r0);
+  const float* q = y + (long)r0 * ldc + col;
+  float v[32];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 32; ++i) {
+    v[i] = i < n ? q[(long)i * ldc] : 0.f;
+    s += v[i];
+  }
+  const float mean = s / (float)n;
+  float m2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < 32; ++i) {
+    const float d = v[i] - mean;
+    if (i < n) m2 += d * d;
+  }
+  float* dst = partial + ((long)blk * N + col) * 2;
+  dst[0] = s;
+  dst[1] = m2;
+}
+
 // y = act(y + shift): second pass of a split-K GEMM that has a bias / activation
 __global__ __launch_bounds__(256) void bias_act_kernel(float* __restrict__ c, int ldc, int M, int N,
                                                        const float* __restrict__ shift, int act) {
@@ -1416,8 +1465,9 @@ bool aligned16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 
 int x3_cus() {
   static const int cus = [] {
     int dev = 0, n = 256;
-    if (hipGetDevice(&dev) == hipSuccess)
-      hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+      n = 256;
     return n >= 8 ? (n / 8) * 8 : 8;
   }();
   return cus;
@@ -1628,7 +1678,7 @@ extern "C" int vlnce_conv2d_fwd(const float* x, const float* w, float* y, const 
     // workgroup walking them alone is pure latency (20-50 us per layer).  Split the reduction
     // over blockIdx.y with atomic accumulation into a zeroed output and apply the epilogue
     // (scale/shift/residual/activation) in a second, row-wise pass.
-    const int sk = (!p.stat_partial && !p.accumulate && p.ldc == p.N &&
+    const int sk = (!p.accumulate && p.ldc == p.N && p.stat_rows <= 32 &&
                     ((p.scale && p.shift) || (!p.scale && !p.residual)))
                        ? choose_splitk(p)
                        : 1;
@@ -1636,12 +1686,20 @@ extern "C" int vlnce_conv2d_fwd(const float* x, const float* w, float* y, const 
       const float* scale = p.scale;
       const float* shift = p.shift;
       const float* residual = p.residual;
+      float* stat_partial = p.stat_partial;
       const int act = p.act, ldr = p.ldr;
       p.scale = p.shift = p.residual = nullptr;
+      p.stat_partial = nullptr;
       p.act = 0;
       p.splitk = sk;
       vlnce_zero(y, M, p.N, p.ldc, s);
       if (int rc = dispatch_small<A_BUF, B_BUF>(p, s)) return rc;
+      if (stat_partial) {  // statistics of the RAW sums, as the one-pass kernels' epilogues take them
+        const int nblk = ceil_div((int)M, p.stat_rows);
+        hipLaunchKernelGGL(rows_stats_kernel, dim3(ceil_div(nblk, 4), ceil_div(p.N, 64)), dim3(256),
+                           0, s, y, p.ldc, (int)M, p.N, p.stat_rows, stat_partial);
+        VLNCE_CHECK_LAUNCH("conv2d_fwd split-K statistics");
+      }
       if (scale) {
         VLNCE_CHECK_ARG(!residual || ldr == p.N, "conv2d_fwd: split-K needs a contiguous residual");
         return vlnce_scale_shift_act(y, scale, shift, nullptr, 0, residual, y, M, p.N, act, stream);
