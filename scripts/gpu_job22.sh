@@ -23,3 +23,13 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf $O/pmc_$c
   grep -n "segment\|conv_x3\|igemm" $O/pmc_$c.txt | head -30 | cut -c1-170
 done
+# other BASELINE.json configurations and the cached-feature data path
+timeout 400 python scripts/bench_policies.py > $O/bench_other_policies.jsonl 2> $O/bench_other_policies.err
+tail -3 $O/bench_other_policies.jsonl | cut -c1-250
+timeout 400 python scripts/bench_data_path.py > $O/bench_data_path.json 2> $O/bench_data_path.err
+tail -1 $O/bench_data_path.json | cut -c1-600
+timeout 300 python bench.py --trainable-encoders --steps 10 --warmup 3 --no-cpu-baseline --no-f32-compare > $O/bench_trainable.json 2>/dev/null
+tail -c 600 $O/bench_trainable.json | head -c 300
+timeout 300 python scripts/conv_launch_times.py > $O/conv_launch_times.txt 2>/dev/null
+head -3 $O/conv_launch_times.txt
+timeout 300 python scripts/trunkbench.py 2>/dev/null | tail -6

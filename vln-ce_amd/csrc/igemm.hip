@@ -1271,7 +1271,13 @@ __global__ __launch_bounds__((WM * WN + X3_PRODUCERS) * 64) void conv_x3_kernel(
       // -------------------------------------------------------------- statistics partials
       if (p.stat_partial != nullptr) {
         const int tile_m = m0 / BM;
-        if (p.stat_rows > 0 && p.stat_rows < WTM)
+        if (p.stat_rows == 32 && MT > 1) {
+          // one partial per 32x32 MFMA block row: exactly the 16 accumulator registers of a lane
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+            wave_stats_block<NT>(acc[i], p.stat_partial, (m0 + wm * WTM) / 32 + i,
+                                 p.M - (m0 + wm * WTM + i * 32), n0 + wn * WTN, p.N, half, l31);
+        } else if (p.stat_rows > 0 && p.stat_rows < WTM)
           wave_stats_fine<MT, NT>(acc, p.stat_partial, p.stat_rows, m0 + wm * WTM, p.M,
                                   n0 + wn * WTN, p.N, half, l31);
         else
