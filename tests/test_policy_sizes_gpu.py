@@ -99,6 +99,44 @@ def test_waypoint_num_envs_32_properties():
     assert (v2 - value).abs().max().item() < 1e-5  # evaluate_actions == act on the same inputs
 
 
+def test_waypoint_graphed_tail_equals_eager(monkeypatch):
+    """Everything downstream of the Waypoint encoders replays as a HIP graph (forward and
+    backward) from the 2nd call with a signature on; values, log-probs and every parameter
+    gradient must agree with the eager path (the tail's split-K GEMMs sum with fp32 atomics, so to
+    rounding, not bit-for-bit)."""
+    case = dict(WP_ACT, hw=64, lengths=[40, 33])
+    _, hip = _pair(case)
+    obs, prev, masks, _ = cases.build_inputs(case)
+    obs, prev, masks = to_dev(obs), to_dev(prev), to_dev(masks)
+    h0 = torch.zeros(2, hip.net.num_recurrent_layers, 256, device=DEV)
+    with torch.no_grad():
+        elems = hip.act(obs, h0, {k: v.clone() for k, v in prev.items()}, masks,
+                        deterministic=True)[2]
+
+    def run():
+        for q in hip.parameters():
+            q.grad = None
+        v, lp, ent, _ = hip.evaluate_actions(obs, h0, {k: v.clone() for k, v in prev.items()},
+                                             masks, elems)
+        (v.sum() + lp.sum() + sum(e.sum() for e in ent.values())).backward()
+        return (v.detach().clone(), lp.detach().clone(),
+                {n: q.grad.clone() for n, q in hip.named_parameters() if q.grad is not None})
+
+    monkeypatch.setenv("VLNCE_HIP_GRAPHS", "0")
+    want = run()
+    monkeypatch.setenv("VLNCE_HIP_GRAPHS", "1")
+    for _ in range(3):  # eager, capturing, replaying
+        got = run()
+    assert any(not isinstance(e, int) for e in hip.net._tail.entries.values()), \
+        "the tail was never captured"
+    for a, b in ((got[0], want[0]), (got[1], want[1])):
+        assert (a - b).abs().max().item() <= 1e-5 * (1.0 + b.abs().max().item())
+    assert set(got[2]) == set(want[2]) and len(want[2]) > 30
+    for n in want[2]:
+        scale = want[2][n].abs().max().item()
+        assert (got[2][n] - want[2][n]).abs().max().item() <= 1e-4 * scale + 1e-6, n
+
+
 CMA_UPDATE = dict(policy="CMAPolicy", hw=256, N=4, T=1, lengths=[80, 74, 80, 61], mode="train",
                   call="update", overrides={"PROGRESS_MONITOR.use": True})
 

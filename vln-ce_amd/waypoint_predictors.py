@@ -15,6 +15,7 @@ from .encoders.instruction_encoder import InstructionEncoder
 from .net_parts import build_depth_encoder, build_rgb_encoder, relu_fc
 from .policy import Net
 from .rnn_state_encoder import build_rnn_state_encoder
+from .streams import GraphedTail
 from .utils import (CustomFixedCategorical, DotProductAttention, MultiHeadDotProductAttention,
                     TemperatureTanh)
 
@@ -25,6 +26,103 @@ ANGLE_FEATURE_SIZE = 4
 
 def _lin(module, x, act=ops.ACT_NONE):
     return ops.linear(x, module.weight, module.bias, act)
+
+
+class _WaypointTail(nn.Module):
+    """Everything of WaypointPredictionNet.forward downstream of the three encoders, as a
+    tensor-only callable with static shapes so that its forward AND backward replay as HIP
+    graphs (streams.GraphedTail): ~150 small launches forward whose host-side issue cost is
+    otherwise on the critical path.  It references the parent's sub-modules and is NOT one of
+    its children.  Heads that the configuration does not have come back as empty tensors."""
+
+    def __init__(self, net):
+        super().__init__()
+        object.__setattr__(self, "net", net)
+        # the sub-modules it uses are (shared) children: make_graphed_callables takes the
+        # parameters to differentiate from module.parameters()
+        for name in ("rgb_pool_linear", "rgb_hist_linear", "depth_hist_linear", "visual_rnn",
+                     "inst_attn_q", "inst_attn_k", "inst_attn", "text_q_linear", "rgb_kv_spatial",
+                     "rgb_spatial_attn", "depth_kv_spatial", "depth_spatial_attn", "pano_attn",
+                     "main_state_compress", "main_state_encoder", "stop_linear",
+                     "compress_x_linear", "distance_linear", "distance_var_linear",
+                     "offset_linear", "offset_var_linear"):
+            if hasattr(net, name):
+                setattr(self, name, getattr(net, name))
+
+    def forward(self, ins, rgb, rgb_hist, dep, dep_hist, pa, angle_features, rnn_states, masks):
+        n = self.net
+        mc, wc = n.model_config, n.wypt_cfg
+        P = n._num_panos
+        hs = n._hidden_size
+        half = hs // 2
+        B = rgb.shape[0]
+        Pr, Cr = rgb.shape[2:]
+        Pd, Cd = dep.shape[2:]
+
+        # visual history GRU (:275-284, 400-427)
+        rl = n.rgb_encoder.resnet_layer_size
+        pooled = ops.mean_rows(rgb.reshape(B * P, Pr, Cr))[:, :rl]  # mean over positions
+        pooled = ops.mean_rows(_lin(n.rgb_pool_linear, pooled).view(B, P, -1))
+        rgb_h = _lin(n.rgb_hist_linear[2], ops.mean_rows(rgb_hist.contiguous()), ops.ACT_RELU)
+        dep_h = ops.linear(dep_hist.reshape(B, Pd * Cd),
+                           nchw_flat_weight(n.depth_hist_linear[1], Cd, Pd),
+                           n.depth_hist_linear[1].bias, ops.ACT_RELU)
+        nv = n.visual_rnn.num_recurrent_layers
+        vis, h1 = n.visual_rnn(torch.cat([pooled, pa, rgb_h, dep_h], dim=1),
+                                  rnn_states[:, 0:nv], masks)
+
+        # instruction attention -- multiplicative mask on PAD (:433-438, App. B-3)
+        q = _lin(n.inst_attn_q[0], vis, ops.ACT_RELU)
+        k = ops.linear(ins, n.inst_attn_k.weight.view(half, -1), n.inst_attn_k.bias)
+        text = ops.attention(q, k, ins, ops.rowzero_mask(ins.detach()), 2,
+                             n.inst_attn._scale_f)
+
+        # spatial attention per pano frame; repeat_interleave WITHOUT dim repeats elements
+        # (:456-462, App. B-4) -- reproduced verbatim
+        tq = _lin(n.text_q_linear, text)
+        tq = tq.repeat_interleave(P).view(B * P, tq.shape[1])
+        rgb_kv = ops.linear(rgb.reshape(B * P, Pr, Cr), n.rgb_kv_spatial.weight.view(-1, Cr),
+                            n.rgb_kv_spatial.bias)
+        dep_kv = ops.linear(dep.reshape(B * P, Pd, Cd), n.depth_kv_spatial.weight.view(-1, Cd),
+                            n.depth_kv_spatial.bias)
+        att_rgb = ops.attention(tq, rgb_kv[..., :half], rgb_kv[..., half:], None, 0,
+                                n.rgb_spatial_attn._scale_f).view(B, P, -1)
+        att_dep = ops.attention(tq, dep_kv[..., :half], dep_kv[..., half:], None, 0,
+                                n.depth_spatial_attn._scale_f).view(B, P, -1)
+
+        vis_feats = torch.cat([att_rgb, att_dep, angle_features], dim=2)  # [B,12,d]
+        shared = vis_feats.permute(0, 2, 1)  # logical [B, d, 12]
+        pano = n.pano_attn(Q=text, K=shared, V=shared)
+
+        x = _lin(n.main_state_compress[0], torch.cat([text, pano, vis, pa], dim=1), ops.ACT_RELU)
+        x, h2 = n.main_state_encoder(x, rnn_states[:, nv:], masks)
+        rnn_states_out = torch.cat([h1, h2], dim=1)
+
+        # heads (:549-625)
+        x_small = _lin(n.compress_x_linear[0], x, ops.ACT_RELU).unsqueeze(1)
+        dotted = (vis_feats * x_small).sum(2)
+        pano_stop_logits = torch.cat([dotted, _lin(n.stop_linear, x)], dim=1)
+        catted = torch.cat([vis_feats, x.unsqueeze(1).expand(-1, P, -1)], dim=2)
+
+        if wc.continuous_distance:
+            d1 = _lin(n.distance_linear[0], catted, ops.ACT_SIGMOID).squeeze(2)
+            d1 = (wc.max_distance_prediction - wc.min_distance_prediction) * d1 \
+                + wc.min_distance_prediction
+            d2 = (wc.max_distance_var - wc.min_distance_var) * _lin(
+                n.distance_var_linear[0], catted, ops.ACT_SIGMOID).squeeze(2) \
+                + wc.min_distance_var
+        else:
+            d1, d2 = _lin(n.distance_linear, catted).squeeze(2), None
+        if wc.continuous_offset:
+            o1 = n.offset_scale * n.offset_linear[1](
+                _lin(n.offset_linear[0], catted)).squeeze(2)
+            o2 = (wc.max_offset_var - wc.min_offset_var) * _lin(
+                n.offset_var_linear[0], catted, ops.ACT_SIGMOID).squeeze(2) + wc.min_offset_var
+        else:
+            o1, o2 = _lin(n.offset_linear, catted).squeeze(2), None
+        empty = x.new_zeros(0)
+        return (pano_stop_logits, o1, o2 if o2 is not None else empty, d1,
+                d2 if d2 is not None else empty, x, rnn_states_out)
 
 
 class WaypointPredictionNet(Net):
@@ -79,6 +177,8 @@ class WaypointPredictionNet(Net):
         nn.init.constant_(self.stop_linear.bias, 0)
         self.compress_x_linear = relu_fc(hs, pano_width)
         self._build_component_heads(hs + pano_width)
+        # kept out of the module tree (it shares our sub-modules): see _WaypointTail
+        object.__setattr__(self, "_tail", GraphedTail(lambda: _WaypointTail(self)))
         self.train()
 
     # ---- class index -> metres / radians (waypoint_predictors.py:184-215)
@@ -180,66 +280,13 @@ class WaypointPredictionNet(Net):
         Pr, Cr = rgb.shape[2:]
         Pd, Cd = dep.shape[2:]
 
-        # visual history GRU (:275-284, 400-427)
-        rl = self.rgb_encoder.resnet_layer_size
-        pooled = ops.mean_rows(rgb.reshape(B * P, Pr, Cr))[:, :rl]  # mean over positions
-        pooled = ops.mean_rows(_lin(self.rgb_pool_linear, pooled).view(B, P, -1))
-        rgb_h = _lin(self.rgb_hist_linear[2], ops.mean_rows(rgb_hist.contiguous()), ops.ACT_RELU)
-        dep_h = ops.linear(dep_hist.reshape(B, Pd * Cd),
-                           nchw_flat_weight(self.depth_hist_linear[1], Cd, Pd),
-                           self.depth_hist_linear[1].bias, ops.ACT_RELU)
-        nv = self.visual_rnn.num_recurrent_layers
-        vis, h1 = self.visual_rnn(torch.cat([pooled, pa, rgb_h, dep_h], dim=1),
-                                  rnn_states[:, 0:nv], masks)
-
-        # instruction attention -- multiplicative mask on PAD (:433-438, App. B-3)
-        q = _lin(self.inst_attn_q[0], vis, ops.ACT_RELU)
-        k = ops.linear(ins, self.inst_attn_k.weight.view(half, -1), self.inst_attn_k.bias)
-        text = ops.attention(q, k, ins, ops.rowzero_mask(ins.detach()), 2,
-                             self.inst_attn._scale_f)
-
-        # spatial attention per pano frame; repeat_interleave WITHOUT dim repeats elements
-        # (:456-462, App. B-4) -- reproduced verbatim
-        tq = _lin(self.text_q_linear, text)
-        tq = tq.repeat_interleave(P).view(B * P, tq.shape[1])
-        rgb_kv = ops.linear(rgb.reshape(B * P, Pr, Cr), self.rgb_kv_spatial.weight.view(-1, Cr),
-                            self.rgb_kv_spatial.bias)
-        dep_kv = ops.linear(dep.reshape(B * P, Pd, Cd), self.depth_kv_spatial.weight.view(-1, Cd),
-                            self.depth_kv_spatial.bias)
-        att_rgb = ops.attention(tq, rgb_kv[..., :half], rgb_kv[..., half:], None, 0,
-                                self.rgb_spatial_attn._scale_f).view(B, P, -1)
-        att_dep = ops.attention(tq, dep_kv[..., :half], dep_kv[..., half:], None, 0,
-                                self.depth_spatial_attn._scale_f).view(B, P, -1)
-
-        vis_feats = torch.cat([att_rgb, att_dep, observations["angle_features"]], dim=2)  # [B,12,d]
-        shared = vis_feats.permute(0, 2, 1)  # logical [B, d, 12]
-        pano = self.pano_attn(Q=text, K=shared, V=shared)
-
-        x = _lin(self.main_state_compress[0], torch.cat([text, pano, vis, pa], dim=1), ops.ACT_RELU)
-        x, h2 = self.main_state_encoder(x, rnn_states[:, nv:], masks)
-        rnn_states_out = torch.cat([h1, h2], dim=1)
-
-        # heads (:549-625)
-        x_small = _lin(self.compress_x_linear[0], x, ops.ACT_RELU).unsqueeze(1)
-        dotted = (vis_feats * x_small).sum(2)
-        pano_stop = CustomFixedCategorical(
-            logits=torch.cat([dotted, _lin(self.stop_linear, x)], dim=1))
-        catted = torch.cat([vis_feats, x.unsqueeze(1).expand(-1, P, -1)], dim=2)
-
-        if wc.continuous_distance:
-            d1 = _lin(self.distance_linear[0], catted, ops.ACT_SIGMOID).squeeze(2)
-            d1 = (wc.max_distance_prediction - wc.min_distance_prediction) * d1 \
-                + wc.min_distance_prediction
-            d2 = (wc.max_distance_var - wc.min_distance_var) * _lin(
-                self.distance_var_linear[0], catted, ops.ACT_SIGMOID).squeeze(2) \
-                + wc.min_distance_var
-        else:
-            d1, d2 = _lin(self.distance_linear, catted).squeeze(2), None
-        if wc.continuous_offset:
-            o1 = self.offset_scale * self.offset_linear[1](
-                _lin(self.offset_linear[0], catted)).squeeze(2)
-            o2 = (wc.max_offset_var - wc.min_offset_var) * _lin(
-                self.offset_var_linear[0], catted, ops.ACT_SIGMOID).squeeze(2) + wc.min_offset_var
-        else:
-            o1, o2 = _lin(self.offset_linear, catted).squeeze(2), None
+        logits, o1, o2, d1, d2, x, rnn_states_out = self._tail(
+            ins, rgb.contiguous(), rgb_hist.contiguous(), dep.contiguous(), dep_hist.contiguous(),
+            pa.contiguous(), observations["angle_features"].contiguous(), rnn_states.contiguous(),
+            masks)
+        pano_stop = CustomFixedCategorical(logits=logits)
+        if not wc.continuous_distance:
+            d2 = None
+        if not wc.continuous_offset:
+            o2 = None
         return pano_stop, o1, o2, d1, d2, x, rnn_states_out
