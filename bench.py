@@ -558,9 +558,13 @@ def main():
             line["config"]["fp32_mfma_only"] = f32_mfma_compare(args)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.num_envs, args.hw, args.tokens)
-        print(json.dumps(line))
+        final = json.dumps(line)
     if use_dist:
         dist.destroy_process_group()
+    if rank == 0:
+        # the JSON line is the LAST thing on stdout (RCCL writes its own lines at teardown)
+        sys.stdout.flush()
+        print(final, flush=True)
 
 
 if __name__ == "__main__":
