@@ -1,12 +1,14 @@
 // Packed-sequence LSTM / GRU over the instruction (instruction_encoder.py:27-32,
 // 80-94): the WHOLE time loop (and its BPTT) runs inside one launch.
 //
-// One workgroup per (direction, 16-sample tile); 4 waves, each owning H/4 hidden
-// units for every gate, so the gate math is wave-local.  Per step the wave
-// computes h_{t-1} W_hh^T for its units with v_mfma_f32_16x16x4_f32 (exact fp32):
-//   A = h tile [16 x H] in LDS (double-buffered, one barrier per step),
-//   B = W_hh fragments, loaded ONCE and kept in registers for all steps (256 VGPRs
-//       of the 512-entry unified file; one wave per SIMD).
+// One workgroup per (direction, 16-sample tile); 4 waves (8 at H = 128), each owning H/NW
+// hidden units for every gate, so the gate math is wave-local.  Per step the wave computes
+// h_{t-1} W_hh^T for its units on the bf16 matrix pipe as six plane products of exactly split
+// fp32 operands (v_mfma_f32_16x16x32_bf16, fp32 accumulate; see split_planes):
+//   A = h tile [16 x H] as three bf16 planes in LDS (double-buffered, one barrier per step),
+//   B = W_hh planes, split ONCE and kept in registers for all steps.
+// What a step reads from global memory (input projection; in the backward pass the saved gates,
+// states and output gradients) is fetched one step ahead.
 // The input projection x W_ih^T (+b_ih) for all steps is a single big MFMA GEMM
 // done beforehand (time-major [L,B,G*H]).  Packed semantics: steps >= len[b]
 // leave the state untouched and emit zeros; the reverse direction walks
@@ -36,13 +38,59 @@ struct RnnSeqParams {
 
 __device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }
 
-template <int KIND, int NTW>
-__global__ __launch_bounds__(256) void rnn_seq_fwd_kernel(RnnSeqParams p) {
+// fp32 recurrent product on the bf16 matrix pipe: both operands are split exactly into three
+// bf16 planes (truncation: 8 + 8 + 8 mantissa bits) and multiplied as the six plane products of
+// order <= 2^-16, fp32 accumulate -- the arithmetic of conv_x3_kernel (igemm.hip).  One
+// v_mfma_f32_16x16x32_bf16 (16 cycles) covers 32 k-values where v_mfma_f32_16x16x4_f32
+// (32 cycles) covers 4: 2.7x less matrix-pipe time per step, on the step's critical path.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4r __attribute__((ext_vector_type(4)));
+struct Planes3 {
+  bf16x8 p[3];
+};
+__device__ __forceinline__ Planes3 split_planes(f32x4 lo4, f32x4 hi4) {
+  const float x[8] = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+  u32x4r h, m, l;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float x0 = x[2 * q], x1 = x[2 * q + 1];
+    const float r0 = x0 - __uint_as_float(__float_as_uint(x0) & 0xffff0000u);
+    const float r1 = x1 - __uint_as_float(__float_as_uint(x1) & 0xffff0000u);
+    const float s0 = r0 - __uint_as_float(__float_as_uint(r0) & 0xffff0000u);
+    const float s1 = r1 - __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
+    h[q] = __builtin_amdgcn_perm(__float_as_uint(x1), __float_as_uint(x0), 0x07060302u);
+    m[q] = __builtin_amdgcn_perm(__float_as_uint(r1), __float_as_uint(r0), 0x07060302u);
+    l[q] = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+  }
+  Planes3 o;
+  o.p[0] = __builtin_bit_cast(bf16x8, h);
+  o.p[1] = __builtin_bit_cast(bf16x8, m);
+  o.p[2] = __builtin_bit_cast(bf16x8, l);
+  return o;
+}
+// one value -> its three plane words
+__device__ __forceinline__ void split_scalar(float x, unsigned short (&o)[3]) {
+  const unsigned xb = __float_as_uint(x);
+  const float r = x - __uint_as_float(xb & 0xffff0000u);
+  const unsigned rb = __float_as_uint(r);
+  const float t = r - __uint_as_float(rb & 0xffff0000u);
+  o[0] = (unsigned short)(xb >> 16);
+  o[1] = (unsigned short)(rb >> 16);
+  o[2] = (unsigned short)(__float_as_uint(t) >> 16);
+}
+constexpr int X3_PA[6] = {2, 0, 1, 1, 0, 0};  // plane pairs, smallest products first
+constexpr int X3_PB[6] = {0, 2, 1, 0, 1, 0};
+
+// NW waves per workgroup, each owning H / NW hidden units for every gate (NW = 8 at H = 128: two
+// waves per SIMD, so that a wave's three weight planes fit its 256 registers)
+template <int KIND, int H, int NW>
+__global__ __launch_bounds__(NW * 64) void rnn_seq_fwd_kernel(RnnSeqParams p) {
   constexpr int G = KIND == 0 ? 4 : 3;
-  constexpr int H = NTW * 64;
-  constexpr int KG = H / 16;
-  constexpr int LDH = H + 4;
-  __shared__ __attribute__((aligned(16))) float h_lds[2][16][LDH];
+  constexpr int NTW = H / (NW * 16);
+  static_assert(NTW >= 1, "units per wave");
+  constexpr int KS = H / 32;     // k-steps of 32 per recurrent product
+  constexpr int LDHB = H + 16;   // bf16 row pitch: conflict-free ds_read_b128 of 8 k-values
+  __shared__ __attribute__((aligned(16))) unsigned short h_pl[2][3][16][LDHB];
   const int d = blockIdx.y;
   const int b0 = blockIdx.x * 16;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -58,31 +106,35 @@ __global__ __launch_bounds__(256) void rnn_seq_fwd_kernel(RnnSeqParams p) {
     const int b = b0 + quad * 4 + r;
     len[r] = b < B ? p.lengths[b] : 0;
   }
-  // recurrent weights -> registers (B operand: lane holds W[n = unit][k = 16g + 4*quad + e])
-  f32x4 wf[G][NTW][KG];
+  // recurrent weights -> registers, split once (B operand: lane holds the three planes of
+  // W[n = unit][k = 32 ks + 8 quad + 0..7])
+  Planes3 wp[G][NTW][KS];
   float bias[G][NTW];
 #pragma unroll
   for (int gt = 0; gt < G; ++gt)
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) {
-      const int n = gt * H + wave * (H / 4) + nt * 16 + l15;
+      const int n = gt * H + wave * (H / NW) + nt * 16 + l15;
       bias[gt][nt] = p.b_hh[d][n];
 #pragma unroll
-      for (int g = 0; g < KG; ++g)
-        wf[gt][nt][g] = *reinterpret_cast<const f32x4*>(W + (long)n * H + 16 * g + 4 * quad);
+      for (int ks = 0; ks < KS; ++ks) {
+        const float* w8 = W + (long)n * H + 32 * ks + 8 * quad;
+        wp[gt][nt][ks] = split_planes(*reinterpret_cast<const f32x4*>(w8),
+                                      *reinterpret_cast<const f32x4*>(w8 + 4));
+      }
     }
   float hreg[NTW][4], creg[NTW][4];
 #pragma unroll
   for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) hreg[nt][r] = creg[nt][r] = 0.f;
-  for (int i = tid; i < 16 * LDH; i += 256) (&h_lds[0][0][0])[i] = 0.f;
+  for (int i = tid; i < 3 * 16 * LDHB; i += NW * 64) (&h_pl[0][0][0][0])[i] = 0;
   __syncthreads();
 
-  for (int s = 0; s < L; ++s) {
-    const int cur = s & 1;
-    f32x4 acc[G][NTW];
-    float xn[NTW][4];  // GRU: input part of the n gate
+  // The input projection of a step is fetched ONE STEP AHEAD (gx): read at the top of the step
+  // it would put a global-load round trip in front of every step's MFMAs.
+  float gx[G][NTW][4];
+  auto fetch = [&](int s) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const bool active = s < len[r];
@@ -91,10 +143,25 @@ __global__ __launch_bounds__(256) void rnn_seq_fwd_kernel(RnnSeqParams p) {
       const float* row = gi + ((long)tt * B + b) * (G * H);
 #pragma unroll
       for (int nt = 0; nt < NTW; ++nt) {
-        const int u = wave * (H / 4) + nt * 16 + l15;
+        const int u = wave * (H / NW) + nt * 16 + l15;
+#pragma unroll
+        for (int gt = 0; gt < G; ++gt) gx[gt][nt][r] = active ? row[gt * H + u] : 0.f;
+      }
+    }
+  };
+  fetch(0);
+
+  for (int s = 0; s < L; ++s) {
+    const int cur = s & 1;
+    f32x4 acc[G][NTW];
+    float xn[NTW][4];  // GRU: input part of the n gate
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
         for (int gt = 0; gt < G; ++gt) {
-          const float x = active ? row[gt * H + u] : 0.f;
+          const float x = gx[gt][nt][r];
           if (KIND == 1 && gt == 2) {
             xn[nt][r] = x;
             acc[gt][nt][r] = bias[gt][nt];
@@ -102,19 +169,21 @@ __global__ __launch_bounds__(256) void rnn_seq_fwd_kernel(RnnSeqParams p) {
             acc[gt][nt][r] = x + bias[gt][nt];
           }
         }
-      }
-    }
+    fetch(s + 1);  // (rows with s + 1 >= len load nothing)
 #pragma unroll
-    for (int g = 0; g < KG; ++g) {
-      const f32x4 a = *reinterpret_cast<const f32x4*>(&h_lds[cur][l15][16 * g + 4 * quad]);
+    for (int ks = 0; ks < KS; ++ks) {
+      bf16x8 a[3];
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
+      for (int q = 0; q < 3; ++q)
+        a[q] = *reinterpret_cast<const bf16x8*>(&h_pl[cur][q][l15][32 * ks + 8 * quad]);
+#pragma unroll
+      for (int q = 0; q < 6; ++q)
 #pragma unroll
         for (int gt = 0; gt < G; ++gt)
 #pragma unroll
           for (int nt = 0; nt < NTW; ++nt)
-            acc[gt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], wf[gt][nt][g][e], acc[gt][nt],
-                                                               0, 0, 0);
+            acc[gt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                a[X3_PA[q]], wp[gt][nt][ks].p[X3_PB[q]], acc[gt][nt], 0, 0, 0);
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -124,7 +193,7 @@ __global__ __launch_bounds__(256) void rnn_seq_fwd_kernel(RnnSeqParams p) {
       const int row_i = quad * 4 + r;
 #pragma unroll
       for (int nt = 0; nt < NTW; ++nt) {
-        const int u = wave * (H / 4) + nt * 16 + l15;
+        const int u = wave * (H / NW) + nt * 16 + l15;
         float hnew;
         if (KIND == 0) {
           const float ig = sigm(acc[0][nt][r]), fg = sigm(acc[1][nt][r]);
@@ -159,7 +228,10 @@ __global__ __launch_bounds__(256) void rnn_seq_fwd_kernel(RnnSeqParams p) {
           hreg[nt][r] = hnew;
           p.out[d][((long)tt * B + b) * H + u] = hnew;
         }
-        h_lds[cur ^ 1][row_i][u] = hreg[nt][r];
+        unsigned short hw[3];
+        split_scalar(hreg[nt][r], hw);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) h_pl[cur ^ 1][q][row_i][u] = hw[q];
       }
     }
     __syncthreads();
@@ -170,18 +242,19 @@ __global__ __launch_bounds__(256) void rnn_seq_fwd_kernel(RnnSeqParams p) {
     if (b < B)
 #pragma unroll
       for (int nt = 0; nt < NTW; ++nt)
-        p.h_final[d][(long)b * H + wave * (H / 4) + nt * 16 + l15] = hreg[nt][r];
+        p.h_final[d][(long)b * H + wave * (H / NW) + nt * 16 + l15] = hreg[nt][r];
   }
 }
 
-template <int KIND, int NTW>
-__global__ __launch_bounds__(256) void rnn_seq_bwd_kernel(RnnSeqParams p) {
+template <int KIND, int H, int NW>
+__global__ __launch_bounds__(NW * 64) void rnn_seq_bwd_kernel(RnnSeqParams p) {
   constexpr int G = KIND == 0 ? 4 : 3;
-  constexpr int H = NTW * 64;
+  constexpr int NTW = H / (NW * 16);
   constexpr int GH = G * H;
-  constexpr int KG = GH / 16;
-  constexpr int LDG = GH + 4;
-  __shared__ __attribute__((aligned(16))) float dg_lds[16][LDG];
+  constexpr int KS = GH / 32;    // k-steps of 32 of dh_{t-1} = dgates * W_hh
+  constexpr int LDGB = GH + 16;  // bf16 row pitch (conflict-free ds_read_b128)
+  static_assert(NTW >= 1, "units per wave");
+  __shared__ __attribute__((aligned(16))) unsigned short dg_pl[3][16][LDGB];
   const int d = blockIdx.y;
   const int b0 = blockIdx.x * 16;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -196,13 +269,16 @@ __global__ __launch_bounds__(256) void rnn_seq_bwd_kernel(RnnSeqParams p) {
     const int b = b0 + quad * 4 + r;
     len[r] = b < B ? p.lengths[b] : 0;
   }
-  f32x4 wt[NTW][KG];
+  Planes3 wt[NTW][KS];  // the three planes of WT[n][32 ks + 8 quad + 0..7]
 #pragma unroll
   for (int nt = 0; nt < NTW; ++nt) {
-    const int n = wave * (H / 4) + nt * 16 + l15;
+    const int n = wave * (H / NW) + nt * 16 + l15;
 #pragma unroll
-    for (int g = 0; g < KG; ++g)
-      wt[nt][g] = *reinterpret_cast<const f32x4*>(WT + (long)n * GH + 16 * g + 4 * quad);
+    for (int ks = 0; ks < KS; ++ks) {
+      const float* w8 = WT + (long)n * GH + 32 * ks + 8 * quad;
+      wt[nt][ks] = split_planes(*reinterpret_cast<const f32x4*>(w8),
+                                *reinterpret_cast<const f32x4*>(w8 + 4));
+    }
   }
   float dh[NTW][4], dc[NTW][4];
 #pragma unroll
@@ -210,38 +286,86 @@ __global__ __launch_bounds__(256) void rnn_seq_bwd_kernel(RnnSeqParams p) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int b = b0 + quad * 4 + r;
-      const int u = wave * (H / 4) + nt * 16 + l15;
+      const int u = wave * (H / NW) + nt * 16 + l15;
       dh[nt][r] = (p.dh_final[d] && b < B) ? p.dh_final[d][(long)b * H + u] : 0.f;
       dc[nt][r] = 0.f;
     }
 
+  // What a step reads from memory (saved gates, cell / candidate state, the output gradient,
+  // the previous step's state) is fetched one step ahead -- two for the previous state, which is
+  // the next step's own state -- so no step starts with a global-load round trip.
+  float pg[G][NTW][4], pa[NTW][4], pa_prev[NTW][4], pd[NTW][4];
+  auto fetch = [&](int s, float (&g_)[G][NTW][4], float (&a_)[NTW][4], float (&d_)[NTW][4]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool active = s >= 0 && s < len[r];
+      const int tt = reverse ? len[r] - 1 - s : s;
+      const int b = b0 + quad * 4 + r;
+      const long base = ((long)tt * B + b);
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt) {
+        const int u = wave * (H / NW) + nt * 16 + l15;
+#pragma unroll
+        for (int gt = 0; gt < G; ++gt) g_[gt][nt][r] = active ? p.gates[d][base * GH + gt * H + u] : 0.f;
+        a_[nt][r] = active ? p.aux[d][base * H + u] : 0.f;
+        d_[nt][r] = (active && p.dout[d]) ? p.dout[d][base * H + u] : 0.f;
+      }
+    }
+  };
+  // previous state of step s: LSTM c_{s-1} = aux of step s-1; GRU h_{s-1} = out of step s-1
+  auto fetch_prev = [&](int s, float (&a_)[NTW][4]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool active = s >= 0 && s < len[r];
+      const int tt = reverse ? len[r] - 1 - s : s;
+      const int b = b0 + quad * 4 + r;
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt) {
+        const int u = wave * (H / NW) + nt * 16 + l15;
+        const float* src = KIND == 0 ? p.aux[d] : p.out[d];
+        a_[nt][r] = active ? src[((long)tt * B + b) * H + u] : 0.f;
+      }
+    }
+  };
+  fetch(L - 1, pg, pa, pd);
+  fetch_prev(L - 2, pa_prev);
+
   for (int s = L - 1; s >= 0; --s) {
     float keep_z[NTW][4];  // GRU: dh * z carried straight to h_prev
+    float cg[G][NTW][4], ca[NTW][4], cprev[NTW][4], cd[NTW][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt) {
+#pragma unroll
+        for (int gt = 0; gt < G; ++gt) cg[gt][nt][r] = pg[gt][nt][r];
+        ca[nt][r] = pa[nt][r];
+        cprev[nt][r] = pa_prev[nt][r];
+        cd[nt][r] = pd[nt][r];
+      }
+    fetch(s - 1, pg, pa, pd);
+    fetch_prev(s - 2, pa_prev);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const bool active = s < len[r];
       const int tt = reverse ? len[r] - 1 - s : s;
-      const int tp = reverse ? tt + 1 : tt - 1;  // time index of the previous step's state
-      const bool has_prev = s > 0;
       const int b = b0 + quad * 4 + r;
       const int row_i = quad * 4 + r;
       const long base = ((long)tt * B + b);
 #pragma unroll
       for (int nt = 0; nt < NTW; ++nt) {
-        const int u = wave * (H / 4) + nt * 16 + l15;
+        const int u = wave * (H / NW) + nt * 16 + l15;
         float dpre[G];
 #pragma unroll
         for (int gt = 0; gt < G; ++gt) dpre[gt] = 0.f;
         float dgh_n = 0.f;
         keep_z[nt][r] = 0.f;
         if (active) {
-          const float* gs = p.gates[d] + base * GH;
-          float dht = dh[nt][r];
-          if (p.dout[d]) dht += p.dout[d][base * H + u];
+          const float dht = dh[nt][r] + cd[nt][r];
           if (KIND == 0) {
-            const float ig = gs[u], fg = gs[H + u], gg = gs[2 * H + u], og = gs[3 * H + u];
-            const float c = p.aux[d][base * H + u];
-            const float cp = has_prev ? p.aux[d][((long)tp * B + b) * H + u] : 0.f;
+            const float ig = cg[0][nt][r], fg = cg[1][nt][r], gg = cg[2][nt][r], og = cg[3][nt][r];
+            const float c = ca[nt][r];
+            const float cp = cprev[nt][r];  // (0 at the sequence's first step)
             const float tc = tanhf(c);
             const float dct = dc[nt][r] + dht * og * (1.f - tc * tc);
             dpre[0] = dct * gg * ig * (1.f - ig);
@@ -250,9 +374,9 @@ __global__ __launch_bounds__(256) void rnn_seq_bwd_kernel(RnnSeqParams p) {
             dpre[3] = dht * tc * og * (1.f - og);
             dc[nt][r] = dct * fg;
           } else {
-            const float rg = gs[u], zg = gs[H + u], ng = gs[2 * H + u];
-            const float hn = p.aux[d][base * H + u];
-            const float hp = has_prev ? p.out[d][((long)tp * B + b) * H + u] : 0.f;
+            const float rg = cg[0][nt][r], zg = cg[1][nt][r], ng = cg[2][nt][r];
+            const float hn = ca[nt][r];
+            const float hp = cprev[nt][r];
             const float dn = dht * (1.f - zg);
             const float dz = dht * (hp - ng);
             const float dnp = dn * (1.f - ng * ng);
@@ -274,8 +398,12 @@ __global__ __launch_bounds__(256) void rnn_seq_bwd_kernel(RnnSeqParams p) {
         }
         // A operand of dh_{t-1} = dgates_h * W_hh  (zeros for finished / padded rows)
 #pragma unroll
-        for (int gt = 0; gt < G; ++gt)
-          dg_lds[row_i][gt * H + u] = (KIND == 1 && gt == 2) ? dgh_n : dpre[gt];
+        for (int gt = 0; gt < G; ++gt) {
+          unsigned short dw[3];
+          split_scalar((KIND == 1 && gt == 2) ? dgh_n : dpre[gt], dw);
+#pragma unroll
+          for (int q = 0; q < 3; ++q) dg_pl[q][row_i][gt * H + u] = dw[q];
+        }
       }
     }
     __syncthreads();
@@ -283,13 +411,17 @@ __global__ __launch_bounds__(256) void rnn_seq_bwd_kernel(RnnSeqParams p) {
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int g = 0; g < KG; ++g) {
-      const f32x4 a = *reinterpret_cast<const f32x4*>(&dg_lds[l15][16 * g + 4 * quad]);
+    for (int ks = 0; ks < KS; ++ks) {
+      bf16x8 a[3];
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
+      for (int q = 0; q < 3; ++q)
+        a[q] = *reinterpret_cast<const bf16x8*>(&dg_pl[q][l15][32 * ks + 8 * quad]);
+#pragma unroll
+      for (int q = 0; q < 6; ++q)
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt)
-          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], wt[nt][g][e], acc[nt], 0, 0, 0);
+          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[X3_PA[q]], wt[nt][ks].p[X3_PB[q]],
+                                                            acc[nt], 0, 0, 0);
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -306,9 +438,9 @@ template <int KIND>
 int launch_fwd(const RnnSeqParams& p, int H, int dirs, hipStream_t s) {
   dim3 grid(ceil_div(p.B, 16), dirs);
   if (H == 64)
-    hipLaunchKernelGGL((rnn_seq_fwd_kernel<KIND, 1>), grid, dim3(256), 0, s, p);
+    hipLaunchKernelGGL((rnn_seq_fwd_kernel<KIND, 64, 4>), grid, dim3(256), 0, s, p);
   else if (H == 128)
-    hipLaunchKernelGGL((rnn_seq_fwd_kernel<KIND, 2>), grid, dim3(256), 0, s, p);
+    hipLaunchKernelGGL((rnn_seq_fwd_kernel<KIND, 128, 8>), grid, dim3(512), 0, s, p);
   else
     return 1;
   return 0;
@@ -317,9 +449,9 @@ template <int KIND>
 int launch_bwd(const RnnSeqParams& p, int H, int dirs, hipStream_t s) {
   dim3 grid(ceil_div(p.B, 16), dirs);
   if (H == 64)
-    hipLaunchKernelGGL((rnn_seq_bwd_kernel<KIND, 1>), grid, dim3(256), 0, s, p);
+    hipLaunchKernelGGL((rnn_seq_bwd_kernel<KIND, 64, 4>), grid, dim3(256), 0, s, p);
   else if (H == 128)
-    hipLaunchKernelGGL((rnn_seq_bwd_kernel<KIND, 2>), grid, dim3(256), 0, s, p);
+    hipLaunchKernelGGL((rnn_seq_bwd_kernel<KIND, 128, 8>), grid, dim3(512), 0, s, p);
   else
     return 1;
   return 0;
