@@ -1,7 +1,7 @@
 #!/bin/bash
 # round-2 evidence run: full GPU tests, bench line, kernel-trace stats of bench, PMC traffic passes
 export TMPDIR=/tmp
-O=$GRAFT_REPO_ROOT/gpurun_out/r02v
+O=$GRAFT_REPO_ROOT/gpurun_out/r02zz
 mkdir -p $O
 cd $GRAFT_REPO_ROOT
 ( time timeout 2400 python -m pytest tests -m gpu -x -q ) > $O/gpu_tests.log 2>&1
