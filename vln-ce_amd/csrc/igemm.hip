@@ -1017,9 +1017,9 @@ __global__ __launch_bounds__((WM * WN + X3_PRODUCERS) * 64) void conv_x3_kernel(
     };
 
     // Register ring of NSET staged K-tiles: NSET-1 tiles of loads are in flight while one is
-    // transformed and written to LDS.  Loads past the last K-tile are issued out of range (the
+    // transformed and written to LDS (8 producer waves per CU: 1 K-tile each = 8 in flight).  Loads past the last K-tile are issued out of range (the
     // hardware returns zeros, no traffic).
-    constexpr int NSET = (DUAL && A_ROWS > 1) ? 2 : 3;
+    constexpr int NSET = 2;  // (3 measured 1-4 % slower: the registers it costs spill)
     typedef X3Staged<A_ROWS, DUAL> Staged;
     Staged st[NSET];
     u32x4 sb[NSET][3];
