@@ -285,3 +285,13 @@ def test_instruction_dedup_equals_row_by_row_encoding(sim, policy_name, final_on
     assert len(ggot) == len(gref) > 0
     for a, b in zip(ggot, gref):
         assert torch.allclose(a, b, atol=1e-5, rtol=1e-4)
+
+
+def test_split_weights_is_gpu_only_and_channel_gated():
+    """The bf16-plane split belongs to the HIP convolution kernel: on the CPU (hostsim) path, and
+    for weights whose input-channel count the kernel does not take, ops.split_weights hands back
+    None and the call goes down the fp32 path."""
+    from vlnce_amd import ops
+
+    assert ops.split_weights(torch.randn(8, 3, 3, 32)) is None      # CPU tensor
+    assert ops.split_weights(torch.randn(8, 7, 7, 3)) is None       # Cin % 32 != 0
