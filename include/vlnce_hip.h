@@ -28,7 +28,7 @@ typedef void* vlnce_stream_t;
 
 enum { VLNCE_ACT_NONE = 0, VLNCE_ACT_RELU = 1, VLNCE_ACT_SIGMOID = 2, VLNCE_ACT_TANH = 3 };
 
-int vlnce_version(void); /* major*100 + minor; 130 = this header */
+int vlnce_version(void); /* major*100 + minor; 131 = this header */
 const char* vlnce_last_error(void);
 
 /* ---------------------------------------------------------------- conv / GEMM
@@ -74,6 +74,11 @@ typedef struct {
    * products on the bf16 matrix pipe (conv_x3_kernel: fp32-equivalent result, DESIGN.md
    * section 6); without it (NULL) they run on v_mfma_f32_32x32x2_f32. */
   const void* w_split;
+  /* Optional: the weights as bf16-plane MFMA B fragments (vlnce_conv2d_pack_weights()).  With it,
+   * stride-1 KxK and all 1x1 convolutions with Cin % 32 == 0 and Cout % 32 == 0 run on
+   * conv_p3_kernel (A operand transformed once per workgroup into an LDS patch, B fragments
+   * straight from L2); NULL = conv_x3_kernel / igemm_kernel as above. */
+  const void* w_frag;
 } vlnce_prologue;
 
 typedef struct {
@@ -95,6 +100,16 @@ int vlnce_conv2d_tile_rows(const vlnce_conv_desc* d); /* BM chosen for `d`      
 /* planes[q][i], q = 0..2: bf16 words with w[i] == planes[0][i] + planes[1][i] + planes[2][i]
  * exactly (truncation split, 8 + 8 + 8 mantissa bits).  `planes` holds 3 * count 16-bit words. */
 int vlnce_conv2d_split_weights(const float* w, void* planes, long count, vlnce_stream_t stream);
+
+/* frag = the weights of `d` as bf16-plane MFMA B fragments, layout
+ * [Cout/32][K/16][3 planes][64 lanes][8 bf16] with the k-slabs ordered (32-channel chunk, filter
+ * tap, 16-channel half) and w == plane0 + plane1 + plane2 exactly (round-to-nearest split).
+ * vlnce_conv2d_pack_bytes() = bytes `frag` must hold (Cout*K*6), or 0 where the fragment kernel
+ * does not apply (Cin % 32 != 0 or Cout % 32 != 0).  Replaces nothing upstream: a cached
+ * re-layout of nn.Conv2d.weight (resnet_encoders.py:136-139). */
+long vlnce_conv2d_pack_bytes(const vlnce_conv_desc* d);
+int vlnce_conv2d_pack_weights(const float* w_ohwi, void* frag, const vlnce_conv_desc* d,
+                              vlnce_stream_t stream);
 
 int vlnce_conv2d_fwd(const float* x, const float* w_ohwi, float* y,
                      const vlnce_conv_desc* d, const vlnce_prologue* pro,

@@ -42,17 +42,62 @@ R50 = [
 ]
 
 
+# habitat GroupNorm ResNet-50 (base 32) on the 128x128 pooled depth frame + compression conv
+DEPTH = [
+    ("d1_1x1_32_32", 32, 32, 32, 1, 1, 1),
+    ("d1_3x3_32_32", 32, 32, 32, 3, 1, 3),
+    ("d1_1x1_32_128", 32, 32, 128, 1, 1, 4),
+    ("d1_1x1_128_32", 32, 128, 32, 1, 1, 2),
+    ("d2_1x1_128_64", 32, 128, 64, 1, 1, 1),
+    ("d2_3x3s2_64_64", 32, 64, 64, 3, 2, 1),
+    ("d2_1x1s2_128_256", 32, 128, 256, 1, 2, 1),
+    ("d2_1x1_64_256", 16, 64, 256, 1, 1, 4),
+    ("d2_1x1_256_64", 16, 256, 64, 1, 1, 3),
+    ("d2_3x3_64_64", 16, 64, 64, 3, 1, 3),
+    ("d3_1x1_256_128", 16, 256, 128, 1, 1, 1),
+    ("d3_3x3s2_128_128", 16, 128, 128, 3, 2, 1),
+    ("d3_1x1s2_256_512", 16, 256, 512, 1, 2, 1),
+    ("d3_1x1_128_512", 8, 128, 512, 1, 1, 6),
+    ("d3_1x1_512_128", 8, 512, 128, 1, 1, 5),
+    ("d3_3x3_128_128", 8, 128, 128, 3, 1, 5),
+    ("d4_1x1_512_256", 8, 512, 256, 1, 1, 1),
+    ("d4_3x3s2_256_256", 8, 256, 256, 3, 2, 1),
+    ("d4_1x1s2_512_1024", 8, 512, 1024, 1, 2, 1),
+    ("d4_1x1_256_1024", 4, 256, 1024, 1, 1, 3),
+    ("d4_1x1_1024_256", 4, 1024, 256, 1, 1, 2),
+    ("d4_3x3_256_256", 4, 256, 256, 3, 1, 2),
+    ("dc_3x3_1024_128", 4, 1024, 128, 3, 1, 1),
+]
+# torchvision ResNet-18 (Waypoint RGB encoder), 3x3 layers only (the 1x1 downsamples are 1.2 %)
+R18 = [
+    ("r18_3x3_64_64", 64, 64, 64, 3, 1, 4),
+    ("r18_3x3s2_64_128", 64, 64, 128, 3, 2, 1),
+    ("r18_3x3_128_128", 32, 128, 128, 3, 1, 3),
+    ("r18_3x3s2_128_256", 32, 128, 256, 3, 2, 1),
+    ("r18_3x3_256_256", 16, 256, 256, 3, 1, 3),
+    ("r18_3x3s2_256_512", 16, 256, 512, 3, 2, 1),
+    ("r18_3x3_512_512", 8, 512, 512, 3, 1, 3),
+]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=64)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--mode", default="eval")
     ap.add_argument("--only", default="")
+    ap.add_argument("--set", default="r50", help="r50 | depth | r18 (comma separated)")
+    ap.add_argument("--pro", action="store_true",
+                    help="train mode: also apply the previous layer's BatchNorm + ReLU in the operand "
+                         "loader, as the trunks do (in_scale / in_shift / in_center / in_relu)")
     args = ap.parse_args()
     dev = "cuda:0"
     tot_t = tot_f = 0.0
     print(f"{'layer':22s} {'M':>8s} {'K':>6s} {'N':>5s} {'us':>9s} {'TF/s':>7s} x cnt")
-    for name, hw, cin, cout, k, s, cnt in R50:
+    layers = []
+    for nm in args.set.split(","):
+        layers += {"r50": R50, "depth": DEPTH, "r18": R18}[nm]
+    for name, hw, cin, cout, k, s, cnt in layers:
         if args.only and not any(o in name for o in args.only.split(",")):
             continue
         x = torch.randn(args.n, hw, hw, cin, device=dev)
@@ -61,6 +106,9 @@ def main():
         sh = torch.randn(cout, device=dev)
         pad = k // 2 if k % 2 else 0
         kw = dict(want_stats=True) if args.mode == "train" else dict(scale=sc, shift=sh, act=1)
+        if args.pro and args.mode == "train" and cin % 32 == 0:
+            kw.update(in_scale=torch.rand(cin, device=dev) + 0.5, in_shift=torch.randn(cin, device=dev),
+                      in_center=torch.randn(cin, device=dev), in_relu=True)
         if cin == 3:
             kw.update(in_scale=torch.full((3,), 1 / 255.0, device=dev),
                       in_shift=torch.zeros(3, device=dev))

@@ -44,6 +44,7 @@ def both(method, tensors, scalars):
     getattr(SIM, method)(**cpu, **scalars)
     if method == "conv2d_fwd":  # the pre-split weights select the bf16-plane kernel where it applies
         gpu["w_split"] = ops.split_weights(gpu["w"])
+        gpu["w_frag"] = ops.pack_weights(gpu["w"])
     getattr(_lib.get_lib(), method)(**gpu, **scalars)
     torch.cuda.synchronize()
     return cpu, gpu
@@ -748,3 +749,83 @@ def test_conv_x3_every_tile_shape(tile):
                         "-k", "conv2d_fwd or bottleneck or block", "-p", "no:cacheprovider"],
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:]
+
+
+# ------------------------------------------------------------------ patch-resident bf16-plane kernel
+def test_pack_weights_layout_and_exactness(hip):
+    """vlnce_conv2d_pack_weights: fragment order [Cout/32][K/16][3][64 lanes][8] with the k-slabs
+    ordered (32-channel chunk, tap, 16-channel half), and plane0 + plane1 + plane2 == w bit for
+    bit (round-to-nearest three-way split), also for huge / tiny / negative values."""
+    torch.manual_seed(5)
+    Cout, KH, KW, Cin = 64, 3, 3, 64
+    w = torch.randn(Cout, KH, KW, Cin) * torch.exp(6 * torch.randn(Cout, 1, 1, 1))
+    w.view(-1)[:6] = torch.tensor([0.0, -0.0, 1e-30, -3e38, 1.0, -1.0 + 2.0 ** -23])
+    wg = w.to(DEV)
+    frag = ops.pack_weights(wg)
+    assert frag is not None and frag.numel() == w.numel() * 3
+    assert ops.pack_weights(wg) is frag  # cached on the tensor
+    T, KS = KH * KW, KH * KW * Cin // 16
+    f = ((frag.cpu().to(torch.int32) & 0xFFFF) << 16).view(torch.float32).double()
+    f = f.view(Cout // 32, KS, 3, 64, 8).sum(2)  # the three planes added up: [nb, ks, lane, e]
+    lane = torch.arange(64)
+    for nb in range(Cout // 32):
+        for ks in range(KS):
+            s, ct = ks & 1, ks >> 1
+            t, c = ct % T, ct // T
+            n = nb * 32 + (lane & 31)
+            ci = c * 32 + s * 16 + (lane >> 5) * 8
+            want = torch.stack([w.view(Cout, T, Cin)[n, t, ci + e] for e in range(8)], 1)
+            assert torch.equal(f[nb, ks].float(), want), (nb, ks)
+    assert ops.pack_weights(torch.randn(48, 1, 1, 32, device=DEV)) is None  # Cout % 32 != 0
+    wg.mul_(2.0)
+    assert ops.pack_weights(wg) is not frag
+
+
+P3_CASES = [
+    # name,          N,  H,  W, Cin, Cout, k, s, p, extras
+    ("p3_3x3_w64",   2, 64, 64,  64,  64, 3, 1, 1, dict(stats=True)),            # 264-row patches
+    ("p3_3x3_w8",    5,  8,  8,  96, 128, 3, 1, 1, dict(scale=True, relu=True)),  # tiles across images
+    ("p3_3x3_w4",    6,  4,  4, 128,  96, 3, 1, 1, dict(prologue=True, in_relu=True, center=True)),
+    ("p3_3x3_rag",   3,  7,  9,  64,  96, 3, 1, 1, dict(prologue=True, in_relu=True)),
+    ("p3_5x5_p2",    2, 11, 13,  32,  64, 5, 1, 2, dict(scale=True)),
+    ("p3_3x3_p0",    2, 12, 10,  64,  32, 3, 1, 0, dict(stats=True)),
+    ("p3_1x1_wide",  3, 24, 24, 128, 512, 1, 1, 0, dict(prologue=True, in_relu=True, center=True,
+                                                        stats=True)),
+    ("p3_1x1_s2",    3, 18, 14, 128, 256, 1, 2, 0, dict(prologue=True, in_relu=True)),
+    ("p3_1x1_rag",   1,  5,  7, 160,  96, 1, 1, 0, dict(scale=True, relu=True)),
+    ("p3_dual_wide", 3, 20, 12, 128, 256, 1, 1, 0, dict(prologue=True, in_relu=True, center=True,
+                                                        dual="bn", stats=True)),
+    ("p3_dual_id",   2, 16, 16,  64,  64, 1, 1, 0, dict(prologue=True, in_relu=True, dual="identity")),
+    ("p3_many_tiles", 40, 32, 32, 64, 64, 3, 1, 1, dict(stats=True)),            # several tiles per CU
+]
+
+
+@pytest.mark.parametrize("case", P3_CASES, ids=[c[0] for c in P3_CASES])
+def test_conv_p3(hip, case):
+    test_conv2d_fwd(hip, case)
+
+
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6])
+def test_conv_p3_every_tile_shape(tile):
+    """conv_p3_kernel has six tile shapes chosen by problem size; force each one (VLNCE_P3_TILE,
+    read once per process) over the conv / block cases: several tiles per workgroup, ragged M,
+    N below the tile width, patches across image borders, the dual-input prologue, statistics."""
+    import subprocess
+    import sys
+    env = dict(os.environ, VLNCE_P3_TILE=str(tile))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu",
+                        "-k", "(conv2d_fwd or bottleneck or block or conv_p3) and not every_tile",
+                        "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:]
+
+
+def test_conv_p3_matches_fp64_better_than_1e_6(hip):
+    """The round-to-nearest bf16x3 split keeps the convolution fp32-class: relative rms error
+    against an fp64 convolution of the same operands below 1e-6 (torch's own fp32 conv: ~2e-7)."""
+    x = rnd(4, 16, 16, 256, seed=21).to(DEV)
+    w = (rnd(256, 3, 3, 256, seed=22) * (256 * 9) ** -0.5).to(DEV)
+    y = ops.conv2d_nhwc(x, w, 1, 1)
+    ref = F.conv2d(x.double().permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2), padding=1)
+    ref = ref.permute(0, 2, 3, 1)
+    rms = ((y.double() - ref).pow(2).mean() / ref.pow(2).mean()).sqrt().item()
+    assert rms < 1e-6, rms

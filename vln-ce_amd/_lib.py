@@ -31,7 +31,7 @@ class ConvDesc(C.Structure):
 class Prologue(C.Structure):
     _fields_ = [("in_scale", _P), ("in_shift", _P), ("in_center", _P), ("in_relu", _I),
                 ("x2", _P), ("in2_scale", _P), ("in2_shift", _P), ("in2_center", _P),
-                ("side_out", _P), ("w_split", _P)]
+                ("side_out", _P), ("w_split", _P), ("w_frag", _P)]
 
 
 class Frames(C.Structure):
@@ -48,6 +48,8 @@ _SIGNATURES = {
     "vlnce_version": (_I, []),
     "vlnce_last_error": (C.c_char_p, []),
     "vlnce_conv2d_split_weights": (_I, [_P, _P, C.c_long, _P]),
+    "vlnce_conv2d_pack_bytes": (C.c_long, [C.POINTER(ConvDesc)]),
+    "vlnce_conv2d_pack_weights": (_I, [_P, _P, C.POINTER(ConvDesc), _P]),
     "vlnce_conv2d_tiles_m": (_I, [C.POINTER(ConvDesc)]),
     "vlnce_conv2d_tile_rows": (_I, [C.POINTER(ConvDesc)]),
     "vlnce_conv2d_fwd": (_I, [_P, _P, _P, C.POINTER(ConvDesc), C.POINTER(Prologue),
@@ -173,7 +175,7 @@ class HipLib:
 
     name = "hip"
 
-    ABI = 130  # include/vlnce_hip.h
+    ABI = 131  # include/vlnce_hip.h
 
     def __init__(self, path=LIB_PATH):
         self.dll = load_cdll(path)
@@ -199,11 +201,11 @@ class HipLib:
     def conv2d_fwd(self, x, w, y, g, in_scale=None, in_shift=None, in_relu=0, scale=None,
                    shift=None, residual=None, ldr=0, act=0, accumulate=0, stat_partial=None,
                    in_center=None, x2=None, in2_scale=None, in2_shift=None, in2_center=None,
-                   side_out=None, w_split=None):
+                   side_out=None, w_split=None, w_frag=None):
         d = self._desc(g)
         pro = Prologue(_ptr(in_scale), _ptr(in_shift), _ptr(in_center), int(in_relu), _ptr(x2),
                        _ptr(in2_scale), _ptr(in2_shift), _ptr(in2_center), _ptr(side_out),
-                       _ptr(w_split))
+                       _ptr(w_split), _ptr(w_frag))
         epi = Epilogue(_ptr(scale), _ptr(shift), _ptr(residual), int(ldr), int(act),
                        int(accumulate), _ptr(stat_partial))
         self._check(self.dll.vlnce_conv2d_fwd(_ptr(x), _ptr(w), _ptr(y), C.byref(d), C.byref(pro),
@@ -212,6 +214,15 @@ class HipLib:
     def conv2d_split_weights(self, w, planes):
         self._check(self.dll.vlnce_conv2d_split_weights(_ptr(w), _ptr(planes), w.numel(),
                                                         _stream()), "vlnce_conv2d_split_weights")
+
+    def conv2d_pack_bytes(self, g):
+        d = self._desc(g)
+        return int(self.dll.vlnce_conv2d_pack_bytes(C.byref(d)))
+
+    def conv2d_pack_weights(self, w, frag, g):
+        d = self._desc(g)
+        self._check(self.dll.vlnce_conv2d_pack_weights(_ptr(w), _ptr(frag), C.byref(d), _stream()),
+                    "vlnce_conv2d_pack_weights")
 
     def gemm(self, A, lda, transA, B, ldb, transB, Cm, ldc, M, N, K, scale=None, shift=None,
              residual=None, ldr=0, act=0, accumulate=0):

@@ -20,169 +20,12 @@
 //   * blockIdx -> tile map is XCD-aware: each XCD (private L2) gets a
 //     contiguous run of tiles with the N-tile index fastest, so blocks that
 //     share an A row-panel hit the same L2.
-#include "common.h"
-#include <stdlib.h>
-#include <type_traits>
+#include "igemm_shared.h"
+
+using namespace vlnce_detail;
 
 namespace {
 
-constexpr int BK = 32;
-constexpr int LDP = 36;  // LDS row pitch in floats (32 + 4 pad)
-
-enum { A_IM2COL_V4 = 0, A_IM2COL_S = 1, A_TRANS = 2, A_BUF = 3 };
-enum { B_NK_V4 = 0, B_NK_S = 1, B_KN = 2, B_BUF = 3, B_IM2COL = 4 };
-
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-constexpr int BUF_OOB = (int)0x80000000;  // voffset beyond any buffer: the load returns zeros
-
-struct IgemmParams {
-  const float* A;
-  const float* B;
-  float* C;
-  int M, N, K;
-  int H, W, Cin, KH, KW, stride, pad, Ho, Wo;  // im2col geometry (plain GEMM: 1x1 "image" row)
-  int lda, ldb, ldc;
-  const float* in_scale;
-  const float* in_shift;
-  const float* in_center;  // optional: x' = (x - center) * scale + shift
-  int in_relu;
-  // dual-input prologue (1x1 convolutions through the buffer loaders only):
-  //   x' = act((A - center)*scale + shift + ((A2 - center2)*scale2 + shift2  |  A2))
-  // and, when side_out is set, the n-tile-0 workgroups store x' to side_out[m, 0..K)
-  const float* A2;
-  const float* in2_scale;
-  const float* in2_shift;
-  const float* in2_center;
-  float* side_out;
-  const void* Bsplit;  // conv_x3_kernel: the weights as three bf16 planes [3][N*K]
-  const float* scale;
-  const float* shift;
-  const float* residual;
-  int ldr;
-  int act;
-  int accumulate;
-  float* stat_partial;
-  int tiles_m, tiles_n;
-  int splitk;  // > 1: blockIdx.y owns a K range and atomically adds into a pre-zeroed C
-  int stat_rows;  // rows per statistics partial (vlnce_conv2d_tile_rows)
-  long a_bytes, b_bytes, c_bytes;  // extents of A / B / C for the buffer descriptors
-};
-
-__device__ __forceinline__ f32x4 ldg4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
-
-// BatchNorm / GroupNorm partial statistics of one wave's accumulator sub-tile (rows x NT*32
-// columns).  Lane (half, l31) holds, per 32x32 MFMA tile, column l31 and rows
-// (r&3) + 8*(r>>2) + 4*half.  Two passes over the registers: column sums -> sub-tile mean ->
-// sum of squared deviations (Chan/Welford form, merged later in fp64).
-template <int MT, int NT>
-__device__ __forceinline__ void wave_stats(const f32x16 (&acc)[MT][NT], float* stat_partial,
-                                           int part_row, int rows_left, int rows_full, int col0,
-                                           int N, int half, int l31) {
-  const int rows_valid = min(rows_full, rows_left);
-#pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (row < rows_valid) s += acc[i][j][r];
-      }
-    s += __shfl_xor(s, 32, 64);
-    const float mean = rows_valid > 0 ? s / (float)rows_valid : 0.f;
-    float m2 = 0.f;
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        const float d = acc[i][j][r] - mean;
-        if (row < rows_valid) m2 += d * d;
-      }
-    m2 += __shfl_xor(m2, 32, 64);
-    const int col = col0 + j * 32 + l31;
-    if (half == 0 && col < N && rows_left > 0) {
-      float* dst = stat_partial + ((long)part_row * N + col) * 2;
-      dst[0] = s;
-      dst[1] = m2;
-    }
-  }
-}
-
-// per-wave partials at a granularity of `rows` = 16 or 32 pixels (GroupNorm over samples of 16 /
-// 32 / ... pixels: partial tiles must not straddle samples).  Block b of 16 rows lives in MFMA
-// tile i = b / 2, accumulator registers [8 * (b % 2), +8) of both half-waves.
-template <int MT, int NT>
-__device__ __forceinline__ void wave_stats_fine(const f32x16 (&acc)[MT][NT], float* stat_partial,
-                                                int rows, int row0, int M, int col0, int N,
-                                                int half, int l31) {
-  const int nblk = MT * 32 / rows;
-  for (int b = 0; b < nblk; ++b) {
-    const int r_first = b * rows;                  // first row of the block inside the wave tile
-    const int left = M - (row0 + r_first);
-    const int valid = min(rows, left);
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      float s = 0.f;
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          if (row >= r_first && row < r_first + valid) s += acc[i][j][r];
-        }
-      s += __shfl_xor(s, 32, 64);
-      const float mean = valid > 0 ? s / (float)valid : 0.f;
-      float m2 = 0.f;
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          const float d = acc[i][j][r] - mean;
-          if (row >= r_first && row < r_first + valid) m2 += d * d;
-        }
-      m2 += __shfl_xor(m2, 32, 64);
-      const int col = col0 + j * 32 + l31;
-      if (half == 0 && col < N && left > 0) {
-        float* dst = stat_partial + ((long)((row0 + r_first) / rows) * N + col) * 2;
-        dst[0] = s;
-        dst[1] = m2;
-      }
-    }
-  }
-}
-
-// the same for ONE 32-row MFMA block (NT 32x32 tiles side by side)
-template <int NT>
-__device__ __forceinline__ void wave_stats_block(const f32x16 (&acc)[NT], float* stat_partial,
-                                                 int part_row, int rows_left, int col0, int N,
-                                                 int half, int l31) {
-  const int rows_valid = min(32, rows_left);
-#pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    float s = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r)
-      if ((r & 3) + 8 * (r >> 2) + 4 * half < rows_valid) s += acc[j][r];
-    s += __shfl_xor(s, 32, 64);
-    const float mean = rows_valid > 0 ? s / (float)rows_valid : 0.f;
-    float m2 = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float d = acc[j][r] - mean;
-      if ((r & 3) + 8 * (r >> 2) + 4 * half < rows_valid) m2 += d * d;
-    }
-    m2 += __shfl_xor(m2, 32, 64);
-    const int col = col0 + j * 32 + l31;
-    if (half == 0 && col < N && rows_left > 0) {
-      float* dst = stat_partial + ((long)part_row * N + col) * 2;
-      dst[0] = s;
-      dst[1] = m2;
-    }
-  }
-}
 
 // CIN_C / KW_C: compile-time Cin and KW for the scalar im2col loader (0 = runtime values);
 // the 7x7 stems (Cin 3 / 1) use them so k -> (r, q, ci) is multiply-shift, not a division.
@@ -859,7 +702,6 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
 // A workgroup walks a strided list of output tiles; the K-tile stream (and the producers'
 // register ring) runs across tile boundaries, so the prologue of a tile (addresses, first loads)
 // and its epilogue are covered by the neighbours' MFMAs.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int X3_PITCH = 80;      // bytes per LDS row of one plane
 constexpr int X3_PRODUCERS = 8;  // producer waves; the matrix waves are WM x WN = 8 (or 4)
 
@@ -895,23 +737,6 @@ __device__ __forceinline__ void x3_split_store(f32x4 x, char* row_ptr, int plane
   *reinterpret_cast<u32x2*>(row_ptr + 2 * plane_bytes) = l;
 }
 
-__device__ __forceinline__ int x3_peek(const int* flag) {
-  return __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-__device__ __forceinline__ void x3_wait(const int* flag, int seen, int need) {
-  while (seen < need) {
-    __builtin_amdgcn_s_sleep(1);
-    seen = x3_peek(flag);
-  }
-  asm volatile("" ::: "memory");
-}
-__device__ __forceinline__ void x3_signal(int* flag) {
-  // one lane's ds_add_u32 (the caller masks to lane 0); written out because the compiler's
-  // atomic optimiser wraps a wave-uniform add in a ballot / mbcnt sequence
-  typedef __attribute__((address_space(3))) int lds_int;
-  const unsigned addr = (unsigned)(__UINTPTR_TYPE__)(lds_int*)flag;
-  asm volatile("ds_add_u32 %0, %1" ::"v"(addr), "v"(1) : "memory");
-}
 
 template <int BM, int BN, int WM, int WN, int DUAL>
 __global__ __launch_bounds__((WM * WN + X3_PRODUCERS) * 64) void conv_x3_kernel(IgemmParams p) {
@@ -1467,18 +1292,6 @@ void fill_epilogue(IgemmParams& p, const vlnce_epilogue* e) {
 
 bool aligned16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
-// CUs of the device, rounded down to a multiple of 8 (one conv_x3 workgroup per CU)
-int x3_cus() {
-  static const int cus = [] {
-    int dev = 0, n = 256;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-      n = 256;
-    return n >= 8 ? (n / 8) * 8 : 8;
-  }();
-  return cus;
-}
-
 // conv_x3_kernel launch: one workgroup (16 or 12 waves) per CU, walking tiles
 template <int BM, int BN, int WM, int WN, int DUAL>
 int launch_x3(const IgemmParams& p, hipStream_t stream) {
@@ -1510,17 +1323,6 @@ int launch_x3(const IgemmParams& p, hipStream_t stream) {
   hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), smem_bytes, stream, q);
   VLNCE_CHECK_LAUNCH("conv_x3");
   return 0;
-}
-
-// convolution arithmetic: 1 = fp32 operands split into three bf16 planes, six products on the
-// bf16 matrix pipe (conv_x3_kernel; fp32-equivalent result, see the kernel's header);
-// 0 = v_mfma_f32_32x32x2_f32 everywhere (igemm_kernel).  VLNCE_CONV_MATH=f32 selects 0.
-int conv_math() {
-  static const int m = [] {
-    const char* e = getenv("VLNCE_CONV_MATH");
-    return (e && (e[0] == 'f' || e[0] == '0')) ? 0 : 1;
-  }();
-  return m;
 }
 
 // what conv_x3_kernel covers: the buffer-descriptor hot path (buf_ok) with whole 32-channel
@@ -1654,6 +1456,7 @@ extern "C" int vlnce_conv2d_fwd(const float* x, const float* w, float* y, const 
   p.in2_center = pro ? pro->in2_center : nullptr;
   p.side_out = pro ? pro->side_out : nullptr;
   p.Bsplit = pro ? pro->w_split : nullptr;
+  p.Bfrag = pro ? pro->w_frag : nullptr;
   VLNCE_CHECK_ARG((p.in_scale == nullptr) == (p.in_shift == nullptr),
                   "conv2d_fwd: in_scale and in_shift must come together");
   fill_epilogue(p, epi);
@@ -1675,6 +1478,7 @@ extern "C" int vlnce_conv2d_fwd(const float* x, const float* w, float* y, const 
                         (!p.in2_center || (p.in2_scale && aligned16(p.in2_center))),
                     "conv2d_fwd: the dual-input prologue needs x2 + in_scale on a 1x1/stride-1/"
                     "pad-0 convolution with Cin %% 32 == 0 and 16-byte aligned operands");
+    if (const int rc = p3_try_launch(p, s); rc >= 0) return rc;
     if (X3Plan t; x3_plan(p, &t)) return dispatch_x3<1>(p, t, s);
     return dispatch_dual(p, s);
   }
@@ -1718,6 +1522,7 @@ extern "C" int vlnce_conv2d_fwd(const float* x, const float* w, float* y, const 
       }
       return 0;
     }
+    if (const int rc = p3_try_launch(p, s); rc >= 0) return rc;
     if (X3Plan t; x3_plan(p, &t)) return dispatch_x3<0>(p, t, s);
     return dispatch_tiles<A_BUF, B_BUF>(p, s);
   }

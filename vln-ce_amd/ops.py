@@ -49,6 +49,28 @@ def split_weights(w_ohwi):
     return hit[1]
 
 
+def pack_weights(w_ohwi):
+    """The weights as bf16-plane MFMA B fragments (vlnce_conv2d_pack_weights) for the
+    patch-resident convolution kernel, or None where it does not apply (Cin or Cout not a
+    multiple of 32).  Cached on the weight tensor like split_weights()."""
+    if (not w_ohwi.is_cuda or w_ohwi.dtype != torch.float32 or w_ohwi.shape[-1] % 32 != 0
+            or w_ohwi.shape[0] % 32 != 0):
+        return None
+    hit = getattr(w_ohwi, "_vlnce_frag", None)
+    if hit is None or hit[0] != w_ohwi._version:
+        Cout, KH, KW, Cin = w_ohwi.shape
+        g = dict(N=1, H=KH, W=KW, Cin=Cin, Cout=Cout, KH=KH, KW=KW, stride=1, pad=0, Ho=1, Wo=1,
+                 ldx=Cin, ldy=Cout)
+        nbytes = L().conv2d_pack_bytes(g)
+        if nbytes <= 0:
+            return None
+        frag = torch.empty((nbytes // 2,), device=w_ohwi.device, dtype=torch.int16)
+        L().conv2d_pack_weights(w_ohwi, frag, g)
+        hit = (w_ohwi._version, frag)
+        w_ohwi._vlnce_frag = hit
+    return hit[1]
+
+
 def conv_geometry(x, w, stride, pad, ldx=None):
     N, H, W, Cin = x.shape
     Cout, KH, KW, Cin2 = w.shape
@@ -86,7 +108,7 @@ def conv2d_nhwc(x, w_ohwi, stride, pad, *, in_scale=None, in_shift=None, in_cent
                     side_out=side_out)
     L().conv2d_fwd(x, w_ohwi, y, g, in_scale=in_scale, in_shift=in_shift, in_center=in_center,
                    in_relu=int(in_relu), **dual, scale=scale, shift=shift, residual=residual, ldr=g["Cout"], act=act,
-                   stat_partial=partial, w_split=split_weights(w_ohwi))
+                   stat_partial=partial, w_split=split_weights(w_ohwi), w_frag=pack_weights(w_ohwi))
     return (y, stats) if want_stats else y
 
 
