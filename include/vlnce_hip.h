@@ -239,6 +239,18 @@ int vlnce_frames_f32(const vlnce_frames* frames, float* y, const float* scale, c
 int vlnce_frames_gather(const void* const* srcs, int F, int elem_bytes, int N, int Hs, int Ws,
                         int C, int y0, int x0, int H, int W, void* out, vlnce_stream_t stream);
 
+/* habitat's ResizeShortestEdge [3P, habitat-lab v0.1.7 habitat_baselines/common/obs_transformers.py;
+ * enabled by every RxR config, rxr_baselines/rxr_cma_en.yaml:27-30, applied at
+ * base_il_trainer.py:284-285] = image_resize_shortest_edge = F.interpolate(mode="area") to
+ * (OH, OW) = (int(Hs*size/min(Hs,Ws)), int(Ws*size/min(Hs,Ws))), cast back to the sensor dtype --
+ * fused with the CenterCropperPerSensor window that follows it:
+ *   out[i, h, w, c] = cast(mean of x[i, hs0:hs1, ws0:ws1, c]),  hs0 = floor((y0+h)*Hs/OH),
+ *   hs1 = ceil((y0+h+1)*Hs/OH), columns likewise (at::adaptive_avg_pool2d's windows and
+ *   summation order; uint8 truncates).  x [NF, Hs, Ws, C] and out [NF, H, W, C] in `dtype`
+ *   (VLNCE_DT_U8 | VLNCE_DT_F32); (y0, x0, H, W) = (0, 0, OH, OW) is the plain resize. */
+int vlnce_frames_resize_area(const void* x, int dtype, int NF, int Hs, int Ws, int C, int OH, int OW,
+                             int y0, int x0, int H, int W, void* out, vlnce_stream_t stream);
+
 int vlnce_adaptive_avgpool(const float* x, float* y, int N, int H, int W, int C, int OH, int OW,
                            int ldy, vlnce_stream_t stream);
 

@@ -30,6 +30,49 @@ import torch.nn.functional as F
 # --------------------------------------------------------------------------
 # minimal gym-like spaces (reference: `from gym import Space, spaces`)
 # --------------------------------------------------------------------------
+# habitat_baselines/utils/common.py::image_resize_shortest_edge and
+# habitat_baselines/common/obs_transformers.py::ResizeShortestEdge [3P-mem, habitat-lab v0.1.7;
+# not under /root/reference, PARITY UNPINNED].  Enabled by every RxR config of the reference
+# (vlnce_baselines/config/rxr_baselines/rxr_cma_en.yaml:27-30: ENABLED_TRANSFORMS
+# [ResizeShortestEdge, CenterCropperPerSensor]) and applied per step at
+# vlnce_baselines/common/base_il_trainer.py:284-285.  Published algorithm: scale =
+# size / min(h, w); (h, w) <- (int(h*scale), int(w*scale)); torch.nn.functional.interpolate(
+# img.float(), size=(h, w), mode="area").to(dtype=img.dtype) on the NCHW view of the frames.
+def image_resize_shortest_edge(img, size, channels_last=False):
+    img = torch.as_tensor(img)
+    no_batch_dim = len(img.shape) == 3
+    if len(img.shape) < 3 or len(img.shape) > 5:
+        raise NotImplementedError()
+    if no_batch_dim:
+        img = img.unsqueeze(0)
+    if channels_last:
+        h, w = img.shape[-3:-1]
+        img = img.permute(0, 3, 1, 2) if len(img.shape) == 4 else img.permute(0, 1, 4, 2, 3)
+    else:
+        h, w = img.shape[-2:]
+    scale = size / min(h, w)
+    h, w = int(h * scale), int(w * scale)
+    lead = img.shape[:-3]
+    flat = img.reshape((-1,) + tuple(img.shape[-3:]))
+    flat = F.interpolate(flat.float(), size=(h, w), mode="area").to(dtype=img.dtype)
+    img = flat.reshape(tuple(lead) + tuple(flat.shape[-3:]))
+    if channels_last:
+        img = img.permute(0, 2, 3, 1) if len(img.shape) == 4 else img.permute(0, 1, 3, 4, 2)
+    if no_batch_dim:
+        img = img.squeeze(dim=0)
+    return img
+
+
+def resize_shortest_edge(observations, size, trans_keys=("rgb", "depth", "semantic")):
+    """ResizeShortestEdge.forward [3P-mem]"""
+    for sensor in trans_keys:
+        if sensor in observations:
+            observations[sensor] = image_resize_shortest_edge(observations[sensor], size,
+                                                              channels_last=True)
+    return observations
+
+
+# --------------------------------------------------------------------------
 class Space:
     pass
 

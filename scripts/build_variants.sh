@@ -9,7 +9,7 @@ while [ $# -ge 2 ]; do
   d=build/variants/obj_$name; mkdir -p $d
   for f in vln-ce_amd/csrc/*.hip vln-ce_amd/csrc/*.cpp; do
     b=$(basename ${f%.*})
-    if [ "$b" = "igemm" ] || [ ! -f build/$b.o ]; then
+    if [ "$b" = "igemm" ] || [ "$b" = "conv_p3" ] || [ ! -f build/$b.o ]; then
       /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $flags -c $f -o $d/$b.o &
     else
       cp build/$b.o $d/$b.o

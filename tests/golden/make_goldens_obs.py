@@ -82,6 +82,15 @@ STACK = [("rgb", ["rgb"] + [f"rgb_{i}" for i in range(1, 12)]),
          ("depth", ["depth"] + [f"depth_{i}" for i in range(1, 12)])]
 
 
+# name -> (Hs, Ws, RESIZE_SHORTEST_EDGE.SIZE, SENSOR_CROPS); RxR itself is 480 x 640 -> 256 ->
+# rgb 224 x 224 / depth 256 x 256 (checked at full size against the oracle in the GPU tier)
+RESIZE_CASES = {
+    "down": (30, 40, 16, [("rgb", (14, 14)), ("depth", (16, 16))]),
+    "portrait": (45, 33, 20, [("rgb", (18, 16)), ("depth", (20, 20))]),
+    "up": (12, 17, 19, [("rgb", (16, 20)), ("depth", (19, 19))]),
+}
+
+
 def main():
     ref = load_reference_transforms()
     # 1. centre crop of single-camera sensors (rxr_cma_en.yaml:27-30 order: crop after resize)
@@ -97,7 +106,19 @@ def main():
     out = ref.CenterCropperPerSensor(CROPS)(ref.ObsStack(STACK)(dict(inputs())))
     np.savez_compressed(os.path.join(HERE, "obs_stack_crop.npz"),
                         **{"out_" + k: v.numpy() for k, v in out.items()})
-    print("wrote obs_center_crop.npz obs_stack.npz obs_stack_crop.npz")
+    # 4. RxR order (rxr_cma_en.yaml:27-30): habitat's ResizeShortestEdge [3P, restated in
+    # oracle/thirdparty.py from the published algorithm: F.interpolate(mode="area"), cast back to
+    # the sensor dtype], then the reference's own CenterCropperPerSensor.  Landscape and portrait
+    # frames, uint8 RGB and fp32 depth, non-integer scale factors down and up.
+    for tag, (hs, ws, size, crops) in RESIZE_CASES.items():
+        o = {k: v for k, v in inputs(seed=11, n=3, hs=hs, ws=ws).items()
+             if k in ("rgb", "depth", "instruction")}
+        rs = tp.resize_shortest_edge(dict(o), size)
+        out = {"resized_" + k: v.numpy() for k, v in rs.items()}
+        cr = ref.CenterCropperPerSensor(crops)(dict(rs))
+        out.update({"out_" + k: v.numpy() for k, v in cr.items()})
+        np.savez_compressed(os.path.join(HERE, f"obs_resize_{tag}.npz"), **out)
+    print("wrote obs_center_crop.npz obs_stack.npz obs_stack_crop.npz obs_resize_*.npz")
 
 
 if __name__ == "__main__":

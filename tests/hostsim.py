@@ -308,6 +308,11 @@ class HostSim:
     def frames_gather(self, srcs, elem_bytes, N, Hs, Ws, Cc, y0, x0, H, W, out):
         out.copy_(torch.stack([t[:, y0:y0 + H, x0:x0 + W] for t in srcs], dim=1))
 
+    def frames_resize_area(self, x, is_u8, NF, Hs, Ws, Cc, OH, OW, y0, x0, H, W, out):
+        v = x.reshape(NF, Hs, Ws, Cc).permute(0, 3, 1, 2).float()
+        r = F.interpolate(v, size=(OH, OW), mode="area").to(x.dtype).permute(0, 2, 3, 1)
+        out.copy_(r[:, y0:y0 + H, x0:x0 + W].reshape(out.shape))
+
     def adaptive_avgpool(self, x, y, N, H, W, Cc, OH, OW, ldy):
         v = F.adaptive_avg_pool2d(x.permute(0, 3, 1, 2), (OH, OW)).permute(0, 2, 3, 1)
         _mat(y, N * OH * OW, Cc, ldy).copy_(v.reshape(-1, Cc))

@@ -789,12 +789,16 @@ P3_CASES = [
     ("p3_3x3_rag",   3,  7,  9,  64,  96, 3, 1, 1, dict(prologue=True, in_relu=True)),
     ("p3_5x5_p2",    2, 11, 13,  32,  64, 5, 1, 2, dict(scale=True)),
     ("p3_3x3_p0",    2, 12, 10,  64,  32, 3, 1, 0, dict(stats=True)),
-    ("p3_1x1_wide",  3, 24, 24, 128, 512, 1, 1, 0, dict(prologue=True, in_relu=True, center=True,
-                                                        stats=True)),
+    ("p3_1x1_wide",  3, 24, 24, 128, 512, 1, 1, 0, dict(prologue=True, in_relu=True, center=True)),
+    ("p3_1x1_stats", 3, 24, 24, 128, 512, 1, 1, 0, dict(stats=True)),
+    ("p3_1x1_tall",  9, 32, 32,  64, 128, 1, 1, 0, dict(stats=True)),            # 256-row tiles
+    ("p3_3x3_tall",  9, 32, 32,  64, 128, 3, 1, 1, dict(scale=True, relu=True)),  # 256-row patches
     ("p3_1x1_s2",    3, 18, 14, 128, 256, 1, 2, 0, dict(prologue=True, in_relu=True)),
     ("p3_1x1_rag",   1,  5,  7, 160,  96, 1, 1, 0, dict(scale=True, relu=True)),
     ("p3_dual_wide", 3, 20, 12, 128, 256, 1, 1, 0, dict(prologue=True, in_relu=True, center=True,
-                                                        dual="bn", stats=True)),
+                                                        dual="bn")),
+    ("p3_dual_tall", 9, 32, 32,  64, 128, 1, 1, 0, dict(prologue=True, in_relu=True, center=True,
+                                                        dual="bn")),
     ("p3_dual_id",   2, 16, 16,  64,  64, 1, 1, 0, dict(prologue=True, in_relu=True, dual="identity")),
     ("p3_many_tiles", 40, 32, 32, 64, 64, 3, 1, 1, dict(stats=True)),            # several tiles per CU
 ]

@@ -63,13 +63,62 @@ def test_observation_space_rewrites():
     assert set(space.spaces) == set(sp)  # the input space is not modified
 
 
-def test_batch_obs_keeps_storage_dtypes():
+def test_batch_obs_dtypes():
+    """uint8 image sensors keep their storage dtype; everything else is fp32 exactly like
+    habitat's batch_obs (`torch.tensor(..., dtype=torch.float)`): the reference's sensors return
+    float64 progress / angle_features and int64 tokens / shortest-path actions."""
     envs = [{"rgb": np.full((4, 5, 3), i, np.uint8), "depth": np.full((4, 5, 1), i / 4, np.float32),
-             "instruction": np.arange(6) + i} for i in range(3)]
+             "instruction": np.arange(6) + i, "progress": np.array([i / 3.0]),
+             "angle_features": np.linspace(0, 1, 48).reshape(12, 4) * i,
+             "shortest_path_sensor": np.array([i], np.int64)} for i in range(3)]
     b = ot.batch_obs(envs, "cpu")
     assert b["rgb"].dtype == torch.uint8 and b["rgb"].shape == (3, 4, 5, 3)
-    assert b["depth"].dtype == torch.float32 and b["instruction"].dtype == torch.int64
     assert torch.equal(b["rgb"][2], torch.full((4, 5, 3), 2, dtype=torch.uint8))
+    for k in ("depth", "instruction", "progress", "angle_features", "shortest_path_sensor"):
+        assert b[k].dtype == torch.float32, (k, b[k].dtype)
+    assert b["progress"].shape == (3, 1) and b["angle_features"].shape == (3, 12, 4)
+    assert torch.equal(b["instruction"][1], torch.arange(6).float() + 1)
+    assert torch.equal(b["progress"], torch.tensor([[0.0], [1 / 3.0], [2 / 3.0]]))
+
+
+def resize_inputs(tag):
+    hs, ws, size, crops = mg.RESIZE_CASES[tag]
+    o = {k: v for k, v in mg.inputs(seed=11, n=3, hs=hs, ws=ws).items()
+         if k in ("rgb", "depth", "instruction")}
+    return o, size, crops
+
+
+@pytest.mark.parametrize("tag", list(mg.RESIZE_CASES))
+def test_resize_shortest_edge_matches_goldens_on_cpu(tag):
+    """habitat's ResizeShortestEdge (oracle/thirdparty.py restatement -> goldens) then the
+    reference's own CenterCropperPerSensor: oracle, product in sequence, product fused."""
+    from oracle import thirdparty as tp
+    o, size, crops = resize_inputs(tag)
+    full = np.load(os.path.join(GOLD, f"obs_resize_{tag}.npz"))
+    want = {k[4:]: torch.from_numpy(full[k]) for k in full if k.startswith("out_")}
+    resized = {k[8:]: torch.from_numpy(full[k]) for k in full if k.startswith("resized_")}
+    same(tp.resize_shortest_edge(dict(o), size), resized)
+    same(oc.center_cropper_per_sensor(tp.resize_shortest_edge(dict(o), size), crops), want)
+    same(ot.ResizeShortestEdge(size)(dict(o)), resized)
+    seq = ot.CenterCropperPerSensor(crops)(ot.ResizeShortestEdge(size)(dict(o)))
+    same(seq, want)
+    fused = ot.apply_obs_transforms_batch(dict(o), [ot.ResizeShortestEdge(size),
+                                                    ot.CenterCropperPerSensor(crops)])
+    same({k: v.contiguous() for k, v in fused.items()}, want)
+
+
+def test_resize_shortest_edge_observation_space_and_config():
+    spaces, _ = vlnce_amd.make_spaces(480, 640)
+    out = ot.ResizeShortestEdge(256).transform_observation_space(spaces)
+    assert out.spaces["rgb"].shape == (256, 341, 3) and out.spaces["depth"].shape == (256, 341, 1)
+    assert spaces.spaces["rgb"].shape == (480, 640, 3)
+    out = ot.CenterCropperPerSensor([("rgb", (224, 224)), ("depth", (256, 256))]) \
+        .transform_observation_space(out)
+    assert out.spaces["rgb"].shape == (224, 224, 3) and out.spaces["depth"].shape == (256, 256, 1)
+    cfg = vlnce_amd.make_config("CMAPolicy")
+    cfg.RL = vlnce_amd.config.Config(POLICY=vlnce_amd.config.Config(OBS_TRANSFORMS=vlnce_amd.config.Config(
+        RESIZE_SHORTEST_EDGE=vlnce_amd.config.Config(SIZE=256))))
+    assert ot.ResizeShortestEdge.from_config(cfg)._size == 256
 
 
 def test_frame_descriptor_reads_crop_views_without_a_copy():
@@ -101,6 +150,58 @@ def test_obs_stack_and_crop_kernels_match_reference_goldens():
     srcs = [dev_in["rgb" + ("" if i == 0 else f"_{i}")] for i in range(12)]
     y0, x0, h, w = ot.center_crop_window(20, 26, (14, 16))
     assert torch.equal(ops.frames_gather(srcs, (y0, x0, h, w)).cpu(), gold("obs_stack_crop.npz")["rgb"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", list(mg.RESIZE_CASES))
+def test_resize_kernel_matches_goldens(tag):
+    """vlnce_frames_resize_area: the whole resized frame and the fused resize + centre crop,
+    uint8 and fp32, bit for bit against the goldens."""
+    o, size, crops = resize_inputs(tag)
+    full = np.load(os.path.join(GOLD, f"obs_resize_{tag}.npz"))
+    want = {k[4:]: torch.from_numpy(full[k]) for k in full if k.startswith("out_")}
+    resized = {k[8:]: torch.from_numpy(full[k]) for k in full if k.startswith("resized_")}
+    dev_in = {k: v.to(DEV) for k, v in o.items()}
+    same(ot.ResizeShortestEdge(size)(dict(dev_in)), resized)
+    fused = ot.apply_obs_transforms_batch(dict(dev_in), [ot.ResizeShortestEdge(size),
+                                                         ot.CenterCropperPerSensor(crops)])
+    assert fused["rgb"].is_contiguous() and fused["rgb"].dtype == torch.uint8
+    same(fused, want)
+
+
+@pytest.mark.gpu
+def test_resize_crop_at_the_rxr_geometry_feeds_the_policy():
+    """RxR sensors: 480 x 640 uint8 RGB + fp32 depth -> ResizeShortestEdge(256) -> centre crop
+    224 x 224 / 256 x 256 (rxr_cma_en.yaml:27-30, config/default.py:132-175), 12-camera stacks
+    included; against the oracle on the CPU, and straight into the CMA policy."""
+    from oracle import thirdparty as tp
+    g = torch.Generator().manual_seed(9)
+    rgb = torch.randint(0, 256, (2, 480, 640, 3), generator=g, dtype=torch.uint8)
+    depth = torch.rand(2, 480, 640, 1, generator=g)
+    crops = [("rgb", (224, 224)), ("depth", (256, 256))]
+    want = oc.center_cropper_per_sensor(tp.resize_shortest_edge({"rgb": rgb.clone(), "depth": depth.clone()}, 256), crops)
+    tf = [ot.ResizeShortestEdge(256), ot.CenterCropperPerSensor(crops)]
+    got = ot.apply_obs_transforms_batch({"rgb": rgb.to(DEV), "depth": depth.to(DEV)}, tf)
+    assert got["rgb"].shape == (2, 224, 224, 3) and got["depth"].shape == (2, 256, 256, 1)
+    assert torch.equal(got["rgb"].cpu(), want["rgb"])
+    assert torch.equal(got["depth"].cpu(), want["depth"])
+    stack = torch.randint(0, 256, (2, 3, 60, 80, 3), generator=g, dtype=torch.uint8)   # [N, cams, H, W, C]
+    w5 = tp.image_resize_shortest_edge(stack.clone(), 32, channels_last=True)
+    assert torch.equal(ot.ResizeShortestEdge(32)({"rgb": stack.to(DEV)})["rgb"].cpu(), w5)
+    # the real sensor geometry: 224 x 224 RGB + 256 x 256 depth (only depth's shape is read
+    # from the observation space, resnet_encoders.py:32-38)
+    torch.manual_seed(0)
+    pol = vlnce_amd.build_model(vlnce_amd.make_config("CMAPolicy"), *vlnce_amd.make_spaces(256, 256))
+    pol.to(DEV).eval()
+    obs = dict(got)
+    ins = torch.zeros(2, 200, dtype=torch.long)
+    ins[:, :7] = torch.randint(1, 2504, (2, 7), generator=g)
+    obs["instruction"] = ins.to(DEV)
+    h0 = torch.zeros(2, pol.net.num_recurrent_layers, 512, device=DEV)
+    with torch.no_grad():
+        a, _ = pol.act(obs, h0, torch.zeros(2, 1, dtype=torch.long, device=DEV),
+                       torch.ones(2, 1, dtype=torch.uint8, device=DEV), deterministic=True)
+    assert a.shape == (2, 1) and a.dtype == torch.int64
 
 
 @pytest.mark.gpu

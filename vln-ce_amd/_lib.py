@@ -76,6 +76,7 @@ _SIGNATURES = {
     "vlnce_frames_avgpool2": (_I, [C.POINTER(Frames), _P, _P]),
     "vlnce_frames_f32": (_I, [C.POINTER(Frames), _P, _P, _P, _P]),
     "vlnce_frames_gather": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "vlnce_frames_resize_area": (_I, [_P] + [_I] * 11 + [_P, _P]),
     "vlnce_adaptive_avgpool": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "vlnce_attn_fwd": (_I, [_P, _P, _I, _P, _I, _P, _I, _F, _P, _P, _I, _I, _I, _I, _P]),
     "vlnce_attn_bwd": (_I, [_P, _P, _P, _I, _P, _I, _P, _I, _F, _P, _P, _P, _I, _P, _I,
@@ -349,6 +350,11 @@ class HipLib:
         arr = (C.c_void_p * len(srcs))(*[_ptr(t) for t in srcs])
         self._check(self.dll.vlnce_frames_gather(arr, len(srcs), elem_bytes, N, Hs, Ws, Cc, y0, x0,
                                                  H, W, _ptr(out), _stream()), "vlnce_frames_gather")
+
+    def frames_resize_area(self, x, is_u8, NF, Hs, Ws, Cc, OH, OW, y0, x0, H, W, out):
+        self._check(self.dll.vlnce_frames_resize_area(_ptr(x), 1 if is_u8 else 0, NF, Hs, Ws, Cc, OH,
+                                                      OW, y0, x0, H, W, _ptr(out), _stream()),
+                    "vlnce_frames_resize_area")
 
     def avgpool2x2(self, x, y, N, H, W, Cc):
         self._check(self.dll.vlnce_avgpool2x2(_ptr(x), _ptr(y), N, H, W, Cc, _stream()),

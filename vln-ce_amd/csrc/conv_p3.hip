@@ -39,7 +39,13 @@ namespace {
 
 constexpr int P3_ROW = 208;      // bytes per patch row (13 x 16 B: consecutive rows are conflict-free)
 constexpr int P3_PRODUCERS = 4;  // producer waves
-constexpr int P3_RING = 4;       // producer items (32 rows x 32 channels) in flight
+#ifndef P3_MPRIO
+#define P3_MPRIO 1   // s_setprio of the matrix waves
+#endif
+#ifndef P3_PPRIO
+#define P3_PPRIO 2   // s_setprio of the producer waves: measured, a producer-bound layer
+                     // (3x3 64->64 at 64x64) runs 140 -> 119 us when the producers win the issue port
+#endif
 
 enum { P3_GATHER = 0, P3_DENSE = 1 };
 
@@ -88,9 +94,17 @@ __global__ __launch_bounds__((WM * WN + P3_PRODUCERS) * 64) void conv_p3_kernel(
   static_assert(MT >= 1 && NT >= 1 && WTM % 32 == 0 && WTN % 32 == 0, "tile");
   static_assert(!DUAL || MODE == P3_GATHER, "dual-input prologue: 1x1 convolutions only");
 
+  // 1x1 convolutions have short reductions: their epilogue stores must not sit in front of any
+  // load of the same wave (vmcnt counts stores too, in order), so there the matrix waves issue NO
+  // vector loads: the producers bring a chunk's B fragments into LDS with LDS-DMA (fragment
+  // order = lane order, 1 KB per instruction) next to the patch, under the same hand-over.  KxK
+  // convolutions (long reductions, large patches) fetch B straight from L2 into registers.
+  constexpr bool B_LDS = MODE == P3_GATHER;
+  constexpr int BST = B_LDS ? BN * 192 : 0;   // bytes of one B stage: BN/32 n-blocks x 2 slabs x 3 KB
   extern __shared__ __attribute__((aligned(16))) char xsm[];
   const int pbuf = p.p3_rows * P3_ROW;                         // bytes of one patch buffer
-  int* const pfull = reinterpret_cast<int*>(xsm + 2 * pbuf);   // [2] producer waves done writing
+  char* const bstage = xsm + 2 * pbuf;                         // [2][BST]
+  int* const pfull = reinterpret_cast<int*>(bstage + 2 * BST);  // [2] producer waves done writing
   int* const pempty = pfull + 2;                               // [2] matrix waves done reading
 
   const int tid = threadIdx.x;
@@ -134,6 +148,7 @@ __global__ __launch_bounds__((WM * WN + P3_PRODUCERS) * 64) void conv_p3_kernel(
 
   if (wave >= MATRIX) {
     // ================================================================ producer waves
+    __builtin_amdgcn_s_setprio(P3_PPRIO);
     const int ptid = tid - MATRIX * 64;
     const int lrow = ptid >> 3;          // row inside a 32-row pass
     const int lk4 = (ptid & 7) * 4;      // first of this thread's 4 channels inside the chunk
@@ -148,96 +163,6 @@ __global__ __launch_bounds__((WM * WN + P3_PRODUCERS) * 64) void conv_p3_kernel(
     const int n_img = p.M / HoWo;
     const bool linear = p.stride == 1;   // GATHER: input pixel index = output pixel index
 
-    struct Item {
-      f32x4 a;
-      f32x4 a2;
-      unsigned ok;
-    };
-    Item st[P3_RING];
-
-    // ---- load cursor: (tile, chunk, pass) of the next item to fetch, plus this thread's row
-    int l_round = 0, l_c = 0, l_p = 0, l_np = 0, l_m0 = 0;
-    int l_img = 0, l_h = 0, l_w = 0;       // DENSE: padded (img, hp, wp) of the row; GATHER: (img, ho, wo)
-    int l_img0 = 0, l_h0 = 0, l_w0 = 0;    // ... of pass 0 (restored at every chunk)
-    int l_rows = 0;
-    auto l_setup = [&](int round) {
-      int m0, n0;
-      tile_of(round, m0, n0);
-      l_m0 = m0;
-      l_rows = patch_rows(m0);
-      l_np = (l_rows + 31) >> 5;
-      if constexpr (MODE == P3_DENSE) {
-        const int u = u0_of(m0) + lrow;
-        l_img0 = u / (Hp * Wp);
-        const int rem = u - l_img0 * (Hp * Wp);
-        l_h0 = rem / Wp;
-        l_w0 = rem - l_h0 * Wp;
-      } else {
-        const int m = m0 + lrow;
-        l_img0 = m / HoWo;
-        const int rem = m - l_img0 * HoWo;
-        l_h0 = rem / p.Wo;
-        l_w0 = rem - l_h0 * p.Wo;
-      }
-      l_img = l_img0;
-      l_h = l_h0;
-      l_w = l_w0;
-    };
-    auto load = [&](Item& s) {
-      int voff = BUF_OOB;
-      if (l_round < my_tiles) {
-        const int j = l_p * 32 + lrow;
-        if constexpr (MODE == P3_DENSE) {
-          const int hi = l_h - p.pad, wi = l_w - p.pad;
-          if (j < l_rows && l_img < n_img && (unsigned)hi < (unsigned)p.H &&
-              (unsigned)wi < (unsigned)p.W)
-            voff = (((l_img * p.H + hi) * p.W + wi) * p.lda + lk4) * 4;
-        } else {
-          if (j < l_rows)
-            voff = ((linear ? l_m0 + j : (l_img * p.H + l_h * p.stride) * p.W + l_w * p.stride) *
-                        p.lda + lk4) * 4;
-        }
-      }
-      s.ok = voff != BUF_OOB;
-      const int soff = l_c * 128;
-      s.a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, voff, soff, 0));
-      if constexpr (DUAL)
-        s.a2 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a2, voff, soff, 0));
-      if (l_round >= my_tiles) return;
-      // advance: next pass of this chunk, else next chunk, else next tile
-      if (++l_p < l_np) {
-        if (MODE == P3_DENSE || !linear) {
-          const int wrap_w = MODE == P3_DENSE ? Wp : p.Wo, wrap_h = MODE == P3_DENSE ? Hp : p.Ho;
-          l_w += 32;
-          while (l_w >= wrap_w) {
-            l_w -= wrap_w;
-            if (++l_h == wrap_h) {
-              l_h = 0;
-              ++l_img;
-            }
-          }
-        }
-      } else {
-        l_p = 0;
-        l_img = l_img0;
-        l_h = l_h0;
-        l_w = l_w0;
-        if (++l_c == NC) {
-          l_c = 0;
-          if (++l_round < my_tiles) l_setup(l_round);
-        }
-      }
-    };
-
-    // ---- store cursor
-    int s_round = 0, s_c = 0, s_p = 0, s_np = 0, s_m0 = 0, s_side = 0, s_h = 0;
-    auto s_setup = [&](int round) {
-      int m0, n0;
-      tile_of(round, m0, n0);
-      s_m0 = m0;
-      s_side = n0 == 0;   // the materialised block output: written once, by the n-tile-0 workgroups
-      s_np = (patch_rows(m0) + 31) >> 5;
-    };
     // prologue vectors of a chunk (its 32 input channels): `cur` in use, `nxt` in flight a chunk ahead
     struct Vec {
       f32x4 s, t, c, s2, t2, c2;
@@ -258,17 +183,15 @@ __global__ __launch_bounds__((WM * WN + P3_PRODUCERS) * 64) void conv_p3_kernel(
         }
       }
     };
-    auto store = [&](const Item& s) {
-      char* const buf = xsm + (s_h & 1) * pbuf;
-      if (s_p == 0) {
-        cur = nxt;
-        if constexpr (DUAL) {
-          if (p.in2_scale != nullptr) cur.t2 = cur.t + cur.t2;   // both shifts in one add
-        }
-        load_vec(nxt, s_c + 1 < NC ? (s_c + 1) * 32 : 0);
-        p3_wait(pempty + (s_h & 1), MATRIX * (s_h >> 1));  // chunk h-2 has been read
+    auto next_vec = [&](int c_next) {  // at the first row group of a chunk
+      cur = nxt;
+      if constexpr (DUAL) {
+        if (p.in2_scale != nullptr) cur.t2 = cur.t + cur.t2;  // both shifts in one add
       }
-      f32x4 v = s.a;
+      load_vec(nxt, c_next < NC ? c_next * 32 : 0);
+    };
+    // one thread's float4 of a patch row: prologue, zero padding, (block output), split, LDS write
+    auto transform_store = [&](f32x4 v, f32x4 v2, bool ok, char* dst, float* side_dst) {
       if (has_pro) {
         // (scalar fma / max per element: packed fp32 VALU beside MFMAs costs more issue time than
         // the two plain instructions it replaces -- MI355X_MICROARCH.md)
@@ -277,11 +200,11 @@ __global__ __launch_bounds__((WM * WN + P3_PRODUCERS) * 64) void conv_p3_kernel(
 #pragma unroll
             for (int e = 0; e < 4; ++e)
               v[e] = fmaxf(fmaf(v[e] - cur.c[e], cur.s[e],
-                                fmaf(s.a2[e] - cur.c2[e], cur.s2[e], cur.t2[e])), relu_floor);
+                                fmaf(v2[e] - cur.c2[e], cur.s2[e], cur.t2[e])), relu_floor);
           } else {  // identity skip: added as is
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-              v[e] = fmaxf(fmaf(v[e] - cur.c[e], cur.s[e], cur.t[e]) + s.a2[e], relu_floor);
+              v[e] = fmaxf(fmaf(v[e] - cur.c[e], cur.s[e], cur.t[e]) + v2[e], relu_floor);
           }
         } else {
 #pragma unroll
@@ -289,39 +212,283 @@ __global__ __launch_bounds__((WM * WN + P3_PRODUCERS) * 64) void conv_p3_kernel(
             v[e] = fmaxf(fmaf(v[e] - cur.c[e], cur.s[e], cur.t[e]), relu_floor);
         }
         // zero padding / rows past M come AFTER the transform
-        if (!s.ok) v = zero4;
+        if (!ok) v = zero4;
         if constexpr (DUAL) {
-          if (p.side_out != nullptr && s_side && s.ok)
-            *reinterpret_cast<f32x4*>(p.side_out + (long)(s_m0 + s_p * 32 + lrow) * p.lda +
-                                      s_c * 32 + lk4) = v;
+          if (side_dst != nullptr && ok) *reinterpret_cast<f32x4*>(side_dst) = v;
         }
       }
-      p3_split_store(v, buf + (s_p * 32 + lrow) * P3_ROW + lk4 * 2);
-      if (++s_p == s_np) {
-        if (lane == 0) x3_signal(pfull + (s_h & 1));  // (in LDS order behind this wave's writes)
-        s_p = 0;
-        ++s_h;
-        if (++s_c == NC) {
-          s_c = 0;
-          if (++s_round < my_tiles) s_setup(s_round);
-        }
-      }
+      p3_split_store(v, dst);
     };
+#ifdef P3_DBG_TIME
+    long long d_wait = 0, d_vmw = 0, d_tr = 0, d_ld = 0;
+    const long long d_t0 = clock64();
+#endif
 
-    l_setup(0);
-    s_setup(0);
-    load_vec(nxt, 0);
+    if constexpr (MODE == P3_GATHER) {
+      // ---- 1x1 convolutions: patch row = output pixel, BM / 32 row groups per chunk, all of a
+      // chunk's loads in flight one chunk ahead (two register sets)
+      constexpr int NP = BM / 32;
+      constexpr int NPI = NP < 4 ? NP : 4;   // row groups per staged item (register budget)
+      constexpr int PARTS = NP / NPI;        // items per chunk: 1, or 2 for 256-row tiles
+      static_assert(PARTS == 1 || PARTS == 2, "tile height");
+      struct Staged {
+        f32x4 a[NPI];
+        f32x4 a2[DUAL ? NPI : 1];
+        unsigned ok;
+        int m0;  // first row of the tile if this workgroup writes side_out for it, else -1
+      };
+      Staged st[2];
+      int a_voff[NP];
+      unsigned a_ok = 0;
+      int l_round = 0, l_c = 0, l_m0 = 0, l_side = 0;
+      auto setup_tile = [&](int round) {
+        int m0, n0;
+        tile_of(round, m0, n0);
+        l_m0 = m0;
+        l_side = n0 == 0;  // the materialised block output: written once, by the n-tile-0 workgroups
+        a_ok = 0;
 #pragma unroll
-    for (int j = 0; j < P3_RING - 1; ++j) load(st[j]);
-    while (s_round < my_tiles) {
+        for (int i = 0; i < NP; ++i) {
+          const int m = m0 + i * 32 + lrow;
+          a_voff[i] = BUF_OOB;
+          if (m < p.M) {
+            int pix = m;
+            if (!linear) {
+              const int img = m / HoWo;
+              const int rem = m - img * HoWo;
+              const int ho = rem / p.Wo;
+              pix = (img * p.H + ho * p.stride) * p.W + (rem - ho * p.Wo) * p.stride;
+            }
+            a_voff[i] = (pix * p.lda + lk4) * 4;
+            a_ok |= 1u << i;
+          }
+        }
+      };
+      // item `it` of the stream is part it % PARTS of chunk it / PARTS; it lives in set it & 1, so
+      // with two parts the part index equals the set index (static register indexing)
+      auto load = [&](Staged& s, int part, bool live) {
+        const int soff = l_c * 128;
+        s.ok = live ? (a_ok >> (part * NPI)) : 0u;
+        s.m0 = l_side ? l_m0 : -1;
 #pragma unroll
-      for (int j = 0; j < P3_RING; ++j) {
+        for (int i = 0; i < NPI; ++i) {
+          const int vo = live ? a_voff[part * NPI + i] : BUF_OOB;
+          s.a[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, vo, soff, 0));
+          if constexpr (DUAL)
+            s.a2[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a2, vo, soff, 0));
+        }
+        if (part == PARTS - 1 && ++l_c == NC) {
+          l_c = 0;
+          if (++l_round < my_tiles) setup_tile(l_round);
+        }
+      };
+      int s_c = 0, s_round = 0, s_n0 = 0;
+      const int KS3 = (p.K / 16) * 3072;   // bytes of one n-block's fragments
+      const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<char*>(reinterpret_cast<const char*>(p.Bfrag)), 0, (int)((long)p.N * p.K * 6),
+          0x00020000);
+      auto stash = [&](const Staged& s, int part, int g) {   // g = chunk index of the stream
+        char* const buf = xsm + (g & 1) * pbuf + (part * NPI * 32 + lrow) * P3_ROW + lk4 * 2;
+        if (part == 0) {
+          next_vec(s_c + 1);
+#ifdef P3_DBG_TIME
+          const long long d_a = clock64();
+#endif
+          p3_wait(pempty + (g & 1), MATRIX * (g >> 1));  // chunk g-2 has been read
+#ifdef P3_DBG_TIME
+          d_wait += clock64() - d_a;
+#endif
+        }
+#pragma unroll
+        for (int i = 0; i < NPI; ++i) {
+          float* side = nullptr;
+          if constexpr (DUAL) {
+            if (p.side_out != nullptr && s.m0 >= 0)
+              side = p.side_out + (long)(s.m0 + (part * NPI + i) * 32 + lrow) * p.lda + s_c * 32 + lk4;
+          }
+          transform_store(s.a[i], s.a2[DUAL ? i : 0], (s.ok >> i) & 1u, buf + i * 32 * P3_ROW, side);
+        }
+        if (part == PARTS - 1) {
+          // this chunk's B fragments: BN/32 runs of 6 KB (2 k-slabs x 3 planes of one n-block),
+          // 1 KB per instruction, instructions dealt round-robin to the producer waves
+          const int pw = wave - MATRIX;
+          typedef __attribute__((address_space(3))) void lds_void;
+#pragma unroll
+          for (int k = 0; k < 6 * (BN / 32) / P3_PRODUCERS; ++k) {
+            const int f = k * P3_PRODUCERS + pw;     // fragment slot inside the stage
+            const int nbl = f / 6, part6 = f - nbl * 6;
+            const int nb = s_n0 / 32 + nbl;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                rsrc_b, (lds_void*)(bstage + (g & 1) * BST + f * 1024), 16,
+                nb * 32 < p.N ? lane * 16 : BUF_OOB, nb * KS3 + s_c * 6144 + part6 * 1024, 0, 0);
+          }
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the DMA has landed
+          if (lane == 0) x3_signal(pfull + (g & 1));  // (in LDS order behind this wave's writes)
+          if (++s_c == NC) {
+            s_c = 0;
+            if (++s_round < my_tiles) {
+              int m0;
+              tile_of(s_round, m0, s_n0);
+            }
+          }
+        }
+      };
+      {
+        int m0;
+        tile_of(0, m0, s_n0);
+      }
+      const int I_total = my_tiles * NC * PARTS;
+      setup_tile(0);
+      load_vec(nxt, 0);
+      load(st[0], 0, true);
+      for (int it = 0; it < I_total; it += 2) {
+        load(st[1], PARTS == 2 ? 1 : 0, it + 1 < I_total);
+        stash(st[0], 0, it / PARTS);
+        if (it + 1 < I_total) {
+          load(st[0], 0, it + 2 < I_total);
+          stash(st[1], PARTS == 2 ? 1 : 0, (it + 1) / PARTS);
+        }
+      }
+    } else {
+      // ---- KxK stride-1 convolutions: the patch is a run of padded-linear pixels, fetched and
+      // transformed as a stream of items of 4 row groups (128 rows x 32 channels), two register
+      // sets: 4 - 8 loads per thread in flight
+      struct Staged {
+        f32x4 a[4];
+        unsigned ok;
+      };
+      Staged st[2];
+      // load cursor: (tile, chunk, part) of the next item to fetch.  The byte offsets of this
+      // thread's (up to 12) patch rows are decoded once per tile -- every chunk re-reads the same
+      // pixels 32 channels further on (soffset)
+      // (scalars and wave-uniform branches: a runtime-indexed array would live in scratch memory)
+      int l_round = 0, l_c = 0, l_part = 0, l_nparts = 0;
+      int r0 = 0, r1 = 0, r2 = 0, r3 = 0, r4 = 0, r5 = 0, r6 = 0, r7 = 0, r8 = 0, r9 = 0, r10 = 0,
+          r11 = 0;   // byte offsets of this thread's rows in row groups 0..11 (p3_rows <= 384)
+      unsigned l_ok = 0;
+      auto l_setup = [&](int round) {
+        int m0, n0;
+        tile_of(round, m0, n0);
+        const int rows = patch_rows(m0);
+        l_nparts = (rows + 127) >> 7;
+        const int u = u0_of(m0) + lrow;
+        int img = u / (Hp * Wp);
+        const int rem = u - img * (Hp * Wp);
+        int hh = rem / Wp;
+        int ww = rem - hh * Wp;
+        l_ok = 0;
+        auto next_row = [&](int g, int& vo) {
+          const int hi = hh - p.pad, wi = ww - p.pad;
+          const bool ok = g * 32 + lrow < rows && img < n_img && (unsigned)hi < (unsigned)p.H &&
+                          (unsigned)wi < (unsigned)p.W;
+          vo = ok ? (((img * p.H + hi) * p.W + wi) * p.lda + lk4) * 4 : BUF_OOB;
+          l_ok |= (ok ? 1u : 0u) << g;
+          ww += 32;
+          while (ww >= Wp) {
+            ww -= Wp;
+            if (++hh == Hp) {
+              hh = 0;
+              ++img;
+            }
+          }
+        };
+        next_row(0, r0); next_row(1, r1); next_row(2, r2); next_row(3, r3);
+        next_row(4, r4); next_row(5, r5); next_row(6, r6); next_row(7, r7);
+        next_row(8, r8); next_row(9, r9); next_row(10, r10); next_row(11, r11);
+      };
+      auto load = [&](Staged& s) {
+        const bool live = l_round < my_tiles;
+        const int soff = l_c * 128;
+        s.ok = live ? (l_ok >> (l_part * 4)) & 15u : 0u;
+#define P3_LD(V) \
+  __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, live ? (V) : BUF_OOB, soff, 0))
+        if (l_part == 0) {           // (wave-uniform branches, scalar variables: no indexed array)
+          s.a[0] = P3_LD(r0); s.a[1] = P3_LD(r1); s.a[2] = P3_LD(r2); s.a[3] = P3_LD(r3);
+        } else if (l_part == 1) {
+          s.a[0] = P3_LD(r4); s.a[1] = P3_LD(r5); s.a[2] = P3_LD(r6); s.a[3] = P3_LD(r7);
+        } else {
+          s.a[0] = P3_LD(r8); s.a[1] = P3_LD(r9); s.a[2] = P3_LD(r10); s.a[3] = P3_LD(r11);
+        }
+#undef P3_LD
+        if (!live) return;
+        if (++l_part == l_nparts) {  // next chunk of this tile, else next tile
+          l_part = 0;
+          if (++l_c == NC) {
+            l_c = 0;
+            if (++l_round < my_tiles) l_setup(l_round);
+          }
+        }
+      };
+      // store cursor
+      int s_round = 0, s_c = 0, s_part = 0, s_nparts = 0, s_h = 0;
+      auto s_setup = [&](int round) {
+        int m0, n0;
+        tile_of(round, m0, n0);
+        s_nparts = (patch_rows(m0) + 127) >> 7;
+      };
+      auto stash = [&](const Staged& s) {
+        char* const buf = xsm + (s_h & 1) * pbuf + lk4 * 2;
+        if (s_part == 0) {
+          next_vec(s_c + 1);
+#ifdef P3_DBG_TIME
+          const long long d_a = clock64();
+#endif
+          p3_wait(pempty + (s_h & 1), MATRIX * (s_h >> 1));  // chunk h-2 has been read
+#ifdef P3_DBG_TIME
+          d_wait += clock64() - d_a;
+#endif
+        }
+#ifdef P3_DBG_TIME
+        const long long d_b = clock64();
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // this item's 4 loads (4 newer ones fly)
+        const long long d_c = clock64();
+        d_vmw += d_c - d_b;
+#endif
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int j = (s_part * 4 + i) * 32 + lrow;
+          if (j < p.p3_rows)  // (the last item may reach past the rows the buffer holds)
+            transform_store(s.a[i], zero4, (s.ok >> i) & 1u, buf + j * P3_ROW, nullptr);
+        }
+#ifdef P3_DBG_TIME
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        d_tr += clock64() - d_c;
+#endif
+        if (++s_part == s_nparts) {
+          if (lane == 0) x3_signal(pfull + (s_h & 1));  // (in LDS order behind this wave's writes)
+          s_part = 0;
+          ++s_h;
+          if (++s_c == NC) {
+            s_c = 0;
+            if (++s_round < my_tiles) s_setup(s_round);
+          }
+        }
+      };
+      l_setup(0);
+      s_setup(0);
+      load_vec(nxt, 0);
+      load(st[0]);
+      while (s_round < my_tiles) {
+#ifdef P3_DBG_TIME
+        const long long d_l = clock64();
+#endif
+        load(st[1]);
+#ifdef P3_DBG_TIME
+        d_ld += clock64() - d_l;
+#endif
+        stash(st[0]);
         if (s_round < my_tiles) {
-          load(st[(j + P3_RING - 1) % P3_RING]);
-          store(st[j]);
+          load(st[0]);
+          stash(st[1]);
         }
       }
     }
+#ifdef P3_DBG_TIME
+    if (blockIdx.x == 8 && ptid == 0)
+      printf("p3 producer: total %lld cycles, waiting for the matrix waves %lld; KxK form: waiting for "
+             "loads %lld, transform + LDS writes %lld, issuing every other item's loads %lld\n",
+             (long long)(clock64() - d_t0), d_wait, d_vmw, d_tr, d_ld);
+#endif
   } else {
     // ================================================================ matrix waves
     const int wm = wave / WN, wn = wave % WN;
@@ -336,13 +503,26 @@ __global__ __launch_bounds__((WM * WN + P3_PRODUCERS) * 64) void conv_p3_kernel(
     bf16x8 b0[NT][3], b1[NT][3];
     f32x16 acc[MT][NT];
     auto loadB = [&](bf16x8 (&b)[NT][3], const int (&vb)[NT], int soff) {
+      if constexpr (!B_LDS) {
 #pragma unroll
-      for (int j = 0; j < NT; ++j)
+        for (int j = 0; j < NT; ++j)
 #pragma unroll
-        for (int q = 0; q < 3; ++q)
-          b[j][q] = __builtin_bit_cast(
-              bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
-                          rsrc_b, vb[j] == BUF_OOB ? BUF_OOB : vb[j] + q * 1024, soff, 0));
+          for (int q = 0; q < 3; ++q)
+            b[j][q] = __builtin_bit_cast(
+                bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
+                            rsrc_b, vb[j] == BUF_OOB ? BUF_OOB : vb[j] + q * 1024, soff, 0));
+      }
+    };
+    // B_LDS: k-slab s of the chunk in stage `st`, this wave's n-blocks, fragment (= lane) order
+    auto readB = [&](bf16x8 (&b)[NT][3], int st, int s) {
+      if constexpr (B_LDS) {
+        const char* base = bstage + st * BST + ((wn * NT) * 2 + s) * 3072 + lane * 16;
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int q = 0; q < 3; ++q)
+            b[j][q] = *reinterpret_cast<const bf16x8*>(base + j * 6144 + q * 1024);
+      }
     };
     auto mma = [&](const bf16x8 (&b)[NT][3]) {
       constexpr int PA[6] = {2, 1, 0, 1, 0, 0};  // smallest products first
@@ -366,7 +546,11 @@ __global__ __launch_bounds__((WM * WN + P3_PRODUCERS) * 64) void conv_p3_kernel(
 
     // the SIMD's VALU issue port is shared with the producer wave: the MFMAs must win it the
     // moment the matrix pipe frees up
-    __builtin_amdgcn_s_setprio(3);
+    __builtin_amdgcn_s_setprio(P3_MPRIO);
+#ifdef P3_DBG_TIME
+    long long d_pf = 0, d_vm = 0, d_lg = 0;
+    const long long d_t0 = clock64(), d_w0 = wall_clock64();
+#endif
     int h = 0;
     int vb[NT], vbn[NT];
     {
@@ -417,7 +601,13 @@ __global__ __launch_bounds__((WM * WN + P3_PRODUCERS) * 64) void conv_p3_kernel(
 
       int ks3 = 0;  // byte offset of the current k-slab pair inside an n-block's fragments
       for (int c = 0; c < NC; ++c, ++h) {
+#ifdef P3_DBG_TIME
+        const long long d_a = clock64();
+#endif
         p3_wait(pfull + (h & 1), P3_PRODUCERS * ((h >> 1) + 1));
+#ifdef P3_DBG_TIME
+        d_pf += clock64() - d_a;
+#endif
         const int bufoff = (h & 1) * pbuf;
         int tr = 0, tq = 0;
         for (int t = 0; t < T; ++t) {
@@ -426,17 +616,30 @@ __global__ __launch_bounds__((WM * WN + P3_PRODUCERS) * 64) void conv_p3_kernel(
           const bool last_of_tile = last_of_chunk && c == NC - 1;
           // ---- k-slab 0 of this (chunk, tap): B fragments in b0 (fetched a slab ago)
           loadB(b1, vb, ks3 + 3072);
+          readB(b0, h & 1, 0);
 #pragma unroll
           for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int q = 0; q < 3; ++q)
               fa[i][q] = *reinterpret_cast<const bf16x8*>(abase + a_row[i] + q * 64);
           __builtin_amdgcn_sched_barrier(0);
+#ifdef P3_DBG_TIME
+          {
+            const long long d_0 = clock64();
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(B_LDS ? 0 : NT * 3) : "memory");
+            const long long d_1 = clock64();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            d_vm += d_1 - d_0;
+            d_lg += clock64() - d_1;
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#endif
           mma(b0);
           __builtin_amdgcn_sched_barrier(0);
           // ---- k-slab 1: B fragments in b1; b0 <- the next step's (or the next tile's first)
           if (last_of_tile) loadB(b0, vbn, 0);
           else loadB(b0, vb, ks3 + 6144);
+          readB(b1, h & 1, 1);
 #pragma unroll
           for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -492,6 +695,14 @@ __global__ __launch_bounds__((WM * WN + P3_PRODUCERS) * 64) void conv_p3_kernel(
         }
     }
     __builtin_amdgcn_s_setprio(0);
+#ifdef P3_DBG_TIME
+    if (blockIdx.x == 8 && (tid == 0 || tid == 64 * (MATRIX - 1))) {
+      const long long c = clock64() - d_t0, w = wall_clock64() - d_w0;
+      printf("p3 matrix wave %d: tiles %d chunks %d taps %d: total %lld cycles = %lld ticks of 100 MHz "
+             "(%.2f GHz); waiting for the patch %lld, slab-0 waits: B fragments %lld, A fragments %lld\n",
+             wave, my_tiles, NC, T, c, w, (double)c / (double)w * 0.1, d_pf, d_vm, d_lg);
+    }
+#endif
   }
 #endif
 }
@@ -536,7 +747,8 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
 
 template <int BM, int BN, int WM, int WN, int DUAL, int MODE>
 int launch_p3(const IgemmParams& p, int rows_alloc, hipStream_t stream) {
-  const int smem_bytes = 2 * rows_alloc * P3_ROW + 16;  // two patch buffers + 4 counters
+  // two patch buffers (+ two B stages for the 1x1 form) + 4 counters
+  const int smem_bytes = 2 * rows_alloc * P3_ROW + (MODE == P3_GATHER ? 2 * BN * 192 : 0) + 16;
   constexpr int threads = (WM * WN + P3_PRODUCERS) * 64;
   auto kern = conv_p3_kernel<BM, BN, WM, WN, DUAL, MODE>;
   static int attr_bytes = 0;  // per instantiation: the largest dynamic LDS size enabled so far
@@ -591,20 +803,29 @@ int p3_rows_for(const IgemmParams& p, int bm, bool dense) {
   return (int)((rows + 31) / 32 * 32);
 }
 
+// Tiles: 8 matrix waves, each a (BM / WM) x 32 sub-tile.  B fragments come straight from L2 (one
+// 1 KB load per plane and k-slab, used for BM / WM / 32 MFMAs), so the sub-tile is TALL: with
+// 128 rows the texture path carries 16 B/clk per CU, with 32 rows it would saturate (64 B/clk).
 template <int DUAL, int MODE>
-int dispatch_p3(const IgemmParams& p, const P3Tile& t, int rows, hipStream_t s) {
-  if (t.bm == 128 && t.bn == 256) return launch_p3<128, 256, 2, 4, DUAL, MODE>(p, rows, s);
-  if (t.bm == 64 && t.bn == 256) return launch_p3<64, 256, 2, 4, DUAL, MODE>(p, rows, s);
-  if (t.bm == 128 && t.bn == 128) return launch_p3<128, 128, 2, 4, DUAL, MODE>(p, rows, s);
-  if (t.bm == 64 && t.bn == 128) return launch_p3<64, 128, 2, 4, DUAL, MODE>(p, rows, s);
-  if (t.bm == 128 && t.bn == 64) return launch_p3<128, 64, 4, 2, DUAL, MODE>(p, rows, s);
-  return launch_p3<64, 64, 2, 2, DUAL, MODE>(p, rows, s);
+int dispatch_p3(const IgemmParams& p, int tile, int rows, hipStream_t s) {
+  switch (tile) {
+    case 0: return launch_p3<128, 256, 1, 8, DUAL, MODE>(p, rows, s);
+    case 1: return launch_p3<64, 256, 1, 8, DUAL, MODE>(p, rows, s);
+    case 2: return launch_p3<256, 128, 2, 4, DUAL, MODE>(p, rows, s);
+    case 3: return launch_p3<128, 128, 2, 4, DUAL, MODE>(p, rows, s);
+    case 4: return launch_p3<256, 64, 4, 2, DUAL, MODE>(p, rows, s);
+    default: return launch_p3<128, 64, 4, 2, DUAL, MODE>(p, rows, s);
+  }
 }
 
 }  // namespace
 
 int p3_try_launch(const IgemmParams& p, hipStream_t stream) {
-  static const int mode_env = getenv("VLNCE_P3") ? atoi(getenv("VLNCE_P3")) : 1;  // 0 = off
+  // VLNCE_P3: 0 = off, 1 = every layer it covers, 2 = the KxK (patch) layers only, 3 = the 1x1
+  // layers only.  Default 2: measured per layer at num_envs 64 (profiles/r03_*_convbench_ab.txt),
+  // the patch form is 1.26-1.51x conv_x3_kernel on every stride-1 3x3 layer of the trunks, the
+  // 1x1 form (4 producer waves) is within +-10 % of it and slower on most.
+  static const int mode_env = getenv("VLNCE_P3") ? atoi(getenv("VLNCE_P3")) : 2;
   static const int force = getenv("VLNCE_P3_TILE") ? atoi(getenv("VLNCE_P3_TILE")) : 0;  // tuning
   if (!mode_env || !conv_math() || !p.Bfrag) return -1;
   if (p.Cin % 32 != 0 || p.N % 32 != 0 || p.lda % 4 != 0 || p.splitk > 1) return -1;
@@ -618,28 +839,31 @@ int p3_try_launch(const IgemmParams& p, hipStream_t stream) {
   if (mode_env == 2 && !dense) return -1;  // VLNCE_P3=2: only the patch (KxK) layers
   if (mode_env == 3 && dense) return -1;   // VLNCE_P3=3: only the 1x1 layers
 
-  const P3Tile cand[6] = {{128, 256}, {64, 256}, {128, 128}, {64, 128}, {128, 64}, {64, 64}};
+  const P3Tile cand[6] = {{128, 256}, {64, 256}, {256, 128}, {128, 128}, {256, 64}, {128, 64}};
   const int cus = x3_cus();
-  P3Tile pick{0, 0};
-  int pick_rows = 0;
+  const bool forced = force >= 1 && force <= 6;
+  // BN: the narrowest of 64 / 128 / 256 that covers N (256 for wider layers); 1x1 layers with
+  // N <= 64 stay on conv_x3_kernel (8 producer waves: the transform per MFMA is what binds there)
+  const int bn = p.N <= 64 ? 64 : p.N <= 128 ? 128 : 256;
+  if (!dense && bn == 64 && !forced) return -1;
+  int pick = -1, pick_rows = 0;
   double best = 0.0;
   for (int ci = 0; ci < 6; ++ci) {
     const P3Tile& c = cand[ci];
-    if (force >= 1 && force <= 6 && ci != force - 1) continue;
-    if (c.bn > 64 && p.N < c.bn && !(force >= 1 && force <= 6)) continue;
+    if (forced ? ci != force - 1 : c.bn > bn) continue;  // (narrower tiles only to fill the CUs)
     const int rows = p3_rows_for(p, c.bm, dense);
-    if (2L * rows * P3_ROW + 16 > 163840) continue;
+    if (2L * rows * P3_ROW + (dense ? 0 : 2L * c.bn * 192) + 16 > 163840) continue;
     const long tiles = (long)ceil_div(p.M, c.bm) * ceil_div(p.N, c.bn);
     const long rounds = (tiles + cus - 1) / cus;
     const double eff = (double)tiles / (double)(rounds * cus);
     if (eff > best) {
       best = eff;
-      pick = c;
+      pick = ci;
       pick_rows = rows;
     }
     if (eff >= 0.8) break;
   }
-  if (pick.bm == 0 || (best < 0.4 && !(force >= 1 && force <= 6))) return -1;
+  if (pick < 0 || (best < 0.4 && !forced)) return -1;
   if (dual) return dispatch_p3<1, P3_GATHER>(p, pick, pick_rows, stream);
   if (dense) return dispatch_p3<0, P3_DENSE>(p, pick, pick_rows, stream);
   return dispatch_p3<0, P3_GATHER>(p, pick, pick_rows, stream);

@@ -133,6 +133,39 @@ __global__ __launch_bounds__(256) void frames_gather_kernel(GatherArg g, int F, 
   }
 }
 
+// habitat's ResizeShortestEdge = F.interpolate(mode="area") = adaptive average pooling to
+// (OH, OW), cast back to the sensor's dtype -- restricted to the crop window [y0, y0+H) x
+// [x0, x0+W) of the resized image (the CenterCropperPerSensor that follows it in every RxR
+// config).  Arithmetic of at::adaptive_avg_pool2d on the CPU: window [floor(o*in/out),
+// ceil((o+1)*in/out)), row-major fp32 sum, sum / kh / kw; uint8 results truncate like
+// Tensor.to(uint8).
+template <typename T>
+__global__ __launch_bounds__(256) void frames_resize_area_kernel(const T* __restrict__ x, int NF,
+                                                                 int Hs, int Ws, int C, int OH, int OW,
+                                                                 int y0, int x0, int H, int W,
+                                                                 T* __restrict__ out) {
+  const long total = (long)NF * H * W * C;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    long t = i / C;
+    const int w = (int)(t % W);
+    t /= W;
+    const int h = (int)(t % H);
+    const long img = t / H;
+    const int oh = y0 + h, ow = x0 + w;
+    const int h0 = (int)(((long)oh * Hs) / OH), h1 = (int)((((long)oh + 1) * Hs + OH - 1) / OH);
+    const int w0 = (int)(((long)ow * Ws) / OW), w1 = (int)((((long)ow + 1) * Ws + OW - 1) / OW);
+    float s = 0.f;
+    for (int a = h0; a < h1; ++a) {
+      const T* row = x + ((img * Hs + a) * (long)Ws + w0) * C + c;
+      for (int b = 0; b < w1 - w0; ++b) s += (float)row[(long)b * C];
+    }
+    const float m = s / (float)(h1 - h0) / (float)(w1 - w0);
+    if constexpr (sizeof(T) == 1) out[i] = (T)m;  // float -> uint8: truncation, value <= 255
+    else out[i] = m;
+  }
+}
+
 inline int grid_for(long work) {
   long g = (work + 255) / 256;
   if (g < 1) g = 1;
@@ -225,5 +258,28 @@ extern "C" int vlnce_frames_gather(const void* const* srcs, int F, int elem_byte
                      0, reinterpret_cast<hipStream_t>(stream), g, F, N, Hs, Ws, rowb_src, y0, xb0, H,
                      rowb, vec, static_cast<unsigned char*>(out));
   VLNCE_CHECK_LAUNCH("frames_gather");
+  return 0;
+}
+
+extern "C" int vlnce_frames_resize_area(const void* x, int dtype, int NF, int Hs, int Ws, int C,
+                                        int OH, int OW, int y0, int x0, int H, int W, void* out,
+                                        vlnce_stream_t stream) {
+  VLNCE_CHECK_ARG(x && out && NF > 0 && Hs > 0 && Ws > 0 && C > 0 && OH > 0 && OW > 0,
+                  "frames_resize_area: bad argument");
+  VLNCE_CHECK_ARG(dtype == VLNCE_DT_F32 || dtype == VLNCE_DT_U8, "frames_resize_area: dtype %d", dtype);
+  VLNCE_CHECK_ARG(H > 0 && W > 0 && y0 >= 0 && x0 >= 0 && y0 + H <= OH && x0 + W <= OW,
+                  "frames_resize_area: window (%d,%d)+(%d,%d) outside the %dx%d resized frame", y0, x0,
+                  H, W, OH, OW);
+  const dim3 grid(grid_for((long)NF * H * W * C));
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == VLNCE_DT_U8)
+    hipLaunchKernelGGL(frames_resize_area_kernel<unsigned char>, grid, dim3(256), 0, s,
+                       static_cast<const unsigned char*>(x), NF, Hs, Ws, C, OH, OW, y0, x0, H, W,
+                       static_cast<unsigned char*>(out));
+  else
+    hipLaunchKernelGGL(frames_resize_area_kernel<float>, grid, dim3(256), 0, s,
+                       static_cast<const float*>(x), NF, Hs, Ws, C, OH, OW, y0, x0, H, W,
+                       static_cast<float*>(out));
+  VLNCE_CHECK_LAUNCH("frames_resize_area");
   return 0;
 }

@@ -320,6 +320,23 @@ def frames_gather(srcs, crop=None):
     return out
 
 
+def frames_resize_area(x, out_hw, crop=None):
+    """habitat's image_resize_shortest_edge arithmetic (F.interpolate(mode="area") to out_hw, cast
+    back to x.dtype) on [..., Hs, Ws, C] uint8 / fp32 frames, restricted to the window
+    crop = (y0, x0, H, W) of the resized image (None = all of it)."""
+    assert x.dtype in (torch.uint8, torch.float32), x.dtype
+    lead, (Hs, Ws, Cc) = x.shape[:-3], x.shape[-3:]
+    x = x if x.is_contiguous() else x.contiguous()
+    OH, OW = out_hw
+    y0, x0, H, W = crop if crop is not None else (0, 0, OH, OW)
+    NF = 1
+    for d in lead:
+        NF *= int(d)
+    out = torch.empty(tuple(lead) + (H, W, Cc), device=x.device, dtype=x.dtype)
+    L().frames_resize_area(x, x.dtype == torch.uint8, NF, Hs, Ws, Cc, OH, OW, y0, x0, H, W, out)
+    return out
+
+
 def avgpool2x2(x):
     N, H, W, Cc = x.shape
     y = torch.empty((N, H // 2, W // 2, Cc), device=x.device, dtype=torch.float32)
