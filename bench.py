@@ -10,17 +10,19 @@ num_envs=64 rollouts PER GPU of synthetic 256x256 RGB + 256x256 depth +
 exactly as the reference constructs it: frozen visual encoders whose
 BatchNorm runs on batch statistics.  value = envs
 processed by all ranks per second (weak scaling, data parallel; gradients are
-all-reduced over RCCL by vlnce_amd.distributed when N > 1).  Every timed step does
-its own trunk passes, tail forward, backward and Adam; the frozen trunks of step k+1 are
-issued (policy.encode_ahead, side HIP streams) before step k's update is enqueued so that
-they overlap its latency-bound tail -- `--no-pipeline` times the plain loop.
+all-reduced over RCCL by vlnce_amd.distributed when N > 1).  `value` is the loop the UNCHANGED
+trainers issue: one update call per batch, every step running its own trunk passes, tail forward,
+backward and Adam, over 4 distinct resident batches in rotation.  Beside it
+(config.encode_ahead_*) the same steps with the optional policy.encode_ahead() API: the frozen
+trunks of batch k+1 issued on side HIP streams before batch k's update is enqueued.
 
-The JSON line also carries `roofline` (dominant kernel = the implicit-GEMM
-convolution: conv_x3_kernel, fp32 operands split exactly into three bf16 planes and multiplied
-as six plane products on the bf16 matrix pipe, plus the fp32-MFMA igemm_kernel for the stems
-and the small layers; timed with HIP events on the launch stream; priced against the fp32
-MFMA peak, the roofline of the arithmetic the reference asks for) and,
-on rank 0 at N=1, `cpu_baseline` (the CPU oracle restatement of the reference
+The JSON line also carries `roofline` (dominant kernel = the implicit-GEMM convolution:
+conv_p3_kernel / conv_x3_kernel, fp32 operands split exactly into three bf16 planes and
+multiplied as six plane products on the bf16 matrix pipe, plus the fp32-MFMA igemm_kernel for
+the stems and the small layers; every launch timed with HIP events on the launch stream and
+attributed to the kernel the library dispatched it to; `frac` prices the ALGORITHMIC fp32 FLOPs
+against the fp32 MFMA peak, `bf16_pipe.frac` the hardware FLOPs of the bf16-plane launches
+against the bf16 MFMA peak) and, on rank 0 at N=1, `cpu_baseline` (the CPU oracle restatement of the reference
 policy timed on the host cores on a bounded sample of the same workload).
 """
 import argparse
@@ -170,7 +172,7 @@ def f32_mfma_compare(args):
                              text=True, timeout=600).stdout.strip().splitlines()
         d = json.loads(out[-1])
         return {"value": d["value"], "ms_per_step": d["ms_per_step"],
-                "no_pipeline_ms_per_step": d["config"]["no_pipeline_ms_per_step"],
+                "encode_ahead_ms_per_step": d["config"]["encode_ahead_ms_per_step"],
                 "roofline_frac": d["roofline"]["frac"],
                 "conv_kernel_ms_per_step": d["roofline"]["kernel_ms_per_step"]}
     except Exception as e:  # never block the main line
@@ -179,11 +181,11 @@ def f32_mfma_compare(args):
 
 def pmc_traffic(n_conv):
     """HBM bytes per conv launch from the committed rocprofv3 PMC passes of this same
-    workload (profiles/r02_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate
+    workload (profiles/r03_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate
     passes of `bench.py --pmc-step`, gfx950 corrections applied as MI355X_MICROARCH.md
     prescribes).  None when the file is absent or was taken for a different launch count."""
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
-                        "r02_pmc_traffic.json")
+                        "r03_pmc_traffic.json")
     try:
         rec = json.load(open(path))
     except OSError:
@@ -217,12 +219,16 @@ def conv_kernel_time(policy, obs, dev, repeats=3):
     orig_conv = ops.conv2d_nhwc
     events = []
 
-    def timed_conv(*a, **k):
+    meta = []  # per launch: (algorithmic FLOPs, kernel path the library dispatched to)
+
+    def timed_conv(x, w, stride, pad, *a, **k):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        out = orig_conv(*a, **k)
+        out = orig_conv(x, w, stride, pad, *a, **k)
         e1.record()
         events.append((e0, e1))
+        y = out[0] if isinstance(out, tuple) else out
+        meta.append((2.0 * y.numel() * w[0].numel(), ops.L().conv2d_last_path()))
         return out
 
     def trunks():
@@ -252,6 +258,7 @@ def conv_kernel_time(policy, obs, dev, repeats=3):
         enc.ops.conv2d_nhwc = timed_conv
         for _ in range(repeats):
             events.clear()
+            meta.clear()
             torch.cuda._sleep(int(backlog_ms * cyc_per_ms))
             nul = [(ev(), ev()) for _ in range(8)]
             for e0, e1 in nul:
@@ -279,8 +286,15 @@ def conv_kernel_time(policy, obs, dev, repeats=3):
     whole = min(totals)
     log(f"conv attribution: {n} launches, {conv_ms:.3f} ms of a {whole:.3f} ms eager single-stream "
         f"trunk pair (empty event pair {1e3 * empty:.1f} us, host issue {host_ms:.1f} ms)")
+    by_path = {}
+    for t, (fl, path) in zip(per_launch, meta):
+        d = by_path.setdefault(path, {"launches": 0, "ms": 0.0, "flop": 0.0})
+        d["launches"] += 1
+        d["ms"] += max(t - empty, 0.0)
+        d["flop"] += fl
     res = {"n": n, "conv_ms": conv_ms, "eager_trunks_ms": whole, "empty_pair_us": 1e3 * empty,
-           "host_issue_ms": host_ms, "reason": None}
+           "host_issue_ms": host_ms, "reason": None, "by_path": by_path,
+           "flop": sum(fl for fl, _ in meta)}
     if not (0.0 < conv_ms <= whole * 1.001):
         res["reason"] = (f"per-launch event sum {conv_ms:.3f} ms is not inside the eager "
                          f"single-stream pass {whole:.3f} ms")
@@ -330,8 +344,8 @@ def main():
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--threads", default="8", help=argparse.SUPPRESS)
     ap.add_argument("--no-pipeline", action="store_true",
-                    help="do not start the next step's frozen visual trunks (encode_ahead) "
-                         "before enqueuing the current step's update")
+                    help="skip the secondary encode_ahead measurement (`value` is the plain "
+                         "trainer loop either way)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise RCCL and run the gradient all-reducer even with one rank "
                          "(exercises the N>1 code path on a 1-GPU box)")
@@ -375,10 +389,20 @@ def main():
         reducer = GradientAllReducer(policy)
         grad_hook = reducer.finish
     vlnce_amd.AuxLosses.activate()
-    batch = synth_batch(args.num_envs, args.hw, args.tokens, dev, seed=1 + rank)
+    # NB distinct resident batches, used in rotation: one batch fed every step would stay warm in
+    # the 256 MiB Infinity Cache (67 MB of frames)
+    NB = 4
+    batches = [synth_batch(args.num_envs, args.hw, args.tokens, dev, seed=1 + rank + 101 * i)
+               for i in range(NB)]
+    batch = batches[0]
+    it = [0]
+
+    def next_batch():
+        it[0] += 1
+        return batches[it[0] % NB]
 
     def step():
-        obs, prev, masks, tgt, w = batch
+        obs, prev, masks, tgt, w = next_batch()
         update_agent(policy, opt, obs, prev, masks, tgt, w, 512, grad_hook=grad_hook)
 
     if os.environ.get("VLNCE_BENCH_CACHED_DEPTH"):  # diagnostic: how much the depth trunk costs
@@ -392,17 +416,18 @@ def main():
     # Adam; trainable encoders cannot run ahead and fall back to the plain loop.
     pipeline = not (args.no_pipeline or args.trainable_encoders)
 
-    def run_steps(n):
-        obs, prev, masks, tgt, w = batch
-        if not pipeline:
+    def run_steps(n, ahead):
+        if not ahead:
             for _ in range(n):
                 step()
             return
-        nxt = policy.encode_ahead(obs)
+        b = next_batch()
+        nxt = policy.encode_ahead(b[0])
         for k in range(n):
-            cur = nxt
+            cur, (_, prev, masks, tgt, w) = nxt, b
             if k + 1 < n:
-                nxt = policy.encode_ahead(obs)
+                b = next_batch()
+                nxt = policy.encode_ahead(b[0])
             update_agent(policy, opt, cur, prev, masks, tgt, w, 512, grad_hook=grad_hook)
 
     if args.pmc_step:
@@ -427,10 +452,7 @@ def main():
     log("policy built, starting warm-up")
     for i in range(args.warmup):
         t0 = time.perf_counter()
-        if pipeline and i >= 2:
-            run_steps(2)  # warms the run-ahead path (its graphs are captured on the side stream)
-        else:
-            step()
+        step()
         torch.cuda.synchronize()
         log(f"warm-up step {i}: {1e3 * (time.perf_counter() - t0):.1f} ms")
 
@@ -439,12 +461,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # ---- the timed region: the loop the UNCHANGED trainers issue (base_il_trainer.py:134-180
+    # per batch): build_distribution on raw frames -> loss -> backward -> Adam, one call per step
     sync()
     t0 = time.perf_counter()
-    run_steps(args.steps)
+    run_steps(args.steps, ahead=False)
     sync()
     elapsed = time.perf_counter() - t0
-    log(f"timed region: {args.steps} steps in {elapsed:.3f}s")
+    log(f"timed region (plain trainer loop): {args.steps} steps in {elapsed:.3f}s")
     from vlnce_amd import streams as _st
     if _st.TIMING:
         per = {}
@@ -457,22 +481,21 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = tmax.item()
 
-    # ---- plain loop (what the unchanged trainers issue: no encode_ahead), same step count
-    no_pipe_ms = None
+    # ---- beside it: the same steps with the optional policy.encode_ahead() API (the frozen
+    # trunks of batch k+1 issued before batch k's update is enqueued), same step count
+    ahead_ms = None
     if pipeline:
-        for _ in range(2):
-            step()
+        run_steps(3, ahead=True)  # warms the run-ahead path (its graphs live on the side streams)
         sync()
         t1 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
+        run_steps(args.steps, ahead=True)
         sync()
-        no_pipe_ms = 1e3 * (time.perf_counter() - t1) / args.steps
+        ahead_ms = 1e3 * (time.perf_counter() - t1) / args.steps
         if use_dist:
-            tm = torch.tensor([no_pipe_ms], device=dev)
+            tm = torch.tensor([ahead_ms], device=dev)
             dist.all_reduce(tm, op=dist.ReduceOp.MAX)
-            no_pipe_ms = tm.item()
-        log(f"plain loop (no encode_ahead): {no_pipe_ms:.3f} ms/step")
+            ahead_ms = tm.item()
+        log(f"with encode_ahead: {ahead_ms:.3f} ms/step")
 
     # ---- dominant-kernel attribution: separate, untimed-for-throughput pass
     conv = conv_kernel_time(policy, batch[0], dev)
@@ -503,48 +526,85 @@ def main():
         conv_ms, n_conv = conv["conv_ms"], conv["n"]
         ok = conv["reason"] is None
         achieved = conv_flop / (conv_ms * 1e-3) / 1e12 if ok else None
+        # per kernel family, from the library's own dispatch record (vlnce_conv2d_last_path)
+        fam = {0: "fp32_mfma", 1: "bf16_planes_x3", 2: "bf16_planes_p3"}
+        paths = {fam.get(k, str(k)): v for k, v in conv["by_path"].items()}
+        bf = [v for k, v in paths.items() if k.startswith("bf16")]
+        bf_ms, bf_flop = sum(v["ms"] for v in bf), sum(v["flop"] for v in bf)
+        f32 = paths.get("fp32_mfma", {"ms": 0.0, "flop": 0.0, "launches": 0})
+
+        def tf(v):
+            return round(v["flop"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 else None
+
         line = {
             "metric": "policy-steps/sec (fwd+bwd)", "value": round(value, 1),
             "unit": "policy-steps/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "CMA policy DAgger update (fwd+bwd+Adam), "
+            "config": {"workload": "CMA policy DAgger update (fwd+bwd+Adam) as the unchanged "
+                                   "trainers call it (one _update_agent per batch, no run-ahead), "
                                    + ("trainable" if args.trainable_encoders else "frozen")
-                                   + " encoders"
-                                   + (" (next step's trunks issued ahead)" if pipeline else "")
-                                   + ", "
+                                   + " encoders, "
                                    f"BatchNorm={args.bn}, num_envs={args.num_envs}/GPU, "
-                                   f"{args.hw}x{args.hw} RGB-D, {args.tokens}-token instruction",
+                                   f"{args.hw}x{args.hw} RGB-D, {args.tokens}-token instruction, "
+                                   f"{NB} distinct batches in rotation",
                        "global_batch": args.num_envs * world, "parallelism": f"dp{world}",
                        "whole_step_tflops": round(step_gflop * value / 1e3, 2),
-                       "no_pipeline_ms_per_step": round(no_pipe_ms, 3) if no_pipe_ms else None,
-                       "no_pipeline_steps_per_sec": (
-                           round(1e3 * args.num_envs * world / no_pipe_ms, 1) if no_pipe_ms
-                           else round(value, 1)),
+                       "encode_ahead_ms_per_step": round(ahead_ms, 3) if ahead_ms else None,
+                       "encode_ahead_steps_per_sec": (
+                           round(1e3 * args.num_envs * world / ahead_ms, 1) if ahead_ms else None),
+                       "encode_ahead_is": "optional API policy.encode_ahead(obs): the frozen "
+                                          "trunks of the next batch issued on side streams before "
+                                          "this batch's update; same results "
+                                          "(tests/test_policy_gpu.py::test_encode_ahead_pipeline_"
+                                          "equals_plain_loop); NOT what `value` measures",
                        "act_fwd_only_eval_steps_per_sec_per_gpu": round(args.num_envs / act_s, 1),
                        "act_latency_ms_by_num_envs": act_small},
             "roofline": {"bound": "mfma",
-                         "kernel": "conv2d fwd: conv_x3_kernel (fp32 operands split exactly into "
-                                   "3 bf16 planes, 6 x v_mfma_f32_32x32x16_bf16 per 32x32x16 "
-                                   "block, fp32 accumulate) + igemm_kernel (v_mfma_f32_32x32x2_f32: "
-                                   "stems, small layers)",
+                         "kernel": "conv2d fwd of the two visual trunks: conv_p3_kernel (stride-1 "
+                                   "KxK: A transformed once per workgroup into an LDS patch, B "
+                                   "fragments from L2) + conv_x3_kernel (1x1 / strided: im2col "
+                                   "K-tiles through LDS), both fp32 operands split exactly into 3 "
+                                   "bf16 planes, 6 x v_mfma_f32_32x32x16_bf16 per 32x32x16 block, "
+                                   "fp32 accumulate; igemm_kernel (v_mfma_f32_32x32x2_f32) for the "
+                                   "stems and the handful-of-tiles layers",
                          "achieved": round(achieved, 2) if ok else None,
                          "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4) if ok else None,
-                         "peak_is": "the fp32 MFMA peak: `achieved` counts ALGORITHMIC fp32 FLOPs, "
-                                    "so frac can exceed what v_mfma_f32_32x32x2_f32 could deliver; "
-                                    "on the bf16 pipe the same work is 6 plane products per "
-                                    "multiply",
+                         "peak_is": "the fp32 MFMA peak: `achieved` counts ALGORITHMIC fp32 FLOPs "
+                                    "over ALL conv launches, so this fraction can exceed 1 -- it is "
+                                    "the reference arithmetic's roofline, not the instruction "
+                                    "stream's; the hardware roofline of the launches that run on "
+                                    "the bf16 pipe is `bf16_pipe`, of the rest `fp32_mfma`",
                          "bf16_pipe": {"instruction": "v_mfma_f32_32x32x16_bf16",
                                        "hw_flops_per_algorithmic_flop": 6,
                                        "peak": BF16_MFMA_PEAK_TFLOPS,
-                                       "frac_if_all_launches_were_x3": (
-                                           round(6 * achieved / BF16_MFMA_PEAK_TFLOPS, 4) if ok
-                                           else None)},
-                         "arithmetic": "fp32-equivalent: max error vs fp64 is 1.1-1.2x the "
-                                       "fp32-MFMA kernel's and equal to rocBLAS/MIOpen fp32 "
-                                       "(profiles/r02_o_conv_accuracy_*.txt); VLNCE_CONV_MATH=f32 "
-                                       "selects the fp32-MFMA kernel everywhere",
+                                       "launches": sum(v["launches"] for v in bf),
+                                       "kernel_ms_per_step": round(bf_ms, 3),
+                                       "achieved_algorithmic_tflops": (
+                                           round(bf_flop / (bf_ms * 1e-3) / 1e12, 2) if bf_ms else None),
+                                       "frac": (round(6 * bf_flop / (bf_ms * 1e-3) / 1e12
+                                                      / BF16_MFMA_PEAK_TFLOPS, 4) if bf_ms and ok
+                                                else None),
+                                       "by_kernel": {k: {"launches": v["launches"],
+                                                         "ms": round(v["ms"], 3), "tflops": tf(v)}
+                                                     for k, v in paths.items() if k.startswith("bf16")}},
+                         "fp32_mfma": {"instruction": "v_mfma_f32_32x32x2_f32",
+                                       "peak": FP32_MFMA_PEAK_TFLOPS, "launches": f32["launches"],
+                                       "kernel_ms_per_step": round(f32["ms"], 3),
+                                       "achieved_tflops": tf(f32),
+                                       "frac": (round(tf(f32) / FP32_MFMA_PEAK_TFLOPS, 4)
+                                                if f32["ms"] and ok else None)},
+                         "flop_check": {"per_launch_geometry_gflop": round(conv["flop"] / 1e9, 2),
+                                        "survey_a3_gflop": round(conv_flop / 1e9, 2)},
+                         "arithmetic": "fp32-class: operands are represented exactly by three bf16 "
+                                       "planes, products are exact, accumulation is fp32; relative "
+                                       "rms error vs an fp64 convolution 2-3x torch's own fp32 "
+                                       "conv for the truncation split of conv_x3_kernel "
+                                       "(profiles/r02_o_conv_accuracy_bf16x6_split.txt), at torch's "
+                                       "level for the round-to-nearest split of conv_p3_kernel "
+                                       "(profiles/r03_conv_accuracy.txt); VLNCE_CONV_MATH=f32 selects "
+                                       "the fp32-MFMA kernel everywhere",
                          "launches_per_step": n_conv,
                          "avg_launch_ms": round(conv_ms / max(n_conv, 1), 4),
                          "kernel_ms_per_step": round(conv_ms, 3),

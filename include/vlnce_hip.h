@@ -111,6 +111,14 @@ long vlnce_conv2d_pack_bytes(const vlnce_conv_desc* d);
 int vlnce_conv2d_pack_weights(const float* w_ohwi, void* frag, const vlnce_conv_desc* d,
                               vlnce_stream_t stream);
 
+/* Which kernel the calling thread's last vlnce_conv2d_fwd was dispatched to: the measurement
+ * harness prices bf16-pipe launches (6 plane products per multiply) and fp32-MFMA launches
+ * against their own peaks.  No reference counterpart. */
+#define VLNCE_CONV_PATH_F32 0 /* igemm_kernel, v_mfma_f32_32x32x2_f32 (incl. split-K)            */
+#define VLNCE_CONV_PATH_X3 1  /* conv_x3_kernel, bf16 planes, im2col K-tiles through LDS          */
+#define VLNCE_CONV_PATH_P3 2  /* conv_p3_kernel, bf16 planes, patch-resident A / fragment-order B */
+int vlnce_conv2d_last_path(void);
+
 int vlnce_conv2d_fwd(const float* x, const float* w_ohwi, float* y,
                      const vlnce_conv_desc* d, const vlnce_prologue* pro,
                      const vlnce_epilogue* epi, vlnce_stream_t stream);

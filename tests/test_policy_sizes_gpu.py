@@ -152,3 +152,51 @@ def test_cma_update_at_baseline_geometry_vs_oracle():
                          hip_update, vlnce_amd.AuxLosses)
     assert len(want["grad_names"]) > 30
     compare(got, want, atol=1e-4, rtol=2e-4)
+
+
+def _cross_kernel(which, tmp_path):
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    outs = {}
+    for tag, env in (("planes", {}), ("f32", {"VLNCE_CONV_MATH": "f32"})):
+        out = str(tmp_path / f"{which}_{tag}.pt")
+        e = dict(os.environ, **env)
+        e.pop("VLNCE_CONV_MATH", None) if not env else None
+        r = subprocess.run([sys.executable, os.path.join(here, "cross_kernel_worker.py"), which, out],
+                           env=e, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs[tag] = torch.load(out)
+    return outs["planes"], outs["f32"]
+
+
+def _rel(a, b):
+    return ((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30)).item()
+
+
+def test_bench_geometry_planes_vs_fp32_mfma_kernels(tmp_path):
+    """Two INDEPENDENT convolution implementations at exactly the geometry bench.py times
+    (num_envs=64, 256x256 RGB-D, 80 tokens, BatchNorm on batch statistics): the default path
+    (conv_p3_kernel / conv_x3_kernel: bf16 planes, their own tile plans at this size) against
+    VLNCE_CONV_MATH=f32 (igemm_kernel on v_mfma_f32_32x32x2_f32, the kernel the small-batch tests
+    pin against the CPU oracle), each in its own process.  Trunk outputs, every BatchNorm running
+    statistic and the H1 loss within 1e-5 relative; tail gradients within 1e-4."""
+    a, b = _cross_kernel("cma", tmp_path)
+    assert set(a) == set(b) and len([k for k in a if k.startswith("bn/")]) > 100
+    assert _rel(a["rgb_trunk"], b["rgb_trunk"]) < 1e-5
+    assert _rel(a["depth_trunk"], b["depth_trunk"]) < 1e-5
+    for k in a:
+        if k.startswith("bn/"):
+            assert _rel(a[k], b[k]) < 1e-5, k
+    assert _rel(a["loss"], b["loss"]) < 1e-5, (a["loss"], b["loss"])
+    assert _rel(a["grad_state_q"], b["grad_state_q"]) < 1e-4
+    assert _rel(a["grad_rgb_kv"], b["grad_rgb_kv"]) < 1e-4
+
+
+def test_waypoint_416_frames_planes_vs_fp32_mfma_kernels(tmp_path):
+    """configs[4] at its full single-GPU size (num_envs=32 -> 416 frames through ResNet-18 and the
+    depth trunk): act() through the bf16-plane kernels against the fp32-MFMA kernels."""
+    a, b = _cross_kernel("waypoint", tmp_path)
+    for k in ("value", "logits", "h"):
+        assert _rel(a[k], b[k]) < 1e-5, k

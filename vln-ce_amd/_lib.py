@@ -48,6 +48,7 @@ _SIGNATURES = {
     "vlnce_version": (_I, []),
     "vlnce_last_error": (C.c_char_p, []),
     "vlnce_conv2d_split_weights": (_I, [_P, _P, C.c_long, _P]),
+    "vlnce_conv2d_last_path": (_I, []),
     "vlnce_conv2d_pack_bytes": (C.c_long, [C.POINTER(ConvDesc)]),
     "vlnce_conv2d_pack_weights": (_I, [_P, _P, C.POINTER(ConvDesc), _P]),
     "vlnce_conv2d_tiles_m": (_I, [C.POINTER(ConvDesc)]),
@@ -215,6 +216,9 @@ class HipLib:
     def conv2d_split_weights(self, w, planes):
         self._check(self.dll.vlnce_conv2d_split_weights(_ptr(w), _ptr(planes), w.numel(),
                                                         _stream()), "vlnce_conv2d_split_weights")
+
+    def conv2d_last_path(self):
+        return int(self.dll.vlnce_conv2d_last_path())
 
     def conv2d_pack_bytes(self, g):
         d = self._desc(g)

@@ -1413,6 +1413,11 @@ extern "C" int vlnce_conv2d_split_weights(const float* w, void* planes, long cou
   return 0;
 }
 
+// which kernel the calling thread's last vlnce_conv2d_fwd went to (bench.py prices the bf16-pipe
+// launches and the fp32-MFMA launches against their own peaks)
+static thread_local int g_last_path = -1;
+extern "C" int vlnce_conv2d_last_path(void) { return g_last_path; }
+
 extern "C" int vlnce_conv2d_fwd(const float* x, const float* w, float* y, const vlnce_conv_desc* d,
                                 const vlnce_prologue* pro, const vlnce_epilogue* epi,
                                 vlnce_stream_t stream) {
@@ -1469,6 +1474,7 @@ extern "C" int vlnce_conv2d_fwd(const float* x, const float* w, float* y, const 
   p.c_bytes = ((M - 1) * p.ldc + d->Cout) * 4;
   p.stat_rows = stat_rows_for(d);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  g_last_path = VLNCE_CONV_PATH_F32;
   if (p.A2 != nullptr || p.side_out != nullptr) {
     VLNCE_CHECK_ARG(p.A2 && p.in_scale && d->KH == 1 && d->KW == 1 && d->stride == 1 &&
                         d->pad == 0 && v4 && buf_ok(p) && aligned16(p.A2) &&
@@ -1478,8 +1484,11 @@ extern "C" int vlnce_conv2d_fwd(const float* x, const float* w, float* y, const 
                         (!p.in2_center || (p.in2_scale && aligned16(p.in2_center))),
                     "conv2d_fwd: the dual-input prologue needs x2 + in_scale on a 1x1/stride-1/"
                     "pad-0 convolution with Cin %% 32 == 0 and 16-byte aligned operands");
+    g_last_path = VLNCE_CONV_PATH_P3;
     if (const int rc = p3_try_launch(p, s); rc >= 0) return rc;
+    g_last_path = VLNCE_CONV_PATH_X3;
     if (X3Plan t; x3_plan(p, &t)) return dispatch_x3<1>(p, t, s);
+    g_last_path = VLNCE_CONV_PATH_F32;
     return dispatch_dual(p, s);
   }
   if (v4 && buf_ok(p)) {
@@ -1522,8 +1531,11 @@ extern "C" int vlnce_conv2d_fwd(const float* x, const float* w, float* y, const 
       }
       return 0;
     }
+    g_last_path = VLNCE_CONV_PATH_P3;
     if (const int rc = p3_try_launch(p, s); rc >= 0) return rc;
+    g_last_path = VLNCE_CONV_PATH_X3;
     if (X3Plan t; x3_plan(p, &t)) return dispatch_x3<0>(p, t, s);
+    g_last_path = VLNCE_CONV_PATH_F32;
     return dispatch_tiles<A_BUF, B_BUF>(p, s);
   }
   if (v4) return dispatch_tiles<A_IM2COL_V4, B_NK_V4>(p, s);
