@@ -10,6 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(HERE, "golden"))
 import torch  # noqa: E402
 
 import vlnce_amd  # noqa: E402
@@ -37,6 +38,9 @@ def cma(out):
            "instruction": torch.zeros(N, 200, dtype=torch.long)}
     obs["instruction"][:, :L] = torch.randint(1, 2504, (N, L), generator=g)
     obs["instruction"] = obs["instruction"].to(DEV)
+    if os.environ.get("VLNCE_TEST_PERTURB"):   # every frame value moved by ONE fp32 rounding
+        obs["rgb"] = obs["rgb"] * (1.0 + 2.0 ** -23)
+        obs["depth"] = obs["depth"] * (1.0 + 2.0 ** -23)
     prev = torch.randint(0, 4, (N, 1), generator=g).to(DEV)
     masks = (torch.rand(N, 1, generator=g) > 0.1).to(torch.uint8).to(DEV)
     tgt = torch.randint(0, 4, (1, N), generator=g).to(DEV)

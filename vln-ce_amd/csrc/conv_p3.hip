@@ -707,6 +707,434 @@ __global__ __launch_bounds__((WM * WN + P3_PRODUCERS) * 64) void conv_p3_kernel(
 #endif
 }
 
+// ====================================================================================
+// conv_u3_kernel: 1x1 convolutions with NO producer waves.
+//
+// What the in-kernel timers of conv_p3_kernel / conv_x3_kernel show for the 1x1 layers (60 % of
+// the trunks' convolution time): a dedicated producer wave next to two MFMA-issuing waves of its
+// SIMD gets one instruction in 15-20 cycles -- it has no second wave to hide its own dependency
+// and LDS latencies behind, and the matrix waves own the issue port -- so the matrix waves wait
+// for the patch.  Here every wave does both jobs, and the compiler interleaves them in ONE
+// instruction stream: 8 waves (two per SIMD, 256 VGPRs each), wave w owns output columns
+// [32 w, 32 w + 32) of a BM x 256 tile for ALL BM rows (MT = BM / 32 MFMA blocks: a B fragment
+// fetched from L2 feeds MT MFMAs), and, between the MFMAs of K-chunk g, transforms its 1/8 share
+// of the rows of K-chunk g + 1 (BatchNorm + ReLU prologue, block end, three-way bf16 split) into
+// the other patch buffer.  One raw s_barrier per K-chunk (48 MFMAs per wave) swaps the buffers;
+// raw A rows are fetched two chunks ahead into registers, B fragments one k-slab ahead.
+// WAVES = 8: two waves per SIMD, 256 registers each, a wave owns BM x 32 outputs;
+// WAVES = 4: ONE wave per SIMD with the whole 512-register file, a wave owns BM x 64 outputs and
+// double-buffers its A fragments (no partner wave to hide LDS latency behind).
+template <int BM, int DUAL, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void conv_u3_kernel(IgemmParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int BN = 256, MT = BM / 32, NT = 8 / WAVES;
+  constexpr int RG = WAVES * 8;                  // rows per group of the transform's thread map
+  constexpr int NPT = BM / RG;                   // float4 of a K-chunk's A rows per thread
+  constexpr bool ADB = WAVES == 4;               // A fragments double-buffered across the k-slabs
+  static_assert(NPT >= 1 && MT >= 1 && (WAVES == 8 || WAVES == 4), "tile");
+  constexpr int PBUF = BM * P3_ROW;
+  extern __shared__ __attribute__((aligned(16))) char xsm[];  // [2][PBUF]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5;
+  const int l31 = lane & 31;
+  const int NC = p.Cin / 32;
+  const int HoWo = p.Ho * p.Wo;
+  const int trow = tid >> 3;          // this thread's row inside a group of RG rows
+  const int lk4 = (tid & 7) * 4;
+
+  const int ntiles = p.tiles_m * p.tiles_n;
+  const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  auto tile_of = [&](int round, int& m0, int& n0) {
+    const int v = blockIdx.x + round * gridDim.x;
+    const int q = ntiles >> 3, r = ntiles & 7, xcd = v & 7, idx = v >> 3;
+    const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int tm = tile / p.tiles_n;
+    m0 = tm * BM;
+    n0 = (tile - tm * p.tiles_n) * BN;
+  };
+  const int G = my_tiles * NC;  // K-chunks this workgroup streams
+
+  const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char*>(reinterpret_cast<const char*>(p.A)), 0, (int)p.a_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rsrc_a2 = rsrc_a;
+  if constexpr (DUAL)
+    rsrc_a2 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(p.A2)), 0, (int)p.a_bytes, 0x00020000);
+  const int KS3 = (p.K / 16) * 3072;
+  const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char*>(reinterpret_cast<const char*>(p.Bfrag)), 0, (int)((long)p.N * p.K * 6),
+      0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_c = __builtin_amdgcn_make_buffer_rsrc(
+      reinterpret_cast<char*>(p.C), 0, (int)p.c_bytes, 0x00020000);
+  const bool has_pro = p.in_scale != nullptr;
+  const float relu_floor = p.in_relu ? 0.f : -__builtin_huge_valf();
+  const bool linear = p.stride == 1;
+
+  // ---------------------------------------------------------------- the A side (every thread)
+  struct Vec {
+    f32x4 s, t, c, s2, t2, c2;
+  };
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f}, one4 = {1.f, 1.f, 1.f, 1.f};
+  Vec cur = {one4, zero4, zero4, one4, zero4, zero4}, nxt = cur;
+  auto load_vec = [&](Vec& v, int ci) {
+    if (has_pro) {
+      v.s = ldg4(p.in_scale + ci + lk4);
+      v.t = ldg4(p.in_shift + ci + lk4);
+      if (p.in_center) v.c = ldg4(p.in_center + ci + lk4);
+      if constexpr (DUAL) {
+        if (p.in2_scale != nullptr) {
+          v.s2 = ldg4(p.in2_scale + ci + lk4);
+          v.t2 = ldg4(p.in2_shift + ci + lk4);
+          if (p.in2_center) v.c2 = ldg4(p.in2_center + ci + lk4);
+        }
+      }
+    }
+  };
+  struct Raw {
+    f32x4 a[NPT];
+    f32x4 a2[DUAL ? NPT : 1];
+    unsigned ok;
+    int m0;  // first row of the tile if this workgroup writes side_out for it, else -1
+    int ci;  // first input channel of the chunk
+  };
+  int a_voff[NPT];
+  unsigned a_ok = 0;
+  int l_round = 0, l_c = 0, l_m0 = 0, l_side = 0;
+  auto setup_tile = [&](int round) {
+    int m0, n0;
+    tile_of(round, m0, n0);
+    l_m0 = m0;
+    l_side = n0 == 0;
+    a_ok = 0;
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) {
+      const int m = m0 + i * RG + trow;
+      a_voff[i] = BUF_OOB;
+      if (m < p.M) {
+        int pix = m;
+        if (!linear) {
+          const int img = m / HoWo;
+          const int rem = m - img * HoWo;
+          const int ho = rem / p.Wo;
+          pix = (img * p.H + ho * p.stride) * p.W + (rem - ho * p.Wo) * p.stride;
+        }
+        a_voff[i] = (pix * p.lda + lk4) * 4;
+        a_ok |= 1u << i;
+      }
+    }
+  };
+  auto load_raw = [&](Raw& r) {   // (branch-free; advance_raw() moves the cursor afterwards)
+    const bool live = l_round < my_tiles;
+    const int soff = l_c * 128;
+    r.ok = live ? a_ok : 0u;
+    r.m0 = l_side ? l_m0 : -1;
+    r.ci = l_c * 32;
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) {
+      const int vo = live ? a_voff[i] : BUF_OOB;
+      r.a[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, vo, soff, 0));
+      if constexpr (DUAL)
+        r.a2[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a2, vo, soff, 0));
+    }
+  };
+  auto advance_raw = [&]() {
+    if (l_round < my_tiles && ++l_c == NC) {
+      l_c = 0;
+      if (++l_round < my_tiles) setup_tile(l_round);
+    }
+  };
+  // prologue + split of this thread's float4s of one chunk into patch buffer `buf`.  Branch-free
+  // in the single-input form (neutral vectors where the convolution has no prologue: x*1+0 and
+  // max(x, -inf) are exact), so that it shares ONE basic block with the MFMAs of the chunk and
+  // the scheduler can interleave the two.
+  // `cur` = the vectors of the chunk being transformed; step_vec() after it: cur <- nxt, and nxt <-
+  // the vectors of the chunk after that (their loads have a whole chunk to land)
+  auto step_vec = [&](int ci_after_next) {
+    cur = nxt;
+    if constexpr (DUAL) {
+      if (p.in2_scale != nullptr) cur.t2 = cur.t + cur.t2;
+    }
+    load_vec(nxt, ci_after_next);
+  };
+  auto transform = [&](const Raw& r, char* buf) {
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) {
+      f32x4 v = r.a[i];
+      const bool ok = (r.ok >> i) & 1u;
+      if constexpr (DUAL) {
+        if (p.in2_scale != nullptr) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            v[e] = fmaxf(fmaf(v[e] - cur.c[e], cur.s[e],
+                              fmaf(r.a2[i][e] - cur.c2[e], cur.s2[e], cur.t2[e])), relu_floor);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            v[e] = fmaxf(fmaf(v[e] - cur.c[e], cur.s[e], cur.t[e]) + r.a2[i][e], relu_floor);
+        }
+        if (!ok) v = zero4;
+        if (p.side_out != nullptr && r.m0 >= 0 && ok)
+          *reinterpret_cast<f32x4*>(p.side_out + (long)(r.m0 + i * RG + trow) * p.lda + r.ci + lk4) = v;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] = fmaxf(fmaf(v[e] - cur.c[e], cur.s[e], cur.t[e]), relu_floor);
+          v[e] = ok ? v[e] : 0.f;
+        }
+      }
+      p3_split_store(v, buf + (i * RG + trow) * P3_ROW + lk4 * 2);
+    }
+  };
+
+  // ---------------------------------------------------------------- the matrix side (per wave)
+  bf16x8 fa[MT][3], fa1[ADB ? MT : 1][3], b0[NT][3], b1[NT][3];
+  f32x16 acc[MT][NT];
+  const int a_off = l31 * P3_ROW + half * 16;   // + i * 32 * P3_ROW + q * 64 + s * 32
+  auto loadB = [&](bf16x8 (&b)[NT][3], const int (&vb)[NT], int soff) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+        b[j][q] = __builtin_bit_cast(
+            bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
+                        rsrc_b, vb[j] == BUF_OOB ? BUF_OOB : vb[j] + q * 1024, soff, 0));
+  };
+  auto readA = [&](bf16x8 (&f)[MT][3], const char* buf, int s) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+        f[i][q] = *reinterpret_cast<const bf16x8*>(buf + a_off + i * 32 * P3_ROW + q * 64 + s * 32);
+  };
+  auto mma = [&](const bf16x8 (&f)[MT][3], const bf16x8 (&b)[NT][3]) {
+    constexpr int PA[6] = {2, 1, 0, 1, 0, 0};  // smallest products first
+    constexpr int PB[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+    for (int q = 0; q < 6; ++q)
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[i][PA[q]], b[j][PB[q]], acc[i][j],
+                                                              0, 0, 0);
+  };
+  auto vb_of = [&](int n0, int (&vb)[NT]) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int nb = n0 / 32 + wave * NT + j;
+      vb[j] = nb * 32 < p.N ? nb * KS3 + lane * 16 : BUF_OOB;
+    }
+  };
+
+  // ---------------------------------------------------------------- prologue of the stream
+  // vector schedule: chunk k's vectors are channels (k % NC) * 32 ..; `cur` must hold chunk k's
+  // when chunk k is transformed
+  Raw rx, ry;
+  setup_tile(0);
+  load_vec(nxt, 0);
+  load_raw(rx);   // chunk 0
+  advance_raw();
+  load_raw(ry);   // chunk 1
+  advance_raw();
+  int m0 = 0, n0 = 0;
+  tile_of(0, m0, n0);
+  int vb[NT], vbn[NT];
+  vb_of(n0, vb);
+#pragma unroll
+  for (int j = 0; j < NT; ++j) vbn[j] = BUF_OOB;
+  if (my_tiles > 1) {
+    int m1, n1;
+    tile_of(1, m1, n1);
+    vb_of(n1, vbn);
+  }
+  loadB(b0, vb, 0);
+  step_vec(NC > 1 ? 32 : 0);      // cur = chunk 0's vectors, nxt <- chunk 1's
+  transform(rx, xsm);
+  step_vec(NC > 2 ? 64 : (2 % NC) * 32);   // cur = chunk 1's, nxt <- chunk 2's
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  int c = 0, round = 0, ks3 = 0;
+#ifdef P3_DBG_TIME
+  long long d_blk = 0, d_epi = 0, d_bar = 0, d_book = 0;
+  const long long d_t0 = clock64(), d_w0 = wall_clock64();
+#endif
+  // one K-chunk: MFMAs on patch (g & 1) / transform of `rn` (chunk g + 1) into patch ((g+1) & 1) /
+  // raw loads of chunk g + 2 into `rf`.  Everything up to the transform is ONE basic block.
+  auto chunk = [&](int g, Raw& rn, Raw& rf) {
+    const char* const pb = xsm + (g & 1) * PBUF;
+    char* const pn = xsm + ((g + 1) & 1) * PBUF;
+    const bool last_of_tile = c == NC - 1;
+    int vb_s0[NT];                                         // slab 0 of the next chunk
+#pragma unroll
+    for (int j = 0; j < NT; ++j) vb_s0[j] = last_of_tile ? vbn[j] : vb[j];
+    const int so_s0 = last_of_tile ? 0 : ks3 + 6144;
+#ifdef P3_DBG_TIME
+    const long long d_0 = clock64();
+#endif
+    load_raw(rf);
+    loadB(b1, vb, ks3 + 3072);
+    readA(fa, pb, 0);
+    if constexpr (ADB) readA(fa1, pb, 1);
+    mma(fa, b0);
+    loadB(b0, vb_s0, so_s0);
+    if constexpr (ADB) {
+      mma(fa1, b1);
+    } else {
+      readA(fa, pb, 1);
+      mma(fa, b1);
+    }
+    transform(rn, pn);
+#ifndef U3_NO_SCHED
+    // Instruction order of the block (the scheduler's own choice bunches the transform behind the
+    // last MFMAs and issues every fragment read right in front of its MFMA): k-slab 0's fragment
+    // reads and the global loads first, a few transform instructions under their latency, then
+    // per MFMA two VALU instructions of the transform and at most one LDS read (k-slab 1's
+    // fragments, each as soon as the MFMAs that still read its registers have issued), one LDS
+    // write, one global load.
+#ifndef U3_VPM
+#define U3_VPM 2   // VALU instructions of the transform per MFMA
+#endif
+#pragma unroll
+    for (int k = 0; k < 12 * MT * NT; ++k) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, U3_VPM, 0);
+    }
+#endif
+    // ---- bookkeeping (branches from here on)
+#ifdef P3_DBG_TIME
+    const long long d_1 = clock64();
+    d_blk += d_1 - d_0;
+#endif
+    advance_raw();
+    step_vec(((g + 3) % NC) * 32);   // cur <- chunk g+2's vectors, nxt <- chunk g+3's
+    ks3 += 6144;
+#ifdef P3_DBG_TIME
+    const long long d_2 = clock64();
+    d_book += d_2 - d_1;
+#endif
+    if (last_of_tile) {
+      // -------------------------------------------------------------- statistics partials
+      if (p.stat_partial != nullptr) {
+        const int col0 = n0 + wave * NT * 32;
+        if (p.stat_rows == 32 && MT > 1) {
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+            wave_stats_block<NT>(acc[i], p.stat_partial, m0 / 32 + i, p.M - (m0 + i * 32), col0, p.N,
+                                 half, l31);
+        } else if (p.stat_rows > 0 && p.stat_rows < BM)
+          wave_stats_fine<MT, NT>(acc, p.stat_partial, p.stat_rows, m0, p.M, col0, p.N, half, l31);
+        else
+          wave_stats<MT, NT>(acc, p.stat_partial, m0 / BM, p.M - m0, BM, col0, p.N, half, l31);
+      }
+      // -------------------------------------------------------------- epilogue from registers
+      float e_sc[NT], e_sh[NT];
+      int e_voff[NT];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int col = n0 + (wave * NT + j) * 32 + l31;
+        const bool okc = col < p.N;
+        e_sc[j] = (okc && p.scale) ? p.scale[col] : 1.f;
+        e_sh[j] = (okc && p.shift) ? p.shift[col] : 0.f;
+        e_voff[j] = okc ? (int)((((long)(m0 + 4 * half)) * p.ldc + col) * 4) : BUF_OOB;
+      }
+      const int rows_left = p.M - (m0 + 4 * half);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int rw = i * 32 + (r & 3) + 8 * (r >> 2);
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            const float v = apply_act(acc[i][j][r] * e_sc[j] + e_sh[j], p.act);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc_c,
+                                                  rw < rows_left ? e_voff[j] : BUF_OOB,
+                                                  rw * p.ldc * 4, 0);
+            acc[i][j][r] = 0.f;
+          }
+        }
+      c = 0;
+      ks3 = 0;
+      if (++round < my_tiles) {
+        tile_of(round, m0, n0);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          vb[j] = vbn[j];
+          vbn[j] = BUF_OOB;
+        }
+        if (round + 1 < my_tiles) {
+          int m1, n1;
+          tile_of(round + 1, m1, n1);
+          vb_of(n1, vbn);
+        }
+      }
+    } else {
+      ++c;
+    }
+#ifdef P3_DBG_TIME
+    const long long d_3 = clock64();
+    d_epi += d_3 - d_2;
+#endif
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this thread's patch writes are in LDS
+    __builtin_amdgcn_s_barrier();
+#ifdef P3_DBG_TIME
+    d_bar += clock64() - d_3;
+#endif
+  };
+  for (int g = 0; g < G; g += 2) {
+    chunk(g, ry, rx);                    // transforms chunk g+1 (in ry), fetches chunk g+2 into rx
+    if (g + 1 < G) chunk(g + 1, rx, ry);
+  }
+#ifdef P3_DBG_TIME
+  if (blockIdx.x == 8 && (tid == 0 || tid == (WAVES - 1) * 64)) {
+    const long long cy = clock64() - d_t0, w = wall_clock64() - d_w0;
+    printf("u3 wave %d: tiles %d chunks/tile %d: total %lld cycles = %lld ticks of 100 MHz (%.2f GHz): "
+           "MFMA+transform blocks %lld, bookkeeping %lld, epilogues %lld, barriers %lld\n",
+           wave, my_tiles, NC, cy, w, (double)cy / (double)w * 0.1, d_blk, d_book, d_epi, d_bar);
+  }
+#endif
+#endif
+}
+
+template <int BM, int DUAL, int WAVES>
+int launch_u3(const IgemmParams& p, hipStream_t stream) {
+  constexpr int smem_bytes = 2 * BM * P3_ROW;
+  auto kern = conv_u3_kernel<BM, DUAL, WAVES>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
+    if (e != hipSuccess) {
+      vlnce_set_error("conv_u3: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      return 2;
+    }
+    attr_set = true;
+  }
+  IgemmParams q = p;
+  q.tiles_m = ceil_div(p.M, BM);
+  q.tiles_n = ceil_div(p.N, 256);
+  q.splitk = 1;
+  const long nwg = (long)q.tiles_m * q.tiles_n;
+  if (nwg <= 0 || nwg > 0x7fffffffL) {
+    vlnce_set_error("conv_u3: bad grid %ld", nwg);
+    return 1;
+  }
+  const int cus = x3_cus();
+  const unsigned grid = nwg <= cus ? (unsigned)nwg : (unsigned)cus;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), smem_bytes, stream, q);
+  VLNCE_CHECK_LAUNCH("conv_u3");
+  return 0;
+}
+
 // w_ohwi [N][KH][KW][Cin] fp32 -> B fragments [N/32][K/16][3][64 lanes][8 bf16]: k-slab
 // ks = ((chunk * T + tap) * 2 + s) holds input channels chunk*32 + s*16 + [0, 16) of that tap;
 // lane (l31, half) holds output channel nb*32 + l31, channels half*8 + [0, 8) of the slab;
@@ -836,6 +1264,27 @@ int p3_try_launch(const IgemmParams& p, hipStream_t stream) {
   if (dense && p.stride != 1) return -1;
   const bool dual = p.A2 != nullptr || p.side_out != nullptr;
   if (dual && !(one && p.stride == 1)) return -1;
+  // 1x1 layers wide enough for 256-column tiles: conv_u3_kernel (no producer waves), where its
+  // 128-row tiles fill the CUs.  VLNCE_U3: 0 = off, 1 = default, 2 = force 64-row tiles.  Measured
+  // per layer at num_envs 64 (profiles/r03_b_convbench_ab_u3.txt): 1.07-1.23x conv_x3_kernel on
+  // every N >= 256 layer of the RGB trunk with M >= 16384.
+  static const int u3_env = getenv("VLNCE_U3") ? atoi(getenv("VLNCE_U3")) : 1;
+  static const int u3_waves = getenv("VLNCE_U3_WAVES") ? atoi(getenv("VLNCE_U3_WAVES")) : 8;
+  if (!dense && u3_env && p.N >= 256) {
+    const int cus = x3_cus();
+    auto eff = [&](int bm) {
+      const long tiles = (long)ceil_div(p.M, bm) * ceil_div(p.N, 256);
+      const long rounds = (tiles + cus - 1) / cus;
+      return (double)tiles / (double)(rounds * cus);
+    };
+    const int bm = u3_env == 2 ? 64 : 128;
+    if (eff(bm) >= 0.8 || u3_env == 2) {
+      if (u3_waves == 4)   // one wave per SIMD, 64 x 256 tiles (a wave owns 64 x 64): experiment
+        return dual ? launch_u3<64, 1, 4>(p, stream) : launch_u3<64, 0, 4>(p, stream);
+      if (bm == 128) return dual ? launch_u3<128, 1, 8>(p, stream) : launch_u3<128, 0, 8>(p, stream);
+      return dual ? launch_u3<64, 1, 8>(p, stream) : launch_u3<64, 0, 8>(p, stream);
+    }
+  }
   if (mode_env == 2 && !dense) return -1;  // VLNCE_P3=2: only the patch (KxK) layers
   if (mode_env == 3 && dense) return -1;   // VLNCE_P3=3: only the 1x1 layers
 
