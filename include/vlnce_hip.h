@@ -390,6 +390,12 @@ int vlnce_mask_rows(const float* x, const uint8_t* mask, float* out, int B, int 
  * and emit zeros, instruction_encoder.py:80-94). */
 int vlnce_select_rows(const uint8_t* mask, const float* a, const float* b, float* out, int B, int H,
                       vlnce_stream_t stream);
+/* Backward of nn.Embedding (instruction_encoder.py:41-45,72-73: the learned token embedding):
+ * grad_weight[tokens[r], :] += grad_rows[r, :] for rows with tokens[r] != padding_idx, fp32
+ * atomics into a grad_weight the caller has zeroed (one launch instead of torch's sort /
+ * segment / scatter chain).  tokens int64 [rows], grad_rows [rows, E], grad_weight [vocab, E]. */
+int vlnce_embedding_bwd(const long* tokens, const float* grad_rows, float* grad_weight, long rows,
+                        int E, long padding_idx, long vocab, vlnce_stream_t stream);
 /* dz = dy * act'(.) written through the activation output y (ReLU/Sigmoid/Tanh backward). */
 int vlnce_act_bwd(const float* dy, const float* y, float* dz, long n, int act,
                   vlnce_stream_t stream);

@@ -308,6 +308,11 @@ class HostSim:
     def frames_gather(self, srcs, elem_bytes, N, Hs, Ws, Cc, y0, x0, H, W, out):
         out.copy_(torch.stack([t[:, y0:y0 + H, x0:x0 + W] for t in srcs], dim=1))
 
+    def embedding_bwd(self, tokens, grad_rows, grad_weight, padding_idx):
+        t = tokens.reshape(-1)
+        keep = t != (-1 if padding_idx is None else padding_idx)
+        grad_weight.index_add_(0, t[keep], grad_rows.reshape(t.numel(), -1)[keep])
+
     def frames_resize_area(self, x, is_u8, NF, Hs, Ws, Cc, OH, OW, y0, x0, H, W, out):
         v = x.reshape(NF, Hs, Ws, Cc).permute(0, 3, 1, 2).float()
         r = F.interpolate(v, size=(OH, OW), mode="area").to(x.dtype).permute(0, 2, 3, 1)

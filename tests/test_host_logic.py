@@ -268,7 +268,7 @@ def test_instruction_dedup_equals_row_by_row_encoding(sim, policy_name, final_on
         eps[i, :L] = torch.randint(1, 2504, (L,), generator=g)
     pad = torch.ones(1, 200, dtype=torch.long)            # collate_fn pads with 1.0 (App. B-7)
     tokens = torch.cat([eps, eps, eps[:2], pad, eps, pad, pad, eps, eps[1:]], dim=0)  # 20 rows
-    assert tokens.size(0) >= enc.DEDUP_MIN_ROWS
+    assert tokens.size(0) >= 16  # (the default threshold, 128 rows, is lowered for this small batch)
     w = torch.randn(1)
 
     def run(min_rows):

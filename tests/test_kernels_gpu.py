@@ -833,3 +833,20 @@ def test_conv_p3_matches_fp64_better_than_1e_6(hip):
     ref = ref.permute(0, 2, 3, 1)
     rms = ((y.double() - ref).pow(2).mean() / ref.pow(2).mean()).sqrt().item()
     assert rms < 1e-6, rms
+
+
+def test_embedding_backward_matches_torch(hip):
+    """vlnce_embedding_bwd (atomic scatter-add) against torch's embedding_dense_backward, with a
+    padding index and repeated tokens (instruction_encoder.py:41-45: Embedding(vocab, 50, padding_idx=0))."""
+    g = torch.Generator().manual_seed(6)
+    tok = torch.randint(0, 97, (64, 80), generator=g)
+    tok[:, 60:] = 0
+    w_ref = rnd(97, 50, seed=31).requires_grad_(True)
+    wts = rnd(64, 80, 50, seed=32)
+    (F.embedding(tok, w_ref, padding_idx=0) * wts).sum().backward()
+    w_hip = w_ref.detach().to(DEV).requires_grad_(True)
+    out = ops.embedding(tok.to(DEV), w_hip, 0)
+    assert torch.equal(out.cpu(), F.embedding(tok, w_ref.detach(), padding_idx=0))
+    (out * wts.to(DEV)).sum().backward()
+    close(w_hip.grad, w_ref.grad, 1e-5, what="embedding grad")
+    assert w_hip.grad[0].abs().max().item() == 0.0   # the padding row gets no gradient

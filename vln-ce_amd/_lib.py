@@ -49,6 +49,7 @@ _SIGNATURES = {
     "vlnce_last_error": (C.c_char_p, []),
     "vlnce_conv2d_split_weights": (_I, [_P, _P, C.c_long, _P]),
     "vlnce_conv2d_last_path": (_I, []),
+    "vlnce_embedding_bwd": (_I, [_P, _P, _P, _L, _I, _L, _L, _P]),
     "vlnce_conv2d_pack_bytes": (C.c_long, [C.POINTER(ConvDesc)]),
     "vlnce_conv2d_pack_weights": (_I, [_P, _P, C.POINTER(ConvDesc), _P]),
     "vlnce_conv2d_tiles_m": (_I, [C.POINTER(ConvDesc)]),
@@ -502,6 +503,13 @@ class HipLib:
     def select_rows(self, mask, a, b, out, B, H):
         self._check(self.dll.vlnce_select_rows(_ptr(mask), _ptr(a), _ptr(b), _ptr(out), B, H,
                                                _stream()), "vlnce_select_rows")
+
+    def embedding_bwd(self, tokens, grad_rows, grad_weight, padding_idx):
+        self._check(self.dll.vlnce_embedding_bwd(_ptr(tokens), _ptr(grad_rows), _ptr(grad_weight),
+                                                 tokens.numel(), grad_weight.size(1),
+                                                 -1 if padding_idx is None else int(padding_idx),
+                                                 grad_weight.size(0), _stream()),
+                    "vlnce_embedding_bwd")
 
     def act_bwd(self, dy, y, dz, n, act):
         self._check(self.dll.vlnce_act_bwd(_ptr(dy), _ptr(y), _ptr(dz), n, act, _stream()),

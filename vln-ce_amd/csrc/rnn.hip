@@ -490,6 +490,31 @@ extern "C" int vlnce_colsum(const float* x, int ldx, int M, int N, float* out, i
   return 0;
 }
 
+// dW[tok[r], :] += g[r, :] for every row r with tok[r] != padding_idx (dW zeroed by the caller)
+__global__ __launch_bounds__(256) void embedding_bwd_kernel(const long* __restrict__ tok,
+                                                            const float* __restrict__ g,
+                                                            float* __restrict__ dw, long rows, int E,
+                                                            long padding_idx, long vocab) {
+  const long total = rows * E;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long r = i / E;
+    const long t = tok[r];
+    if (t != padding_idx && t >= 0 && t < vocab) atomicAdd(dw + t * E + (i - r * E), g[i]);
+  }
+}
+
+extern "C" int vlnce_embedding_bwd(const long* tokens, const float* grad_rows, float* grad_weight,
+                                   long rows, int E, long padding_idx, long vocab,
+                                   vlnce_stream_t stream) {
+  VLNCE_CHECK_ARG(tokens && grad_rows && grad_weight && rows > 0 && E > 0 && vocab > 0,
+                  "embedding_bwd: bad argument");
+  hipLaunchKernelGGL(embedding_bwd_kernel, dim3(grid_for(rows * E)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), tokens, grad_rows, grad_weight, rows, E,
+                     padding_idx, vocab);
+  VLNCE_CHECK_LAUNCH("embedding_bwd");
+  return 0;
+}
+
 extern "C" int vlnce_select_rows(const uint8_t* mask, const float* a, const float* b, float* out,
                                  int B, int H, vlnce_stream_t stream) {
   VLNCE_CHECK_ARG(mask && out && B > 0 && H > 0, "select_rows: bad argument");

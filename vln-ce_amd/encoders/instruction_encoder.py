@@ -71,7 +71,10 @@ class InstructionEncoder(nn.Module):
                     c = ops.select_rows(m, c_new, c)
         return outs, h
 
-    DEDUP_MIN_ROWS = 16  # below this a batch is one step of distinct environments
+    # Below this a batch is one step of distinct environments (up to 64 envs per GPU in the
+    # reference's configs): looking for duplicates there costs three host syncs and finds none.
+    # Sequence-mode batches (T*N rows: 5 episodes x ~100 steps, or a DD-PPO minibatch) are larger.
+    DEDUP_MIN_ROWS = 128
 
     def forward(self, observations):
         """Sequence-mode batches ([T*N, 200] tokens: a cached-feature DAgger batch,
@@ -85,13 +88,13 @@ class InstructionEncoder(nn.Module):
             if tokens.size(0) >= self.DEDUP_MIN_ROWS and os.environ.get("VLNCE_INSTR_DEDUP", "1") != "0":
                 uniq, inverse = self._distinct_rows(tokens)
                 if uniq is not None and uniq.size(0) < tokens.size(0):
-                    out = self._encode(F.embedding(uniq, self.embedding_layer.weight,
-                                                   padding_idx=self.embedding_layer.padding_idx))
+                    out = self._encode(ops.embedding(uniq, self.embedding_layer.weight,
+                                                     self.embedding_layer.padding_idx))
                     # [U, C, L] / [U, H] -> rows; the stacked bidirectional final state is [2, U, H]
                     dim = 1 if (cfg.final_state_only and out.dim() == 3) else 0
                     return out.index_select(dim, inverse)
-            feats = F.embedding(tokens, self.embedding_layer.weight,
-                                padding_idx=self.embedding_layer.padding_idx)
+            feats = ops.embedding(tokens, self.embedding_layer.weight,
+                                  self.embedding_layer.padding_idx)
         else:
             feats = observations["rxr_instruction"]
         return self._encode(feats)

@@ -453,6 +453,31 @@ def attention(q, K, V, mask=None, mask_mode=1, scale=1.0):
 
 
 # ----------------------------------------------------------------- row utilities
+class EmbeddingFn(Function):
+    """F.embedding with the backward as one atomic scatter-add launch (vlnce_embedding_bwd)."""
+
+    @staticmethod
+    def forward(ctx, tokens, weight, padding_idx):
+        ctx.save_for_backward(tokens)
+        ctx.padding_idx = padding_idx
+        ctx.wshape = weight.shape
+        return torch.nn.functional.embedding(tokens, weight, padding_idx=padding_idx)
+
+    @staticmethod
+    def backward(ctx, g):
+        (tokens,) = ctx.saved_tensors
+        gw = torch.zeros(ctx.wshape, device=g.device, dtype=torch.float32)
+        L().embedding_bwd(tokens.contiguous(), _f32c(g).reshape(-1, ctx.wshape[1]), gw,
+                          ctx.padding_idx)
+        return None, gw, None
+
+
+def embedding(tokens, weight, padding_idx=None):
+    if weight.requires_grad and torch.is_grad_enabled() and weight.is_cuda:
+        return EmbeddingFn.apply(tokens, weight, padding_idx)
+    return torch.nn.functional.embedding(tokens, weight, padding_idx=padding_idx)
+
+
 class MaskRowsFn(Function):
     @staticmethod
     def forward(ctx, x, mask_u8):
