@@ -333,3 +333,65 @@ def test_waypoint_policy_under_torch_ddp_reducer(tmp_path, monkeypatch):
     gmax = max(v.abs().max().item() for v in want.values())
     for n in want:
         assert torch.allclose(got[n], want[n], rtol=1e-4, atol=1e-6 * max(gmax, 1.0)), n
+
+
+class Branchy(nn.Module):
+    """A head that only SOME ranks use in a given step (a data-dependent branch)."""
+
+    def __init__(self):
+        super().__init__()
+        self.trunk = nn.Linear(12, 64)
+        self.sometimes = nn.Linear(64, 64)   # early in parameter order, late or never in backward
+        self.head = nn.Linear(64, 4)
+
+    def forward(self, x, use_branch):
+        h = torch.relu(self.trunk(x))
+        if use_branch:
+            h = h + torch.tanh(self.sometimes(h))
+        return self.head(h)
+
+
+def divergent_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    model = Branchy()
+    red = GradientAllReducer(model, bucket_bytes=512, divergent_unused=True)  # head | sometimes | trunk
+    assert len(red.buckets) >= 3
+    x, tgt, w = make_data()
+    sl = shard_rows(x.size(1), rank, world)
+    issued = []
+    launch = red._launch
+    red._launch = lambda b: (issued.append(red.buckets.index(b)), launch(b))[1]
+    for step in range(3):
+        model.zero_grad()
+        # the ranks disagree on which parameters get a gradient: rank 0 takes the branch on even
+        # steps, rank 1 on odd steps
+        use = (step + rank) % 2 == 0
+        logits = model(x[:, sl].reshape(-1, 12), use).view(3, -1, 4)
+        ce = torch.nn.functional.cross_entropy(logits.permute(0, 2, 1), tgt[:, sl], reduction="none")
+        ((w[:, sl] * ce).sum(0) / w[:, sl].sum(0)).mean().backward()
+        red.finish()
+    # every step issued the buckets in index order on this rank (hence on every rank)
+    n = len(red.buckets)
+    assert issued == list(range(n)) * 3, issued
+    if rank == 0:
+        torch.save({k: (None if p.grad is None else p.grad.clone()) for k, p in model.named_parameters()}, out)
+    dist.destroy_process_group()
+
+
+def test_reducer_issues_buckets_in_order_when_ranks_disagree_on_unused_parameters(tmp_path):
+    """ROUND-2 review: a bucket whose last gradient never arrives used to be launched in finish(),
+    i.e. AFTER later buckets; with rank-divergent unused parameters the ranks then issue their
+    collectives in different orders and hang.  Buckets are now launched strictly in index order."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "g.pt")
+    mp.spawn(divergent_worker, args=(2, port, out), nprocs=2, join=True)
+    g = torch.load(out)
+    assert g["head.weight"] is not None and torch.isfinite(g["head.weight"]).all()
+    # last step (2): rank 0 took the branch, rank 1 did not -- and on step 1 the other way round;
+    # either way the parameter ends up with the averaged gradient on BOTH ranks
+    assert g["sometimes.weight"] is not None and g["sometimes.weight"].abs().max() > 0

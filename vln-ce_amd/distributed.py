@@ -27,7 +27,7 @@ import torch.distributed as dist
 
 
 class _Bucket:
-    __slots__ = ("params", "pending", "work", "tensors")
+    __slots__ = ("params", "pending", "work", "tensors", "flags")
 
 
 class GradientAllReducer:
@@ -35,7 +35,7 @@ class GradientAllReducer:
     .grad tensors themselves (ncclGroupStart/End underneath, no flatten / unflatten copies and,
     on RCCL, ReduceOp.AVG so there is no scaling pass either)."""
 
-    def __init__(self, module, bucket_bytes=8 << 20, process_group=None):
+    def __init__(self, module, bucket_bytes=8 << 20, process_group=None, divergent_unused=False):
         self.group = process_group
         self.world = dist.get_world_size(process_group)
         # gloo (CPU tests) has no AVG: sum, then one fused multiply
@@ -64,6 +64,10 @@ class GradientAllReducer:
         if cur:
             self.buckets.append(self._make_bucket(cur))
         self._bucket_of = {}
+        self._next = 0  # index of the first bucket whose collective has not been issued yet
+        # rank-divergent parameter use: every rank must put the SAME tensors into a bucket's
+        # coalesced collective, so the used-flag vector is sent by all ranks for every bucket
+        self._divergent = bool(divergent_unused)
         self._handles = []
         self._zeros = {}
         # the hooks pin every AccumulateGrad node to the stream current here, which is what
@@ -83,6 +87,7 @@ class GradientAllReducer:
         b.pending = len(params)
         b.work = None
         b.tensors = None
+        b.flags = None
         return b
 
     def _zero_like(self, p):
@@ -96,6 +101,17 @@ class GradientAllReducer:
     def _launch(self, b):
         # a parameter without a gradient this step contributes zeros (and keeps .grad None)
         b.tensors = [p.grad if p.grad is not None else self._zero_like(p) for p in b.params]
+        b.flags = None
+        if self._divergent:
+            # which parameters received a gradient on SOME rank: a parameter this rank did not use
+            # but another one did must end up with the averaged gradient here too.  The flag
+            # vector rides in the same coalesced collective and is sent by EVERY rank for every
+            # bucket (all ranks must put the same tensors into a collective).  Without
+            # divergent_unused the set of unused parameters is the same on all ranks (e.g.
+            # WaypointPolicy.action_distribution.*): they contribute zeros and keep .grad None.
+            b.flags = torch.tensor([0.0 if p.grad is None else 1.0 for p in b.params],
+                                   device=b.tensors[0].device)
+            b.tensors = b.tensors + [b.flags]
         op = dist.ReduceOp.AVG if self.avg else dist.ReduceOp.SUM
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
@@ -112,26 +128,39 @@ class GradientAllReducer:
     def _on_grad(self, p):
         b = self._bucket_of[p]
         b.pending -= 1
-        if b.pending == 0:
-            self._launch(b)
+        # Collectives are issued STRICTLY in bucket order: a complete bucket waits for every bucket
+        # before it.  If the set of parameters that receive a gradient ever differs between ranks
+        # (data-dependent branches, unused heads), a bucket one rank can only launch in finish()
+        # must not be overtaken by later buckets there while another rank launches it early --
+        # ranks issuing collectives in different orders hang.
+        while self._next < len(self.buckets) and self.buckets[self._next].pending == 0:
+            self._launch(self.buckets[self._next])
+            self._next += 1
 
     def finish(self):
         """Call after loss.backward(): waits for every bucket (the gradients were averaged in
         place) and re-arms the hooks for the next step."""
-        for b in self.buckets:
-            if b.work is None:  # some parameter never produced a gradient this step
-                self._launch(b)
+        for b in self.buckets[self._next:]:  # held back by a parameter without a gradient
+            self._launch(b)
+        self._next = 0
         for b in self.buckets:
             if self.comm is None:
                 b.work.wait()
             else:
                 torch.cuda.current_stream(self.comm.device).wait_event(b.work)
             if not self.avg:
-                torch._foreach_mul_([t for t, p in zip(b.tensors, b.params) if p.grad is not None],
-                                    1.0 / self.world)
+                have = [t for t, p in zip(b.tensors, b.params) if p.grad is not None]
+                if have:
+                    torch._foreach_mul_(have, 1.0 / self.world)
+            if b.flags is not None:
+                used = b.flags.tolist()  # (host sync: only on the unused-parameter path)
+                for t, p, u in zip(b.tensors, b.params, used):
+                    if p.grad is None and u > 0:   # used elsewhere: adopt the averaged gradient
+                        p.grad = t.clone() if self.avg else t * (1.0 / self.world)
             b.pending = len(b.params)
             b.work = None
             b.tensors = None
+            b.flags = None
 
     def remove(self):
         for h in self._handles:

@@ -239,15 +239,19 @@ def _frame_view(t):
         t4 = torch.as_strided(t, (imgs, H, W, Cc), t.stride()[1:], t.storage_offset())
     if t4 is not None and imgs > 1 and t4.stride(3) == 1 and t4.stride(2) == Cc:
         sN, sH = t4.stride(0), t4.stride(1)
-        if sH % Cc == 0 and sH > 0 and sN % sH == 0:
+        # (sN == 0: an expanded / broadcast frame, e.g. a zero history frame made with .expand)
+        if sH % Cc == 0 and sH > 0 and sN > 0 and sN % sH == 0:
             Ws, Hs = sH // Cc, sN // sH
             off = t4.storage_offset() % sN
             y0, rem = divmod(off, sH)
             if rem % Cc == 0 and y0 + H <= Hs and rem // Cc + W <= Ws:
                 x0 = rem // Cc
-                base = torch.as_strided(t4, (imgs, Hs, Ws, Cc), (sN, sH, Cc, 1),
-                                        t4.storage_offset() - off)
-                return base, Hs, Ws, y0, x0
+                try:
+                    base = torch.as_strided(t4, (imgs, Hs, Ws, Cc), (sN, sH, Cc, 1),
+                                            t4.storage_offset() - off)
+                    return base, Hs, Ws, y0, x0
+                except RuntimeError:  # the decoded base would reach outside the storage
+                    pass
     return t.contiguous().reshape(imgs, H, W, Cc), H, W, 0, 0
 
 
