@@ -890,7 +890,10 @@ __global__ __launch_bounds__(WAVES * 64) void conv_u3_kernel(IgemmParams p) {
   };
 
   // ---------------------------------------------------------------- the matrix side (per wave)
-  bf16x8 fa[MT][3], fa1[ADB ? MT : 1][3], b0[NT][3], b1[NT][3];
+  constexpr int HM = MT / 2;  // row blocks per half (two-wave form)
+  static_assert(ADB || HM >= 1, "tile");
+  bf16x8 fa[ADB ? MT : 1][3], fa1[ADB ? MT : 1][3], fh0[ADB ? 1 : HM][3], fh1[ADB ? 1 : HM][3];
+  bf16x8 b0[NT][3], b1[NT][3];
   f32x16 acc[MT][NT];
   const int a_off = l31 * P3_ROW + half * 16;   // + i * 32 * P3_ROW + q * 64 + s * 32
   auto loadB = [&](bf16x8 (&b)[NT][3], const int (&vb)[NT], int soff) {
@@ -902,24 +905,42 @@ __global__ __launch_bounds__(WAVES * 64) void conv_u3_kernel(IgemmParams p) {
             bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
                         rsrc_b, vb[j] == BUF_OOB ? BUF_OOB : vb[j] + q * 1024, soff, 0));
   };
-  auto readA = [&](bf16x8 (&f)[MT][3], const char* buf, int s) {
+  auto readA = [&](bf16x8 (&f)[ADB ? MT : 1][3], const char* buf, int s) {
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+    for (int i = 0; i < (ADB ? MT : 1); ++i)
 #pragma unroll
       for (int q = 0; q < 3; ++q)
         f[i][q] = *reinterpret_cast<const bf16x8*>(buf + a_off + i * 32 * P3_ROW + q * 64 + s * 32);
   };
-  auto mma = [&](const bf16x8 (&f)[MT][3], const bf16x8 (&b)[NT][3]) {
-    constexpr int PA[6] = {2, 1, 0, 1, 0, 0};  // smallest products first
-    constexpr int PB[6] = {0, 1, 2, 0, 1, 0};
+  auto readH = [&](bf16x8 (&f)[ADB ? 1 : HM][3], const char* buf, int s, int h) {
+#pragma unroll
+    for (int i = 0; i < (ADB ? 1 : HM); ++i)
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+        f[i][q] = *reinterpret_cast<const bf16x8*>(buf + a_off + (h * HM + i) * 32 * P3_ROW + q * 64 +
+                                                   s * 32);
+  };
+  constexpr int PA[6] = {2, 1, 0, 1, 0, 0};  // smallest products first
+  constexpr int PB[6] = {0, 1, 2, 0, 1, 0};
+  auto mma = [&](const bf16x8 (&f)[ADB ? MT : 1][3], const bf16x8 (&b)[NT][3]) {
 #pragma unroll
     for (int q = 0; q < 6; ++q)
 #pragma unroll
-      for (int i = 0; i < MT; ++i)
+      for (int i = 0; i < (ADB ? MT : 1); ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[i][PA[q]], b[j][PB[q]], acc[i][j],
                                                               0, 0, 0);
+  };
+  auto mmaH = [&](const bf16x8 (&f)[ADB ? 1 : HM][3], const bf16x8 (&b)[NT][3], int h) {
+#pragma unroll
+    for (int q = 0; q < 6; ++q)
+#pragma unroll
+      for (int i = 0; i < (ADB ? 1 : HM); ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          acc[h * HM + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+              f[i][PA[q]], b[j][PB[q]], acc[h * HM + i][j], 0, 0, 0);
   };
   auto vb_of = [&](int n0, int (&vb)[NT]) {
 #pragma unroll
@@ -983,15 +1004,24 @@ __global__ __launch_bounds__(WAVES * 64) void conv_u3_kernel(IgemmParams p) {
 #endif
     load_raw(rf);
     loadB(b1, vb, ks3 + 3072);
-    readA(fa, pb, 0);
-    if constexpr (ADB) readA(fa1, pb, 1);
-    mma(fa, b0);
-    loadB(b0, vb_s0, so_s0);
     if constexpr (ADB) {
+      readA(fa, pb, 0);
+      readA(fa1, pb, 1);
+      mma(fa, b0);
+      loadB(b0, vb_s0, so_s0);
       mma(fa1, b1);
     } else {
-      readA(fa, pb, 1);
-      mma(fa, b1);
+      // the MT row blocks in two halves with a fragment set each: the reads of one half land
+      // under the MFMAs of the other (no spare registers for a second full set)
+      readH(fh0, pb, 0, 0);
+      readH(fh1, pb, 0, 1);
+      mmaH(fh0, b0, 0);
+      readH(fh0, pb, 1, 0);
+      mmaH(fh1, b0, 1);
+      loadB(b0, vb_s0, so_s0);
+      readH(fh1, pb, 1, 1);
+      mmaH(fh0, b1, 0);
+      mmaH(fh1, b1, 1);
     }
     transform(rn, pn);
 #ifndef U3_NO_SCHED
@@ -1004,10 +1034,27 @@ __global__ __launch_bounds__(WAVES * 64) void conv_u3_kernel(IgemmParams p) {
 #ifndef U3_VPM
 #define U3_VPM 2   // VALU instructions of the transform per MFMA
 #endif
+    if constexpr (ADB) {
 #pragma unroll
-    for (int k = 0; k < 12 * MT * NT; ++k) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x002, U3_VPM, 0);
+      for (int k = 0; k < 12 * MT * NT; ++k) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, U3_VPM, 0);
+      }
+    } else {
+      // four phases of 6 * HM * NT MFMAs (half 0 / half 1 of k-slab 0, then of k-slab 1).  Only
+      // the first half's fragments are read before the first MFMA (all eight waves read at once
+      // right after the barrier: every kilobyte in front of the first MFMA is exposed); the
+      // other reads trickle, one per MFMA, a phase ahead of their use.
+      __builtin_amdgcn_sched_group_barrier(0x100, 3 * HM, 0);
+#pragma unroll
+      for (int ph = 0; ph < 4; ++ph) {
+#pragma unroll
+        for (int k = 0; k < 6 * HM * NT; ++k) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, U3_VPM, 0);
+          if (ph < 3 && k < 3 * HM) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+      }
     }
 #endif
     // ---- bookkeeping (branches from here on)

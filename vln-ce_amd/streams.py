@@ -237,7 +237,8 @@ class GraphedTail:
         # signature gets its own (cheap: it only references the shared sub-modules) instance
         self.make_module = make_module
         self.module = make_module()
-        self.entries = OrderedDict()  # signature -> sightings (int) | graphed callable; LRU
+        self.entries = OrderedDict()  # signature -> graphed callable; LRU over CAPTURED graphs
+        self.sightings = OrderedDict()  # signature -> times seen before capture (bounded, no graphs)
 
     def __call__(self, *tensors):
         t0 = tensors[0]
@@ -247,18 +248,21 @@ class GraphedTail:
         key = tuple((tuple(t.shape), t.dtype, t.requires_grad) for t in tensors) + (
             torch.is_grad_enabled(),)
         ent = self.entries.get(key)
-        if ent is None or isinstance(ent, int):
-            seen = (ent or 0) + 1
+        if ent is None:
+            # first sightings are counted apart from the captured graphs: a stream of new
+            # signatures (e.g. the waypoint tail's batch-dependent Lmax) must not evict graphs
+            seen = self.sightings.pop(key, 0) + 1
             if seen < self.CAPTURE_AFTER:
-                while len(self.entries) >= self.MAX_GRAPHS:
-                    self.entries.popitem(last=False)  # least recently used
-                self.entries[key] = seen
-                self.entries.move_to_end(key)
+                while len(self.sightings) >= 8 * self.MAX_GRAPHS:
+                    self.sightings.popitem(last=False)
+                self.sightings[key] = seen
                 return self.module(*tensors)
             sample = tuple(t.detach().clone().requires_grad_(t.requires_grad) for t in tensors)
             with capture_guard():
                 ent = torch.cuda.make_graphed_callables(self.make_module(), sample,
                                                         allow_unused_input=True)
+            while len(self.entries) >= self.MAX_GRAPHS:
+                self.entries.popitem(last=False)  # least recently used captured graph
             self.entries[key] = ent
         self.entries.move_to_end(key)
         return ent(*tensors)
