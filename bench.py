@@ -598,13 +598,13 @@ def main():
                          "flop_check": {"per_launch_geometry_gflop": round(conv["flop"] / 1e9, 2),
                                         "survey_a3_gflop": round(conv_flop / 1e9, 2)},
                          "arithmetic": "fp32-class: operands are represented exactly by three bf16 "
-                                       "planes, products are exact, accumulation is fp32; relative "
-                                       "rms error vs an fp64 convolution 2-3x torch's own fp32 "
-                                       "conv for the truncation split of conv_x3_kernel "
-                                       "(profiles/r02_o_conv_accuracy_bf16x6_split.txt), at torch's "
-                                       "level for the round-to-nearest split of conv_p3_kernel "
-                                       "(profiles/r03_conv_accuracy.txt); VLNCE_CONV_MATH=f32 selects "
-                                       "the fp32-MFMA kernel everywhere",
+                                       "planes (round-to-nearest split), products are exact, six of "
+                                       "the nine are kept (dropped <= 2^-26 relative), accumulation "
+                                       "is fp32; measured relative rms error vs an fp64 convolution "
+                                       "1.6-2.8x torch's own fp32 convolution on the same operands "
+                                       "(profiles/r03_e_conv_accuracy_*.txt; the truncation split of "
+                                       "round 2 was 2-5x); VLNCE_CONV_MATH=f32 selects the fp32-MFMA "
+                                       "kernel everywhere",
                          "launches_per_step": n_conv,
                          "avg_launch_ms": round(conv_ms / max(n_conv, 1), 4),
                          "kernel_ms_per_step": round(conv_ms, 3),

@@ -276,6 +276,27 @@ class HostSim:
     def avgpool2x2(self, x, y, N, H, W, Cc):
         y.copy_(F.avg_pool2d(x.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1))
 
+    def gru_rollout_supported(self, N, H):
+        return 0 < N <= 16 and H in (64, 128, 256, 512)
+
+    def gru_rollout_fwd(self, gi, h0, mask, w_hh, b_hh, hp, out, gates, aux, sync_word, T, N, H):
+        h = h0
+        for t in range(T):
+            hp[t] = h * mask[t].view(N, 1).float()
+            gh = hp[t] @ w_hh.t() + b_hh
+            self.gru_gates_fwd(gi[t], gh, hp[t], None, out[t], gates[t], aux[t], N, H)
+            h = out[t]
+
+    def gru_rollout_bwd(self, dout, dh_final, gates, aux, hp, mask, w_hh_t, dgi, dgh, dh0,
+                        sync_word, T, N, H):
+        carry = torch.zeros(N, H) if dh_final is None else dh_final.clone()
+        acc = torch.empty(N, H)
+        for t in range(T - 1, -1, -1):
+            d = carry if dout is None else dout.view(T, N, H)[t] + carry
+            self.gru_gates_bwd(d, gates[t], aux[t], hp[t], None, dgi[t], dgh[t], acc, N, H)
+            carry = (acc + dgh[t] @ w_hh_t.t()) * mask[t].view(N, 1).float()
+        dh0.copy_(carry)
+
     def rnn_step_supported(self, N, H, lstm):
         return False  # the fused steps are a launch-count optimisation of the same arithmetic
 

@@ -125,15 +125,17 @@ def test_encode_ahead_is_transparent_without_side_streams(sim):
     compare(outs, gold, atol=1e-4, rtol=1e-4)
 
 
+@pytest.mark.parametrize("H", [16, 64])
 @pytest.mark.parametrize("lstm", [False, True])
-def test_masked_rnn_rollout_matches_torch_cells(sim, lstm):
+def test_masked_rnn_rollout_matches_torch_cells(sim, lstm, H):
     """ops.MaskedRNNSeqFn (T-step rollout, one autograd node) against torch GRUCell / LSTMCell
     stepped with the not-done masks (habitat RNNStateEncoder.seq_forward semantics), forward and
-    every gradient, with an episode boundary in the middle of the rollout."""
+    every gradient, with an episode boundary in the middle of the rollout.  H = 64 takes the
+    one-launch GRU rollout entry points (vlnce_gru_rollout_fwd / _bwd), H = 16 the per-step ones."""
     from vlnce_amd import ops
 
     torch.manual_seed(3)
-    T, N, D, H = 5, 3, 7, 16
+    T, N, D = 5, 3, 7
     cell = (torch.nn.LSTMCell if lstm else torch.nn.GRUCell)(D, H)
     x = torch.randn(T * N, D, requires_grad=True)
     h0 = torch.randn(N, H, requires_grad=True)

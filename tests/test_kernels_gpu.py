@@ -665,7 +665,8 @@ def test_conv_group_norm_from_epilogue_stats(hip, N, hw, Cin, Cout, k, groups):
 
 
 @pytest.mark.parametrize("lstm", [False, True])
-@pytest.mark.parametrize("T,N,H", [(40, 5, 512), (7, 64, 256), (9, 16, 256), (5, 3, 24)])
+@pytest.mark.parametrize("T,N,H", [(40, 5, 512), (7, 64, 256), (9, 16, 256), (5, 3, 24),
+                                   (100, 5, 512), (33, 16, 512), (12, 8, 64), (6, 1, 128)])
 def test_masked_rnn_rollout_vs_torch_cells(hip, lstm, T, N, H):
     """ops.MaskedRNNSeqFn on the GPU (the T-step state-encoder rollout of a cached-feature DAgger
     batch / DD-PPO minibatch) against torch cells stepped on the CPU, forward and all gradients."""
@@ -715,9 +716,61 @@ def test_masked_rnn_rollout_vs_torch_cells(hip, lstm, T, N, H):
         close(a, b, 3e-4, what=f"rollout grad {i}")
 
 
+@pytest.mark.parametrize("T,N,H", [(100, 5, 512), (17, 16, 512), (9, 9, 256), (3, 2, 64)])
+def test_gru_rollout_one_launch_equals_step_launches(hip, T, N, H):
+    """vlnce_gru_rollout_fwd / _bwd (the whole recurrence in one persistent launch, H/16 workgroups
+    meeting at a device-scope barrier per step) against T x vlnce_rnn_step_fwd / _bwd: same saved
+    tensors and gradients to fp32 rounding (the summation order of the recurrent dot products
+    differs), repeated to catch a barrier that lets a workgroup read a stale state."""
+    lib = ops.L()
+    assert lib.gru_rollout_supported(N, H)
+    torch.manual_seed(11)
+    GH = 3 * H
+    gi = (torch.randn(T, N, GH) * 0.7).to(DEV)
+    h0 = (torch.randn(N, H) * 0.4).to(DEV)
+    w = (torch.randn(GH, H) * H ** -0.5).to(DEV)
+    b = (torch.randn(GH) * 0.1).to(DEV)
+    mask = (torch.rand(T, N) > 0.1).to(torch.uint8).to(DEV)
+    dout = torch.randn(T, N, H).to(DEV)
+    dhf = torch.randn(N, H).to(DEV)
+
+    def buffers():
+        return [torch.full((T, N, H), float("nan"), device=DEV), torch.full((T, N, H), float("nan"), device=DEV),
+                torch.full((T, N, GH), float("nan"), device=DEV), torch.full((T, N, H), float("nan"), device=DEV)]
+
+    hp_s, out_s, gates_s, aux_s = buffers()
+    h = h0
+    for t in range(T):
+        lib.rnn_step_fwd(False, gi[t], h, None, mask[t], w, b, hp_s[t], out_s[t], aux_s[t], gates_s[t], N, H)
+        h = out_s[t]
+    wt = w.t().contiguous()
+    dgi_s, dgh_s = torch.empty(T, N, GH, device=DEV), torch.empty(T, N, GH, device=DEV)
+    carry, acc = dhf.clone(), torch.empty(N, H, device=DEV)
+    for t in range(T - 1, -1, -1):
+        lib.rnn_step_bwd(False, dout[t], carry, None, gates_s[t], aux_s[t], hp_s[t], None, mask[t], wt,
+                         dgi_s[t], dgh_s[t], acc, None, N, H)
+    word = torch.zeros(4, dtype=torch.int32, device=DEV)
+    for rep in range(3):
+        hp_r, out_r, gates_r, aux_r = buffers()
+        lib.gru_rollout_fwd(gi, h0, mask, w, b, hp_r, out_r, gates_r, aux_r, word, T, N, H)
+        for a, r_, what in ((out_r, out_s, "out"), (hp_r, hp_s, "hp"), (gates_r, gates_s, "gates"),
+                            (aux_r, aux_s, "aux")):
+            close(a, r_, 2e-5, what=f"rollout fwd {what} (rep {rep})")
+        dgi_r = torch.full((T, N, GH), float("nan"), device=DEV)
+        dgh_r = torch.full((T, N, GH), float("nan"), device=DEV)
+        dh0_r = torch.full((N, H), float("nan"), device=DEV)
+        lib.gru_rollout_bwd(dout, dhf, gates_s, aux_s, hp_s, mask, wt, dgi_r, dgh_r, dh0_r, word, T, N, H)
+        close(dgi_r, dgi_s, 1e-4, what=f"rollout dgi (rep {rep})")
+        close(dgh_r, dgh_s, 1e-4, what=f"rollout dgh (rep {rep})")
+        close(dh0_r, carry, 1e-4, what=f"rollout dh0 (rep {rep})")
+    # no output gradient, no final-state gradient: NULL operands
+    lib.gru_rollout_bwd(None, None, gates_s, aux_s, hp_s, mask, wt, dgi_r, dgh_r, dh0_r, word, T, N, H)
+    assert float(dgi_r.abs().max()) == 0.0 and float(dh0_r.abs().max()) == 0.0
+
+
 # ------------------------------------------------------------------ bf16-plane convolution kernel
 def test_split_weights_is_exact(hip):
-    """w == plane0 + plane1 + plane2 bit for bit (truncation split: 8 + 8 + 8 mantissa bits),
+    """w == plane0 + plane1 + plane2 bit for bit (round-to-nearest split: 8 + 8 + 8 mantissa bits),
     including huge, tiny and negative values.  (Only where a residual would be an fp32 denormal,
     |w| < ~2^-110, the GPU flushes it: absolute error below 2^-126, checked separately.)"""
     torch.manual_seed(3)

@@ -100,6 +100,9 @@ _SIGNATURES = {
     "vlnce_rnn_seq_supported": (_I, [_I, _I]),
     "vlnce_rnn_seq_fwd": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "vlnce_rnn_seq_bwd": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "vlnce_gru_rollout_supported": (_I, [_I, _I]),
+    "vlnce_gru_rollout_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "vlnce_gru_rollout_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "vlnce_rnn_step_supported": (_I, [_I, _I, _I]),
     "vlnce_rnn_step_fwd": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "vlnce_rnn_step_bwd": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
@@ -178,7 +181,7 @@ class HipLib:
 
     name = "hip"
 
-    ABI = 131  # include/vlnce_hip.h
+    ABI = 132  # include/vlnce_hip.h
 
     def __init__(self, path=LIB_PATH):
         self.dll = load_cdll(path)
@@ -480,6 +483,23 @@ class HipLib:
             kind, dirs, pa(w_hh_t, dirs), _ptr(lengths), pa(out, dirs), pa(gates_save, dirs),
             pa(aux_save, dirs), pa(dout, dirs), pa(dh_final, dirs), pa(dgi, dirs), pa(dgh, dirs),
             B, Lm, H, _stream()), "vlnce_rnn_seq_bwd")
+
+    def gru_rollout_supported(self, N, H):
+        if os.environ.get("VLNCE_GRU_ROLLOUT", "1") == "0":  # A/B switch (scripts/bench_data_path.py)
+            return False
+        return bool(self.dll.vlnce_gru_rollout_supported(N, H))
+
+    def gru_rollout_fwd(self, gi, h0, mask, w_hh, b_hh, hp, out, gates, aux, sync_word, T, N, H):
+        self._check(self.dll.vlnce_gru_rollout_fwd(
+            _ptr(gi), _ptr(h0), _ptr(mask), _ptr(w_hh), _ptr(b_hh), _ptr(hp), _ptr(out),
+            _ptr(gates), _ptr(aux), _ptr(sync_word), T, N, H, _stream()), "vlnce_gru_rollout_fwd")
+
+    def gru_rollout_bwd(self, dout, dh_final, gates, aux, hp, mask, w_hh_t, dgi, dgh, dh0,
+                        sync_word, T, N, H):
+        self._check(self.dll.vlnce_gru_rollout_bwd(
+            _ptr(dout), _ptr(dh_final), _ptr(gates), _ptr(aux), _ptr(hp), _ptr(mask),
+            _ptr(w_hh_t), _ptr(dgi), _ptr(dgh), _ptr(dh0), _ptr(sync_word), T, N, H, _stream()),
+            "vlnce_gru_rollout_bwd")
 
     def rnn_step_supported(self, N, H, lstm):
         if os.environ.get("VLNCE_RNN_STEP_FUSED", "1") == "0":  # A/B switch (scripts/bench_data_path.py)

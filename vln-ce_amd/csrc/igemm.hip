@@ -1,4 +1,9 @@
-// fp32 implicit-GEMM convolution / general GEMM on v_mfma_f32_32x32x2_f32.
+// Implicit-GEMM convolution / general GEMM.  Two kernels live here:
+//   * igemm_kernel: exact fp32 on v_mfma_f32_32x32x2_f32 (described right below) -- every GEMM of
+//     the trainable tail, the 7x7 stems, the handful-of-tiles layers, VLNCE_CONV_MATH=f32;
+//   * conv_x3_kernel (further down): fp32 operands split into three bf16 planes, six plane
+//     products on v_mfma_f32_32x32x16_bf16 -- the 1x1 / strided convolutions of the frozen trunks
+//     that conv_p3.hip (conv_p3_kernel / conv_u3_kernel) does not take.
 //
 //   C[M,N] = epilogue( A[M,K] * B[K,N] )
 //
@@ -669,13 +674,15 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
 //
 // fp32 convolution on the bf16 matrix pipe.  gfx950 has no fp32-rate matrix instruction beyond
 // v_mfma_f32_32x32x2_f32 (157 TF/s, = the vector rate); v_mfma_f32_32x32x16_bf16 is 16x faster.
-// Every fp32 operand is split EXACTLY into three bf16 planes by truncation,
+// Every fp32 operand is split EXACTLY into three bf16 planes (round to nearest at each step),
 //     x = x1 + x2 + x3   (8 + 8 + 8 mantissa bits, same exponent range as fp32),
 // and a product a*b is the six plane products of order <= 2^-16,
 //     a1 b1 + (a1 b2 + a2 b1) + (a2 b2 + a1 b3 + a3 b1),
-// each exact in the fp32 accumulator; the dropped terms are O(2^-24) relative, the size of an
-// fp32 rounding.  Measured against fp64 the result error is 1.1-1.2x that of the fp32-MFMA
-// kernel above and the same as rocBLAS/MIOpen fp32 (profiles/r02_o_conv_accuracy_*.txt).  Six
+// each exact in the fp32 accumulator; the dropped terms are <= 2^-26 relative.  Round 2 split by
+// TRUNCATION (dropped terms 2^-24): measured against fp64 that was rms 3.4-5.0e-7 on the 3x3
+// layers = 1.1-1.2x the fp32-MFMA kernel above and 2-3x torch's own fp32 convolution (1.6-1.7e-7;
+// profiles/r02_o_conv_accuracy_*.txt) -- fp32-class, NOT equal to it as round 2's text claimed.
+// With the round-to-nearest split: profiles/r03_*_conv_accuracy*.txt.  Six
 // bf16 MFMAs of 32 cycles replace eight fp32 MFMAs of 64 cycles per 32x32x16 block: 2.7x less
 // matrix-pipe time.
 //
@@ -713,30 +720,34 @@ struct X3Staged {
   int m0;
 };
 
-// x (4 consecutive k of one row) -> the three planes' 8-byte LDS words
+// x (4 consecutive k of one row) -> the three planes' 8-byte LDS words.  Round-to-nearest split
+// (v_cvt_pk_bf16_f32): x = x1 + x2 + x3 exactly, |x2| <= 2^-9 |x|, |x3| <= 2^-18 |x|, so the three
+// dropped cross terms are <= 2^-26 relative (truncation, rounds 2: 2^-24); same instruction count.
 __device__ __forceinline__ void x3_split_store(f32x4 x, char* row_ptr, int plane_bytes) {
   typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  u32x2 w[3];
+#pragma unroll
+  for (int pr = 0; pr < 2; ++pr) {
+    f32x2 v = {x[2 * pr], x[2 * pr + 1]};
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
 #ifdef X3_DBG_NOSPLIT  // ceiling probe: what the kernel does when the split costs nothing
-  const f32x4 r = x, s = x;
+      const unsigned hb = __builtin_bit_cast(unsigned, v[0]);
 #else
-  const u32x4 xm = __builtin_bit_cast(u32x4, x) & 0xffff0000u;
-  const f32x4 r = x - __builtin_bit_cast(f32x4, xm);
-  const u32x4 rm = __builtin_bit_cast(u32x4, r) & 0xffff0000u;
-  const f32x4 s = r - __builtin_bit_cast(f32x4, rm);
+      const unsigned hb = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
 #endif
-  const u32x4 xb = __builtin_bit_cast(u32x4, x), rb = __builtin_bit_cast(u32x4, r),
-              sb = __builtin_bit_cast(u32x4, s);
-  const u32x2 h = {__builtin_amdgcn_perm(xb[1], xb[0], 0x07060302u),
-                   __builtin_amdgcn_perm(xb[3], xb[2], 0x07060302u)};
-  const u32x2 m = {__builtin_amdgcn_perm(rb[1], rb[0], 0x07060302u),
-                   __builtin_amdgcn_perm(rb[3], rb[2], 0x07060302u)};
-  const u32x2 l = {__builtin_amdgcn_perm(sb[1], sb[0], 0x07060302u),
-                   __builtin_amdgcn_perm(sb[3], sb[2], 0x07060302u)};
-  *reinterpret_cast<u32x2*>(row_ptr) = h;
-  *reinterpret_cast<u32x2*>(row_ptr + plane_bytes) = m;
-  *reinterpret_cast<u32x2*>(row_ptr + 2 * plane_bytes) = l;
+      w[q][pr] = hb;
+      if (q < 2) {
+        v[0] -= __builtin_bit_cast(float, hb << 16);
+        v[1] -= __builtin_bit_cast(float, hb & 0xffff0000u);
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 3; ++q) *reinterpret_cast<u32x2*>(row_ptr + q * plane_bytes) = w[q];
 }
-
 
 template <int BM, int BN, int WM, int WN, int DUAL>
 __global__ __launch_bounds__((WM * WN + X3_PRODUCERS) * 64) void conv_x3_kernel(IgemmParams p) {
@@ -1386,19 +1397,19 @@ extern "C" int vlnce_conv2d_tiles_m(const vlnce_conv_desc* d) {
   return ceil_div(M, stat_rows_for(d));
 }
 
-// w[i] -> planes[q][i], q = 0..2: the exact three-way bf16 split of conv_x3_kernel's B operand
+// w[i] -> planes[q][i], q = 0..2: the exact three-way (round-to-nearest) bf16 split of
+// conv_x3_kernel's B operand
 __global__ __launch_bounds__(256) void split_weights_kernel(const float* __restrict__ w,
                                                             unsigned short* __restrict__ planes,
                                                             long count) {
   for (long i = blockIdx.x * 256L + threadIdx.x; i < count; i += gridDim.x * 256L) {
-    const float x = w[i];
-    const unsigned xb = __float_as_uint(x);
-    const float r = x - __uint_as_float(xb & 0xffff0000u);
-    const unsigned rb = __float_as_uint(r);
-    const float t = r - __uint_as_float(rb & 0xffff0000u);
-    planes[i] = (unsigned short)(xb >> 16);
-    planes[count + i] = (unsigned short)(rb >> 16);
-    planes[2 * count + i] = (unsigned short)(__float_as_uint(t) >> 16);
+    float v = w[i];   // round-to-nearest three-way split, exact: w == plane0 + plane1 + plane2
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const __bf16 hb = (__bf16)v;
+      planes[q * count + i] = __builtin_bit_cast(unsigned short, hb);
+      v -= (float)hb;
+    }
   }
 }
 

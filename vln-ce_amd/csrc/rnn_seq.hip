@@ -106,6 +106,13 @@ __global__ __launch_bounds__(NW * 64) void rnn_seq_fwd_kernel(RnnSeqParams p) {
     const int b = b0 + quad * 4 + r;
     len[r] = b < B ? p.lengths[b] : 0;
   }
+  // steps past the longest sequence of this tile change nothing (state kept, zeros emitted into
+  // the pre-zeroed outputs): the loop ends there, not at the padded length (80 of 200 tokens
+  // in the R2R batches)
+  int Lt = max(max(len[0], len[1]), max(len[2], len[3]));
+  Lt = max(Lt, __shfl_xor(Lt, 16, 64));
+  Lt = max(Lt, __shfl_xor(Lt, 32, 64));
+  Lt = min(Lt, L);
   // recurrent weights -> registers, split once (B operand: lane holds the three planes of
   // W[n = unit][k = 32 ks + 8 quad + 0..7])
   Planes3 wp[G][NTW][KS];
@@ -151,7 +158,7 @@ __global__ __launch_bounds__(NW * 64) void rnn_seq_fwd_kernel(RnnSeqParams p) {
   };
   fetch(0);
 
-  for (int s = 0; s < L; ++s) {
+  for (int s = 0; s < Lt; ++s) {
     const int cur = s & 1;
     f32x4 acc[G][NTW];
     float xn[NTW][4];  // GRU: input part of the n gate
@@ -269,6 +276,10 @@ __global__ __launch_bounds__(NW * 64) void rnn_seq_bwd_kernel(RnnSeqParams p) {
     const int b = b0 + quad * 4 + r;
     len[r] = b < B ? p.lengths[b] : 0;
   }
+  int Lt = max(max(len[0], len[1]), max(len[2], len[3]));  // (see the forward kernel)
+  Lt = max(Lt, __shfl_xor(Lt, 16, 64));
+  Lt = max(Lt, __shfl_xor(Lt, 32, 64));
+  Lt = min(Lt, L);
   Planes3 wt[NTW][KS];  // the three planes of WT[n][32 ks + 8 quad + 0..7]
 #pragma unroll
   for (int nt = 0; nt < NTW; ++nt) {
@@ -327,10 +338,10 @@ __global__ __launch_bounds__(NW * 64) void rnn_seq_bwd_kernel(RnnSeqParams p) {
       }
     }
   };
-  fetch(L - 1, pg, pa, pd);
-  fetch_prev(L - 2, pa_prev);
+  fetch(Lt - 1, pg, pa, pd);
+  fetch_prev(Lt - 2, pa_prev);
 
-  for (int s = L - 1; s >= 0; --s) {
+  for (int s = Lt - 1; s >= 0; --s) {
     float keep_z[NTW][4];  // GRU: dh * z carried straight to h_prev
     float cg[G][NTW][4], ca[NTW][4], cprev[NTW][4], cd[NTW][4];
 #pragma unroll

@@ -623,14 +623,32 @@ def lstm_cell(x_gates, h_prev, c_prev, w_hh, b_hh):
     return LSTMGatesFn.apply(x_gates, gh, c_prev)
 
 
+_SYNC_WORDS = {}
+
+
+def _sync_word(dev):
+    """The arrival counter of a persistent rollout launch: one 4-byte word per (device, stream) --
+    launches on one stream are ordered, so they can share it; the library zeroes it per call."""
+    if dev.type == "cuda" and torch.cuda.is_current_stream_capturing():
+        return torch.zeros(4, dtype=torch.int32, device=dev)  # lives in the graph's own pool
+    key = (str(dev), torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0)
+    w = _SYNC_WORDS.get(key)
+    if w is None:
+        w = _SYNC_WORDS[key] = torch.zeros(4, dtype=torch.int32, device=dev)
+    return w
+
+
 class MaskedRNNSeqFn(Function):
     """T > 1 steps of a masked GRU / LSTM state encoder as ONE autograd node (habitat
     RNNStateEncoder.seq_forward semantics: h (and c) are multiplied by the not-done mask of step
     t before step t).  A T-step rollout of N episodes -- the cached-feature DAgger batch
     (dagger_trainer.py:39-114) or a DD-PPO minibatch (rollout_storage.py:154-276) -- costs
-    3 launches per step forward (mask, h W_hh^T, gates) and 3 backward (gates', dgates W_hh,
-    mask + skip add) instead of one autograd cell per step, and the recurrent weight / bias
-    gradients are ONE GEMM / column sum over all T*N rows instead of T accumulated ones.
+    ONE launch forward and ONE backward for a GRU over N <= 16 episodes (gru_rollout.hip: the
+    recurrent weights stay in the registers of H/16 resident workgroups, one device-scope
+    barrier per step); otherwise 1-3 launches per step forward (mask, h W_hh^T, gates) and 2-3
+    backward (gates', dgates W_hh, mask + skip add) instead of one autograd cell per step.  The
+    recurrent weight / bias gradients are ONE GEMM / column sum over all T*N rows instead of T
+    accumulated ones.
 
     forward(lstm, gi [T*N, G*H], h0 [N,H], c0 [N,H] | None, mask_u8 [T*N], w_hh [G*H,H], b_hh)
       -> out [T*N, H], h_T [N,H], c_T [N,H] (c_T = h_T for a GRU)."""
@@ -651,6 +669,13 @@ class MaskedRNNSeqFn(Function):
         gi3, m2 = gi.view(T, N, GH), mask.view(T, N)
         h, c = h0, (_f32c(c0) if lstm else None)
         b_hh = _f32c(b_hh)
+        ctx.rollout = (not lstm) and T > 1 and lib.gru_rollout_supported(N, H)
+        if ctx.rollout:  # the whole recurrence in ONE launch (gru_rollout.hip)
+            lib.gru_rollout_fwd(gi3, h0, m2.contiguous(), w_hh, b_hh, hp, out, gates, aux,
+                                _sync_word(dev), T, N, H)
+            ctx.lstm, ctx.dims = lstm, (T, N, H, GH)
+            ctx.save_for_backward(hp, gates, aux, m2, w_hh, h0)
+            return out.view(T * N, H), out[T - 1], out[T - 1]
         fused = lib.rnn_step_supported(N, H, lstm)
         for t in range(T):
             if fused:  # mask, h W_hh^T and the gates of this step in ONE launch
@@ -679,6 +704,21 @@ class MaskedRNNSeqFn(Function):
         T, N, H, GH = ctx.dims
         lstm = ctx.lstm
         dev = hp.device
+        if ctx.rollout:
+            dgi = torch.empty((T, N, GH), device=dev, dtype=torch.float32)
+            dgh = torch.empty_like(dgi)
+            dh0 = torch.empty((N, H), device=dev, dtype=torch.float32)
+            carry = None if dh_fin is None else _f32c(dh_fin)
+            if dc_fin is not None:  # the GRU's second output aliases h_T
+                carry = _f32c(dc_fin) if carry is None else carry + dc_fin
+            lib.gru_rollout_bwd(None if dout is None else _f32c(dout), carry, gates, aux, hp,
+                                m2.contiguous(), w_hh.t().contiguous(), dgi, dgh, dh0,
+                                _sync_word(dev), T, N, H)
+            dw = torch.empty_like(w_hh)
+            lib.gemm(dgh.view(T * N, GH), GH, 1, hp.view(T * N, H), H, 1, dw, H, GH, H, T * N)
+            db = torch.empty((GH,), device=dev, dtype=torch.float32)
+            lib.colsum(dgh.view(T * N, GH), GH, T * N, GH, db, 0)
+            return None, dgi.view(T * N, GH), dh0, None, None, dw, db
         dout = _f32c(dout).view(T, N, H)
         mf = m2.to(torch.float32).unsqueeze(-1)                        # [T, N, 1]
         dgi = torch.empty((T, N, GH), device=dev, dtype=torch.float32)
