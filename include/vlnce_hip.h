@@ -389,24 +389,26 @@ int vlnce_mask_rows(const float* x, const uint8_t* mask, float* out, int B, int 
  * (habitat RNNStateEncoder.seq_forward: h is multiplied by the not-done mask of step t before
  * step t; call sites cma_policy.py:249-256,287-294, seq2seq_policy.py:128-136) for N <= 16
  * episodes and H in {64,128,256,512}: H/16 workgroups keep their rows of W_hh in registers for
- * all T steps and exchange the state through out[t] (backward: dgh[t]) at one device-scope
- * barrier per step.  Same arithmetic (fp32 FMA) and the same saved tensors as T calls of
+ * all T steps and hand each other the new state (backward: the gate gradients) as (value, step
+ * tag) pairs, one 64-bit device-scope atomic store / polling load each: no fence, no counter.  Same arithmetic (fp32 FMA) and the same saved tensors as T calls of
  * vlnce_rnn_step_fwd / _bwd:
  *   fwd: gi [T,N,3H] (x W_ih^T + b_ih), h0 [N,H], mask [T,N] -> hp [T,N,H] (mask_t * h_{t-1}),
  *        out [T,N,H], gates [T,N,3H] (r, z, n), aux [T,N,H] (W_hn hp + b_hn);
  *   bwd: dout [T,N,H] (NULL = zeros), dh_final [N,H] (NULL = zeros), w_hh_t = W_hh^T [H,3H]
  *        -> dgi, dgh [T,N,3H], dh0 [N,H] (gradient wrt h0, the step-0 mask applied).
- * sync_word: 4 bytes of device memory owned by the caller for the duration of the launch (the
- * arrival counter; zeroed by the call).  All H/16 workgroups must become resident: do not run it
- * beside a kernel that holds every CU for longer than a few seconds (a lost workgroup traps). */
+ * workspace: vlnce_gru_rollout_workspace_bytes(N, H) bytes of device memory owned by the caller
+ * for the duration of the launch (the double-buffered exchange area of (value, step tag) pairs;
+ * zeroed by the call).  All H/16 workgroups must become resident: do not run it beside a kernel
+ * that holds every CU for longer than a few seconds (a lost workgroup traps). */
 int vlnce_gru_rollout_supported(int N, int H);
+long vlnce_gru_rollout_workspace_bytes(int N, int H);
 int vlnce_gru_rollout_fwd(const float* gi, const float* h0, const uint8_t* mask, const float* w_hh,
                           const float* b_hh, float* hp, float* out, float* gates, float* aux,
-                          unsigned* sync_word, int T, int N, int H, vlnce_stream_t stream);
+                          void* workspace, int T, int N, int H, vlnce_stream_t stream);
 int vlnce_gru_rollout_bwd(const float* dout, const float* dh_final, const float* gates,
                           const float* aux, const float* hp, const uint8_t* mask,
                           const float* w_hh_t, float* dgi, float* dgh, float* dh0,
-                          unsigned* sync_word, int T, int N, int H, vlnce_stream_t stream);
+                          void* workspace, int T, int N, int H, vlnce_stream_t stream);
 
 /* out[b, :] = mask[b] ? a[b, :] : b[b, :]  (NULL operand = zeros): packed-sequence
  * semantics of the instruction RNN (steps past a sample's length keep the state

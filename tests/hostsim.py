@@ -279,7 +279,10 @@ class HostSim:
     def gru_rollout_supported(self, N, H):
         return 0 < N <= 16 and H in (64, 128, 256, 512)
 
-    def gru_rollout_fwd(self, gi, h0, mask, w_hh, b_hh, hp, out, gates, aux, sync_word, T, N, H):
+    def gru_rollout_workspace_bytes(self, N, H):
+        return 2 * N * 3 * H * 8
+
+    def gru_rollout_fwd(self, gi, h0, mask, w_hh, b_hh, hp, out, gates, aux, workspace, T, N, H):
         h = h0
         for t in range(T):
             hp[t] = h * mask[t].view(N, 1).float()
@@ -288,7 +291,7 @@ class HostSim:
             h = out[t]
 
     def gru_rollout_bwd(self, dout, dh_final, gates, aux, hp, mask, w_hh_t, dgi, dgh, dh0,
-                        sync_word, T, N, H):
+                        workspace, T, N, H):
         carry = torch.zeros(N, H) if dh_final is None else dh_final.clone()
         acc = torch.empty(N, H)
         for t in range(T - 1, -1, -1):

@@ -719,7 +719,7 @@ def test_masked_rnn_rollout_vs_torch_cells(hip, lstm, T, N, H):
 @pytest.mark.parametrize("T,N,H", [(100, 5, 512), (17, 16, 512), (9, 9, 256), (3, 2, 64)])
 def test_gru_rollout_one_launch_equals_step_launches(hip, T, N, H):
     """vlnce_gru_rollout_fwd / _bwd (the whole recurrence in one persistent launch, H/16 workgroups
-    meeting at a device-scope barrier per step) against T x vlnce_rnn_step_fwd / _bwd: same saved
+    handing the state over as tagged 64-bit pairs) against T x vlnce_rnn_step_fwd / _bwd: same saved
     tensors and gradients to fp32 rounding (the summation order of the recurrent dot products
     differs), repeated to catch a barrier that lets a workgroup read a stale state."""
     lib = ops.L()
@@ -749,7 +749,7 @@ def test_gru_rollout_one_launch_equals_step_launches(hip, T, N, H):
     for t in range(T - 1, -1, -1):
         lib.rnn_step_bwd(False, dout[t], carry, None, gates_s[t], aux_s[t], hp_s[t], None, mask[t], wt,
                          dgi_s[t], dgh_s[t], acc, None, N, H)
-    word = torch.zeros(4, dtype=torch.int32, device=DEV)
+    word = torch.empty(lib.gru_rollout_workspace_bytes(N, H), dtype=torch.uint8, device=DEV)
     for rep in range(3):
         hp_r, out_r, gates_r, aux_r = buffers()
         lib.gru_rollout_fwd(gi, h0, mask, w, b, hp_r, out_r, gates_r, aux_r, word, T, N, H)

@@ -101,6 +101,7 @@ _SIGNATURES = {
     "vlnce_rnn_seq_fwd": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "vlnce_rnn_seq_bwd": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "vlnce_gru_rollout_supported": (_I, [_I, _I]),
+    "vlnce_gru_rollout_workspace_bytes": (C.c_long, [_I, _I]),
     "vlnce_gru_rollout_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "vlnce_gru_rollout_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "vlnce_rnn_step_supported": (_I, [_I, _I, _I]),
@@ -489,16 +490,19 @@ class HipLib:
             return False
         return bool(self.dll.vlnce_gru_rollout_supported(N, H))
 
-    def gru_rollout_fwd(self, gi, h0, mask, w_hh, b_hh, hp, out, gates, aux, sync_word, T, N, H):
+    def gru_rollout_workspace_bytes(self, N, H):
+        return int(self.dll.vlnce_gru_rollout_workspace_bytes(N, H))
+
+    def gru_rollout_fwd(self, gi, h0, mask, w_hh, b_hh, hp, out, gates, aux, workspace, T, N, H):
         self._check(self.dll.vlnce_gru_rollout_fwd(
             _ptr(gi), _ptr(h0), _ptr(mask), _ptr(w_hh), _ptr(b_hh), _ptr(hp), _ptr(out),
-            _ptr(gates), _ptr(aux), _ptr(sync_word), T, N, H, _stream()), "vlnce_gru_rollout_fwd")
+            _ptr(gates), _ptr(aux), _ptr(workspace), T, N, H, _stream()), "vlnce_gru_rollout_fwd")
 
     def gru_rollout_bwd(self, dout, dh_final, gates, aux, hp, mask, w_hh_t, dgi, dgh, dh0,
-                        sync_word, T, N, H):
+                        workspace, T, N, H):
         self._check(self.dll.vlnce_gru_rollout_bwd(
             _ptr(dout), _ptr(dh_final), _ptr(gates), _ptr(aux), _ptr(hp), _ptr(mask),
-            _ptr(w_hh_t), _ptr(dgi), _ptr(dgh), _ptr(dh0), _ptr(sync_word), T, N, H, _stream()),
+            _ptr(w_hh_t), _ptr(dgi), _ptr(dgh), _ptr(dh0), _ptr(workspace), T, N, H, _stream()),
             "vlnce_gru_rollout_bwd")
 
     def rnn_step_supported(self, N, H, lstm):

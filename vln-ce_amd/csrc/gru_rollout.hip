@@ -11,16 +11,21 @@
 //   * workgroup b owns hidden units [16b, 16b+16): their 3 x 16 rows of W_hh (forward) or their
 //     16 columns (backward, rows of W_hh^T) live in REGISTERS for all T steps -- thread
 //     (unit u = tid/16, slice s = tid%16) holds the k-slice [s K/16, (s+1) K/16) of its rows;
-//   * per step the workgroups exchange the state through the tensors the step has to write
-//     anyway (forward: out[t]; backward: dgh[t]) and meet at ONE device-scope barrier (a monotonic
-//     arrival counter in global memory; release = wave-0 thread fence after the workgroup
-//     barrier, acquire = fence after the spin -- the cooperative-groups grid-sync pattern);
+//   * per step the workgroups exchange the new state (backward: the gate gradients) through a
+//     small double-buffered area of (value, step tag) PAIRS written with one 64-bit device-scope
+//     atomic store each and polled with 64-bit atomic loads until the tag is the step's: data
+//     and flag travel together, so a step costs one store -> load latency across the chip and
+//     needs no fence, no counter and no second round trip (a first version with an arrival
+//     counter + thread fences, the cooperative-groups grid-sync pattern, measured 6.2 us per
+//     step; profiles/r03_f_*);
 //   * the [N, K] operand of the step (N <= 16 episodes) is staged in LDS, each thread multiplies
 //     its register slice with all N rows (fp32 FMA: this is the literal fp32 arithmetic of the
 //     step kernels in rnn.hip, only the summation order differs), slice partials meet in LDS and
 //     thread (u, n) finishes unit u of episode n: gates, new state, what backward needs.
 // What a step reads that does not depend on the recurrence (gi; in the backward pass the saved
 // gates / states / output gradient) is fetched one step ahead.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -45,31 +50,22 @@ struct GruRolloutParams {
   float* dgi;           // [T,N,3H]
   float* dgh;           // [T,N,3H]
   float* dh0;           // [N,H]
-  unsigned* counter;    // zero at launch
+  unsigned long long* ex;  // [2][N][K] (value, tag) pairs, zero at launch; K = H (fwd) | 3H (bwd)
   int T, N;
+  int spread;  // 1, or 8: only every 8th workgroup works, i.e. all of them on one XCD (experiment)
 };
 
 __device__ __forceinline__ float ro_sigm(float x) { return 1.f / (1.f + expf(-x)); }
 
-// every workgroup's stores so far become visible device-wide, then it counts itself in
-__device__ __forceinline__ void grid_arrive(unsigned* c) {
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __threadfence();
-    __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
+constexpr int ro_chunk(int ld) {
+  int c = ld < 16 ? ld : 16;
+  while (ld % c) --c;
+  return c;
 }
-// until `target` arrivals; bounded: a lost workgroup ends in a trap, not in a hung device
-__device__ __forceinline__ void grid_wait(unsigned* c, unsigned target) {
-  if (threadIdx.x == 0) {
-    long spins = 0;
-    while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-      __builtin_amdgcn_s_sleep(2);
-      if (++spins > (1L << 24)) __builtin_trap();
-    }
-    __threadfence();
-  }
-  __syncthreads();
+
+__device__ __forceinline__ void ex_store(unsigned long long* p, float v, unsigned tag) {
+  const unsigned long long w = ((unsigned long long)tag << 32) | __float_as_uint(v);
+  __hip_atomic_store(p, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // stage src [N, K] (K-contiguous rows) into LDS rows of 16 slices x (SL + 4) floats, scaled per row
@@ -98,6 +94,51 @@ __device__ __forceinline__ void stage_operand(float* __restrict__ Xs, const floa
   }
 }
 
+// the same from the exchange area: every thread polls its share of the N*K pairs until each
+// carries `tag` (bounded: a lost workgroup ends in a trap, not in a hung device)
+template <int K, int NT, bool MASKED>
+__device__ __forceinline__ void stage_exchanged(float* __restrict__ Xs,
+                                                const unsigned long long* __restrict__ ex,
+                                                unsigned tag, const uint8_t* __restrict__ mrow,
+                                                int N) {
+  constexpr int SL = K / RO_SLICES, PITCH = SL + 4, ROW = RO_SLICES * PITCH;
+  constexpr int LD = (NT * K + 255) / 256;
+  constexpr int CH = ro_chunk(LD);  // pairs in flight per thread: the largest divisor <= 16
+  static_assert(LD % CH == 0, "whole chunks");
+  const int total = N * K;
+  long spins = 0;
+  for (int c0 = 0; c0 < LD; c0 += CH) {
+    if (threadIdx.x + c0 * 256 >= total) break;
+    unsigned long long w[CH];
+    bool again;
+    do {
+      again = false;
+#pragma unroll
+      for (int q = 0; q < CH; ++q) {
+        const int i = threadIdx.x + (c0 + q) * 256;
+        if (i < total)
+          w[q] = __hip_atomic_load(ex + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+#pragma unroll
+      for (int q = 0; q < CH; ++q) {
+        const int i = threadIdx.x + (c0 + q) * 256;
+        if (i < total && (unsigned)(w[q] >> 32) != tag) again = true;
+      }
+      if (again && ++spins > (1L << 22)) __builtin_trap();
+    } while (again);
+#pragma unroll
+    for (int q = 0; q < CH; ++q) {
+      const int i = threadIdx.x + (c0 + q) * 256;
+      if (i < total) {
+        const int n = i / K, k = i - n * K;
+        float x = __uint_as_float((unsigned)w[q]);
+        if (MASKED) x *= (float)mrow[n];
+        Xs[n * ROW + (k / SL) * PITCH + (k % SL)] = x;
+      }
+    }
+  }
+}
+
 template <int H, int NT>
 __global__ __launch_bounds__(256) void gru_rollout_fwd_kernel(GruRolloutParams p) {
   constexpr int SL = H / RO_SLICES, PITCH = SL + 4, ROW = RO_SLICES * PITCH;
@@ -108,9 +149,9 @@ __global__ __launch_bounds__(256) void gru_rollout_fwd_kernel(GruRolloutParams p
   const int tid = threadIdx.x;
   const int u = tid >> 4, sl = tid & 15;
   const int n_own = sl;  // final stage: this thread finishes (unit u, episode sl)
-  const int j = blockIdx.x * RO_UNITS + u;
+  if (blockIdx.x % p.spread) return;
+  const int j = (blockIdx.x / p.spread) * RO_UNITS + u;
   const int N = p.N, T = p.T;
-  const unsigned W = gridDim.x;
   const bool fin = n_own < N;
 
   float w[3][SL];
@@ -139,9 +180,11 @@ __global__ __launch_bounds__(256) void gru_rollout_fwd_kernel(GruRolloutParams p
 #pragma unroll
       for (int g = 0; g < 3; ++g) gnext[g] = p.gi[((long)(t + 1) * N + n_own) * 3 * H + g * H + j];
     }
-    if (t > 0) grid_wait(p.counter, W * (unsigned)t);
-    const float* src = t == 0 ? p.h0 : p.out + (long)(t - 1) * N * H;
-    stage_operand<H, NT, true>(Xs, src, p.mask + (long)t * N, N);
+    if (t == 0)
+      stage_operand<H, NT, true>(Xs, p.h0, p.mask, N);
+    else
+      stage_exchanged<H, NT, true>(Xs, p.ex + (long)((t - 1) & 1) * N * H, (unsigned)t,
+                                   p.mask + (long)t * N, N);
     __syncthreads();
     float acc[3][NT];
 #pragma unroll
@@ -177,7 +220,10 @@ __global__ __launch_bounds__(256) void gru_rollout_fwd_kernel(GruRolloutParams p
       const float z = ro_sigm(gx[1] + gh[1]);
       const float nn = tanhf(gx[2] + r * gh[2]);
       const long o = ((long)t * N + n_own) * H + j;
-      p.out[o] = (1.f - z) * nn + z * hpv;
+      const float hnew = (1.f - z) * nn + z * hpv;
+      if (t + 1 < T)  // first: the other workgroups are waiting for it
+        ex_store(p.ex + (long)(t & 1) * N * H + (long)n_own * H + j, hnew, (unsigned)(t + 1));
+      p.out[o] = hnew;
       p.hp[o] = hpv;
       p.aux[o] = gh[2];
       float* gs = p.gates + ((long)t * N + n_own) * 3 * H;
@@ -187,7 +233,7 @@ __global__ __launch_bounds__(256) void gru_rollout_fwd_kernel(GruRolloutParams p
 #pragma unroll
       for (int g = 0; g < 3; ++g) gx[g] = gnext[g];
     }
-    grid_arrive(p.counter);  // (its workgroup barrier also frees Xs / part for the next step)
+    __syncthreads();  // Xs / part are free for the next step
   }
 }
 
@@ -202,9 +248,9 @@ __global__ __launch_bounds__(256) void gru_rollout_bwd_kernel(GruRolloutParams p
   const int tid = threadIdx.x;
   const int u = tid >> 4, sl = tid & 15;
   const int n_own = sl;
-  const int j = blockIdx.x * RO_UNITS + u;
+  if (blockIdx.x % p.spread) return;
+  const int j = (blockIdx.x / p.spread) * RO_UNITS + u;
   const int N = p.N, T = p.T;
-  const unsigned W = gridDim.x;
   const bool fin = n_own < N;
 
   float w[SL];  // row j of W_hh^T = column j of W_hh, slice sl of the 3H gate rows
@@ -252,6 +298,10 @@ __global__ __launch_bounds__(256) void gru_rollout_bwd_kernel(GruRolloutParams p
       const float dnp = dn * (1.f - cur.nn * cur.nn);
       const float drp = dnp * cur.hn * cur.r * (1.f - cur.r);
       const float dzp = dz * cur.z * (1.f - cur.z);
+      unsigned long long* e = p.ex + (long)(t & 1) * N * GH + (long)n_own * GH;
+      ex_store(e + j, drp, (unsigned)(T - t));  // first: the other workgroups are waiting for them
+      ex_store(e + H + j, dzp, (unsigned)(T - t));
+      ex_store(e + 2 * H + j, dnp * cur.r, (unsigned)(T - t));
       const long b = (long)t * N + n_own;
       float* a = p.dgi + b * GH;
       a[j] = drp;
@@ -263,9 +313,7 @@ __global__ __launch_bounds__(256) void gru_rollout_bwd_kernel(GruRolloutParams p
       c[2 * H + j] = dnp * cur.r;
       acc0 = d * cur.z;
     }
-    grid_arrive(p.counter);
-    grid_wait(p.counter, W * (unsigned)(T - t));
-    stage_operand<GH, NT, false>(Xs, p.dgh + (long)t * N * GH, nullptr, N);
+    stage_exchanged<GH, NT, false>(Xs, p.ex + (long)(t & 1) * N * GH, (unsigned)(T - t), nullptr, N);
     __syncthreads();
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
@@ -291,7 +339,7 @@ __global__ __launch_bounds__(256) void gru_rollout_bwd_kernel(GruRolloutParams p
       for (int q = 1; q < 4; ++q) s4 += *reinterpret_cast<const f32x4*>(pr + 4 * q);
       cr = (acc0 + ((s4[0] + s4[1]) + (s4[2] + s4[3]))) * cur.mk;
     }
-    // Xs / part are next written after the next step's grid_arrive (a workgroup barrier)
+    __syncthreads();  // Xs / part are free for the next step
   }
   if (fin) p.dh0[(long)n_own * H + j] = cr;
 }
@@ -311,8 +359,9 @@ int launch_rollout(const GruRolloutParams& p, bool bwd, hipStream_t s) {
       return 1;
     done = true;
   }
-  vlnce_zero(reinterpret_cast<float*>(p.counter), 1, 1, 1, s);
-  const dim3 grid(H / RO_UNITS);
+  const long words = 2L * 2 * p.N * (bwd ? K : H);  // [2][N][K] pairs as 32-bit words
+  vlnce_zero(reinterpret_cast<float*>(p.ex), 1, (int)words, words, s);
+  const dim3 grid(H / RO_UNITS * p.spread);
   if (bwd)
     hipLaunchKernelGGL((gru_rollout_bwd_kernel<H, NT>), grid, dim3(256), lds, s, p);
   else
@@ -320,7 +369,12 @@ int launch_rollout(const GruRolloutParams& p, bool bwd, hipStream_t s) {
   return 0;
 }
 
-int dispatch_rollout(const GruRolloutParams& p, int H, bool bwd, hipStream_t s) {
+int dispatch_rollout(GruRolloutParams& p, int H, bool bwd, hipStream_t s) {
+  static const int spread = [] {
+    const char* e = getenv("VLNCE_ROLLOUT_ONE_XCD");
+    return e && e[0] == '1' ? 8 : 1;
+  }();
+  p.spread = spread;
   const bool small = p.N <= 8;
   switch (H) {
     case 64: return small ? launch_rollout<64, 8>(p, bwd, s) : launch_rollout<64, 16>(p, bwd, s);
@@ -337,11 +391,15 @@ extern "C" int vlnce_gru_rollout_supported(int N, int H) {
   return N > 0 && N <= RO_MAXN && (H == 64 || H == 128 || H == 256 || H == 512);
 }
 
+extern "C" long vlnce_gru_rollout_workspace_bytes(int N, int H) {
+  return vlnce_gru_rollout_supported(N, H) ? 2L * N * 3 * H * 8 : 0;
+}
+
 extern "C" int vlnce_gru_rollout_fwd(const float* gi, const float* h0, const uint8_t* mask,
                                      const float* w_hh, const float* b_hh, float* hp, float* out,
-                                     float* gates, float* aux, unsigned* sync_word, int T, int N,
+                                     float* gates, float* aux, void* workspace, int T, int N,
                                      int H, vlnce_stream_t stream) {
-  VLNCE_CHECK_ARG(gi && h0 && mask && w_hh && b_hh && hp && out && gates && aux && sync_word,
+  VLNCE_CHECK_ARG(gi && h0 && mask && w_hh && b_hh && hp && out && gates && aux && workspace,
                   "gru_rollout_fwd: null argument");
   VLNCE_CHECK_ARG(T > 0, "gru_rollout_fwd: T must be positive");
   VLNCE_CHECK_ARG(vlnce_gru_rollout_supported(N, H), "gru_rollout_fwd: unsupported N/H (%d,%d)", N, H);
@@ -355,7 +413,7 @@ extern "C" int vlnce_gru_rollout_fwd(const float* gi, const float* h0, const uin
   p.out = out;
   p.gates = gates;
   p.aux = aux;
-  p.counter = sync_word;
+  p.ex = static_cast<unsigned long long*>(workspace);
   p.T = T;
   p.N = N;
   VLNCE_CHECK_ARG(dispatch_rollout(p, H, false, reinterpret_cast<hipStream_t>(stream)) == 0,
@@ -367,9 +425,9 @@ extern "C" int vlnce_gru_rollout_fwd(const float* gi, const float* h0, const uin
 extern "C" int vlnce_gru_rollout_bwd(const float* dout, const float* dh_final, const float* gates,
                                      const float* aux, const float* hp, const uint8_t* mask,
                                      const float* w_hh_t, float* dgi, float* dgh, float* dh0,
-                                     unsigned* sync_word, int T, int N, int H,
+                                     void* workspace, int T, int N, int H,
                                      vlnce_stream_t stream) {
-  VLNCE_CHECK_ARG(gates && aux && hp && mask && w_hh_t && dgi && dgh && dh0 && sync_word,
+  VLNCE_CHECK_ARG(gates && aux && hp && mask && w_hh_t && dgi && dgh && dh0 && workspace,
                   "gru_rollout_bwd: null argument");
   VLNCE_CHECK_ARG(T > 0, "gru_rollout_bwd: T must be positive");
   VLNCE_CHECK_ARG(vlnce_gru_rollout_supported(N, H), "gru_rollout_bwd: unsupported N/H (%d,%d)", N, H);
@@ -384,7 +442,7 @@ extern "C" int vlnce_gru_rollout_bwd(const float* dout, const float* dh_final, c
   p.dgi = dgi;
   p.dgh = dgh;
   p.dh0 = dh0;
-  p.counter = sync_word;
+  p.ex = static_cast<unsigned long long*>(workspace);
   p.T = T;
   p.N = N;
   VLNCE_CHECK_ARG(dispatch_rollout(p, H, true, reinterpret_cast<hipStream_t>(stream)) == 0,

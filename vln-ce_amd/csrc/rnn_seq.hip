@@ -36,7 +36,16 @@ struct RnnSeqParams {
   int B, L;
 };
 
-__device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }
+// Gate non-linearities on the hardware exp2 / rcp (v_exp_f32, v_rcp_f32; absolute error < 3e-7,
+// tests at 1e-5): libm's expf / tanhf are ~25 / ~50 VALU instructions each and a step evaluates
+// five per (row, unit) -- 2/3 of the forward step's instruction stream, which the two waves of a
+// SIMD execute one after the other (measured: 5.0 -> see profiles/r03_f_seqbench.txt us per step).
+__device__ __forceinline__ float sigm(float x) {
+  return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+__device__ __forceinline__ float tanh_fast(float x) {
+  return 1.f - 2.f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(2.8853900817779268f * x) + 1.f);
+}
 
 // fp32 recurrent product on the bf16 matrix pipe: both operands are split exactly into three
 // bf16 planes (truncation: 8 + 8 + 8 mantissa bits) and multiplied as the six plane products of
@@ -141,7 +150,7 @@ __global__ __launch_bounds__(NW * 64) void rnn_seq_fwd_kernel(RnnSeqParams p) {
   // The input projection of a step is fetched ONE STEP AHEAD (gx): read at the top of the step
   // it would put a global-load round trip in front of every step's MFMAs.
   float gx[G][NTW][4];
-  auto fetch = [&](int s) {
+  auto fetch_into = [&](int s, float (&dst)[G][NTW][4]) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const bool active = s < len[r];
@@ -152,10 +161,11 @@ __global__ __launch_bounds__(NW * 64) void rnn_seq_fwd_kernel(RnnSeqParams p) {
       for (int nt = 0; nt < NTW; ++nt) {
         const int u = wave * (H / NW) + nt * 16 + l15;
 #pragma unroll
-        for (int gt = 0; gt < G; ++gt) gx[gt][nt][r] = active ? row[gt * H + u] : 0.f;
+        for (int gt = 0; gt < G; ++gt) dst[gt][nt][r] = active ? row[gt * H + u] : 0.f;
       }
     }
   };
+  auto fetch = [&](int s) { fetch_into(s, gx); };
   fetch(0);
 
   for (int s = 0; s < Lt; ++s) {
@@ -204,9 +214,9 @@ __global__ __launch_bounds__(NW * 64) void rnn_seq_fwd_kernel(RnnSeqParams p) {
         float hnew;
         if (KIND == 0) {
           const float ig = sigm(acc[0][nt][r]), fg = sigm(acc[1][nt][r]);
-          const float gg = tanhf(acc[2][nt][r]), og = sigm(acc[3][nt][r]);
+          const float gg = tanh_fast(acc[2][nt][r]), og = sigm(acc[3][nt][r]);
           const float cn = fg * creg[nt][r] + ig * gg;
-          hnew = og * tanhf(cn);
+          hnew = og * tanh_fast(cn);
           if (active) {
             creg[nt][r] = cn;
             if (p.gates[d]) {
@@ -221,7 +231,7 @@ __global__ __launch_bounds__(NW * 64) void rnn_seq_fwd_kernel(RnnSeqParams p) {
         } else {
           const float rg = sigm(acc[0][nt][r]), zg = sigm(acc[1][nt][r]);
           const float hn = acc[2][nt][r];
-          const float ng = tanhf(xn[nt][r] + rg * hn);
+          const float ng = tanh_fast(xn[nt][r] + rg * hn);
           hnew = (1.f - zg) * ng + zg * hreg[nt][r];
           if (active && p.gates[d]) {
             float* gs = p.gates[d] + ((long)tt * B + b) * (G * H);
@@ -377,7 +387,7 @@ __global__ __launch_bounds__(NW * 64) void rnn_seq_bwd_kernel(RnnSeqParams p) {
             const float ig = cg[0][nt][r], fg = cg[1][nt][r], gg = cg[2][nt][r], og = cg[3][nt][r];
             const float c = ca[nt][r];
             const float cp = cprev[nt][r];  // (0 at the sequence's first step)
-            const float tc = tanhf(c);
+            const float tc = tanh_fast(c);
             const float dct = dc[nt][r] + dht * og * (1.f - tc * tc);
             dpre[0] = dct * gg * ig * (1.f - ig);
             dpre[1] = dct * cp * fg * (1.f - fg);

@@ -623,18 +623,19 @@ def lstm_cell(x_gates, h_prev, c_prev, w_hh, b_hh):
     return LSTMGatesFn.apply(x_gates, gh, c_prev)
 
 
-_SYNC_WORDS = {}
+_ROLLOUT_WS = {}
 
 
-def _sync_word(dev):
-    """The arrival counter of a persistent rollout launch: one 4-byte word per (device, stream) --
-    launches on one stream are ordered, so they can share it; the library zeroes it per call."""
+def _rollout_workspace(dev, N, H):
+    """The exchange area of a persistent rollout launch: one per (device, stream) -- launches on
+    one stream are ordered, so they can share it; the library zeroes it per call."""
+    nbytes = L().gru_rollout_workspace_bytes(N, H)
     if dev.type == "cuda" and torch.cuda.is_current_stream_capturing():
-        return torch.zeros(4, dtype=torch.int32, device=dev)  # lives in the graph's own pool
+        return torch.empty(nbytes, dtype=torch.uint8, device=dev)  # lives in the graph's own pool
     key = (str(dev), torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0)
-    w = _SYNC_WORDS.get(key)
-    if w is None:
-        w = _SYNC_WORDS[key] = torch.zeros(4, dtype=torch.int32, device=dev)
+    w = _ROLLOUT_WS.get(key)
+    if w is None or w.numel() < nbytes:
+        w = _ROLLOUT_WS[key] = torch.empty(max(nbytes, 1 << 19), dtype=torch.uint8, device=dev)
     return w
 
 
@@ -672,7 +673,7 @@ class MaskedRNNSeqFn(Function):
         ctx.rollout = (not lstm) and T > 1 and lib.gru_rollout_supported(N, H)
         if ctx.rollout:  # the whole recurrence in ONE launch (gru_rollout.hip)
             lib.gru_rollout_fwd(gi3, h0, m2.contiguous(), w_hh, b_hh, hp, out, gates, aux,
-                                _sync_word(dev), T, N, H)
+                                _rollout_workspace(dev, N, H), T, N, H)
             ctx.lstm, ctx.dims = lstm, (T, N, H, GH)
             ctx.save_for_backward(hp, gates, aux, m2, w_hh, h0)
             return out.view(T * N, H), out[T - 1], out[T - 1]
@@ -713,7 +714,7 @@ class MaskedRNNSeqFn(Function):
                 carry = _f32c(dc_fin) if carry is None else carry + dc_fin
             lib.gru_rollout_bwd(None if dout is None else _f32c(dout), carry, gates, aux, hp,
                                 m2.contiguous(), w_hh.t().contiguous(), dgi, dgh, dh0,
-                                _sync_word(dev), T, N, H)
+                                _rollout_workspace(dev, N, H), T, N, H)
             dw = torch.empty_like(w_hh)
             lib.gemm(dgh.view(T * N, GH), GH, 1, hp.view(T * N, H), H, 1, dw, H, GH, H, T * N)
             db = torch.empty((GH,), device=dev, dtype=torch.float32)
