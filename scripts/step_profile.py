@@ -19,10 +19,12 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=12)
 ap.add_argument("--warmup", type=int, default=6)
 ap.add_argument("--num-envs", type=int, default=64)
+ap.add_argument("--trainable-encoders", action="store_true")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
-policy = vlnce_amd.build_model(vlnce_amd.make_config("CMAPolicy"), *vlnce_amd.make_spaces(256, 256)).to(dev)
+over = {"RGB_ENCODER.trainable": True, "DEPTH_ENCODER.trainable": True} if args.trainable_encoders else {}
+policy = vlnce_amd.build_model(vlnce_amd.make_config("CMAPolicy", **over), *vlnce_amd.make_spaces(256, 256)).to(dev)
 opt = torch.optim.Adam(policy.parameters(), lr=2.5e-4)
 vlnce_amd.AuxLosses.activate()
 batches = [bench.synth_batch(args.num_envs, 256, 80, dev, seed=1 + 101 * i) for i in range(4)]

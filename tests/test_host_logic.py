@@ -289,6 +289,34 @@ def test_instruction_dedup_equals_row_by_row_encoding(sim, policy_name, final_on
         assert torch.allclose(a, b, atol=1e-5, rtol=1e-4)
 
 
+@pytest.mark.parametrize("rows", [4, 20])
+def test_instruction_length_counts_embedded_vectors_not_token_ids(sim, rows):
+    """instruction_encoder.py:79-80 overwrites the token-id count of :72 with "steps whose EMBEDDED
+    vector is not all-zero": a non-pad token whose table row is zero (pretrained tables have
+    such rows) does not count.  Both the plain and the de-duplicating path follow the table."""
+    from oracle import policy_cpu as oc
+    from vlnce_amd.encoders.instruction_encoder import InstructionEncoder
+
+    torch.manual_seed(5)
+    cfg = vlnce_amd.make_config("CMAPolicy").MODEL.INSTRUCTION_ENCODER
+    cfg.final_state_only = True
+    enc = InstructionEncoder(cfg)
+    ref = oc.InstructionEncoder(cfg)
+    ref.load_state_dict(enc.state_dict())
+    with torch.no_grad():
+        enc.embedding_layer.weight[7] = 0.0
+        ref.embedding_layer.weight[7] = 0.0
+    base = torch.zeros(2, 200, dtype=torch.long)
+    base[0, :6] = torch.tensor([3, 9, 7, 7, 11, 7])   # zero-row token inside and at the end
+    base[1, :4] = torch.tensor([5, 6, 8, 2])
+    tokens = base.repeat(rows // 2, 1)
+    enc.DEDUP_MIN_ROWS = 16
+    got = enc({"instruction": tokens})
+    want = ref({"instruction": tokens})
+    assert got.shape == want.shape
+    assert torch.allclose(got, want, atol=1e-5, rtol=1e-5)
+
+
 def test_split_weights_is_gpu_only_and_channel_gated():
     """The bf16-plane split belongs to the HIP convolution kernel: on the CPU (hostsim) path, and
     for weights whose input-channel count the kernel does not take, ops.split_weights hands back

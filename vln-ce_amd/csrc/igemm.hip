@@ -1667,9 +1667,17 @@ extern "C" int vlnce_conv2d_wgrad(const float* x, const float* dy, float* dw_ohw
   VLNCE_CHECK_ARG(aligned16(dy) && aligned16(x) && aligned16(dw_ohwi),
                   "conv2d_wgrad: operands must be 16-byte aligned");
   fill_epilogue(p, nullptr);
-  const long tiles = (long)ceil_div(p.M, 64) * ceil_div(p.N, 64);
+  // 128x128 tiles where both output dimensions allow (half the operand traffic through LDS per
+  // FLOP); VLNCE_WGRAD_TILE=64 keeps the 64x64 tiles everywhere (A/B switch)
+  static const int tile_pref = [] {
+    const char* e = getenv("VLNCE_WGRAD_TILE");
+    return e ? atoi(e) : 128;
+  }();
+  const bool big = tile_pref >= 128 && p.M >= 128 && p.N >= 128;
+  const int T = big ? 128 : 64;
+  const long tiles = (long)ceil_div(p.M, T) * ceil_div(p.N, T);
   const int KT = ceil_div(p.K, BK);
-  long sk = (1024 + tiles - 1) / tiles;
+  long sk = ((big ? 512 : 1024) + tiles - 1) / tiles;
   if (sk > KT / 4) sk = KT / 4;
   if (sk > 512) sk = 512;
   p.splitk = sk < 2 ? 1 : (int)sk;
@@ -1677,5 +1685,6 @@ extern "C" int vlnce_conv2d_wgrad(const float* x, const float* dy, float* dw_ohw
   if (p.splitk > 1) {
     vlnce_zero(dw_ohwi, 1, p.M * p.N, (long)p.M * p.N, s);
   }
+  if (big) return launch<128, 128, 2, 2, A_TRANS, B_IM2COL>(p, s);
   return launch<64, 64, 2, 2, A_TRANS, B_IM2COL>(p, s);
 }

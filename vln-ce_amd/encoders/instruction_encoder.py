@@ -85,45 +85,66 @@ class InstructionEncoder(nn.Module):
         cfg = self.config
         if cfg.sensor_uuid == "instruction":
             tokens = observations["instruction"].long()
+            # :79-80 a step counts iff its embedded vector is not all-zero (the token-id count of
+            # :72 is overwritten upstream): per-token flag of the table, gathered like the rows
+            nonzero_row = (self.embedding_layer.weight.detach() != 0).any(dim=1)
             if tokens.size(0) >= self.DEDUP_MIN_ROWS and os.environ.get("VLNCE_INSTR_DEDUP", "1") != "0":
-                uniq, inverse = self._distinct_rows(tokens)
+                uniq, inverse, lengths, lmin, lmax = self._distinct_rows(tokens, nonzero_row)
                 if uniq is not None and uniq.size(0) < tokens.size(0):
                     out = self._encode(ops.embedding(uniq, self.embedding_layer.weight,
-                                                     self.embedding_layer.padding_idx))
+                                                     self.embedding_layer.padding_idx),
+                                       (lengths, lmin, lmax))
                     # [U, C, L] / [U, H] -> rows; the stacked bidirectional final state is [2, U, H]
                     dim = 1 if (cfg.final_state_only and out.dim() == 3) else 0
                     return out.index_select(dim, inverse)
             feats = ops.embedding(tokens, self.embedding_layer.weight,
                                   self.embedding_layer.padding_idx)
-        else:
-            feats = observations["rxr_instruction"]
-        return self._encode(feats)
+            lengths = nonzero_row[tokens].sum(dim=1)
+            lmin, lmax = (int(v) for v in torch.stack([lengths.min(), lengths.max()]).tolist())
+            return self._encode(feats, (lengths, lmin, lmax))
+        return self._encode(observations["rxr_instruction"])
 
     @staticmethod
-    def _distinct_rows(tokens):
-        """(distinct rows [U, L], inverse [B]) of an int64 token matrix, or (None, None).
-        torch.unique(dim=0) sorts whole rows (a 2 ms block sort for 500 x 200 tokens); here rows
-        are told apart by a 64-bit multiplicative hash, the [B] hash vector is what gets sorted,
-        and the result is verified against the tokens (a collision falls back to no de-duplication)."""
+    def _distinct_rows(tokens, nonzero_row):
+        """(distinct rows [U, L], inverse [B], their lengths [U], min length, max length) of an
+        int64 token matrix, or (None, ...) -- with ONE host sync.  torch.unique(dim=0) sorts whole
+        rows (a 2 ms block sort for 500 x 200 tokens) and syncs for its output size; here rows are
+        told apart by a 64-bit multiplicative hash, the [B] hash vector is sorted and ranked with
+        fixed-size operations, the candidates are verified against the tokens on the device (a
+        collision falls back to no de-duplication), and the number of distinct rows, the verdict
+        and the length range come back in one transfer."""
         B, L = tokens.shape
-        mult = torch.arange(1, L + 1, device=tokens.device, dtype=torch.int64) * 0x9E3779B97F4A7C15
+        dev = tokens.device
+        mult = torch.arange(1, L + 1, device=dev, dtype=torch.int64) * 0x9E3779B97F4A7C15
         key = ((tokens + 0x632BE59BD9B4E019) * mult).sum(dim=1)  # int64 wrap-around arithmetic
-        _, inverse = torch.unique(key, return_inverse=True)
-        n_uniq = int(inverse.max().item()) + 1
-        # first row carrying each key
-        first = torch.full((n_uniq,), B, device=tokens.device, dtype=torch.int64)
-        first.scatter_reduce_(0, inverse, torch.arange(B, device=tokens.device), reduce="amin")
-        uniq = tokens.index_select(0, first)
-        if not torch.equal(uniq.index_select(0, inverse), tokens):
-            return None, None
-        return uniq, inverse
+        skey, order = key.sort()
+        new_group = torch.ones(B, device=dev, dtype=torch.int64)
+        new_group[1:] = (skey[1:] != skey[:-1]).to(torch.int64)
+        rank = new_group.cumsum(0) - 1                       # group index of every sorted row
+        inverse = torch.empty(B, device=dev, dtype=torch.int64)
+        inverse[order] = rank
+        # first row carrying each key (slots past the number of groups keep B -> clamped: a real row)
+        first = torch.full((B,), B, device=dev, dtype=torch.int64)
+        first.scatter_reduce_(0, inverse, torch.arange(B, device=dev), reduce="amin")
+        cand = tokens.index_select(0, first.clamp_max(B - 1))
+        same = (cand.index_select(0, inverse) == tokens).all()
+        lengths = nonzero_row[cand].sum(dim=1)
+        n_uniq, ok, lmin, lmax = torch.stack(
+            [rank[-1] + 1, same.to(torch.int64), lengths.min(), lengths.max()]).tolist()
+        if not ok:
+            return None, None, None, 0, 0
+        return cand[:n_uniq], inverse, lengths[:n_uniq], int(lmin), int(lmax)
 
-    def _encode(self, feats):
+    def _encode(self, feats, length_info=None):
         cfg = self.config
-        # :77-78 a step counts iff its feature vector is not all-zero; pack_padded_sequence
-        # then keeps the first `length` steps of each sample.  One host sync, as upstream (.cpu()).
-        lengths = (feats != 0.0).any(dim=2).sum(dim=1)
-        lmin, lmax = (int(v) for v in torch.stack([lengths.min(), lengths.max()]).tolist())
+        if length_info is None:
+            # :79-80 (rxr features) a step counts iff its feature vector is not all-zero;
+            # pack_padded_sequence then keeps the first `length` steps of each sample.  One host
+            # sync, as upstream (.cpu()).
+            lengths = (feats != 0.0).any(dim=2).sum(dim=1)
+            lmin, lmax = (int(v) for v in torch.stack([lengths.min(), lengths.max()]).tolist())
+        else:
+            lengths, lmin, lmax = length_info
         if lmin <= 0:
             raise RuntimeError("Length of all samples has to be greater than 0, "
                                "but found an element in 'lengths' that is <= 0")
