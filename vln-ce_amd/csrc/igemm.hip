@@ -1667,11 +1667,12 @@ extern "C" int vlnce_conv2d_wgrad(const float* x, const float* dy, float* dw_ohw
   VLNCE_CHECK_ARG(aligned16(dy) && aligned16(x) && aligned16(dw_ohwi),
                   "conv2d_wgrad: operands must be 16-byte aligned");
   fill_epilogue(p, nullptr);
-  // 128x128 tiles where both output dimensions allow (half the operand traffic through LDS per
-  // FLOP); VLNCE_WGRAD_TILE=64 keeps the 64x64 tiles everywhere (A/B switch)
+  // VLNCE_WGRAD_TILE=128: 128x128 tiles where both output dimensions allow.  Measured slower on
+  // the trainable-encoder step (46.7 vs 45.0 ms, profiles/r03_g_*): fewer workgroups per
+  // split-K slice, and the transposed-operand LDS writes do not get cheaper.  Default 64.
   static const int tile_pref = [] {
     const char* e = getenv("VLNCE_WGRAD_TILE");
-    return e ? atoi(e) : 128;
+    return e ? atoi(e) : 64;
   }();
   const bool big = tile_pref >= 128 && p.M >= 128 && p.N >= 128;
   const int T = big ? 128 : 64;
