@@ -174,7 +174,13 @@ __global__ __launch_bounds__(NW * 64) void rnn_seq_fwd_kernel(RnnSeqParams p) {
   auto fetch = [&](int s) { fetch_into(s, gx); };
   fetch(0);
 
+#ifdef RNN_SEQ_DBG_TIME
+  long long f_m = 0, f_g = 0, f_b = 0;
+#endif
   for (int s = 0; s < Lt; ++s) {
+#ifdef RNN_SEQ_DBG_TIME
+    const long long f_t0 = clock64();
+#endif
     const int cur = s & 1;
     f32x4 acc[G][NTW];
     float xn[NTW][4];  // GRU: input part of the n gate
@@ -208,6 +214,9 @@ __global__ __launch_bounds__(NW * 64) void rnn_seq_fwd_kernel(RnnSeqParams p) {
             acc[gt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                 a[X3_PA[q]], wp[gt][nt][ks].p[X3_PB[q]], acc[gt][nt], 0, 0, 0);
     }
+#ifdef RNN_SEQ_DBG_TIME
+    const long long f_t1 = clock64();
+#endif
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const bool active = s < len[r];
@@ -257,8 +266,22 @@ __global__ __launch_bounds__(NW * 64) void rnn_seq_fwd_kernel(RnnSeqParams p) {
         for (int q = 0; q < 3; ++q) h_pl[cur ^ 1][q][row_i][u] = hw[q];
       }
     }
+#ifdef RNN_SEQ_DBG_TIME
+    const long long f_t2 = clock64();
+#endif
     __syncthreads();
+#ifdef RNN_SEQ_DBG_TIME
+    const long long f_t3 = clock64();
+    f_m += f_t1 - f_t0;
+    f_g += f_t2 - f_t1;
+    f_b += f_t3 - f_t2;
+#endif
   }
+#ifdef RNN_SEQ_DBG_TIME
+  if (blockIdx.x == 0 && blockIdx.y == 0 && (tid == 0 || tid == 64 * (NW - 1)))
+    printf("rnn_seq_fwd wave %d: %d steps; per step: init+fetch+reads+MFMA %lld, gates+stores+LDS write %lld, "
+           "barrier %lld cycles\n", wave, Lt, f_m / Lt, f_g / Lt, f_b / Lt);
+#endif
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int b = b0 + quad * 4 + r;
@@ -357,7 +380,13 @@ __global__ __launch_bounds__(NW * 64) void rnn_seq_bwd_kernel(RnnSeqParams p) {
   fetch(Lt - 1, pg, pa, pd);
   fetch_prev(Lt - 2, pa_prev);
 
+#ifdef RNN_SEQ_DBG_TIME
+  long long d_a = 0, d_b1 = 0, d_m = 0, d_b2 = 0;
+#endif
   for (int s = Lt - 1; s >= 0; --s) {
+#ifdef RNN_SEQ_DBG_TIME
+    const long long d_t0 = clock64();
+#endif
     float keep_z[NTW][4];  // GRU: dh * z carried straight to h_prev
     float cg[G][NTW][4], ca[NTW][4], cprev[NTW][4], cd[NTW][4];
 #pragma unroll
@@ -433,7 +462,13 @@ __global__ __launch_bounds__(NW * 64) void rnn_seq_bwd_kernel(RnnSeqParams p) {
         }
       }
     }
+#ifdef RNN_SEQ_DBG_TIME
+    const long long d_t1 = clock64();
+#endif
     __syncthreads();
+#ifdef RNN_SEQ_DBG_TIME
+    const long long d_t2 = clock64();
+#endif
     f32x4 acc[NTW];
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -458,8 +493,23 @@ __global__ __launch_bounds__(NW * 64) void rnn_seq_bwd_kernel(RnnSeqParams p) {
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt) dh[nt][r] = acc[nt][r] + keep_z[nt][r];
     }
+#ifdef RNN_SEQ_DBG_TIME
+    const long long d_t3 = clock64();
+#endif
     __syncthreads();
+#ifdef RNN_SEQ_DBG_TIME
+    const long long d_t4 = clock64();
+    d_a += d_t1 - d_t0;
+    d_b1 += d_t2 - d_t1;
+    d_m += d_t3 - d_t2;
+    d_b2 += d_t4 - d_t3;
+#endif
   }
+#ifdef RNN_SEQ_DBG_TIME
+  if (blockIdx.x == 0 && blockIdx.y == 0 && (tid == 0 || tid == 64 * (NW - 1)))
+    printf("rnn_seq_bwd wave %d: %d steps; per step: gates+LDS write %lld, barrier %lld, reads+MFMA %lld, "
+           "barrier %lld cycles\n", wave, Lt, d_a / Lt, d_b1 / Lt, d_m / Lt, d_b2 / Lt);
+#endif
 }
 
 template <int KIND>
