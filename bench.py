@@ -39,6 +39,8 @@ import torch.distributed as dist  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense
+HBM_PEAK_TBS = 8.0           # MI355X_MICROARCH.md: HBM3E spec
+HBM_ACHIEVABLE_TBS = 6.3     # MI355X_MICROARCH.md: measured float4 copy (79 % of spec)
 # algorithmic FLOPs per policy-step (one env), CMA 256x256 L=80
 CMA_FWD_GFLOP = 11.461
 CMA_FWD_BWD_FROZEN_GFLOP = 11.630
@@ -228,7 +230,12 @@ def conv_kernel_time(policy, obs, dev, repeats=3):
         e1.record()
         events.append((e0, e1))
         y = out[0] if isinstance(out, tuple) else out
-        meta.append((2.0 * y.numel() * w[0].numel(), ops.L().conv2d_last_path()))
+        # algorithmic HBM bytes of the launch: input (+ second input and the materialised block
+        # output of a fused block end), weights, output -- each once
+        nbytes = 4.0 * (x.numel() + w.numel() + y.numel())
+        if k.get("x2") is not None:
+            nbytes += 4.0 * x.numel() * (2 if k.get("side_out") is not None else 1)
+        meta.append((2.0 * y.numel() * w[0].numel(), ops.L().conv2d_last_path(), nbytes))
         return out
 
     def trunks():
@@ -287,14 +294,27 @@ def conv_kernel_time(policy, obs, dev, repeats=3):
     log(f"conv attribution: {n} launches, {conv_ms:.3f} ms of a {whole:.3f} ms eager single-stream "
         f"trunk pair (empty event pair {1e3 * empty:.1f} us, host issue {host_ms:.1f} ms)")
     by_path = {}
-    for t, (fl, path) in zip(per_launch, meta):
+    # per-launch floor = max(time of its algorithmic bytes at the achievable HBM rate, time of its
+    # instruction FLOPs on the pipe it runs on); `hbm_bound` = launches whose floor is the HBM term
+    floor_ms, hbm_bound_ms, hbm_bound_n, hbm_floor_ms = 0.0, 0.0, 0, 0.0
+    for t, (fl, path, nb) in zip(per_launch, meta):
         d = by_path.setdefault(path, {"launches": 0, "ms": 0.0, "flop": 0.0})
         d["launches"] += 1
         d["ms"] += max(t - empty, 0.0)
         d["flop"] += fl
+        t_hbm = nb / (HBM_ACHIEVABLE_TBS * 1e12) * 1e3
+        t_pipe = (fl / (FP32_MFMA_PEAK_TFLOPS * 1e12) if path == 0
+                  else 6.0 * fl / (BF16_MFMA_PEAK_TFLOPS * 1e12)) * 1e3
+        floor_ms += max(t_hbm, t_pipe)
+        if t_hbm >= t_pipe:
+            hbm_bound_n += 1
+            hbm_bound_ms += max(t - empty, 0.0)
+            hbm_floor_ms += t_hbm
     res = {"n": n, "conv_ms": conv_ms, "eager_trunks_ms": whole, "empty_pair_us": 1e3 * empty,
            "host_issue_ms": host_ms, "reason": None, "by_path": by_path,
-           "flop": sum(fl for fl, _ in meta)}
+           "flop": sum(m[0] for m in meta), "bytes": sum(m[2] for m in meta),
+           "floor_ms": floor_ms, "hbm_bound_n": hbm_bound_n, "hbm_bound_ms": hbm_bound_ms,
+           "hbm_floor_ms": hbm_floor_ms}
     if not (0.0 < conv_ms <= whole * 1.001):
         res["reason"] = (f"per-launch event sum {conv_ms:.3f} ms is not inside the eager "
                          f"single-stream pass {whole:.3f} ms")
@@ -563,11 +583,14 @@ def main():
             "roofline": {"bound": "mfma",
                          "kernel": "conv2d fwd of the two visual trunks: conv_p3_kernel (stride-1 "
                                    "KxK: A transformed once per workgroup into an LDS patch, B "
-                                   "fragments from L2) + conv_x3_kernel (1x1 / strided: im2col "
-                                   "K-tiles through LDS), both fp32 operands split exactly into 3 "
-                                   "bf16 planes, 6 x v_mfma_f32_32x32x16_bf16 per 32x32x16 block, "
-                                   "fp32 accumulate; igemm_kernel (v_mfma_f32_32x32x2_f32) for the "
-                                   "stems and the handful-of-tiles layers",
+                                   "fragments from L2), conv_u3_kernel (wide 1x1: no producer "
+                                   "waves, the matrix waves transform the next K-chunk between "
+                                   "their MFMAs) and conv_x3_kernel (the other 1x1 / strided: "
+                                   "im2col K-tiles through LDS, 8 producer + 8 matrix waves); all "
+                                   "three: fp32 operands split exactly into 3 bf16 planes, 6 x "
+                                   "v_mfma_f32_32x32x16_bf16 per 32x32x16 block, fp32 accumulate; "
+                                   "igemm_kernel (v_mfma_f32_32x32x2_f32) for the stems and the "
+                                   "handful-of-tiles layers",
                          "achieved": round(achieved, 2) if ok else None,
                          "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4) if ok else None,
@@ -605,6 +628,23 @@ def main():
                                        "(profiles/r03_e_conv_accuracy_*.txt; the truncation split of "
                                        "round 2 was 2-5x); VLNCE_CONV_MATH=f32 selects the fp32-MFMA "
                                        "kernel everywhere",
+                         "per_launch_floor": {
+                             "what": "sum over the conv launches of max(algorithmic bytes / "
+                                     "achievable HBM rate, instruction FLOPs / the peak of the pipe "
+                                     "the launch runs on): the time the launches would take if "
+                                     "each sat on its own roofline; hbm_bound = the launches whose "
+                                     "HBM term is the larger one",
+                             "hbm_achievable_TBps": HBM_ACHIEVABLE_TBS, "hbm_peak_TBps": HBM_PEAK_TBS,
+                             "floor_ms": round(conv["floor_ms"], 3),
+                             "frac": round(conv["floor_ms"] / conv_ms, 4) if ok else None,
+                             "algorithmic_GB": round(conv["bytes"] / 1e9, 3),
+                             "hbm_bound": {"launches": conv["hbm_bound_n"],
+                                           "ms": round(conv["hbm_bound_ms"], 3),
+                                           "floor_ms": round(conv["hbm_floor_ms"], 3),
+                                           "achieved_TBps": (round(
+                                               conv["hbm_floor_ms"] * HBM_ACHIEVABLE_TBS
+                                               / conv["hbm_bound_ms"], 2)
+                                               if conv["hbm_bound_ms"] > 0 else None)}},
                          "launches_per_step": n_conv,
                          "avg_launch_ms": round(conv_ms / max(n_conv, 1), 4),
                          "kernel_ms_per_step": round(conv_ms, 3),

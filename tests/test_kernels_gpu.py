@@ -854,6 +854,8 @@ P3_CASES = [
                                                         dual="bn")),
     ("p3_dual_id",   2, 16, 16,  64,  64, 1, 1, 0, dict(prologue=True, in_relu=True, dual="identity")),
     ("p3_many_tiles", 40, 32, 32, 64, 64, 3, 1, 1, dict(stats=True)),            # several tiles per CU
+    ("u3_rag_768",   2, 13, 11,  96, 768, 1, 1, 0, dict(stats=True)),             # ragged M, 3 column tiles
+    ("u3_scale_act", 5, 16, 16,  64, 256, 1, 1, 0, dict(scale=True, relu=True)),  # epilogue scale/shift/act
 ]
 
 
@@ -873,6 +875,22 @@ def test_conv_p3_every_tile_shape(tile):
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu",
                         "-k", "(conv2d_fwd or bottleneck or block or conv_p3) and not every_tile",
                         "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:]
+
+
+@pytest.mark.parametrize("mode", [2, 3])
+def test_conv_u3_forced(mode):
+    """conv_u3_kernel (1x1, no producer waves) takes a layer
+    only when its 128-row tiles fill the CUs, which no unit-test shape does: force it
+    (VLNCE_U3=2: 64-row tiles, 3: 128-row tiles; read once per process) over the 1x1 cases with
+    N >= 256 -- prologue, statistics, stride 2, dual input, ragged M -- and the block tests."""
+    import subprocess
+    import sys
+    env = dict(os.environ, VLNCE_U3=str(mode))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu",
+                        "-k", "(conv2d_fwd or bottleneck or block or conv_p3) and not every_tile "
+                              "and not u3_forced", "-p", "no:cacheprovider"],
+                       env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:]
 
 

@@ -1084,6 +1084,13 @@ __global__ __launch_bounds__(WAVES * 64) void conv_u3_kernel(IgemmParams p) {
           wave_stats<MT, NT>(acc, p.stat_partial, m0 / BM, p.M - m0, BM, col0, p.N, half, l31);
       }
       // -------------------------------------------------------------- epilogue from registers
+      // (Measured alternatives, round 3, profiles/r03_h_*: turning each 32x32 block around in a
+      // per-wave LDS square and storing 128-byte rows with 16-byte stores -- a quarter of the
+      // store instructions -- changes nothing (126 vs 122 us on the 64->256 layer): the burst
+      // drains at ~5.6 TB/s either way, and what is lost is that a wave's next loads queue
+      // behind its own stores in the one in-order vmcnt.  64-row tiles held to 128 VGPRs so that
+      // TWO workgroups share a CU and one computes while the other drains: 2x slower, 50
+      // registers spilled into the chunk loop.)
       float e_sc[NT], e_sh[NT];
       int e_voff[NT];
 #pragma unroll
@@ -1312,7 +1319,8 @@ int p3_try_launch(const IgemmParams& p, hipStream_t stream) {
   const bool dual = p.A2 != nullptr || p.side_out != nullptr;
   if (dual && !(one && p.stride == 1)) return -1;
   // 1x1 layers wide enough for 256-column tiles: conv_u3_kernel (no producer waves), where its
-  // 128-row tiles fill the CUs.  VLNCE_U3: 0 = off, 1 = default, 2 = force 64-row tiles.  Measured
+  // 128-row tiles fill the CUs.  VLNCE_U3: 0 = off, 1 = default, 2 / 3 = force 64- / 128-row tiles
+  // for every N >= 256 1x1 layer (tests).  Measured
   // per layer at num_envs 64 (profiles/r03_b_convbench_ab_u3.txt): 1.07-1.23x conv_x3_kernel on
   // every N >= 256 layer of the RGB trunk with M >= 16384.
   static const int u3_env = getenv("VLNCE_U3") ? atoi(getenv("VLNCE_U3")) : 1;
@@ -1325,7 +1333,7 @@ int p3_try_launch(const IgemmParams& p, hipStream_t stream) {
       return (double)tiles / (double)(rounds * cus);
     };
     const int bm = u3_env == 2 ? 64 : 128;
-    if (eff(bm) >= 0.8 || u3_env == 2) {
+    if (eff(bm) >= 0.8 || u3_env >= 2) {
       if (u3_waves == 4)   // one wave per SIMD, 64 x 256 tiles (a wave owns 64 x 64): experiment
         return dual ? launch_u3<64, 1, 4>(p, stream) : launch_u3<64, 0, 4>(p, stream);
       if (bm == 128) return dual ? launch_u3<128, 1, 8>(p, stream) : launch_u3<128, 0, 8>(p, stream);
