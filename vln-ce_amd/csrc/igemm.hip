@@ -42,8 +42,12 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
   constexpr int WTN = BN / WN;
   constexpr int MT = WTM / 32;
   constexpr int NT = WTN / 32;
-  constexpr int A_TILE = BM * LDP;
+  constexpr bool A_KMAJOR = AMODE == A_TRANS;
+  constexpr bool B_KMAJOR = BMODE == B_KN || BMODE == B_IM2COL;
+  constexpr int LDT_A = BM + 8, LDT_B = BN + 8;  // k-major LDS images: [BK][B? + 8]
+  constexpr int A_TILE = BM * LDP;  // (BK * LDT <= B? * LDP: the k-major image fits the same space)
   constexpr int B_TILE = BN * LDP;
+  static_assert(BK * LDT_A <= A_TILE && BK * LDT_B <= B_TILE, "k-major LDS image");
   constexpr int STAGE = A_TILE + B_TILE;
   static_assert(WM * WN == 4, "4 waves");
   static_assert(MT >= 1 && NT >= 1, "tile");
@@ -448,18 +452,19 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
     float* As = stage;
     float* Bs = stage + A_TILE;
     if constexpr (AMODE == A_TRANS) {
+      // a k-major operand stays k-major in LDS ([k][BM + 8]): the staged float4 (four
+      // consecutive m of one k) is ONE conflict-free 16-byte write, and the fragment reads below
+      // take one float per lane and MFMA from consecutive m = consecutive banks (the pitch puts
+      // the other half-wave's k + 4 on the other 32 banks).  Writing it transposed into the
+      // [m][k] image of the row-major modes was four 4-byte writes, 4-way bank-conflicted, and
+      // bound the weight-gradient GEMMs (profiles/r03_i_*).
       constexpr int TPR = BM / 4;
       constexpr int KPP = 256 / TPR;
       const int km = tid / TPR;
       const int m4 = (tid - km * TPR) * 4;
 #pragma unroll
-      for (int i = 0; i < A_ROWS; ++i) {
-        const int kk = i * KPP + km;
-        As[(m4 + 0) * LDP + kk] = a_reg[i].x;
-        As[(m4 + 1) * LDP + kk] = a_reg[i].y;
-        As[(m4 + 2) * LDP + kk] = a_reg[i].z;
-        As[(m4 + 3) * LDP + kk] = a_reg[i].w;
-      }
+      for (int i = 0; i < A_ROWS; ++i)
+        *reinterpret_cast<f32x4*>(As + (i * KPP + km) * LDT_A + m4) = a_reg[i];
     } else {
       if (p.in_scale != nullptr) {
 #pragma unroll
@@ -502,13 +507,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
       const int kn = tid / TPR;
       const int n4 = (tid - kn * TPR) * 4;
 #pragma unroll
-      for (int i = 0; i < B_ROWS; ++i) {
-        const int kk = i * KPP + kn;
-        Bs[(n4 + 0) * LDP + kk] = b_reg[i].x;
-        Bs[(n4 + 1) * LDP + kk] = b_reg[i].y;
-        Bs[(n4 + 2) * LDP + kk] = b_reg[i].z;
-        Bs[(n4 + 3) * LDP + kk] = b_reg[i].w;
-      }
+      for (int i = 0; i < B_ROWS; ++i)  // k-major in LDS, see A_TRANS above
+        *reinterpret_cast<f32x4*>(Bs + (i * KPP + kn) * LDT_B + n4) = b_reg[i];
     } else {
 #pragma unroll
       for (int i = 0; i < B_ROWS; ++i)
@@ -537,15 +537,31 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
       load_a((kt0 + t + 1) * BK);
       load_b((kt0 + t + 1) * BK);
     }
-    const float* Aw = cur + (wm * WTM + l31) * LDP + 4 * half;
-    const float* Bw = cur + A_TILE + (wn * WTN + l31) * LDP + 4 * half;
+    const float* Aw = A_KMAJOR ? cur + (4 * half) * LDT_A + wm * WTM + l31
+                               : cur + (wm * WTM + l31) * LDP + 4 * half;
+    const float* Bw = B_KMAJOR ? cur + A_TILE + (4 * half) * LDT_B + wn * WTN + l31
+                               : cur + A_TILE + (wn * WTN + l31) * LDP + 4 * half;
 #pragma unroll
     for (int g = 0; g < BK / 8; ++g) {
       f32x4 af[MT], bf[NT];
 #pragma unroll
-      for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const f32x4*>(Aw + i * 32 * LDP + 8 * g);
+      for (int i = 0; i < MT; ++i) {
+        if constexpr (A_KMAJOR) {
 #pragma unroll
-      for (int j = 0; j < NT; ++j) bf[j] = *reinterpret_cast<const f32x4*>(Bw + j * 32 * LDP + 8 * g);
+          for (int e = 0; e < 4; ++e) af[i][e] = Aw[(8 * g + e) * LDT_A + i * 32];
+        } else {
+          af[i] = *reinterpret_cast<const f32x4*>(Aw + i * 32 * LDP + 8 * g);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        if constexpr (B_KMAJOR) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) bf[j][e] = Bw[(8 * g + e) * LDT_B + j * 32];
+        } else {
+          bf[j] = *reinterpret_cast<const f32x4*>(Bw + j * 32 * LDP + 8 * g);
+        }
+      }
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
