@@ -1,0 +1,8 @@
+#!/bin/bash
+# round 3, job 35: in-kernel timers of conv_s3
+export TMPDIR=/tmp
+O=$GRAFT_REPO_ROOT/gpurun_out/r03ai
+mkdir -p $O
+cd $GRAFT_REPO_ROOT
+VLNCE_HIP_LIB=$GRAFT_REPO_ROOT/build/variants/libvlnce_p3time.so timeout 200 python scripts/convbench.py --mode train --pro --set r50 --iters 1 --rounds 1 --only l1_1x1_64_256,l2_1x1_128_512 > $O/s3time.txt 2>&1
+grep "s3 wave" $O/s3time.txt | sort | uniq -c | sort -rn | head -8 | cut -c1-330

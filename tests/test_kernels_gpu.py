@@ -856,6 +856,9 @@ P3_CASES = [
     ("p3_many_tiles", 40, 32, 32, 64, 64, 3, 1, 1, dict(stats=True)),            # several tiles per CU
     ("u3_rag_768",   2, 13, 11,  96, 768, 1, 1, 0, dict(stats=True)),             # ragged M, 3 column tiles
     ("u3_scale_act", 5, 16, 16,  64, 256, 1, 1, 0, dict(scale=True, relu=True)),  # epilogue scale/shift/act
+    ("s3_rag_m",     1,  8, 20, 128, 256, 1, 1, 0, dict(stats=True)),             # 64 + 64 + 32 rows
+    ("s3_many",     48, 32, 32,  64, 256, 1, 1, 0, dict(prologue=True, in_relu=True, center=True)),  # 3 tiles per workgroup
+    ("s3_many_512", 40, 32, 32, 128, 512, 1, 1, 0, dict(stats=True)),             # two column tiles, 5 rounds
 ]
 
 
@@ -873,7 +876,8 @@ def test_conv_p3_every_tile_shape(tile):
     import sys
     env = dict(os.environ, VLNCE_P3_TILE=str(tile))
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu",
-                        "-k", "(conv2d_fwd or bottleneck or block or conv_p3) and not every_tile",
+                        "-k", "(conv2d_fwd or bottleneck or block or conv_p3) and not every_tile and not u3_forced "
+                              "and not s3_forced",
                         "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:]
 
@@ -889,7 +893,22 @@ def test_conv_u3_forced(mode):
     env = dict(os.environ, VLNCE_U3=str(mode))
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu",
                         "-k", "(conv2d_fwd or bottleneck or block or conv_p3) and not every_tile "
-                              "and not u3_forced", "-p", "no:cacheprovider"],
+                              "and not u3_forced and not s3_forced", "-p", "no:cacheprovider"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:]
+
+
+def test_conv_s3_forced():
+    """conv_s3_kernel (short-K wide 1x1: B fragments and prologue vectors resident, raw rows two
+    tiles ahead) takes a layer by default only when every CU gets at least four of its 64-row tiles;
+    VLNCE_S3=2 (read once per process) sends every eligible shape to it: prologue + centre,
+    statistics, epilogue scale / act, ragged M, several tiles per workgroup, two column tiles."""
+    import subprocess
+    import sys
+    env = dict(os.environ, VLNCE_S3="2")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu",
+                        "-k", "(conv2d_fwd or bottleneck or block or conv_p3) and not every_tile "
+                              "and not u3_forced and not s3_forced", "-p", "no:cacheprovider"],
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:]
 

@@ -1189,6 +1189,232 @@ int launch_u3(const IgemmParams& p, hipStream_t stream) {
   return 0;
 }
 
+// conv_s3_kernel: stride-1 1x1 convolutions with SHORT K (64 or 128 input channels) and wide N
+// (the 64->256 / 128->512 expansions of the bottlenecks: 268 / 134 MB of output per launch).
+// These launches are bound by the HBM write of their output, and in conv_u3_kernel they reach
+// 2.2-2.7 TB/s: a tile there is 2-4 K-chunks of MFMAs and a 128 KB store burst, and the loads of
+// the next tile (B fragments of its second k-slab, raw A two chunks ahead) queue behind the burst
+// in the wave's one in-order vmcnt, so a wave alternates between draining and computing
+// (profiles/r03_h_u3_phase_timers_short_k.txt).  Here nothing a tile needs is loaded less than
+// two tiles before its use:
+//   * the B fragments of the wave's 32 columns for ALL of K stay in registers for the whole
+//     launch (K = 64: 48 VGPRs, K = 128: 96) -- a workgroup keeps its column tile;
+//   * the raw A rows of tile t + 2 are requested while tile t is transformed (64-row tiles: one
+//     float4 per thread and chunk), so the wait for them allows every store issued since to
+//     be outstanding;
+//   * the tile loop is straight-line code (NCC = K / 32 at compile time, two tiles per trip for
+//     the register ring), so the compiler's s_waitcnt counts are exact instead of the minimum
+//     over an `if (last chunk of the tile)`.
+// 8 waves (two per SIMD), wave w owns columns [32w, 32w + 32) of a 64 x 256 tile; one barrier
+// per tile; transform and MFMAs of a wave are sequential (the launch is HBM-bound: the matrix
+// pipe has 3x the time it needs).  Arithmetic, patch rows, fragment layout, statistics and
+// epilogue are conv_u3_kernel's.
+template <int NCC>
+__global__ __launch_bounds__(512) void conv_s3_kernel(IgemmParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int BM = 64, MT = 2, KS = NCC * 2;
+  constexpr int CBUF = BM * P3_ROW;            // one chunk of a tile's patch
+  constexpr int PBUF = NCC * CBUF;             // one tile's patch
+  extern __shared__ __attribute__((aligned(16))) char xsm[];  // [2][PBUF]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5;
+  const int l31 = lane & 31;
+  const int trow = tid >> 3;          // this thread's row of the tile (transform side)
+  const int lk4 = (tid & 7) * 4;      // its four channels inside a 32-channel chunk
+
+  // this workgroup's tiles: a fixed column tile, row tiles strided over the workgroups that
+  // share it (gridDim.x is a multiple of tiles_n)
+  const int n0 = ((int)blockIdx.x % p.tiles_n) * 256;
+  const int wg = (int)blockIdx.x / p.tiles_n, nwg = (int)gridDim.x / p.tiles_n;
+  const int my_tiles = (p.tiles_m - wg + nwg - 1) / nwg;
+
+  const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char*>(reinterpret_cast<const char*>(p.A)), 0, (int)p.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char*>(reinterpret_cast<const char*>(p.Bfrag)), 0, (int)((long)p.N * p.K * 6),
+      0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_c = __builtin_amdgcn_make_buffer_rsrc(
+      reinterpret_cast<char*>(p.C), 0, (int)p.c_bytes, 0x00020000);
+  const float relu_floor = p.in_relu ? 0.f : -__builtin_huge_valf();
+
+  // ---- resident operands: B fragments (all k-slabs), prologue vectors (all chunks)
+  bf16x8 bres[KS][3];
+  {
+    const int vb = (n0 / 32 + wave) * KS * 3072 + lane * 16;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+        bres[ks][q] = __builtin_bit_cast(
+            bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, vb + q * 1024, ks * 3072, 0));
+  }
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f}, one4 = {1.f, 1.f, 1.f, 1.f};
+  f32x4 vs[NCC], vt[NCC], vc[NCC];
+#pragma unroll
+  for (int c = 0; c < NCC; ++c) {
+    vs[c] = one4;
+    vt[c] = vc[c] = zero4;
+    if (p.in_scale != nullptr) {
+      vs[c] = ldg4(p.in_scale + c * 32 + lk4);
+      vt[c] = ldg4(p.in_shift + c * 32 + lk4);
+      if (p.in_center) vc[c] = ldg4(p.in_center + c * 32 + lk4);
+    }
+  }
+  const int col = n0 + wave * 32 + l31;
+  const float e_sc = p.scale ? p.scale[col] : 1.f;
+  const float e_sh = p.shift ? p.shift[col] : 0.f;
+
+  // ---- raw A ring: two tiles in flight
+  f32x4 raw[2][NCC];
+  auto load_raw = [&](f32x4 (&r)[NCC], int round) {
+    const int m = (wg + round * nwg) * BM + trow;
+    const int vo = (round < my_tiles && m < p.M) ? (m * p.lda + lk4) * 4 : BUF_OOB;
+#pragma unroll
+    for (int c = 0; c < NCC; ++c)
+      r[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, vo, c * 128, 0));
+  };
+  load_raw(raw[0], 0);
+  load_raw(raw[1], 1);
+  f32x16 acc[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  constexpr int PA[6] = {2, 1, 0, 1, 0, 0};  // smallest products first
+  constexpr int PB[6] = {0, 1, 2, 0, 1, 0};
+  const int a_off = l31 * P3_ROW + half * 16;
+
+#ifdef P3_DBG_TIME
+  long long d_tr = 0, d_bar = 0, d_mm = 0, d_ep = 0;
+  const long long d_t0 = clock64(), d_w0 = wall_clock64();
+#endif
+  auto tile = [&](int round, f32x4 (&r)[NCC]) {
+#ifdef P3_DBG_TIME
+    const long long d_0 = clock64();
+#endif
+    const int m0 = (wg + round * nwg) * BM;
+    char* const pb = xsm + (round & 1) * PBUF;
+    // transform this tile's rows (rows past M are zero: the buffer load returned zeros and the
+    // prologue of a zero is not zero, so they are forced)
+    const bool row_ok = m0 + trow < p.M;
+#pragma unroll
+    for (int c = 0; c < NCC; ++c) {
+      f32x4 v = r[c];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[e] = fmaxf(fmaf(v[e] - vc[c][e], vs[c][e], vt[c][e]), relu_floor);
+        v[e] = row_ok ? v[e] : 0.f;
+      }
+      p3_split_store(v, pb + c * CBUF + trow * P3_ROW + lk4 * 2);
+    }
+    load_raw(r, round + 2);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifdef P3_DBG_TIME
+    const long long d_1 = clock64();
+#endif
+    __builtin_amdgcn_s_barrier();
+#ifdef P3_DBG_TIME
+    const long long d_2 = clock64();
+#endif
+    // MFMAs over all of K from the patch
+#pragma unroll
+    for (int c = 0; c < NCC; ++c)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        bf16x8 f[MT][3];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int q = 0; q < 3; ++q)
+            f[i][q] = *reinterpret_cast<const bf16x8*>(pb + c * CBUF + a_off + i * 32 * P3_ROW +
+                                                       q * 64 + s2 * 32);
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[i][PA[q]], bres[c * 2 + s2][PB[q]],
+                                                             acc[i], 0, 0, 0);
+      }
+#ifdef P3_DBG_TIME
+    asm volatile("s_nop 0" ::"v"(acc[0][0]), "v"(acc[1][15]));
+    const long long d_3 = clock64();
+#endif
+    // statistics partials of the raw accumulators (32-row blocks), then the epilogue
+    if (p.stat_partial != nullptr) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+        wave_stats_block<1>(reinterpret_cast<const f32x16(&)[1]>(acc[i]), p.stat_partial,
+                            m0 / 32 + i, p.M - (m0 + i * 32), n0 + wave * 32, p.N, half, l31);
+    }
+    // (Measured on this kernel, profiles/r03_j_*: with the loads out of the way the store phase is
+    // 54 % of the launch at ~12 B/cycle/CU.  That rate is the CU's own: the same through 16-byte
+    // row stores out of an LDS square, the same with half of the workgroups started half a tile
+    // late, and 64 workgroups on 64 CUs still need 5.2 k cycles per 64 KB.  What is left is to
+    // put one tile's stores under another's MFMAs inside a CU.)
+    const int rows_left = p.M - (m0 + 4 * half);
+    const int e_voff = (int)((((long)(m0 + 4 * half)) * p.ldc + col) * 4);
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int r2 = 0; r2 < 16; ++r2) {
+        const int rw = i * 32 + (r2 & 3) + 8 * (r2 >> 2);
+        const float v = apply_act(acc[i][r2] * e_sc + e_sh, p.act);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc_c,
+                                              rw < rows_left ? e_voff : BUF_OOB, rw * p.ldc * 4, 0);
+        acc[i][r2] = 0.f;
+      }
+#ifdef P3_DBG_TIME
+    const long long d_4 = clock64();
+    d_tr += d_1 - d_0;
+    d_bar += d_2 - d_1;
+    d_mm += d_3 - d_2;
+    d_ep += d_4 - d_3;
+#endif
+  };
+  for (int round = 0; round < my_tiles; round += 2) {
+    tile(round, raw[0]);
+    if (round + 1 < my_tiles) tile(round + 1, raw[1]);
+  }
+#ifdef P3_DBG_TIME
+  if (blockIdx.x == 8 && (tid == 0 || tid == 448)) {
+    const long long cy = clock64() - d_t0, w = wall_clock64() - d_w0;
+    printf("s3 wave %d: tiles %d chunks/tile %d: total %lld cycles = %lld ticks of 100 MHz (%.2f GHz): "
+           "wait raw + transform %lld, barrier %lld, reads + MFMA %lld, statistics + stores %lld\n",
+           wave, my_tiles, NCC, cy, w, (double)cy / (double)w * 0.1, d_tr, d_bar, d_mm, d_ep);
+  }
+#endif
+#endif
+}
+
+template <int NCC>
+int launch_s3(const IgemmParams& p, hipStream_t stream) {
+  constexpr int smem_bytes = 2 * NCC * 64 * P3_ROW;
+  auto kern = conv_s3_kernel<NCC>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
+    if (e != hipSuccess) {
+      vlnce_set_error("conv_s3: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      return 2;
+    }
+    attr_set = true;
+  }
+  IgemmParams q = p;
+  q.tiles_m = ceil_div(p.M, 64);
+  q.tiles_n = p.N / 256;
+  q.splitk = 1;
+  const int cus = x3_cus();
+  long grid = (long)q.tiles_m * q.tiles_n;
+  if (grid > cus) grid = cus - cus % q.tiles_n;  // resident workgroups, a multiple of tiles_n
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), smem_bytes, stream, q);
+  VLNCE_CHECK_LAUNCH("conv_s3");
+  return 0;
+}
+
 // w_ohwi [N][KH][KW][Cin] fp32 -> B fragments [N/32][K/16][3][64 lanes][8 bf16]: k-slab
 // ks = ((chunk * T + tap) * 2 + s) holds input channels chunk*32 + s*16 + [0, 16) of that tap;
 // lane (l31, half) holds output channel nb*32 + l31, channels half*8 + [0, 8) of the slab;
@@ -1323,6 +1549,13 @@ int p3_try_launch(const IgemmParams& p, hipStream_t stream) {
   // for every N >= 256 1x1 layer (tests).  Measured
   // per layer at num_envs 64 (profiles/r03_b_convbench_ab_u3.txt): 1.07-1.23x conv_x3_kernel on
   // every N >= 256 layer of the RGB trunk with M >= 16384.
+  // short-K wide 1x1 (the bottleneck expansions): conv_s3_kernel.  VLNCE_S3: 0 = off, 1 = default
+  // (where the 64-row tiles give every CU at least four), 2 = every eligible shape (tests)
+  static const int s3_env = getenv("VLNCE_S3") ? atoi(getenv("VLNCE_S3")) : 1;
+  if (!dense && !dual && s3_env && p.stride == 1 && (p.Cin == 64 || p.Cin == 128) && p.K == p.Cin &&
+      p.N % 256 == 0 && p.N / 256 <= 8 && (p.stat_partial == nullptr || p.stat_rows == 32) &&
+      (s3_env == 2 || (long)ceil_div(p.M, 64) * (p.N / 256) >= 4L * x3_cus()))
+    return p.Cin == 64 ? launch_s3<2>(p, stream) : launch_s3<4>(p, stream);
   static const int u3_env = getenv("VLNCE_U3") ? atoi(getenv("VLNCE_U3")) : 1;
   static const int u3_waves = getenv("VLNCE_U3_WAVES") ? atoi(getenv("VLNCE_U3_WAVES")) : 8;
   if (!dense && u3_env && p.N >= 256) {
