@@ -28,7 +28,7 @@ typedef void* vlnce_stream_t;
 
 enum { VLNCE_ACT_NONE = 0, VLNCE_ACT_RELU = 1, VLNCE_ACT_SIGMOID = 2, VLNCE_ACT_TANH = 3 };
 
-int vlnce_version(void); /* major*100 + minor; 132 = this header */
+int vlnce_version(void); /* major*100 + minor; 133 = this header */
 const char* vlnce_last_error(void);
 
 /* ---------------------------------------------------------------- conv / GEMM
@@ -192,6 +192,13 @@ int vlnce_gn_finalize_tiles(const float* stat_partial, int tile_rows, int Nimg, 
                             int groups, const float* gamma, const float* beta, float eps,
                             float* scale_out, float* shift_out, float* center_out,
                             float* mean_out, float* rstd_out, vlnce_stream_t stream);
+/* y = act(GroupNorm(x) + residual) of a small activation x [N, HW, C] in ONE launch (one
+ * workgroup per (sample, group): mean, centred second moment, apply): what the policy uses at
+ * one to a few environments (act(), resnet_encoders.py:31-43 GroupNorm trunk), where the three
+ * launches of the pipeline above are latency, not bandwidth.  residual may be NULL; y may alias x. */
+int vlnce_group_norm_small(const float* x, int Nimg, int HW, int C, int groups, const float* gamma,
+                           const float* beta, float eps, const float* residual, int act, float* y,
+                           vlnce_stream_t stream);
 
 /* ------------------------------------------------------------------ pooling
  * NHWC. maxpool 3x3/s2/p1 (torchvision + habitat stems), avg_pool2d(2)

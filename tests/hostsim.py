@@ -276,6 +276,13 @@ class HostSim:
     def avgpool2x2(self, x, y, N, H, W, Cc):
         y.copy_(F.avg_pool2d(x.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1))
 
+    def group_norm_small(self, x, N, HW, Cc, groups, gamma, beta, eps, residual, act, y):
+        v = F.group_norm(x.reshape(N, HW, Cc).permute(0, 2, 1), groups, gamma, beta, eps)
+        v = v.permute(0, 2, 1).reshape(y.shape)
+        if residual is not None:
+            v = v + residual.reshape(y.shape)
+        y.copy_(_act(v, act))
+
     def gru_rollout_supported(self, N, H):
         return 0 < N <= 16 and H in (64, 128, 256, 512)
 

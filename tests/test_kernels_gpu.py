@@ -218,9 +218,19 @@ def test_bn_finalize_contract(hip, tiles, Cc):
         close(gpu[k], cpu[k], what=k)
 
 
+@pytest.fixture(params=["one_launch", "pipeline"])
+def gn_path(request, monkeypatch):
+    """GroupNorm of a small activation is one launch (vlnce_group_norm_small), of a large one
+    statistics + finalize + apply: run the small test shapes through both."""
+    if request.param == "pipeline":
+        monkeypatch.setattr(ops, "GN_SMALL_ELEMENTS", 0)
+    return request.param
+
+
 @pytest.mark.parametrize("shape", [(4, 32, 32, 32, 16), (2, 8, 8, 256, 16), (3, 4, 4, 1024, 16),
-                                   (2, 4, 4, 128, 1), (2, 2, 2, 2048, 1), (5, 16, 16, 64, 16)])
-def test_group_norm(hip, shape):
+                                   (2, 4, 4, 128, 1), (2, 2, 2, 2048, 1), (5, 16, 16, 64, 16),
+                                   (1, 64, 64, 128, 16), (1, 3, 5, 48, 16)])
+def test_group_norm(hip, shape, gn_path):
     N, H, W, Cc, G = shape
     x = rnd(N, H, W, Cc, seed=1) + 0.5
     gamma, beta = rnd(Cc, seed=2), rnd(Cc, seed=3)
@@ -650,7 +660,7 @@ def test_s2d_stem_matches_direct_conv(hip, Cc, Cout, hw, N):
 @pytest.mark.parametrize("N,hw,Cin,Cout,k,groups", [(3, 32, 32, 32, 3, 16), (2, 16, 64, 128, 1, 16),
                                                     (4, 8, 128, 256, 3, 16), (2, 4, 256, 512, 1, 16),
                                                     (2, 16, 32, 64, 3, 1)])
-def test_conv_group_norm_from_epilogue_stats(hip, N, hw, Cin, Cout, k, groups):
+def test_conv_group_norm_from_epilogue_stats(hip, N, hw, Cin, Cout, k, groups, gn_path):
     """depth trunk: GroupNorm statistics taken from the convolution epilogue's tile moments
     (falls back to the activation pass when a tile would straddle two samples: the 4x4 case)."""
     x = rnd(N, hw, hw, Cin, seed=1)

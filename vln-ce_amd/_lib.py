@@ -100,6 +100,7 @@ _SIGNATURES = {
     "vlnce_rnn_seq_supported": (_I, [_I, _I]),
     "vlnce_rnn_seq_fwd": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "vlnce_rnn_seq_bwd": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "vlnce_group_norm_small": (_I, [_P, _I, _I, _I, _I, _P, _P, _F, _P, _I, _P, _P]),
     "vlnce_gru_rollout_supported": (_I, [_I, _I]),
     "vlnce_gru_rollout_workspace_bytes": (C.c_long, [_I, _I]),
     "vlnce_gru_rollout_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
@@ -182,7 +183,7 @@ class HipLib:
 
     name = "hip"
 
-    ABI = 132  # include/vlnce_hip.h
+    ABI = 133  # include/vlnce_hip.h
 
     def __init__(self, path=LIB_PATH):
         self.dll = load_cdll(path)
@@ -484,6 +485,11 @@ class HipLib:
             kind, dirs, pa(w_hh_t, dirs), _ptr(lengths), pa(out, dirs), pa(gates_save, dirs),
             pa(aux_save, dirs), pa(dout, dirs), pa(dh_final, dirs), pa(dgi, dirs), pa(dgh, dirs),
             B, Lm, H, _stream()), "vlnce_rnn_seq_bwd")
+
+    def group_norm_small(self, x, N, HW, Cc, groups, gamma, beta, eps, residual, act, y):
+        self._check(self.dll.vlnce_group_norm_small(
+            _ptr(x), N, HW, Cc, groups, _ptr(gamma), _ptr(beta), eps, _ptr(residual), act, _ptr(y),
+            _stream()), "vlnce_group_norm_small")
 
     def gru_rollout_supported(self, N, H):
         if os.environ.get("VLNCE_GRU_ROLLOUT", "1") == "0":  # A/B switch (scripts/bench_data_path.py)

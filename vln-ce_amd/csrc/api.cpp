@@ -16,4 +16,4 @@ void vlnce_set_error(const char* fmt, ...) {
 extern "C" const char* vlnce_last_error(void) { return g_err; }
 // major*100 + minor; 1.x: round-1 ABI (centered normalisation vectors, dual-input prologue,
 // backward / data-path / returns entry points).  Struct layouts only ever grow at the end.
-extern "C" int vlnce_version(void) { return 132; }
+extern "C" int vlnce_version(void) { return 133; }

@@ -426,6 +426,103 @@ extern "C" int vlnce_gn_finalize(const float* partial, int Nimg, int HW, int C, 
   return 0;
 }
 
+// GroupNorm (+residual)(+act) of a SMALL activation in one launch: one workgroup per (sample,
+// group, up to 1024 threads) reads its [HW, C/groups] slab twice out of L2 (shifted sum and sum
+// of squares; apply) -- at one to a few environments a GroupNorm layer is otherwise statistics + finalize +
+// apply, three launches of ~5 us each on the critical path of act() (the depth trunk is 54 such
+// layers).  The arithmetic of the apply is scale_shift_act's: (x - mean) * (gamma * rstd) + beta.
+template <int VEC>
+__global__ __launch_bounds__(1024) void gn_small_kernel(const float* __restrict__ x, int HW, int C,
+                                                        int groups, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float eps,
+                                                        const float* __restrict__ residual,
+                                                        float* __restrict__ y, int act) {
+  __shared__ double red[2][16];
+  const int n = blockIdx.x / groups, g = blockIdx.x - n * groups;
+  const int cpg = C / groups;
+  const long base = (long)n * HW * C + (long)g * cpg;
+  const int cv = cpg / VEC;            // vectors per pixel of this group's channels
+  const int total = HW * cv;
+  typedef float vec_t __attribute__((ext_vector_type(VEC)));
+  // pass 1: sum and sum of squares about the slab's first element (the shift keeps the
+  // cancellation of E[x^2] - mean^2 harmless when |mean| >> std)
+  const float x0 = x[base];
+  float s = 0.f, q = 0.f;
+  for (int e = threadIdx.x; e < total; e += blockDim.x) {
+    const int px = e / cv, c = (e - px * cv) * VEC;
+    const vec_t v = *reinterpret_cast<const vec_t*>(x + base + (long)px * C + c);
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      const float d = v[k] - x0;
+      s += d;
+      q = fmaf(d, d, q);
+    }
+  }
+  double ds = s, dq = q;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    ds += __shfl_xor(ds, o, 64);
+    dq += __shfl_xor(dq, o, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = ds;
+    red[1][threadIdx.x >> 6] = dq;
+  }
+  __syncthreads();
+  double ts = 0.0, tq = 0.0;
+  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) {
+    ts += red[0][w];
+    tq += red[1][w];
+  }
+  const double cnt = (double)HW * (double)cpg;
+  const double md = ts / cnt;                       // mean - x0
+  const float mean = (float)(md + (double)x0);
+  const float rstd = (float)(1.0 / sqrt(fmax(tq / cnt - md * md, 0.0) + (double)eps));
+  // pass 2: apply
+  for (int e = threadIdx.x; e < total; e += blockDim.x) {
+    const int px = e / cv, c = (e - px * cv) * VEC;
+    const long o = base + (long)px * C + c;
+    const vec_t v = *reinterpret_cast<const vec_t*>(x + o);
+    vec_t r;
+    if (residual) r = *reinterpret_cast<const vec_t*>(residual + o);
+    vec_t out;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      const int ch = g * cpg + c + k;
+      const float sc = (gamma ? gamma[ch] : 1.f) * rstd;
+      float t = (v[k] - mean) * sc + (beta ? beta[ch] : 0.f);
+      if (residual) t += r[k];
+      out[k] = apply_act(t, act);
+    }
+    *reinterpret_cast<vec_t*>(y + o) = out;
+  }
+}
+
+extern "C" int vlnce_group_norm_small(const float* x, int Nimg, int HW, int C, int groups,
+                                      const float* gamma, const float* beta, float eps,
+                                      const float* residual, int act, float* y,
+                                      vlnce_stream_t stream) {
+  VLNCE_CHECK_ARG(x && y, "group_norm_small: null argument");
+  VLNCE_CHECK_ARG(Nimg > 0 && HW > 0 && groups > 0 && C % groups == 0,
+                  "group_norm_small: bad shape (N %d, HW %d, C %d, groups %d)", Nimg, HW, C, groups);
+  VLNCE_CHECK_ARG((long)HW * (C / groups) < (1L << 30), "group_norm_small: slab too large");
+  const int cpg = C / groups;
+  const long slab = (long)HW * cpg;
+  const int threads = slab >= 4096 ? 1024 : slab >= 1024 ? 512 : 256;
+  const bool vec4 = cpg % 4 == 0 && C % 4 == 0 && ((reinterpret_cast<uintptr_t>(x) |
+                    reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(residual)) & 15) == 0;
+  if (vec4)
+    hipLaunchKernelGGL(gn_small_kernel<4>, dim3((unsigned)(Nimg * groups)), dim3(threads), 0,
+                       reinterpret_cast<hipStream_t>(stream), x, HW, C, groups, gamma, beta, eps,
+                       residual, y, act);
+  else
+    hipLaunchKernelGGL(gn_small_kernel<1>, dim3((unsigned)(Nimg * groups)), dim3(threads), 0,
+                       reinterpret_cast<hipStream_t>(stream), x, HW, C, groups, gamma, beta, eps,
+                       residual, y, act);
+  VLNCE_CHECK_LAUNCH("group_norm_small");
+  return 0;
+}
+
 extern "C" int vlnce_gn_finalize_tiles(const float* stat_partial, int tile_rows, int Nimg, int HW,
                                        int C, int groups, const float* gamma, const float* beta,
                                        float eps, float* scale_out, float* shift_out,

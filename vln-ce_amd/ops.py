@@ -6,6 +6,8 @@ hand-written backward for the trainable tail (linear / 1x1 conv, attention,
 GRU / LSTM cells, masked state reset, packed-sequence selects).
 All tensors are fp32; images are channels-last [N,H,W,C].
 """
+import os
+
 import torch
 from torch.autograd import Function
 
@@ -142,12 +144,26 @@ def scale_shift_act(x, scale, shift, *, center=None, rows_per_sample=0, residual
     return y
 
 
+GN_SMALL_ELEMENTS = 1 << 20  # activations up to this size take the one-launch GroupNorm
+
+
+def _gn_small(x):
+    """True where GroupNorm is latency, not bandwidth: a few environments (act(), evaluation),
+    16 * N workgroups re-reading a slab of at most a few hundred KB out of L2."""
+    return (x.is_cuda and x.numel() <= GN_SMALL_ELEMENTS
+            and os.environ.get("VLNCE_GN_SMALL", "1") != "0")
+
+
 def group_norm_act(x, groups, gamma, beta, eps, *, residual=None, act=ACT_NONE):
     """GroupNorm over channels-last x[N,H,W,C] (+residual)(+act)."""
     assert x.is_contiguous()
     N, H, W, Cc = x.shape
     HW = H * W
     lib = L()
+    if _gn_small(x):  # statistics + finalize + apply in ONE launch
+        y = torch.empty_like(x)
+        lib.group_norm_small(x, N, HW, Cc, groups, gamma, beta, float(eps), residual, act, y)
+        return y
     chunks = lib.gn_chunks(HW)
     partial = torch.empty((N, chunks, Cc, 2), device=x.device, dtype=torch.float32)
     lib.gn_partial(x, N, HW, Cc, partial)
@@ -164,6 +180,12 @@ def conv_group_norm_act(x, w_ohwi, stride, pad, groups, gamma, beta, eps, *, res
                         act=ACT_NONE):
     """act(GroupNorm(conv(x)) + residual).  The GroupNorm statistics come from the convolution's
     own epilogue when its M-tiles do not straddle samples; otherwise from a pass over y."""
+    g = conv_geometry(x, w_ohwi, stride, pad)
+    if x.is_cuda and g["N"] * g["Ho"] * g["Wo"] * g["Cout"] <= GN_SMALL_ELEMENTS and \
+            os.environ.get("VLNCE_GN_SMALL", "1") != "0":
+        # small activation: the plain convolution, then GroupNorm in one launch
+        return group_norm_act(conv2d_nhwc(x, w_ohwi, stride, pad), groups, gamma, beta, eps,
+                              residual=residual, act=act)
     y, stats = conv2d_nhwc(x, w_ohwi, stride, pad, want_stats=True)
     partial, _tiles_m, tile_rows = stats
     N, Ho, Wo, Cc = y.shape
