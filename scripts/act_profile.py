@@ -42,3 +42,14 @@ with torch.no_grad():
     torch.cuda.synchronize()
 print(f"act() at num_envs={n}: {1e3 * (time.perf_counter() - t0) / args.iters:.3f} ms per call"
       f"{' (synchronized)' if args.sync else ''}")
+
+g = policy.__dict__.get("_act_graph")
+if g is not None:
+    ents = [v for v in g.entries.values() if isinstance(v, list)]
+    if ents:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.iters):
+            ents[-1][0].replay()
+        torch.cuda.synchronize()
+        print(f"bare replay of the captured act() graph: {1e3 * (time.perf_counter() - t0) / args.iters:.3f} ms")

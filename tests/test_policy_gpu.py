@@ -158,6 +158,53 @@ def test_graph_replay_equals_eager(monkeypatch):
     assert (results["1"][0][4] - results["1"][0][5]).abs().max().item() < 1e-5
 
 
+@pytest.mark.parametrize("pol", ["CMAPolicy", "Seq2SeqPolicy"])
+def test_whole_act_graph_equals_eager(monkeypatch, pol):
+    """streams.ActGraph: the whole forward-only act() as ONE HIP graph per signature (encoders on
+    forked streams inside the capture, instruction at its static padded length, no host sync)
+    against the eager path on the same inputs: eager call, capturing call, replays with NEW
+    inputs (different frames, instruction lengths, recurrent state, masks), an in-place parameter
+    update (new key: derived tensors must not go stale), deterministic and sampled modes."""
+    hip = vlnce_amd.build_model(vlnce_amd.make_config(pol), *vlnce_amd.make_spaces(128, 128))
+    hip.load_state_dict(tp.synth_state_dict(hip))
+    hip.to(DEV).eval()
+    n_layers = hip.net.num_recurrent_layers
+    steps = []
+    for k in range(5):
+        o, prev, masks = synth_batch(3, 128, 12 + 3 * k, seed=40 + k, ragged=True)
+        h = torch.randn(3, n_layers, 512, generator=torch.Generator().manual_seed(90 + k)) * 0.3
+        steps.append((to_dev(o), h.to(DEV), prev.to(DEV), masks.to(DEV)))
+
+    def run(graph):
+        monkeypatch.setenv("VLNCE_ACT_GRAPH", "1" if graph else "0")
+        hip.__dict__.pop("_act_graph", None)
+        out = []
+        with torch.no_grad():
+            for k, (o, h, prev, masks) in enumerate(steps):
+                if k == 3:  # an optimizer step between two calls
+                    for prm in hip.parameters():
+                        prm.mul_(1.0 + 1e-3)
+                a, s_ = hip.act(o, h, prev, masks, deterministic=True)
+                out.append((a.clone(), s_.clone()))
+            for _ in range(3):  # sampled mode: eager, capture, replay -- the states must still agree
+                a, s_ = hip.act(*steps[4], deterministic=False)
+                assert a.shape == (3, 1) and int(a.min()) >= 0
+            out.append((None, s_.clone()))
+            for prm in hip.parameters():
+                prm.div_(1.0 + 1e-3)
+        torch.cuda.synchronize()
+        return out
+
+    eager = run(False)
+    graphed = run(True)
+    g = hip.__dict__["_act_graph"]
+    assert sum(isinstance(v, list) for v in g.entries.values()) >= 3  # before / after the update, sampled
+    for k, ((ae, se), (ag, sg)) in enumerate(zip(eager, graphed)):
+        assert float((se - sg).abs().max()) < 2e-5, (k, float((se - sg).abs().max()))
+        if ae is not None:
+            assert torch.equal(ae, ag), k
+
+
 @pytest.mark.parametrize("version,spatial", [("resnet18", True), ("resnet50", False)])
 def test_rgb_encoder_train_then_eval_vs_oracle(version, spatial):
     """TorchVisionResNet on HIP vs the CPU oracle: two train-mode forwards (batch statistics,

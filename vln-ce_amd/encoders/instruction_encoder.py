@@ -100,6 +100,11 @@ class InstructionEncoder(nn.Module):
             feats = ops.embedding(tokens, self.embedding_layer.weight,
                                   self.embedding_layer.padding_idx)
             lengths = nonzero_row[tokens].sum(dim=1)
+            if tokens.is_cuda and torch.cuda.is_current_stream_capturing():
+                # inside a graph capture (streams.ActGraph): no host sync -- the recurrence runs
+                # at the static padded length with the lengths on the device (steps past a row's
+                # length keep its state and emit zeros: the same values, more padding)
+                return self._encode(feats, (lengths, 1, tokens.size(1)))
             lmin, lmax = (int(v) for v in torch.stack([lengths.min(), lengths.max()]).tolist())
             return self._encode(feats, (lengths, lmin, lmax))
         return self._encode(observations["rxr_instruction"])
@@ -142,7 +147,10 @@ class InstructionEncoder(nn.Module):
             # pack_padded_sequence then keeps the first `length` steps of each sample.  One host
             # sync, as upstream (.cpu()).
             lengths = (feats != 0.0).any(dim=2).sum(dim=1)
-            lmin, lmax = (int(v) for v in torch.stack([lengths.min(), lengths.max()]).tolist())
+            if feats.is_cuda and torch.cuda.is_current_stream_capturing():
+                lmin, lmax = 1, feats.size(1)  # (see forward: static length inside a capture)
+            else:
+                lmin, lmax = (int(v) for v in torch.stack([lengths.min(), lengths.max()]).tolist())
         else:
             lengths, lmin, lmax = length_info
         if lmin <= 0:

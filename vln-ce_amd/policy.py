@@ -2,9 +2,11 @@
 and habitat-lab v0.1.7 rl/ppo/policy.py + utils/common.py)."""
 import abc
 
+import torch
 import torch.nn as nn
 
 from . import ops
+from .streams import ActGraph
 from .utils import CustomFixedCategorical
 
 
@@ -20,7 +22,11 @@ class CategoricalNet(nn.Module):
         nn.init.constant_(self.linear.bias, 0)
 
     def forward(self, x):
-        return CustomFixedCategorical(logits=ops.linear(x, self.linear.weight, self.linear.bias))
+        logits = ops.linear(x, self.linear.weight, self.linear.bias)
+        if x.is_cuda and torch.cuda.is_current_stream_capturing():
+            # (argument validation is a host sync: not inside a graph capture, streams.ActGraph)
+            return CustomFixedCategorical(logits=logits, validate_args=False)
+        return CustomFixedCategorical(logits=logits)
 
 
 class CriticHead(nn.Module):
@@ -80,6 +86,15 @@ class ILPolicy(Policy):
         return self._step(observations, rnn_states, prev_actions, masks)[0]
 
     def act(self, observations, rnn_states, prev_actions, masks, deterministic=False):
+        graph = self.__dict__.get("_act_graph")
+        if graph is None:
+            graph = ActGraph(self)
+            object.__setattr__(self, "_act_graph", graph)  # (not a sub-module, not in state_dict)
+        if graph.usable(observations, rnn_states):
+            return graph(observations, rnn_states, prev_actions, masks, deterministic)
+        return self._act_eager(observations, rnn_states, prev_actions, masks, deterministic)
+
+    def _act_eager(self, observations, rnn_states, prev_actions, masks, deterministic):
         dist, new_states = self._step(observations, rnn_states, prev_actions, masks)
         return (dist.mode() if deterministic else dist.sample()), new_states
 
