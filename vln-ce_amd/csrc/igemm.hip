@@ -3,7 +3,7 @@
 //     the trainable tail, the 7x7 stems, the handful-of-tiles layers, VLNCE_CONV_MATH=f32;
 //   * conv_x3_kernel (further down): fp32 operands split into three bf16 planes, six plane
 //     products on v_mfma_f32_32x32x16_bf16 -- the 1x1 / strided convolutions of the frozen trunks
-//     that conv_p3.hip (conv_p3_kernel / conv_u3_kernel) does not take.
+//     that conv_p3.hip (conv_p3_kernel / conv_u3_kernel / conv_s3_kernel) does not take.
 //
 //   C[M,N] = epilogue( A[M,K] * B[K,N] )
 //
@@ -18,6 +18,9 @@
 //     of tile t+1 are issued before the MFMAs of tile t and written to LDS after.
 //   * LDS rows are K-contiguous with a 36-float pitch: every lane fetches its
 //     MFMA operands for four k-steps with one conflict-free ds_read_b128.
+//     (Operands that are k-major in memory -- transposed A, [K,N] B, the weight
+//     gradient's im2col -- stay k-major in LDS, [k][tile + 8]: one 16-byte write
+//     per staged float4, one float per lane and MFMA on the read side.)
 //     The k order inside a group of 8 is permuted identically for A and B
 //     (lanes 0-31 take k 0..3, lanes 32-63 take k 4..7), which a dot product
 //     does not care about.
