@@ -662,8 +662,14 @@ def main():
     if use_dist:
         dist.destroy_process_group()
     if rank == 0:
-        # the JSON line is the LAST thing on stdout (RCCL writes its own lines at teardown)
+        # the JSON line is the LAST thing on stdout: RCCL's version banner sits in the C runtime's
+        # stdout buffer until it is flushed (at exit it would land behind the line)
         sys.stdout.flush()
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
         print(final, flush=True)
 
 
