@@ -106,6 +106,12 @@ __global__ __launch_bounds__(NW * 64) void rnn_seq_fwd_kernel(RnnSeqParams p) {
   constexpr int KS = H / 32;     // k-steps of 32 per recurrent product
   constexpr int LDHB = H + 16;   // bf16 row pitch: conflict-free ds_read_b128 of 8 k-values
   __shared__ __attribute__((aligned(16))) unsigned short h_pl[2][3][16][LDHB];
+  // The LSTM at H = 128 needs 16 weight fragments of 12 registers per wave: with everything else
+  // that is past 256 VGPRs, and what the compiler spills it reloads from scratch inside the MFMA
+  // loop.  The last gate's fragments of k-steps 1..3 live in LDS instead (one 16-byte slot per
+  // thread and plane: conflict-free) and are read right before their k-step.
+  constexpr int KL = (KIND == 0 && H == 128) ? 3 : 0;
+  __shared__ __attribute__((aligned(16))) bf16x8 w_lds[KL > 0 ? KL : 1][3][NW * 64];
   const int d = blockIdx.y;
   const int b0 = blockIdx.x * 16;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -143,6 +149,10 @@ __global__ __launch_bounds__(NW * 64) void rnn_seq_fwd_kernel(RnnSeqParams p) {
         const float* w8 = W + (long)n * H + 32 * ks + 8 * quad;
         wp[gt][nt][ks] = split_planes(*reinterpret_cast<const f32x4*>(w8),
                                       *reinterpret_cast<const f32x4*>(w8 + 4));
+        if (KL > 0 && gt == G - 1 && nt == 0 && ks >= KS - KL) {
+#pragma unroll
+          for (int q = 0; q < 3; ++q) w_lds[ks - (KS - KL)][q][tid] = wp[gt][nt][ks].p[q];
+        }
       }
     }
   float hreg[NTW][4], creg[NTW][4];
@@ -198,22 +208,34 @@ __global__ __launch_bounds__(NW * 64) void rnn_seq_fwd_kernel(RnnSeqParams p) {
             acc[gt][nt][r] = x + bias[gt][nt];
           }
         }
-    fetch(s + 1);  // (rows with s + 1 >= len load nothing)
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       bf16x8 a[3];
 #pragma unroll
       for (int q = 0; q < 3; ++q)
         a[q] = *reinterpret_cast<const bf16x8*>(&h_pl[cur][q][l15][32 * ks + 8 * quad]);
+      Planes3 wl;  // the LDS-resident fragment of this k-step, if any
+      const bool from_lds = KL > 0 && ks >= KS - KL;
+      if (from_lds) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) wl.p[q] = w_lds[KL > 0 ? ks - (KS - KL) : 0][q][tid];
+      }
 #pragma unroll
       for (int q = 0; q < 6; ++q)
 #pragma unroll
         for (int gt = 0; gt < G; ++gt)
 #pragma unroll
-          for (int nt = 0; nt < NTW; ++nt)
-            acc[gt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                a[X3_PA[q]], wp[gt][nt][ks].p[X3_PB[q]], acc[gt][nt], 0, 0, 0);
+          for (int nt = 0; nt < NTW; ++nt) {
+            const bf16x8 wb = (from_lds && gt == G - 1 && nt == 0) ? wl.p[X3_PB[q]]
+                                                                   : wp[gt][nt][ks].p[X3_PB[q]];
+            acc[gt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[X3_PA[q]], wb, acc[gt][nt], 0, 0, 0);
+          }
     }
+    // The next step's input projection is requested HERE, behind the MFMAs (it has the gate
+    // phase and the barrier to land): requested at the top of the step its 16 registers were live
+    // through the MFMA loop, the kernel went past 256 VGPRs and the compiler reloaded spilled
+    // weight planes from scratch inside the loop.
+    fetch(s + 1);  // (rows with s + 1 >= len load nothing)
 #ifdef RNN_SEQ_DBG_TIME
     const long long f_t1 = clock64();
 #endif
@@ -301,6 +323,8 @@ __global__ __launch_bounds__(NW * 64) void rnn_seq_bwd_kernel(RnnSeqParams p) {
   constexpr int LDGB = GH + 16;  // bf16 row pitch (conflict-free ds_read_b128)
   static_assert(NTW >= 1, "units per wave");
   __shared__ __attribute__((aligned(16))) unsigned short dg_pl[3][16][LDGB];
+  constexpr int KL = (KIND == 0 && H == 128) ? 4 : 0;  // weight fragments kept in LDS (see the forward kernel)
+  __shared__ __attribute__((aligned(16))) bf16x8 w_lds[KL > 0 ? KL : 1][3][NW * 64];
   const int d = blockIdx.y;
   const int b0 = blockIdx.x * 16;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -328,6 +352,10 @@ __global__ __launch_bounds__(NW * 64) void rnn_seq_bwd_kernel(RnnSeqParams p) {
       const float* w8 = WT + (long)n * GH + 32 * ks + 8 * quad;
       wt[nt][ks] = split_planes(*reinterpret_cast<const f32x4*>(w8),
                                 *reinterpret_cast<const f32x4*>(w8 + 4));
+      if (KL > 0 && nt == 0 && ks >= KS - KL) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) w_lds[ks - (KS - KL)][q][tid] = wt[nt][ks].p[q];
+      }
     }
   }
   float dh[NTW][4], dc[NTW][4];
@@ -345,9 +373,8 @@ __global__ __launch_bounds__(NW * 64) void rnn_seq_bwd_kernel(RnnSeqParams p) {
   // the previous step's state) is fetched one step ahead -- two for the previous state, which is
   // the next step's own state -- so no step starts with a global-load round trip.
   float pg[G][NTW][4], pa[NTW][4], pa_prev[NTW][4], pd[NTW][4];
-  auto fetch = [&](int s, float (&g_)[G][NTW][4], float (&a_)[NTW][4], float (&d_)[NTW][4]) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
+  auto fetch_row = [&](int s, int r, float (&g_)[G][NTW][4], float (&a_)[NTW][4], float (&d_)[NTW][4]) {
+    {
       const bool active = s >= 0 && s < len[r];
       const int tt = reverse ? len[r] - 1 - s : s;
       const int b = b0 + quad * 4 + r;
@@ -363,9 +390,12 @@ __global__ __launch_bounds__(NW * 64) void rnn_seq_bwd_kernel(RnnSeqParams p) {
     }
   };
   // previous state of step s: LSTM c_{s-1} = aux of step s-1; GRU h_{s-1} = out of step s-1
-  auto fetch_prev = [&](int s, float (&a_)[NTW][4]) {
+  auto fetch = [&](int s, float (&g_)[G][NTW][4], float (&a_)[NTW][4], float (&d_)[NTW][4]) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    for (int r = 0; r < 4; ++r) fetch_row(s, r, g_, a_, d_);
+  };
+  auto fetch_prev_row = [&](int s, int r, float (&a_)[NTW][4]) {
+    {
       const bool active = s >= 0 && s < len[r];
       const int tt = reverse ? len[r] - 1 - s : s;
       const int b = b0 + quad * 4 + r;
@@ -376,6 +406,10 @@ __global__ __launch_bounds__(NW * 64) void rnn_seq_bwd_kernel(RnnSeqParams p) {
         a_[nt][r] = active ? src[((long)tt * B + b) * H + u] : 0.f;
       }
     }
+  };
+  auto fetch_prev = [&](int s, float (&a_)[NTW][4]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) fetch_prev_row(s, r, a_);
   };
   fetch(Lt - 1, pg, pa, pd);
   fetch_prev(Lt - 2, pa_prev);
@@ -388,6 +422,9 @@ __global__ __launch_bounds__(NW * 64) void rnn_seq_bwd_kernel(RnnSeqParams p) {
     const long long d_t0 = clock64();
 #endif
     float keep_z[NTW][4];  // GRU: dh * z carried straight to h_prev
+    // (fetched at the top, consumed from copies: requesting the next step's values only after
+    // this step's last use of the registers -- no second set -- measured 5.2 -> 6.6 us per step:
+    // the loads then have too little time to land)
     float cg[G][NTW][4], ca[NTW][4], cprev[NTW][4], cd[NTW][4];
 #pragma unroll
     for (int r = 0; r < 4; ++r)
@@ -478,12 +515,19 @@ __global__ __launch_bounds__(NW * 64) void rnn_seq_bwd_kernel(RnnSeqParams p) {
 #pragma unroll
       for (int q = 0; q < 3; ++q)
         a[q] = *reinterpret_cast<const bf16x8*>(&dg_pl[q][l15][32 * ks + 8 * quad]);
+      Planes3 wl;
+      const bool from_lds = KL > 0 && ks >= KS - KL;
+      if (from_lds) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) wl.p[q] = w_lds[KL > 0 ? ks - (KS - KL) : 0][q][tid];
+      }
 #pragma unroll
       for (int q = 0; q < 6; ++q)
 #pragma unroll
-        for (int nt = 0; nt < NTW; ++nt)
-          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[X3_PA[q]], wt[nt][ks].p[X3_PB[q]],
-                                                            acc[nt], 0, 0, 0);
+        for (int nt = 0; nt < NTW; ++nt) {
+          const bf16x8 wb = (from_lds && nt == 0) ? wl.p[X3_PB[q]] : wt[nt][ks].p[X3_PB[q]];
+          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[X3_PA[q]], wb, acc[nt], 0, 0, 0);
+        }
     }
     // (two accumulator chains instead of one change nothing: 5.21 us per step either way)
 #pragma unroll
