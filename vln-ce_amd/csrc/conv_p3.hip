@@ -724,7 +724,11 @@ __global__ __launch_bounds__((WM * WN + P3_PRODUCERS) * 64) void conv_p3_kernel(
 // WAVES = 8: two waves per SIMD, 256 registers each, a wave owns BM x 32 outputs;
 // WAVES = 4: ONE wave per SIMD with the whole 512-register file, a wave owns BM x 64 outputs and
 // double-buffers its A fragments (no partner wave to hide LDS latency behind).
-template <int BM, int DUAL, int WAVES>
+// LINEAR: stride 1 (input pixel = output pixel).  A compile-time flag: as a runtime one the
+// strided path's division constants stayed live through the chunk loop, were spilled, and were
+// reloaded from scratch behind every chunk's MFMAs -- each reload followed by an
+// s_waitcnt vmcnt(0) that drained the wave's whole prefetch queue (profiles/r03_n_*).
+template <int BM, int DUAL, int WAVES, int LINEAR>
 __global__ __launch_bounds__(WAVES * 64) void conv_u3_kernel(IgemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int BN = 256, MT = BM / 32, NT = 8 / WAVES;
@@ -771,7 +775,7 @@ __global__ __launch_bounds__(WAVES * 64) void conv_u3_kernel(IgemmParams p) {
       reinterpret_cast<char*>(p.C), 0, (int)p.c_bytes, 0x00020000);
   const bool has_pro = p.in_scale != nullptr;
   const float relu_floor = p.in_relu ? 0.f : -__builtin_huge_valf();
-  const bool linear = p.stride == 1;
+  constexpr bool linear = LINEAR != 0;
 
   // ---------------------------------------------------------------- the A side (every thread)
   struct Vec {
@@ -815,7 +819,7 @@ __global__ __launch_bounds__(WAVES * 64) void conv_u3_kernel(IgemmParams p) {
       a_voff[i] = BUF_OOB;
       if (m < p.M) {
         int pix = m;
-        if (!linear) {
+        if constexpr (!linear) {
           const int img = m / HoWo;
           const int rem = m - img * HoWo;
           const int ho = rem / p.Wo;
@@ -1159,10 +1163,10 @@ __global__ __launch_bounds__(WAVES * 64) void conv_u3_kernel(IgemmParams p) {
 #endif
 }
 
-template <int BM, int DUAL, int WAVES>
-int launch_u3(const IgemmParams& p, hipStream_t stream) {
+template <int BM, int DUAL, int WAVES, int LINEAR>
+int launch_u3_(const IgemmParams& p, hipStream_t stream) {
   constexpr int smem_bytes = 2 * BM * P3_ROW;
-  auto kern = conv_u3_kernel<BM, DUAL, WAVES>;
+  auto kern = conv_u3_kernel<BM, DUAL, WAVES, LINEAR>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -1413,6 +1417,11 @@ int launch_s3(const IgemmParams& p, hipStream_t stream) {
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), smem_bytes, stream, q);
   VLNCE_CHECK_LAUNCH("conv_s3");
   return 0;
+}
+
+template <int BM, int DUAL, int WAVES>
+int launch_u3(const IgemmParams& p, hipStream_t stream) {
+  return p.stride == 1 ? launch_u3_<BM, DUAL, WAVES, 1>(p, stream) : launch_u3_<BM, DUAL, WAVES, 0>(p, stream);
 }
 
 // w_ohwi [N][KH][KW][Cin] fp32 -> B fragments [N/32][K/16][3][64 lanes][8 bf16]: k-slab
