@@ -1255,18 +1255,34 @@ __global__ __launch_bounds__(512) void conv_s3_kernel(IgemmParams p) {
         bres[ks][q] = __builtin_bit_cast(
             bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, vb + q * 1024, ks * 3072, 0));
   }
+  // prologue vectors of all chunks: in registers for K = 64; for K = 128 (48 registers on top of
+  // 96 of B fragments: the kernel spilled, and a scratch reload with its s_waitcnt vmcnt(0) in
+  // front of the raw-row request drained the wave's stores every tile) in LDS, read per chunk
+  constexpr bool VEC_LDS = NCC > 2;
+  float* const vlds = reinterpret_cast<float*>(xsm + 2 * PBUF);  // [3][NCC * 32]
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f}, one4 = {1.f, 1.f, 1.f, 1.f};
-  f32x4 vs[NCC], vt[NCC], vc[NCC];
+  f32x4 vs[VEC_LDS ? 1 : NCC], vt[VEC_LDS ? 1 : NCC], vc[VEC_LDS ? 1 : NCC];
 #pragma unroll
   for (int c = 0; c < NCC; ++c) {
-    vs[c] = one4;
-    vt[c] = vc[c] = zero4;
+    f32x4 s_ = one4, t_ = zero4, c_ = zero4;
     if (p.in_scale != nullptr) {
-      vs[c] = ldg4(p.in_scale + c * 32 + lk4);
-      vt[c] = ldg4(p.in_shift + c * 32 + lk4);
-      if (p.in_center) vc[c] = ldg4(p.in_center + c * 32 + lk4);
+      s_ = ldg4(p.in_scale + c * 32 + lk4);
+      t_ = ldg4(p.in_shift + c * 32 + lk4);
+      if (p.in_center) c_ = ldg4(p.in_center + c * 32 + lk4);
+    }
+    if constexpr (VEC_LDS) {
+      if (tid < 8) {
+        *reinterpret_cast<f32x4*>(vlds + c * 32 + lk4) = s_;
+        *reinterpret_cast<f32x4*>(vlds + NCC * 32 + c * 32 + lk4) = t_;
+        *reinterpret_cast<f32x4*>(vlds + 2 * NCC * 32 + c * 32 + lk4) = c_;
+      }
+    } else {
+      vs[c] = s_;
+      vt[c] = t_;
+      vc[c] = c_;
     }
   }
+  if constexpr (VEC_LDS) __syncthreads();
   const int col = n0 + wave * 32 + l31;
   const float e_sc = p.scale ? p.scale[col] : 1.f;
   const float e_sh = p.shift ? p.shift[col] : 0.f;
@@ -1307,9 +1323,19 @@ __global__ __launch_bounds__(512) void conv_s3_kernel(IgemmParams p) {
 #pragma unroll
     for (int c = 0; c < NCC; ++c) {
       f32x4 v = r[c];
+      f32x4 s_, t_, c_;
+      if constexpr (VEC_LDS) {
+        s_ = *reinterpret_cast<const f32x4*>(vlds + c * 32 + lk4);
+        t_ = *reinterpret_cast<const f32x4*>(vlds + NCC * 32 + c * 32 + lk4);
+        c_ = *reinterpret_cast<const f32x4*>(vlds + 2 * NCC * 32 + c * 32 + lk4);
+      } else {
+        s_ = vs[c];
+        t_ = vt[c];
+        c_ = vc[c];
+      }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        v[e] = fmaxf(fmaf(v[e] - vc[c][e], vs[c][e], vt[c][e]), relu_floor);
+        v[e] = fmaxf(fmaf(v[e] - c_[e], s_[e], t_[e]), relu_floor);
         v[e] = row_ok ? v[e] : 0.f;
       }
       p3_split_store(v, pb + c * CBUF + trow * P3_ROW + lk4 * 2);
@@ -1395,7 +1421,7 @@ __global__ __launch_bounds__(512) void conv_s3_kernel(IgemmParams p) {
 
 template <int NCC>
 int launch_s3(const IgemmParams& p, hipStream_t stream) {
-  constexpr int smem_bytes = 2 * NCC * 64 * P3_ROW;
+  constexpr int smem_bytes = 2 * NCC * 64 * P3_ROW + 3 * NCC * 32 * 4;  // two tile patches + the prologue vectors
   auto kern = conv_s3_kernel<NCC>;
   static bool attr_set = false;
   if (!attr_set) {
