@@ -728,6 +728,9 @@ __global__ __launch_bounds__((WM * WN + P3_PRODUCERS) * 64) void conv_p3_kernel(
 // strided path's division constants stayed live through the chunk loop, were spilled, and were
 // reloaded from scratch behind every chunk's MFMAs -- each reload followed by an
 // s_waitcnt vmcnt(0) that drained the wave's whole prefetch queue (profiles/r03_n_*).
+// DUAL: 0 = one input; 1 = block end with an identity skip (second input added as is); 2 = block
+// end whose skip path has its own BatchNorm.  Compile-time: the identity form carries half the
+// prologue vectors and its chunk body has no branch.
 template <int BM, int DUAL, int WAVES, int LINEAR>
 __global__ __launch_bounds__(WAVES * 64) void conv_u3_kernel(IgemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -789,7 +792,7 @@ __global__ __launch_bounds__(WAVES * 64) void conv_u3_kernel(IgemmParams p) {
       v.t = ldg4(p.in_shift + ci + lk4);
       if (p.in_center) v.c = ldg4(p.in_center + ci + lk4);
       if constexpr (DUAL) {
-        if (p.in2_scale != nullptr) {
+        if constexpr (DUAL == 2) {
           v.s2 = ldg4(p.in2_scale + ci + lk4);
           v.t2 = ldg4(p.in2_shift + ci + lk4);
           if (p.in2_center) v.c2 = ldg4(p.in2_center + ci + lk4);
@@ -859,7 +862,7 @@ __global__ __launch_bounds__(WAVES * 64) void conv_u3_kernel(IgemmParams p) {
   auto step_vec = [&](int ci_after_next) {
     cur = nxt;
     if constexpr (DUAL) {
-      if (p.in2_scale != nullptr) cur.t2 = cur.t + cur.t2;
+      if constexpr (DUAL == 2) cur.t2 = cur.t + cur.t2;
     }
     load_vec(nxt, ci_after_next);
   };
@@ -869,7 +872,7 @@ __global__ __launch_bounds__(WAVES * 64) void conv_u3_kernel(IgemmParams p) {
       f32x4 v = r.a[i];
       const bool ok = (r.ok >> i) & 1u;
       if constexpr (DUAL) {
-        if (p.in2_scale != nullptr) {
+        if constexpr (DUAL == 2) {
 #pragma unroll
           for (int e = 0; e < 4; ++e)
             v[e] = fmaxf(fmaf(v[e] - cur.c[e], cur.s[e],
@@ -1602,10 +1605,15 @@ int p3_try_launch(const IgemmParams& p, hipStream_t stream) {
     };
     const int bm = u3_env == 2 ? 64 : 128;
     if (eff(bm) >= 0.8 || u3_env >= 2) {
+      const int kind = !dual ? 0 : (p.in2_scale != nullptr ? 2 : 1);
       if (u3_waves == 4)   // one wave per SIMD, 64 x 256 tiles (a wave owns 64 x 64): experiment
-        return dual ? launch_u3<64, 1, 4>(p, stream) : launch_u3<64, 0, 4>(p, stream);
-      if (bm == 128) return dual ? launch_u3<128, 1, 8>(p, stream) : launch_u3<128, 0, 8>(p, stream);
-      return dual ? launch_u3<64, 1, 8>(p, stream) : launch_u3<64, 0, 8>(p, stream);
+        return kind == 2 ? launch_u3<64, 2, 4>(p, stream)
+                         : kind ? launch_u3<64, 1, 4>(p, stream) : launch_u3<64, 0, 4>(p, stream);
+      if (bm == 128)
+        return kind == 2 ? launch_u3<128, 2, 8>(p, stream)
+                         : kind ? launch_u3<128, 1, 8>(p, stream) : launch_u3<128, 0, 8>(p, stream);
+      return kind == 2 ? launch_u3<64, 2, 8>(p, stream)
+                       : kind ? launch_u3<64, 1, 8>(p, stream) : launch_u3<64, 0, 8>(p, stream);
     }
   }
   if (mode_env == 2 && !dense) return -1;  // VLNCE_P3=2: only the patch (KxK) layers
