@@ -325,3 +325,26 @@ def test_split_weights_is_gpu_only_and_channel_gated():
 
     assert ops.split_weights(torch.randn(8, 3, 3, 32)) is None      # CPU tensor
     assert ops.split_weights(torch.randn(8, 7, 7, 3)) is None       # Cin % 32 != 0
+
+
+def test_moving_a_policy_drops_its_captured_graphs():
+    """Module._apply (.to / .float / .double) gives parameters new storage without touching the
+    version counters the graph keys are made of: every graph holder of the policy (trunk graphs,
+    tail graphs, the whole-act graph) must come out of it empty."""
+    case = cases.CASES["cma_act_64"]
+    policy, _ = cases.build_policy(vlnce_amd, case, vlnce_amd.make_config, vlnce_amd.make_spaces,
+                                   tp.synth_state_dict)
+    from vlnce_amd.streams import ActGraph
+
+    object.__setattr__(policy, "_act_graph", ActGraph(policy))
+    holders = [policy._act_graph, policy.net._tail, policy.net.rgb_encoder.cnn._graphs,
+               policy.net.depth_encoder.visual_encoder._graphs]
+    for h in holders:
+        h.entries["stale"] = "seen"
+    policy.net._tail.sightings["stale"] = 1
+    policy._act_graph._tracked = ([], [])
+    versions = [p._version for p in policy.parameters()]
+    policy.double()
+    assert [p._version for p in policy.parameters()] == versions  # (why the keys cannot see it)
+    assert all(len(h.entries) == 0 for h in holders)
+    assert len(policy.net._tail.sightings) == 0 and policy._act_graph._tracked is None

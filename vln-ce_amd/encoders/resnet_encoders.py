@@ -25,7 +25,7 @@ import torch.nn as nn
 
 from .. import ops
 from ..config import Box, Dict
-from ..streams import capture_guard, wait_ready
+from ..streams import DropsGraphsOnApply, capture_guard, wait_ready
 from . import trunk_backward as tb
 
 
@@ -215,7 +215,7 @@ class SpatialAvgPool(nn.Module):
     out_hw = (4, 4)
 
 
-class HipResNetTrunk(nn.Sequential):
+class HipResNetTrunk(DropsGraphsOnApply, nn.Sequential):
     """torchvision ResNet children[:-1] (conv1, bn1, relu, maxpool, layer1..4,
     [avgpool]) with indices/keys preserved; forward = fused HIP plan."""
 
@@ -675,7 +675,7 @@ def resnet50(in_channels, base_planes, ngroups):
     return GNResNet(in_channels, base_planes, ngroups, GNBottleneck, [3, 4, 6, 3])
 
 
-class HipResNetEncoder(nn.Module):
+class HipResNetEncoder(DropsGraphsOnApply, nn.Module):
     """habitat ResNetEncoder (depth-only use in VLN-CE): avg_pool2d(2) ->
     GroupNorm ResNet -> 3x3 compression conv + GroupNorm(1, C) + ReLU."""
 

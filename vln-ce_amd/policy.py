@@ -6,11 +6,11 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .streams import ActGraph
+from .streams import ActGraph, DropsGraphsOnApply
 from .utils import CustomFixedCategorical
 
 
-class Net(nn.Module, metaclass=abc.ABCMeta):
+class Net(DropsGraphsOnApply, nn.Module, metaclass=abc.ABCMeta):
     pass
 
 
@@ -58,7 +58,7 @@ def _not_part_of_imitation_learning(self, *args, **kwargs):
     raise NotImplementedError
 
 
-class ILPolicy(Policy):
+class ILPolicy(DropsGraphsOnApply, Policy):
     """Imitation-learning policy: net + categorical action head, NO critic -- Policy.__init__ is
     deliberately bypassed as upstream (models/policy.py:10-23, App. B-6).  `act()` and
     `build_distribution()` are what the DAgger / recollect trainers call."""

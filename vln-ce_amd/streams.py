@@ -363,6 +363,28 @@ class ActGraph:
         return ent[2][0].clone(), ent[2][1].clone()
 
 
+class DropsGraphsOnApply:
+    """Mixin (in front of nn.Module in the bases) for modules that hold captured HIP graphs in
+    `_graphs` / `_tail` / `_act_graph`.  nn.Module._apply -- .to(), .cuda(), .float(), .half() --
+    gives the parameters new storage WITHOUT bumping their version counters, which are what the
+    graph keys carry; a graph captured before the move would replay on the old pointers.  The
+    captured graphs are dropped instead; the next calls run eagerly and capture again."""
+
+    _graph_holders = ("_graphs", "_tail", "_act_graph")
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        for name in self._graph_holders:
+            holder = self.__dict__.get(name)
+            if holder is not None:
+                holder.entries.clear()
+                if hasattr(holder, "sightings"):
+                    holder.sightings.clear()
+                if hasattr(holder, "_tracked"):
+                    holder._tracked = None
+        return out
+
+
 def bucket_rows(n, step=8):
     """smallest multiple of `step` >= n: instruction lengths are padded to buckets before a
     graphed tail so that batches whose longest instruction differs by a few tokens share one
