@@ -14,7 +14,10 @@ PARITY UNPINNED for this file: neither package is installed here and the
 reference carries no test that pins these modules, so they are restated from
 their published structure.  Every block reduces to
 torch.nn primitives whose CPU kernels are the per-op oracle.  The reference's
-call sites are cited next to each class.
+call sites are cited next to each class.  The torchvision graphs are held to
+the facts torchvision publishes about them (parameter counts, multiply-
+accumulates per 224x224 frame, checkpoint key layout, stride placement):
+tests/test_thirdparty_published_facts.py; habitat-lab publishes no such table.
 
 This module is shared by (a) tools/oracle/shims.py, which injects it under the
 third-party module names so the reference's own model files import unchanged,
