@@ -1,6 +1,8 @@
 """Pieces the Seq2Seq, CMA and waypoint nets share: construction of the visual encoders from
 `config.MODEL`, the three-branch encoder pass on side HIP streams, ablation switches, the
 previous-action index and the progress-monitor auxiliary loss."""
+import os
+
 import torch
 
 from . import ops
@@ -57,9 +59,15 @@ def encode_three_branches(net, observations, device):
         rgb = net.rgb_encoder(observations)
         ins, join_ins = branches.run(fork, 0, device, lambda: net.instruction_encoder(observations))
     else:
+        # training step: both side branches share side stream 0 (the instruction encoder's ~1 ms
+        # then the depth trunk's ~1.5 ms, beside the RGB trunk's ~5 ms on the caller's stream).
+        # VLNCE_TRAIN_BRANCHES=split puts the depth trunk on its own stream as under no_grad --
+        # unmeasured (it competes with the RGB trunk's one-workgroup-per-CU launches), off by default
+        split = os.environ.get("VLNCE_TRAIN_BRANCHES", "") == "split"
         rgb = net.rgb_encoder(observations)
         ins, join_ins = branches.run(fork, 0, device, lambda: net.instruction_encoder(observations))
-        dep, join_dep = branches.run(fork, 0, device, lambda: net.depth_encoder(observations))
+        dep, join_dep = branches.run(fork, 2 if split else 0, device,
+                                     lambda: net.depth_encoder(observations))
     join_ins()
     join_dep()
     return ins, dep, rgb
