@@ -923,6 +923,22 @@ def test_conv_s3_forced():
     assert r.returncode == 0, r.stdout[-3000:]
 
 
+@pytest.mark.skipif(os.environ.get("VLNCE_TEST_EXPERIMENTAL") != "1",
+                    reason="conv_s3p_kernel was written after round 3's GPU budget was spent: it has "
+                           "never run; VLNCE_TEST_EXPERIMENTAL=1 includes it")
+def test_conv_s3_pipelined_epilogue_forced():
+    """conv_s3p_kernel (VLNCE_S3_PIPE=1: the previous tile's stores under this tile's MFMAs, two
+    accumulator sets) over the same cases as test_conv_s3_forced."""
+    import subprocess
+    import sys
+    env = dict(os.environ, VLNCE_S3="2", VLNCE_S3_PIPE="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu",
+                        "-k", "(conv2d_fwd or bottleneck or block or conv_p3) and not every_tile "
+                              "and not u3_forced and not s3_forced and not pipelined", "-p", "no:cacheprovider"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:]
+
+
 def test_conv_p3_matches_fp64_better_than_1e_6(hip):
     """The round-to-nearest bf16x3 split keeps the convolution fp32-class: relative rms error
     against an fp64 convolution of the same operands below 1e-6 (torch's own fp32 conv: ~2e-7)."""

@@ -1422,10 +1422,220 @@ __global__ __launch_bounds__(512) void conv_s3_kernel(IgemmParams p) {
 #endif
 }
 
+// conv_s3p_kernel: conv_s3_kernel with the epilogue of tile t - 1 issued UNDER the matrix
+// instructions of tile t (EXPERIMENT, VLNCE_S3_PIPE=1, not measured yet -- written at the end of
+// round 3 after the GPU budget was spent; conv_s3_kernel above is untouched and stays the
+// default).  conv_s3_kernel's phases are serial per wave: transform, barrier, 48-96 MFMAs, then 32
+// store instructions at the CU's ~12 B/cycle (54 % of the launch).  Stores are fire-and-forget,
+// so the only coupling between a wave's stores and its MFMAs is the issue order: here a wave
+// keeps TWO accumulator sets (+32 VGPRs), and while the MFMAs of tile t fill one, the stores of
+// tile t - 1 drain the other, a few behind every k-slab (sched_group_barrier keeps the
+// interleaving).  When the store queue is full the wave stalls at a store and the SIMD's other
+// wave issues its MFMAs; per tile the CU then needs max(stores, MFMAs) instead of their sum.
+// Loads stay two tiles ahead as in conv_s3_kernel, so nothing waits behind the stores.
 template <int NCC>
+__global__ __launch_bounds__(512) void conv_s3p_kernel(IgemmParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int BM = 64, MT = 2, KS = NCC * 2;
+  constexpr int CBUF = BM * P3_ROW;            // one chunk of a tile's patch
+  constexpr int PBUF = NCC * CBUF;             // one tile's patch
+  constexpr int SPS = 32 / KS;                 // stores of the previous tile behind each k-slab
+  extern __shared__ __attribute__((aligned(16))) char xsm[];  // [2][PBUF] + prologue vectors
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5;
+  const int l31 = lane & 31;
+  const int trow = tid >> 3;
+  const int lk4 = (tid & 7) * 4;
+
+  const int n0 = ((int)blockIdx.x % p.tiles_n) * 256;
+  const int wg = (int)blockIdx.x / p.tiles_n, nwg = (int)gridDim.x / p.tiles_n;
+  const int my_tiles = (p.tiles_m - wg + nwg - 1) / nwg;
+
+  const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char*>(reinterpret_cast<const char*>(p.A)), 0, (int)p.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char*>(reinterpret_cast<const char*>(p.Bfrag)), 0, (int)((long)p.N * p.K * 6),
+      0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_c = __builtin_amdgcn_make_buffer_rsrc(
+      reinterpret_cast<char*>(p.C), 0, (int)p.c_bytes, 0x00020000);
+  const float relu_floor = p.in_relu ? 0.f : -__builtin_huge_valf();
+  const bool relu_out = p.act == VLNCE_ACT_RELU;  // the launcher admits VLNCE_ACT_NONE / _RELU only
+
+  bf16x8 bres[KS][3];
+  {
+    const int vb = (n0 / 32 + wave) * KS * 3072 + lane * 16;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+        bres[ks][q] = __builtin_bit_cast(
+            bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, vb + q * 1024, ks * 3072, 0));
+  }
+  // prologue vectors always in LDS here: the second accumulator set takes their registers
+  float* const vlds = reinterpret_cast<float*>(xsm + 2 * PBUF);  // [3][NCC * 32]
+  if (tid < 8) {
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f}, one4 = {1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+    for (int c = 0; c < NCC; ++c) {
+      f32x4 s_ = one4, t_ = zero4, c_ = zero4;
+      if (p.in_scale != nullptr) {
+        s_ = ldg4(p.in_scale + c * 32 + lk4);
+        t_ = ldg4(p.in_shift + c * 32 + lk4);
+        if (p.in_center) c_ = ldg4(p.in_center + c * 32 + lk4);
+      }
+      *reinterpret_cast<f32x4*>(vlds + c * 32 + lk4) = s_;
+      *reinterpret_cast<f32x4*>(vlds + NCC * 32 + c * 32 + lk4) = t_;
+      *reinterpret_cast<f32x4*>(vlds + 2 * NCC * 32 + c * 32 + lk4) = c_;
+    }
+  }
+  __syncthreads();
+  const int col = n0 + wave * 32 + l31;
+  const float e_sc = p.scale ? p.scale[col] : 1.f;
+  const float e_sh = p.shift ? p.shift[col] : 0.f;
+
+  // raw A ring: two tiles ahead for K = 64 as in conv_s3_kernel; ONE for K = 128, where the second
+  // accumulator set leaves no registers for it (with the stores spread over the MFMA phase the
+  // request of tile t + 1 sits behind the stores of tile t - 2 only, a whole tile old)
+  constexpr int RING = NCC > 2 ? 1 : 2;
+  f32x4 raw[RING][NCC];
+  auto load_raw = [&](f32x4 (&r)[NCC], int round) {
+    const int m = (wg + round * nwg) * BM + trow;
+    const int vo = (round < my_tiles && m < p.M) ? (m * p.lda + lk4) * 4 : BUF_OOB;
+#pragma unroll
+    for (int c = 0; c < NCC; ++c)
+      r[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, vo, c * 128, 0));
+  };
+#pragma unroll
+  for (int k = 0; k < RING; ++k) load_raw(raw[k], k);
+  f32x16 acc[2][MT];  // [tile parity][row block]
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[b][i][r] = 0.f;
+  constexpr int PA[6] = {2, 1, 0, 1, 0, 0};  // smallest products first
+  constexpr int PB[6] = {0, 1, 2, 0, 1, 0};
+  const int a_off = l31 * P3_ROW + half * 16;
+
+  // statistics partials of a finished tile (raw accumulators, 32-row blocks)
+  auto stats = [&](const f32x16 (&a)[MT], int m0) {
+    if (p.stat_partial != nullptr) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+        wave_stats_block<1>(reinterpret_cast<const f32x16(&)[1]>(a[i]), p.stat_partial,
+                            m0 / 32 + i, p.M - (m0 + i * 32), n0 + wave * 32, p.N, half, l31);
+    }
+  };
+  // stores [first, first + count) of the 32 of a finished tile; the registers are cleared behind
+  auto stores = [&](f32x16 (&a)[MT], int m0, int first, int count) {
+    const int rows_left = p.M - (m0 + 4 * half);
+    const int e_voff = (int)((((long)(m0 + 4 * half)) * p.ldc + col) * 4);
+#pragma unroll
+    for (int k = first; k < first + count; ++k) {
+      const int i = k >> 4, r2 = k & 15;
+      const int rw = i * 32 + (r2 & 3) + 8 * (r2 >> 2);
+      const float lin = a[i][r2] * e_sc + e_sh;
+      const float v = relu_out ? (lin > 0.f ? lin : 0.f) : lin;  // (act is none or ReLU: selects, no branch)
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc_c,
+                                            rw < rows_left ? e_voff : BUF_OOB, rw * p.ldc * 4, 0);
+      a[i][r2] = 0.f;
+    }
+  };
+
+  // one tile: cur = accumulator set of this tile, prv = the set of the tile before it (its
+  // statistics and stores are issued here, under this tile's MFMAs)
+  auto tile = [&](int round, f32x4 (&r)[NCC], f32x16 (&cur)[MT], f32x16 (&prv)[MT]) {
+    const int m0 = (wg + round * nwg) * BM;
+    const int m0_prev = (wg + (round - 1) * nwg) * BM;
+    const bool has_prev = round > 0;
+    char* const pb = xsm + (round & 1) * PBUF;
+    const bool row_ok = m0 + trow < p.M;
+#pragma unroll
+    for (int c = 0; c < NCC; ++c) {
+      f32x4 v = r[c];
+      const f32x4 s_ = *reinterpret_cast<const f32x4*>(vlds + c * 32 + lk4);
+      const f32x4 t_ = *reinterpret_cast<const f32x4*>(vlds + NCC * 32 + c * 32 + lk4);
+      const f32x4 c_ = *reinterpret_cast<const f32x4*>(vlds + 2 * NCC * 32 + c * 32 + lk4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[e] = fmaxf(fmaf(v[e] - c_[e], s_[e], t_[e]), relu_floor);
+        v[e] = row_ok ? v[e] : 0.f;
+      }
+      p3_split_store(v, pb + c * CBUF + trow * P3_ROW + lk4 * 2);
+    }
+    load_raw(r, round + RING);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (has_prev) stats(prv, m0_prev);
+#pragma unroll
+    for (int c = 0; c < NCC; ++c)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        bf16x8 f[MT][3];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int q = 0; q < 3; ++q)
+            f[i][q] = *reinterpret_cast<const bf16x8*>(pb + c * CBUF + a_off + i * 32 * P3_ROW +
+                                                       q * 64 + s2 * 32);
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+            cur[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[i][PA[q]], bres[c * 2 + s2][PB[q]],
+                                                             cur[i], 0, 0, 0);
+        // the previous tile's next SPS stores ride behind this slab's 12 MFMAs (a tile whose
+        // predecessor does not exist stores to the out-of-range offset: no branch in the body)
+        stores(prv, has_prev ? m0_prev : p.M, (c * 2 + s2) * SPS, SPS);
+        // schedule of the slab: its 12 MFMAs with the SPS stores spread evenly between them
+        // (K = 64: 2 MFMAs, store, 1 MFMA, store, four times; K = 128: 3 MFMAs, store, four times)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          if constexpr (SPS == 8) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);  // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);  // VMEM write
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);
+          } else {
+            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);
+          }
+        }
+      }
+  };
+  // The first two tiles are peeled: the compiler's s_waitcnt at a loop header is the minimum
+  // over the paths into it, and entered straight from the preamble the first wait for raw rows
+  // would be vmcnt(3) on EVERY trip -- i.e. the stores of the tile before would be drained every
+  // second tile (conv_s3_kernel has exactly that: vmcnt(3) / vmcnt(35) alternate in its ISA).
+  // Behind the peeled tiles both ways into the loop have a tile's 32 stores after the request.
+  tile(0, raw[0], acc[0], acc[1]);
+  if (1 < my_tiles) tile(1, raw[RING - 1], acc[1], acc[0]);
+  for (int round = 2; round < my_tiles; round += 2) {
+    tile(round, raw[0], acc[0], acc[1]);
+    if (round + 1 < my_tiles) tile(round + 1, raw[RING - 1], acc[1], acc[0]);
+  }
+  // the last tile's epilogue has nothing left to hide under
+  if (my_tiles > 0) {
+    const int m0 = (wg + (my_tiles - 1) * nwg) * BM;
+    if ((my_tiles - 1) & 1) {
+      stats(acc[1], m0);
+      stores(acc[1], m0, 0, 32);
+    } else {
+      stats(acc[0], m0);
+      stores(acc[0], m0, 0, 32);
+    }
+  }
+#endif
+}
+
+template <int NCC, int PIPE>
 int launch_s3(const IgemmParams& p, hipStream_t stream) {
   constexpr int smem_bytes = 2 * NCC * 64 * P3_ROW + 3 * NCC * 32 * 4;  // two tile patches + the prologue vectors
-  auto kern = conv_s3_kernel<NCC>;
+  auto kern = PIPE ? conv_s3p_kernel<NCC> : conv_s3_kernel<NCC>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -1593,7 +1803,12 @@ int p3_try_launch(const IgemmParams& p, hipStream_t stream) {
   if (!dense && !dual && s3_env && p.stride == 1 && (p.Cin == 64 || p.Cin == 128) && p.K == p.Cin &&
       p.N % 256 == 0 && p.N / 256 <= 8 && (p.stat_partial == nullptr || p.stat_rows == 32) &&
       (s3_env == 2 || (long)ceil_div(p.M, 64) * (p.N / 256) >= 4L * x3_cus()))
-    return p.Cin == 64 ? launch_s3<2>(p, stream) : launch_s3<4>(p, stream);
+  {
+    // VLNCE_S3_PIPE=1: conv_s3p_kernel (previous tile's stores under this tile's MFMAs): experiment
+    static const int s3_pipe = getenv("VLNCE_S3_PIPE") ? atoi(getenv("VLNCE_S3_PIPE")) : 0;
+    if (s3_pipe && (p.act == VLNCE_ACT_NONE || p.act == VLNCE_ACT_RELU)) return p.Cin == 64 ? launch_s3<2, 1>(p, stream) : launch_s3<4, 1>(p, stream);
+    return p.Cin == 64 ? launch_s3<2, 0>(p, stream) : launch_s3<4, 0>(p, stream);
+  }
   static const int u3_env = getenv("VLNCE_U3") ? atoi(getenv("VLNCE_U3")) : 1;
   static const int u3_waves = getenv("VLNCE_U3_WAVES") ? atoi(getenv("VLNCE_U3_WAVES")) : 8;
   if (!dense && u3_env && p.N >= 256) {
