@@ -13,6 +13,14 @@ for pipe in 0 1; do
   echo "S3_PIPE=$pipe: $(VLNCE_S3_PIPE=$pipe timeout 120 python scripts/convbench.py --mode train --pro --set r50 \
      --iters 10 --rounds 3 --only l1_1x1_64_256,l2_1x1_128_512 2>&1 | grep '^l[12]_' | awk '{printf "%s %s us  ", $1, $5}')"
 done | tee $out/s3p_convbench.txt
+# conv_u3 with the chunk's raw-row / slab-1 loads pinned in front of the first MFMA: build the
+# variant in the CPU container first:  scripts/build_variants.sh u3lf "-DU3_LOADS_FIRST"
+if [ -f build/variants/libvlnce_u3lf.so ]; then
+  for lib in "" build/variants/libvlnce_u3lf.so; do
+    echo "lib='$lib': $(VLNCE_HIP_LIB=$lib timeout 200 python scripts/convbench.py --mode train --pro --set r50 \
+       --iters 10 --rounds 3 --only 1x1 2>&1 | grep '^l[1-4]_' | awk '{printf "%s %s  ", $1, $5}')"
+  done | tee $out/u3_loads_first_convbench.txt
+fi
 for br in "" split; do
   echo "TRAIN_BRANCHES='$br': $(VLNCE_TRAIN_BRANCHES=$br timeout 200 python bench.py --no-cpu-baseline --no-f32-compare \
      2>/dev/null | python -c 'import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d["ms_per_step"], d["config"]["encode_ahead_ms_per_step"])')"

@@ -1052,6 +1052,13 @@ __global__ __launch_bounds__(WAVES * 64) void conv_u3_kernel(IgemmParams p) {
       // the first half's fragments are read before the first MFMA (all eight waves read at once
       // right after the barrier: every kilobyte in front of the first MFMA is exposed); the
       // other reads trickle, one per MFMA, a phase ahead of their use.
+#ifdef U3_LOADS_FIRST
+      // (variant build, unmeasured: in the default schedule the compiler places k-slab 1's three
+      // B-fragment loads ~4 MFMAs in front of the s_waitcnt vmcnt(0) that consumes them -- see the
+      // ISA -- although the source requests them at the top of the chunk; this pins the chunk's
+      // raw-row and slab-1 loads in front of the first MFMA)
+      __builtin_amdgcn_sched_group_barrier(0x020, NPT + 3 * NT, 0);
+#endif
       __builtin_amdgcn_sched_group_barrier(0x100, 3 * HM, 0);
 #pragma unroll
       for (int ph = 0; ph < 4; ++ph) {
