@@ -1619,6 +1619,7 @@ __global__ __launch_bounds__(512) void conv_s3p_kernel(IgemmParams p) {
   // would be vmcnt(3) on EVERY trip -- i.e. the stores of the tile before would be drained every
   // second tile (conv_s3_kernel has exactly that: vmcnt(3) / vmcnt(35) alternate in its ISA).
   // Behind the peeled tiles both ways into the loop have a tile's 32 stores after the request.
+  if (my_tiles <= 0) return;  // (cannot happen with launch_s3's grid; uniform per workgroup)
   tile(0, raw[0], acc[0], acc[1]);
   if (1 < my_tiles) tile(1, raw[RING - 1], acc[1], acc[0]);
   for (int round = 2; round < my_tiles; round += 2) {
@@ -1626,7 +1627,7 @@ __global__ __launch_bounds__(512) void conv_s3p_kernel(IgemmParams p) {
     if (round + 1 < my_tiles) tile(round + 1, raw[RING - 1], acc[1], acc[0]);
   }
   // the last tile's epilogue has nothing left to hide under
-  if (my_tiles > 0) {
+  {
     const int m0 = (wg + (my_tiles - 1) * nwg) * BM;
     if ((my_tiles - 1) & 1) {
       stats(acc[1], m0);
