@@ -9,8 +9,10 @@
  *   - every function returns 0 on success, non-zero on error; the message is
  *     available through vlnce_last_error() (thread-local).
  *   - all pointers are DEVICE pointers valid on `stream`; the library never
- *     allocates, never synchronises and keeps no mutable global state besides
- *     the error string.  Workspaces are caller-allocated.
+ *     allocates, never synchronises and never reads the environment.  Its only
+ *     mutable state is the thread-local error string and the process-wide
+ *     dispatch options below (vlnce_set_option), which select between kernels
+ *     that compute the same function.  Workspaces are caller-allocated.
  *   - activations are fp32, channels-last: images [N,H,W,C], matrices row-major.
  *   - `stream` is a hipStream_t passed as void* (0 = default stream).
  */
@@ -28,8 +30,32 @@ typedef void* vlnce_stream_t;
 
 enum { VLNCE_ACT_NONE = 0, VLNCE_ACT_RELU = 1, VLNCE_ACT_SIGMOID = 2, VLNCE_ACT_TANH = 3 };
 
-int vlnce_version(void); /* major*100 + minor; 133 = this header */
+int vlnce_version(void); /* major*100 + minor; 134 = this header */
 const char* vlnce_last_error(void);
+
+/* Dispatch options: which of the library's equivalent kernels a launch is given to.  Explicit
+ * state instead of environment variables, so that a host (or a test) can force a kernel onto a
+ * shape in-process and restore the default afterwards.  No reference counterpart (torch picks its
+ * cuDNN / MIOpen algorithm through torch.backends.cudnn.benchmark, never set by the reference).
+ *   name               default  meaning
+ *   "conv_math"        1        1: fp32 operands as three bf16 planes on the bf16 matrix pipe
+ *                               (conv_p3 / conv_u3 / conv_s3 / conv_x3); 0: v_mfma_f32_32x32x2_f32 only
+ *   "p3"               2        conv_p3_kernel: 0 off, 1 every layer it covers, 2 KxK only, 3 1x1 only
+ *   "p3_tile"          0        0: by CU fill; 1..6: forced tile shape
+ *   "s3"               1        conv_s3_kernel (short-K wide 1x1): 0 off, 1 default rule, 2 every eligible shape
+ *   "u3"               1        conv_u3_kernel (wide 1x1): 0 off, 1 default rule, 2 / 3 force 64- / 128-row tiles
+ *   "u3_waves"         8        8, or 4 (one wave per SIMD)
+ *   "x3_tile"          0        conv_x3_kernel: 0 by CU fill, 1..4 forced tile shape
+ *   "igemm_tile"       0        igemm_kernel: 0 rule, 1 128x128, 2 128x64, 3 64x64
+ *   "igemm_nobuf"      0        1: no buffer-descriptor operand loads
+ *   "igemm_no_splitk"  0        1: no split-K
+ *   "wgrad_tile"       64       64 or 128 (vlnce_conv2d_wgrad)
+ *   "rollout_one_xcd"  0        1: all workgroups of vlnce_gru_rollout_* on one XCD
+ * Set options between launches, not concurrently with them (relaxed atomics).  Unknown names
+ * return non-zero. */
+int vlnce_set_option(const char* name, int value);
+int vlnce_get_option(const char* name, int* value);
+int vlnce_option_default(const char* name, int* value);
 
 /* ---------------------------------------------------------------- conv / GEMM
  * Implicit-GEMM convolution on v_mfma_f32_32x32x2_f32 (exact fp32):

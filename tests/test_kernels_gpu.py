@@ -800,18 +800,27 @@ def test_split_weights_is_exact(hip):
     assert (q.view(torch.float32).double().sum(0) - 1e-38).abs().max().item() < 2.0 ** -126
 
 
+def _conv_cases_under(hip, cases, want_path=None, **opts):
+    """every case of `cases` through test_conv2d_fwd with the dispatch options `opts` set
+    (vlnce_set_option: in-process, restored afterwards); `want_path`: the kernel family at
+    least one of the cases must really have been given to (vlnce_conv2d_last_path)."""
+    seen = set()
+    with hip.options(**opts):
+        for case in cases:
+            try:
+                test_conv2d_fwd(hip, case)
+            except AssertionError as e:
+                raise AssertionError(f"case {case[0]} under options {opts}: {e}") from e
+            seen.add(hip.conv2d_last_path())
+    assert want_path is None or want_path in seen, (opts, seen)
+
+
 @pytest.mark.parametrize("tile", [1, 2, 3, 4])
-def test_conv_x3_every_tile_shape(tile):
-    """conv_x3_kernel has four tile shapes chosen by problem size; force each one (VLNCE_X3_TILE,
-    read once per process) over the conv / block cases, including several tiles per workgroup,
-    ragged M, N below the tile width, the dual-input prologue and statistics partials."""
-    import subprocess
-    import sys
-    env = dict(os.environ, VLNCE_X3_TILE=str(tile))
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu",
-                        "-k", "conv2d_fwd or bottleneck or block", "-p", "no:cacheprovider"],
-                       env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-3000:]
+def test_conv_x3_every_tile_shape(hip, tile):
+    """conv_x3_kernel has four tile shapes chosen by problem size; force each one (option
+    "x3_tile") over the conv cases, including several tiles per workgroup, ragged M, N below the
+    tile width, the dual-input prologue and statistics partials."""
+    _conv_cases_under(hip, CONV_CASES, want_path=1, x3_tile=tile)
 
 
 # ------------------------------------------------------------------ patch-resident bf16-plane kernel
@@ -878,65 +887,40 @@ def test_conv_p3(hip, case):
 
 
 @pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6])
-def test_conv_p3_every_tile_shape(tile):
-    """conv_p3_kernel has six tile shapes chosen by problem size; force each one (VLNCE_P3_TILE,
-    read once per process) over the conv / block cases: several tiles per workgroup, ragged M,
-    N below the tile width, patches across image borders, the dual-input prologue, statistics."""
-    import subprocess
-    import sys
-    env = dict(os.environ, VLNCE_P3_TILE=str(tile))
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu",
-                        "-k", "(conv2d_fwd or bottleneck or block or conv_p3) and not every_tile and not u3_forced "
-                              "and not s3_forced",
-                        "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-3000:]
+def test_conv_p3_every_tile_shape(hip, tile):
+    """conv_p3_kernel has six tile shapes chosen by problem size; force each one (option
+    "p3_tile") over the conv cases: several tiles per workgroup, ragged M, N below the tile width,
+    patches across image borders, the dual-input prologue, statistics."""
+    _conv_cases_under(hip, CONV_CASES + P3_CASES, want_path=2, p3_tile=tile)
 
 
 @pytest.mark.parametrize("mode", [2, 3])
-def test_conv_u3_forced(mode):
-    """conv_u3_kernel (1x1, no producer waves) takes a layer
-    only when its 128-row tiles fill the CUs, which no unit-test shape does: force it
-    (VLNCE_U3=2: 64-row tiles, 3: 128-row tiles; read once per process) over the 1x1 cases with
-    N >= 256 -- prologue, statistics, stride 2, dual input, ragged M -- and the block tests."""
-    import subprocess
-    import sys
-    env = dict(os.environ, VLNCE_U3=str(mode))
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu",
-                        "-k", "(conv2d_fwd or bottleneck or block or conv_p3) and not every_tile "
-                              "and not u3_forced and not s3_forced", "-p", "no:cacheprovider"],
-                       env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-3000:]
+def test_conv_u3_forced(hip, mode):
+    """conv_u3_kernel (1x1, no producer waves) takes a layer only when its tiles fill the CUs,
+    which no unit-test shape does: force it (option "u3" = 2: 64-row tiles, 3: 128-row tiles)
+    over the 1x1 cases with N >= 256 -- prologue, statistics, stride 2, dual input, ragged M."""
+    _conv_cases_under(hip, CONV_CASES + P3_CASES, want_path=2, u3=mode)
 
 
-def test_conv_s3_forced():
-    """conv_s3_kernel (short-K wide 1x1: B fragments and prologue vectors resident, raw rows two
-    tiles ahead) takes a layer by default only when every CU gets at least four of its 64-row tiles;
-    VLNCE_S3=2 (read once per process) sends every eligible shape to it: prologue + centre,
-    statistics, epilogue scale / act, ragged M, several tiles per workgroup, two column tiles."""
-    import subprocess
-    import sys
-    env = dict(os.environ, VLNCE_S3="2")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu",
-                        "-k", "(conv2d_fwd or bottleneck or block or conv_p3) and not every_tile "
-                              "and not u3_forced and not s3_forced", "-p", "no:cacheprovider"],
-                       env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-3000:]
+def test_conv_s3_forced(hip):
+    """conv_s3_kernel (short-K wide 1x1: B fragments resident, raw rows two tiles ahead, the
+    previous tile's stores under this tile's MFMAs) takes a layer by default only when every CU
+    gets at least four of its 64-row tiles; option "s3" = 2 sends every eligible shape to it:
+    prologue + centre, statistics, epilogue scale / act, ragged M, one to five tiles per
+    workgroup (the peeled first two and the loop), two column tiles."""
+    _conv_cases_under(hip, CONV_CASES + P3_CASES, want_path=2, s3=2)
 
 
-@pytest.mark.skipif(os.environ.get("VLNCE_TEST_EXPERIMENTAL") != "1",
-                    reason="conv_s3p_kernel was written after round 3's GPU budget was spent: it has "
-                           "never run; VLNCE_TEST_EXPERIMENTAL=1 includes it")
-def test_conv_s3_pipelined_epilogue_forced():
-    """conv_s3p_kernel (VLNCE_S3_PIPE=1: the previous tile's stores under this tile's MFMAs, two
-    accumulator sets) over the same cases as test_conv_s3_forced."""
-    import subprocess
-    import sys
-    env = dict(os.environ, VLNCE_S3="2", VLNCE_S3_PIPE="1")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu",
-                        "-k", "(conv2d_fwd or bottleneck or block or conv_p3) and not every_tile "
-                              "and not u3_forced and not s3_forced and not pipelined", "-p", "no:cacheprovider"],
-                       env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-3000:]
+def test_options_are_explicit_state(hip):
+    """vlnce_set_option / vlnce_get_option / vlnce_option_default: set, read back, restore; an
+    unknown name is an error (the library reads no environment variable)."""
+    for name in hip.OPTION_NAMES:
+        d = hip.option_default(name)
+        with hip.options(**{name: d + 1}):
+            assert hip.get_option(name) == d + 1
+        assert hip.get_option(name) == hip.option_default(name) or os.environ.get("VLNCE_" + name.upper())
+    with pytest.raises(RuntimeError, match="unknown option"):
+        hip.set_option("no_such_option", 1)
 
 
 def test_conv_p3_matches_fp64_better_than_1e_6(hip):

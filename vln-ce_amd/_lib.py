@@ -47,6 +47,9 @@ class Epilogue(C.Structure):
 _SIGNATURES = {
     "vlnce_version": (_I, []),
     "vlnce_last_error": (C.c_char_p, []),
+    "vlnce_set_option": (_I, [C.c_char_p, _I]),
+    "vlnce_get_option": (_I, [C.c_char_p, C.POINTER(_I)]),
+    "vlnce_option_default": (_I, [C.c_char_p, C.POINTER(_I)]),
     "vlnce_conv2d_split_weights": (_I, [_P, _P, C.c_long, _P]),
     "vlnce_conv2d_last_path": (_I, []),
     "vlnce_embedding_bwd": (_I, [_P, _P, _P, _L, _I, _L, _L, _P]),
@@ -183,7 +186,7 @@ class HipLib:
 
     name = "hip"
 
-    ABI = 133  # include/vlnce_hip.h
+    ABI = 134  # include/vlnce_hip.h
 
     def __init__(self, path=LIB_PATH):
         self.dll = load_cdll(path)
@@ -191,6 +194,55 @@ class HipLib:
         if have != self.ABI:  # struct layouts / signatures moved: a stale .so would corrupt memory
             raise RuntimeError(f"{path} has ABI {have}, this package binds ABI {self.ABI}: "
                                "rebuild it (python __graft_entry__.py)")
+
+        self._options_from_env()
+
+    # ---- dispatch options (vlnce_set_option): the library itself never reads the environment;
+    # the VLNCE_* variables of INTEGRATION.md section 8 are translated here, once, at load
+    OPTION_NAMES = ("conv_math", "p3", "p3_tile", "s3", "u3", "u3_waves", "x3_tile", "igemm_tile",
+                    "igemm_nobuf", "igemm_no_splitk", "wgrad_tile", "rollout_one_xcd")
+
+    def _options_from_env(self):
+        for name in self.OPTION_NAMES:
+            v = os.environ.get("VLNCE_" + name.upper())
+            if v is None:
+                continue
+            if name == "conv_math":
+                v = 0 if v[:1] in ("f", "0") else 1
+            elif name in ("igemm_nobuf", "igemm_no_splitk"):
+                v = 0 if v in ("", "0") else 1
+            self.set_option(name, int(v))
+
+    def set_option(self, name, value):
+        self._check(self.dll.vlnce_set_option(name.encode(), int(value)), "vlnce_set_option")
+
+    def get_option(self, name):
+        v = _I(0)
+        self._check(self.dll.vlnce_get_option(name.encode(), C.byref(v)), "vlnce_get_option")
+        return v.value
+
+    def option_default(self, name):
+        v = _I(0)
+        self._check(self.dll.vlnce_option_default(name.encode(), C.byref(v)), "vlnce_option_default")
+        return v.value
+
+    def options(self, **kw):
+        """`with lib.options(u3=2, s3=0): ...` -- sets, then restores what was there before."""
+        lib = self
+
+        class _Scope:
+            def __enter__(self_inner):
+                self_inner.old = {k: lib.get_option(k) for k in kw}
+                for k, v in kw.items():
+                    lib.set_option(k, v)
+                return lib
+
+            def __exit__(self_inner, *exc):
+                for k, v in self_inner.old.items():
+                    lib.set_option(k, v)
+                return False
+
+        return _Scope()
 
     def _check(self, rc, what):
         _leave_device()

@@ -1,8 +1,11 @@
 // Error string + version of libvlnce_hip.so.
 #include <stdarg.h>
 #include <stdio.h>
+#include <string.h>
 
-#include "../../include/vlnce_hip.h"
+#include <atomic>
+
+#include "common_opts.h"
 
 static thread_local char g_err[512] = "";
 
@@ -16,4 +19,60 @@ void vlnce_set_error(const char* fmt, ...) {
 extern "C" const char* vlnce_last_error(void) { return g_err; }
 // major*100 + minor; 1.x: round-1 ABI (centered normalisation vectors, dual-input prologue,
 // backward / data-path / returns entry points).  Struct layouts only ever grow at the end.
-extern "C" int vlnce_version(void) { return 133; }
+// 134: vlnce_set_option / vlnce_get_option (the library no longer reads environment variables).
+extern "C" int vlnce_version(void) { return 134; }
+
+// ---- dispatch options: one int per name, process-wide, relaxed atomics (a tuning / test knob,
+// not a synchronisation point: set them before the launches they are meant for)
+namespace {
+struct OptDef {
+  const char* name;
+  int def;
+};
+const OptDef kOpts[VLNCE_OPT_COUNT] = {
+    {"conv_math", 1},   {"p3", 2},          {"p3_tile", 0},         {"s3", 1},
+    {"u3", 1},          {"u3_waves", 8},    {"x3_tile", 0},         {"igemm_tile", 0},
+    {"igemm_nobuf", 0}, {"igemm_no_splitk", 0}, {"wgrad_tile", 64}, {"rollout_one_xcd", 0},
+};
+std::atomic<int> g_opt[VLNCE_OPT_COUNT] = {
+    {1}, {2}, {0}, {1}, {1}, {8}, {0}, {0}, {0}, {0}, {64}, {0},
+};
+int opt_index(const char* name) {
+  if (name)
+    for (int i = 0; i < VLNCE_OPT_COUNT; ++i)
+      if (strcmp(name, kOpts[i].name) == 0) return i;
+  return -1;
+}
+}  // namespace
+
+int vlnce_opt(int id) { return g_opt[id].load(std::memory_order_relaxed); }
+
+extern "C" int vlnce_set_option(const char* name, int value) {
+  const int i = opt_index(name);
+  if (i < 0) {
+    vlnce_set_error("vlnce_set_option: unknown option '%s'", name ? name : "(null)");
+    return 1;
+  }
+  g_opt[i].store(value, std::memory_order_relaxed);
+  return 0;
+}
+
+extern "C" int vlnce_get_option(const char* name, int* value) {
+  const int i = opt_index(name);
+  if (i < 0 || !value) {
+    vlnce_set_error("vlnce_get_option: unknown option '%s'", name ? name : "(null)");
+    return 1;
+  }
+  *value = g_opt[i].load(std::memory_order_relaxed);
+  return 0;
+}
+
+extern "C" int vlnce_option_default(const char* name, int* value) {
+  const int i = opt_index(name);
+  if (i < 0 || !value) {
+    vlnce_set_error("vlnce_option_default: unknown option '%s'", name ? name : "(null)");
+    return 1;
+  }
+  *value = kOpts[i].def;
+  return 0;
+}

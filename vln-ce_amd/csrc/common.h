@@ -4,12 +4,11 @@
 #include <stdint.h>
 #include <stdio.h>
 
-#include "../../include/vlnce_hip.h"
+#include "common_opts.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-void vlnce_set_error(const char* fmt, ...);
 
 #define VLNCE_CHECK_ARG(cond, ...)      \
   do {                                  \

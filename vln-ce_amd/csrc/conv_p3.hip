@@ -1052,13 +1052,9 @@ __global__ __launch_bounds__(WAVES * 64) void conv_u3_kernel(IgemmParams p) {
       // the first half's fragments are read before the first MFMA (all eight waves read at once
       // right after the barrier: every kilobyte in front of the first MFMA is exposed); the
       // other reads trickle, one per MFMA, a phase ahead of their use.
-#ifdef U3_LOADS_FIRST
-      // (variant build, unmeasured: in the default schedule the compiler places k-slab 1's three
-      // B-fragment loads ~4 MFMAs in front of the s_waitcnt vmcnt(0) that consumes them -- see the
-      // ISA -- although the source requests them at the top of the chunk; this pins the chunk's
-      // raw-row and slab-1 loads in front of the first MFMA)
-      __builtin_amdgcn_sched_group_barrier(0x020, NPT + 3 * NT, 0);
-#endif
+      // (Measured and dropped, profiles/r04_a_convbench_u3_loads_first.txt: pinning the chunk's raw-row
+      // and slab-1 B loads in front of the first MFMA with a VMEM-read group changes no layer by
+      // more than 2 %.)
       __builtin_amdgcn_sched_group_barrier(0x100, 3 * HM, 0);
 #pragma unroll
       for (int ph = 0; ph < 4; ++ph) {
@@ -1210,238 +1206,26 @@ int launch_u3_(const IgemmParams& p, hipStream_t stream) {
 // the next tile (B fragments of its second k-slab, raw A two chunks ahead) queue behind the burst
 // in the wave's one in-order vmcnt, so a wave alternates between draining and computing
 // (profiles/r03_h_u3_phase_timers_short_k.txt).  Here nothing a tile needs is loaded less than
-// two tiles before its use:
+// a tile before its use, and a tile's stores are issued UNDER the next tile's MFMAs:
 //   * the B fragments of the wave's 32 columns for ALL of K stay in registers for the whole
 //     launch (K = 64: 48 VGPRs, K = 128: 96) -- a workgroup keeps its column tile;
-//   * the raw A rows of tile t + 2 are requested while tile t is transformed (64-row tiles: one
-//     float4 per thread and chunk), so the wait for them allows every store issued since to
-//     be outstanding;
-//   * the tile loop is straight-line code (NCC = K / 32 at compile time, two tiles per trip for
-//     the register ring), so the compiler's s_waitcnt counts are exact instead of the minimum
-//     over an `if (last chunk of the tile)`.
+//   * the raw A rows of tile t + 2 (K = 128: t + 1) are requested while tile t is transformed
+//     (64-row tiles: one float4 per thread and chunk);
+//   * TWO accumulator sets: while the MFMAs of tile t fill one, the 32 stores of tile t - 1 drain
+//     the other, a few behind every k-slab (sched_group_barrier pins the interleave; the epilogue
+//     activation is a select so the slab body stays one basic block).  Stores are fire-and-forget:
+//     when the store queue is full the wave stalls at a store and the SIMD's other wave issues
+//     its MFMAs, so per tile a CU needs max(stores, MFMAs) instead of their sum.  Round 3's
+//     serial form (transform, barrier, MFMAs, then 32 stores at the CU's ~12 B/cycle = 54 % of
+//     the launch) measured 90.4 / 75.0 us on 64->256 / 128->512 at num_envs 64; this form 71.4 /
+//     72.1 us (profiles/r04_a_conv_s3_pipelined_epilogue.txt);
+//   * the first two tiles are peeled: the compiler's s_waitcnt at a loop header is the minimum
+//     over the paths into it, and entered from the preamble the wait for the raw rows would
+//     drain the previous tile's stores on every trip.
 // 8 waves (two per SIMD), wave w owns columns [32w, 32w + 32) of a 64 x 256 tile; one barrier
-// per tile; transform and MFMAs of a wave are sequential (the launch is HBM-bound: the matrix
-// pipe has 3x the time it needs).  Arithmetic, patch rows, fragment layout, statistics and
-// epilogue are conv_u3_kernel's.
+// per tile.  Arithmetic, patch rows, fragment layout and statistics are conv_u3_kernel's.
 template <int NCC>
 __global__ __launch_bounds__(512) void conv_s3_kernel(IgemmParams p) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  constexpr int BM = 64, MT = 2, KS = NCC * 2;
-  constexpr int CBUF = BM * P3_ROW;            // one chunk of a tile's patch
-  constexpr int PBUF = NCC * CBUF;             // one tile's patch
-  extern __shared__ __attribute__((aligned(16))) char xsm[];  // [2][PBUF]
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int half = lane >> 5;
-  const int l31 = lane & 31;
-  const int trow = tid >> 3;          // this thread's row of the tile (transform side)
-  const int lk4 = (tid & 7) * 4;      // its four channels inside a 32-channel chunk
-
-  // this workgroup's tiles: a fixed column tile, row tiles strided over the workgroups that
-  // share it (gridDim.x is a multiple of tiles_n)
-  const int n0 = ((int)blockIdx.x % p.tiles_n) * 256;
-  const int wg = (int)blockIdx.x / p.tiles_n, nwg = (int)gridDim.x / p.tiles_n;
-  const int my_tiles = (p.tiles_m - wg + nwg - 1) / nwg;
-
-  const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<char*>(reinterpret_cast<const char*>(p.A)), 0, (int)p.a_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<char*>(reinterpret_cast<const char*>(p.Bfrag)), 0, (int)((long)p.N * p.K * 6),
-      0x00020000);
-  const __amdgpu_buffer_rsrc_t rsrc_c = __builtin_amdgcn_make_buffer_rsrc(
-      reinterpret_cast<char*>(p.C), 0, (int)p.c_bytes, 0x00020000);
-  const float relu_floor = p.in_relu ? 0.f : -__builtin_huge_valf();
-
-  // ---- resident operands: B fragments (all k-slabs), prologue vectors (all chunks)
-  bf16x8 bres[KS][3];
-  {
-    const int vb = (n0 / 32 + wave) * KS * 3072 + lane * 16;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-      for (int q = 0; q < 3; ++q)
-        bres[ks][q] = __builtin_bit_cast(
-            bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, vb + q * 1024, ks * 3072, 0));
-  }
-  // prologue vectors of all chunks: in registers for K = 64; for K = 128 (48 registers on top of
-  // 96 of B fragments: the kernel spilled, and a scratch reload with its s_waitcnt vmcnt(0) in
-  // front of the raw-row request drained the wave's stores every tile) in LDS, read per chunk
-  constexpr bool VEC_LDS = NCC > 2;
-  float* const vlds = reinterpret_cast<float*>(xsm + 2 * PBUF);  // [3][NCC * 32]
-  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f}, one4 = {1.f, 1.f, 1.f, 1.f};
-  f32x4 vs[VEC_LDS ? 1 : NCC], vt[VEC_LDS ? 1 : NCC], vc[VEC_LDS ? 1 : NCC];
-#pragma unroll
-  for (int c = 0; c < NCC; ++c) {
-    f32x4 s_ = one4, t_ = zero4, c_ = zero4;
-    if (p.in_scale != nullptr) {
-      s_ = ldg4(p.in_scale + c * 32 + lk4);
-      t_ = ldg4(p.in_shift + c * 32 + lk4);
-      if (p.in_center) c_ = ldg4(p.in_center + c * 32 + lk4);
-    }
-    if constexpr (VEC_LDS) {
-      if (tid < 8) {
-        *reinterpret_cast<f32x4*>(vlds + c * 32 + lk4) = s_;
-        *reinterpret_cast<f32x4*>(vlds + NCC * 32 + c * 32 + lk4) = t_;
-        *reinterpret_cast<f32x4*>(vlds + 2 * NCC * 32 + c * 32 + lk4) = c_;
-      }
-    } else {
-      vs[c] = s_;
-      vt[c] = t_;
-      vc[c] = c_;
-    }
-  }
-  if constexpr (VEC_LDS) __syncthreads();
-  const int col = n0 + wave * 32 + l31;
-  const float e_sc = p.scale ? p.scale[col] : 1.f;
-  const float e_sh = p.shift ? p.shift[col] : 0.f;
-
-  // ---- raw A ring: two tiles in flight
-  f32x4 raw[2][NCC];
-  auto load_raw = [&](f32x4 (&r)[NCC], int round) {
-    const int m = (wg + round * nwg) * BM + trow;
-    const int vo = (round < my_tiles && m < p.M) ? (m * p.lda + lk4) * 4 : BUF_OOB;
-#pragma unroll
-    for (int c = 0; c < NCC; ++c)
-      r[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, vo, c * 128, 0));
-  };
-  load_raw(raw[0], 0);
-  load_raw(raw[1], 1);
-  f32x16 acc[MT];
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-  constexpr int PA[6] = {2, 1, 0, 1, 0, 0};  // smallest products first
-  constexpr int PB[6] = {0, 1, 2, 0, 1, 0};
-  const int a_off = l31 * P3_ROW + half * 16;
-
-#ifdef P3_DBG_TIME
-  long long d_tr = 0, d_bar = 0, d_mm = 0, d_ep = 0;
-  const long long d_t0 = clock64(), d_w0 = wall_clock64();
-#endif
-  auto tile = [&](int round, f32x4 (&r)[NCC]) {
-#ifdef P3_DBG_TIME
-    const long long d_0 = clock64();
-#endif
-    const int m0 = (wg + round * nwg) * BM;
-    char* const pb = xsm + (round & 1) * PBUF;
-    // transform this tile's rows (rows past M are zero: the buffer load returned zeros and the
-    // prologue of a zero is not zero, so they are forced)
-    const bool row_ok = m0 + trow < p.M;
-#pragma unroll
-    for (int c = 0; c < NCC; ++c) {
-      f32x4 v = r[c];
-      f32x4 s_, t_, c_;
-      if constexpr (VEC_LDS) {
-        s_ = *reinterpret_cast<const f32x4*>(vlds + c * 32 + lk4);
-        t_ = *reinterpret_cast<const f32x4*>(vlds + NCC * 32 + c * 32 + lk4);
-        c_ = *reinterpret_cast<const f32x4*>(vlds + 2 * NCC * 32 + c * 32 + lk4);
-      } else {
-        s_ = vs[c];
-        t_ = vt[c];
-        c_ = vc[c];
-      }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        v[e] = fmaxf(fmaf(v[e] - c_[e], s_[e], t_[e]), relu_floor);
-        v[e] = row_ok ? v[e] : 0.f;
-      }
-      p3_split_store(v, pb + c * CBUF + trow * P3_ROW + lk4 * 2);
-    }
-    load_raw(r, round + 2);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#ifdef P3_DBG_TIME
-    const long long d_1 = clock64();
-#endif
-    __builtin_amdgcn_s_barrier();
-#ifdef P3_DBG_TIME
-    const long long d_2 = clock64();
-#endif
-    // MFMAs over all of K from the patch
-#pragma unroll
-    for (int c = 0; c < NCC; ++c)
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        bf16x8 f[MT][3];
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-          for (int q = 0; q < 3; ++q)
-            f[i][q] = *reinterpret_cast<const bf16x8*>(pb + c * CBUF + a_off + i * 32 * P3_ROW +
-                                                       q * 64 + s2 * 32);
-#pragma unroll
-        for (int q = 0; q < 6; ++q)
-#pragma unroll
-          for (int i = 0; i < MT; ++i)
-            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[i][PA[q]], bres[c * 2 + s2][PB[q]],
-                                                             acc[i], 0, 0, 0);
-      }
-#ifdef P3_DBG_TIME
-    asm volatile("s_nop 0" ::"v"(acc[0][0]), "v"(acc[1][15]));
-    const long long d_3 = clock64();
-#endif
-    // statistics partials of the raw accumulators (32-row blocks), then the epilogue
-    if (p.stat_partial != nullptr) {
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-        wave_stats_block<1>(reinterpret_cast<const f32x16(&)[1]>(acc[i]), p.stat_partial,
-                            m0 / 32 + i, p.M - (m0 + i * 32), n0 + wave * 32, p.N, half, l31);
-    }
-    // (Measured on this kernel, profiles/r03_j_*: with the loads out of the way the store phase is
-    // 54 % of the launch at ~12 B/cycle/CU.  That rate is the CU's own: the same through 16-byte
-    // row stores out of an LDS square, the same with half of the workgroups started half a tile
-    // late, and 64 workgroups on 64 CUs still need 5.2 k cycles per 64 KB.  What is left is to
-    // put one tile's stores under another's MFMAs inside a CU.)
-    const int rows_left = p.M - (m0 + 4 * half);
-    const int e_voff = (int)((((long)(m0 + 4 * half)) * p.ldc + col) * 4);
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-      for (int r2 = 0; r2 < 16; ++r2) {
-        const int rw = i * 32 + (r2 & 3) + 8 * (r2 >> 2);
-        const float v = apply_act(acc[i][r2] * e_sc + e_sh, p.act);
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc_c,
-                                              rw < rows_left ? e_voff : BUF_OOB, rw * p.ldc * 4, 0);
-        acc[i][r2] = 0.f;
-      }
-#ifdef P3_DBG_TIME
-    const long long d_4 = clock64();
-    d_tr += d_1 - d_0;
-    d_bar += d_2 - d_1;
-    d_mm += d_3 - d_2;
-    d_ep += d_4 - d_3;
-#endif
-  };
-  for (int round = 0; round < my_tiles; round += 2) {
-    tile(round, raw[0]);
-    if (round + 1 < my_tiles) tile(round + 1, raw[1]);
-  }
-#ifdef P3_DBG_TIME
-  if (blockIdx.x == 8 && (tid == 0 || tid == 448)) {
-    const long long cy = clock64() - d_t0, w = wall_clock64() - d_w0;
-    printf("s3 wave %d: tiles %d chunks/tile %d: total %lld cycles = %lld ticks of 100 MHz (%.2f GHz): "
-           "wait raw + transform %lld, barrier %lld, reads + MFMA %lld, statistics + stores %lld\n",
-           wave, my_tiles, NCC, cy, w, (double)cy / (double)w * 0.1, d_tr, d_bar, d_mm, d_ep);
-  }
-#endif
-#endif
-}
-
-// conv_s3p_kernel: conv_s3_kernel with the epilogue of tile t - 1 issued UNDER the matrix
-// instructions of tile t (EXPERIMENT, VLNCE_S3_PIPE=1, not measured yet -- written at the end of
-// round 3 after the GPU budget was spent; conv_s3_kernel above is untouched and stays the
-// default).  conv_s3_kernel's phases are serial per wave: transform, barrier, 48-96 MFMAs, then 32
-// store instructions at the CU's ~12 B/cycle (54 % of the launch).  Stores are fire-and-forget,
-// so the only coupling between a wave's stores and its MFMAs is the issue order: here a wave
-// keeps TWO accumulator sets (+32 VGPRs), and while the MFMAs of tile t fill one, the stores of
-// tile t - 1 drain the other, a few behind every k-slab (sched_group_barrier keeps the
-// interleaving).  When the store queue is full the wave stalls at a store and the SIMD's other
-// wave issues its MFMAs; per tile the CU then needs max(stores, MFMAs) instead of their sum.
-// Loads stay two tiles ahead as in conv_s3_kernel, so nothing waits behind the stores.
-template <int NCC>
-__global__ __launch_bounds__(512) void conv_s3p_kernel(IgemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int BM = 64, MT = 2, KS = NCC * 2;
   constexpr int CBUF = BM * P3_ROW;            // one chunk of a tile's patch
@@ -1503,7 +1287,7 @@ __global__ __launch_bounds__(512) void conv_s3p_kernel(IgemmParams p) {
   const float e_sc = p.scale ? p.scale[col] : 1.f;
   const float e_sh = p.shift ? p.shift[col] : 0.f;
 
-  // raw A ring: two tiles ahead for K = 64 as in conv_s3_kernel; ONE for K = 128, where the second
+  // raw A ring: two tiles ahead for K = 64; ONE for K = 128, where the second
   // accumulator set leaves no registers for it (with the stores spread over the MFMA phase the
   // request of tile t + 1 sits behind the stores of tile t - 2 only, a whole tile old)
   constexpr int RING = NCC > 2 ? 1 : 2;
@@ -1617,7 +1401,7 @@ __global__ __launch_bounds__(512) void conv_s3p_kernel(IgemmParams p) {
   // The first two tiles are peeled: the compiler's s_waitcnt at a loop header is the minimum
   // over the paths into it, and entered straight from the preamble the first wait for raw rows
   // would be vmcnt(3) on EVERY trip -- i.e. the stores of the tile before would be drained every
-  // second tile (conv_s3_kernel has exactly that: vmcnt(3) / vmcnt(35) alternate in its ISA).
+  // second tile (round 3's unpeeled form had exactly that: vmcnt(3) / vmcnt(35) alternated in its ISA).
   // Behind the peeled tiles both ways into the loop have a tile's 32 stores after the request.
   if (my_tiles <= 0) return;  // (cannot happen with launch_s3's grid; uniform per workgroup)
   tile(0, raw[0], acc[0], acc[1]);
@@ -1640,10 +1424,10 @@ __global__ __launch_bounds__(512) void conv_s3p_kernel(IgemmParams p) {
 #endif
 }
 
-template <int NCC, int PIPE>
+template <int NCC>
 int launch_s3(const IgemmParams& p, hipStream_t stream) {
   constexpr int smem_bytes = 2 * NCC * 64 * P3_ROW + 3 * NCC * 32 * 4;  // two tile patches + the prologue vectors
-  auto kern = PIPE ? conv_s3p_kernel<NCC> : conv_s3_kernel<NCC>;
+  auto kern = conv_s3_kernel<NCC>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -1785,12 +1569,12 @@ int dispatch_p3(const IgemmParams& p, int tile, int rows, hipStream_t s) {
 }  // namespace
 
 int p3_try_launch(const IgemmParams& p, hipStream_t stream) {
-  // VLNCE_P3: 0 = off, 1 = every layer it covers, 2 = the KxK (patch) layers only, 3 = the 1x1
+  // option "p3": 0 = off, 1 = every layer it covers, 2 = the KxK (patch) layers only, 3 = the 1x1
   // layers only.  Default 2: measured per layer at num_envs 64 (profiles/r03_*_convbench_ab.txt),
   // the patch form is 1.26-1.51x conv_x3_kernel on every stride-1 3x3 layer of the trunks, the
   // 1x1 form (4 producer waves) is within +-10 % of it and slower on most.
-  static const int mode_env = getenv("VLNCE_P3") ? atoi(getenv("VLNCE_P3")) : 2;
-  static const int force = getenv("VLNCE_P3_TILE") ? atoi(getenv("VLNCE_P3_TILE")) : 0;  // tuning
+  const int mode_env = vlnce_opt(VLNCE_OPT_P3);
+  const int force = vlnce_opt(VLNCE_OPT_P3_TILE);  // tuning
   if (!mode_env || !conv_math() || !p.Bfrag) return -1;
   if (p.Cin % 32 != 0 || p.N % 32 != 0 || p.lda % 4 != 0 || p.splitk > 1) return -1;
   if (p.residual || p.accumulate || p.c_bytes >= 0x7fffffffL || p.a_bytes >= 0x7fffffffL) return -1;
@@ -1801,24 +1585,22 @@ int p3_try_launch(const IgemmParams& p, hipStream_t stream) {
   const bool dual = p.A2 != nullptr || p.side_out != nullptr;
   if (dual && !(one && p.stride == 1)) return -1;
   // 1x1 layers wide enough for 256-column tiles: conv_u3_kernel (no producer waves), where its
-  // 128-row tiles fill the CUs.  VLNCE_U3: 0 = off, 1 = default, 2 / 3 = force 64- / 128-row tiles
+  // 128-row tiles fill the CUs.  option "u3": 0 = off, 1 = default, 2 / 3 = force 64- / 128-row tiles
   // for every N >= 256 1x1 layer (tests).  Measured
   // per layer at num_envs 64 (profiles/r03_b_convbench_ab_u3.txt): 1.07-1.23x conv_x3_kernel on
   // every N >= 256 layer of the RGB trunk with M >= 16384.
-  // short-K wide 1x1 (the bottleneck expansions): conv_s3_kernel.  VLNCE_S3: 0 = off, 1 = default
+  // short-K wide 1x1 (the bottleneck expansions): conv_s3_kernel.  option "s3": 0 = off, 1 = default
   // (where the 64-row tiles give every CU at least four), 2 = every eligible shape (tests)
-  static const int s3_env = getenv("VLNCE_S3") ? atoi(getenv("VLNCE_S3")) : 1;
+  const int s3_env = vlnce_opt(VLNCE_OPT_S3);
   if (!dense && !dual && s3_env && p.stride == 1 && (p.Cin == 64 || p.Cin == 128) && p.K == p.Cin &&
       p.N % 256 == 0 && p.N / 256 <= 8 && (p.stat_partial == nullptr || p.stat_rows == 32) &&
+      (p.act == VLNCE_ACT_NONE || p.act == VLNCE_ACT_RELU) &&
       (s3_env == 2 || (long)ceil_div(p.M, 64) * (p.N / 256) >= 4L * x3_cus()))
   {
-    // VLNCE_S3_PIPE=1: conv_s3p_kernel (previous tile's stores under this tile's MFMAs): experiment
-    static const int s3_pipe = getenv("VLNCE_S3_PIPE") ? atoi(getenv("VLNCE_S3_PIPE")) : 0;
-    if (s3_pipe && (p.act == VLNCE_ACT_NONE || p.act == VLNCE_ACT_RELU)) return p.Cin == 64 ? launch_s3<2, 1>(p, stream) : launch_s3<4, 1>(p, stream);
-    return p.Cin == 64 ? launch_s3<2, 0>(p, stream) : launch_s3<4, 0>(p, stream);
+    return p.Cin == 64 ? launch_s3<2>(p, stream) : launch_s3<4>(p, stream);
   }
-  static const int u3_env = getenv("VLNCE_U3") ? atoi(getenv("VLNCE_U3")) : 1;
-  static const int u3_waves = getenv("VLNCE_U3_WAVES") ? atoi(getenv("VLNCE_U3_WAVES")) : 8;
+  const int u3_env = vlnce_opt(VLNCE_OPT_U3);
+  const int u3_waves = vlnce_opt(VLNCE_OPT_U3_WAVES);
   if (!dense && u3_env && p.N >= 256) {
     const int cus = x3_cus();
     auto eff = [&](int bm) {

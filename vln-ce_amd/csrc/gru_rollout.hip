@@ -370,10 +370,7 @@ int launch_rollout(const GruRolloutParams& p, bool bwd, hipStream_t s) {
 }
 
 int dispatch_rollout(GruRolloutParams& p, int H, bool bwd, hipStream_t s) {
-  static const int spread = [] {
-    const char* e = getenv("VLNCE_ROLLOUT_ONE_XCD");
-    return e && e[0] == '1' ? 8 : 1;
-  }();
+  const int spread = vlnce_opt(VLNCE_OPT_ROLLOUT_ONE_XCD) ? 8 : 1;
   p.spread = spread;
   const bool small = p.N <= 8;
   switch (H) {

@@ -1251,7 +1251,7 @@ struct TileChoice {
   int bm, bn;
 };
 TileChoice choose_tile(long M, int N) {
-  static const int force = getenv("VLNCE_IGEMM_TILE") ? atoi(getenv("VLNCE_IGEMM_TILE")) : 0;
+  const int force = vlnce_opt(VLNCE_OPT_IGEMM_TILE);
   if (force == 1) return {128, 128};  // tuning knob (scripts/convbench.py)
   if (force == 2) return {128, 64};
   if (force == 3) return {64, 64};
@@ -1284,7 +1284,7 @@ int dispatch_small(const IgemmParams& p, hipStream_t s) {
 // buffer-descriptor hot path: channels-last im2col / row-major A with Cin % 32 == 0, at most
 // 32 filter taps, [N,K] weights, operands below 2 GiB
 bool buf_ok(const IgemmParams& p) {
-  static const bool off = getenv("VLNCE_IGEMM_NOBUF") != nullptr;
+  const bool off = vlnce_opt(VLNCE_OPT_IGEMM_NOBUF) != 0;
   const long bias = ((long)p.pad * p.W + p.pad) * p.lda * 4;
   return !off && (p.Cin % 32 == 0) && (p.K % 32 == 0) && (p.lda % 4 == 0) && (p.ldb % 4 == 0) &&
          p.KH * p.KW <= 32 && p.a_bytes + bias < 0x7fffffffL && p.b_bytes < 0x7fffffffL;
@@ -1299,7 +1299,7 @@ int dispatch_stem(const IgemmParams& p, hipStream_t s) {
 
 // split-K factor for a plain GEMM with few output tiles and a long reduction
 int choose_splitk(const IgemmParams& p) {
-  static const bool off = getenv("VLNCE_IGEMM_NO_SPLITK") != nullptr;  // diagnostic switch
+  const bool off = vlnce_opt(VLNCE_OPT_IGEMM_NO_SPLITK) != 0;  // diagnostic switch
   if (off) return 1;
   const long tiles = (long)ceil_div(p.M, 64) * ceil_div(p.N, 64);
   const int KT = ceil_div(p.K, BK);
@@ -1365,7 +1365,7 @@ struct X3Plan {
 bool x3_plan(const IgemmParams& p, X3Plan* out) {
   if (!conv_math() || !p.Bsplit || !buf_ok(p) || p.splitk > 1) return false;
   if (p.residual || p.accumulate || p.c_bytes >= 0x7fffffffL) return false;
-  static const int force = getenv("VLNCE_X3_TILE") ? atoi(getenv("VLNCE_X3_TILE")) : 0;  // tuning
+  const int force = vlnce_opt(VLNCE_OPT_X3_TILE);  // tuning
   const X3Plan cand[4] = {{128, 128}, {64, 128}, {128, 64}, {64, 64}};
   if (force >= 1 && force <= 4) {
     *out = cand[force - 1];
@@ -1686,13 +1686,10 @@ extern "C" int vlnce_conv2d_wgrad(const float* x, const float* dy, float* dw_ohw
   VLNCE_CHECK_ARG(aligned16(dy) && aligned16(x) && aligned16(dw_ohwi),
                   "conv2d_wgrad: operands must be 16-byte aligned");
   fill_epilogue(p, nullptr);
-  // VLNCE_WGRAD_TILE=128: 128x128 tiles where both output dimensions allow.  Measured slower on
+  // option "wgrad_tile" = 128: 128x128 tiles where both output dimensions allow.  Measured slower on
   // the trainable-encoder step (46.7 vs 45.0 ms, profiles/r03_g_*): fewer workgroups per
   // split-K slice, and the transposed-operand LDS writes do not get cheaper.  Default 64.
-  static const int tile_pref = [] {
-    const char* e = getenv("VLNCE_WGRAD_TILE");
-    return e ? atoi(e) : 64;
-  }();
+  const int tile_pref = vlnce_opt(VLNCE_OPT_WGRAD_TILE);
   const bool big = tile_pref >= 128 && p.M >= 128 && p.N >= 128;
   const int T = big ? 128 : 64;
   const long tiles = (long)ceil_div(p.M, T) * ceil_div(p.N, T);

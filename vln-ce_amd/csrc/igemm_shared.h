@@ -200,14 +200,8 @@ static inline int x3_cus() {
 
 // convolution arithmetic: 1 = fp32 operands split into three bf16 planes, six products on the
 // bf16 matrix pipe (conv_p3_kernel / conv_x3_kernel; fp32-class result, see the kernels'
-// headers); 0 = v_mfma_f32_32x32x2_f32 everywhere (igemm_kernel).  VLNCE_CONV_MATH=f32 selects 0.
-static inline int conv_math() {
-  static const int m = [] {
-    const char* e = getenv("VLNCE_CONV_MATH");
-    return (e && (e[0] == 'f' || e[0] == '0')) ? 0 : 1;
-  }();
-  return m;
-}
+// headers); 0 = v_mfma_f32_32x32x2_f32 everywhere (igemm_kernel).  Option "conv_math".
+static inline int conv_math() { return vlnce_opt(VLNCE_OPT_CONV_MATH) != 0; }
 
 // conv_p3.hip: the patch-resident bf16-plane convolution.  Returns -1 when the problem is not
 // one it covers (the caller falls through to conv_x3_kernel / igemm_kernel), else a C-ABI status.

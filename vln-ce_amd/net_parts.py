@@ -1,8 +1,6 @@
 """Pieces the Seq2Seq, CMA and waypoint nets share: construction of the visual encoders from
 `config.MODEL`, the three-branch encoder pass on side HIP streams, ablation switches, the
 previous-action index and the progress-monitor auxiliary loss."""
-import os
-
 import torch
 
 from . import ops
@@ -60,14 +58,16 @@ def encode_three_branches(net, observations, device):
         ins, join_ins = branches.run(fork, 0, device, lambda: net.instruction_encoder(observations))
     else:
         # training step: both side branches share side stream 0 (the instruction encoder's ~1 ms
-        # then the depth trunk's ~1.5 ms, beside the RGB trunk's ~5 ms on the caller's stream).
-        # VLNCE_TRAIN_BRANCHES=split puts the depth trunk on its own stream as under no_grad --
-        # unmeasured (it competes with the RGB trunk's one-workgroup-per-CU launches), off by default
-        split = os.environ.get("VLNCE_TRAIN_BRANCHES", "") == "split"
+        # then the depth trunk's ~1.9 ms, beside the RGB trunk's ~6.8 ms on the caller's stream).
+        # Measured with GPU event stamps (profiles/r04_d_overlap_probe2_event_stamps.txt): the side
+        # work does run under the RGB trunk (instruction encoder done at 1.0 ms, depth trunk at
+        # 6.6 ms, RGB trunk 6.8 -> 7.6 ms); a rocprofv3 kernel trace shows the two queues
+        # serialised, which is the profiler, not the run.  Issue orders tried and dropped
+        # (profiles/r04_b_*): side branches first 11.1 ms/step, depth trunk first on its own
+        # stream 10.3-10.9, this order 10.2-10.7.
         rgb = net.rgb_encoder(observations)
         ins, join_ins = branches.run(fork, 0, device, lambda: net.instruction_encoder(observations))
-        dep, join_dep = branches.run(fork, 2 if split else 0, device,
-                                     lambda: net.depth_encoder(observations))
+        dep, join_dep = branches.run(fork, 0, device, lambda: net.depth_encoder(observations))
     join_ins()
     join_dep()
     return ins, dep, rgb
