@@ -2,6 +2,10 @@
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
 
+N > 1: one rank per GPU.  Under a launcher (torch.distributed.run sets RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_*) the process is one of the N ranks; started plainly, `python bench.py
+--gpus N` launches the N ranks itself (self_launch) and rank 0 prints the one JSON line.
+
 One "step" = one DAgger inner-loop update (BaseVLNCETrainer._update_agent,
 base_il_trainer.py:134-180: build_distribution on raw frames, inflection-
 weighted cross-entropy, backward, Adam step) of the CMA policy over a batch of
@@ -343,6 +347,30 @@ def act_latency(policy, batch, dev, sizes=(1, 4, 8), iters=20):
     return out
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` with no launcher around it (no WORLD_SIZE in the environment):
+    re-run this very command line as N ranks, one per GPU, under torch.distributed.run on this
+    node -- how the reference starts its distributed trainer (`python -u -m
+    torch.distributed.launch --use_env --nproc_per_node N run.py ...`,
+    sbatch_scripts/waypoint_train_single_node.sh:24-30; init at ddppo_waypoint_trainer.py:310-312).
+    The ranks inherit stdout: rank 0's JSON line is the one line printed there.  Returns the
+    launcher's exit code."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this driver (RCCL)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    log(f"--gpus {n} without a launcher: starting {n} ranks: {' '.join(cmd[1:9])} ...")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -369,22 +397,49 @@ def main():
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise RCCL and run the gradient all-reducer even with one rank "
                          "(exercises the N>1 code path on a 1-GPU box)")
+    # tests only (tests/test_bench_launcher.py): the bench's HOST logic -- self-launch, rank
+    # set-up, sharded update with the gradient all-reducer, max-over-ranks timing, the one JSON
+    # line -- on CPU through tests/hostsim.py over gloo; the line it prints says so and carries
+    # no roofline.  Never a measurement.
+    ap.add_argument("--hostsim", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_only:
         cpu_baseline_worker(args.num_envs, args.hw, args.tokens, args.threads)
         return
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))
 
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE={world}")
+    sim = args.hostsim
+    if sim:
+        sys.path.insert(0, os.path.join(REPO, "tests"))
+        import hostsim
+        from vlnce_amd import _lib as _l
+
+        _l._LIB = hostsim.HostSim()
+        dev = torch.device("cpu")
+    else:
+        if torch.cuda.device_count() <= local:
+            raise SystemExit(f"bench.py: rank {rank} wants cuda:{local} but this node shows "
+                             f"{torch.cuda.device_count()} GPU(s)")
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
     use_dist = world > 1 or args.force_dist
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if sim:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    def dev_sync():
+        if not sim:
+            torch.cuda.synchronize()
 
     import vlnce_amd
     from vlnce_amd import ops
@@ -434,7 +489,7 @@ def main():
     # k+1 are issued (on their own streams) BEFORE step k's update is enqueued and overlap its
     # latency-bound tail.  Every step still runs its own trunk pass, tail forward, backward and
     # Adam; trainable encoders cannot run ahead and fall back to the plain loop.
-    pipeline = not (args.no_pipeline or args.trainable_encoders)
+    pipeline = not (args.no_pipeline or args.trainable_encoders or sim)
 
     def run_steps(n, ahead):
         if not ahead:
@@ -473,13 +528,13 @@ def main():
     for i in range(args.warmup):
         t0 = time.perf_counter()
         step()
-        torch.cuda.synchronize()
+        dev_sync()
         log(f"warm-up step {i}: {1e3 * (time.perf_counter() - t0):.1f} ms")
 
     def sync():
         if use_dist:
             dist.barrier()
-        torch.cuda.synchronize()
+        dev_sync()
 
     # ---- the timed region: the loop the UNCHANGED trainers issue (base_il_trainer.py:134-180
     # per batch): build_distribution on raw frames -> loss -> backward -> Adam, one call per step
@@ -500,6 +555,21 @@ def main():
         tmax = torch.tensor([elapsed], device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = tmax.item()
+
+    if sim:
+        if rank == 0:
+            print(json.dumps({
+                "metric": "policy-steps/sec (fwd+bwd)", "value": None, "unit": "policy-steps/sec",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
+                "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+                "data": "hostsim: CPU simulator of the C ABI (tests/hostsim.py) over gloo -- a test "
+                        "of the launcher and the rank logic, NOT a measurement",
+                "config": {"workload": "launcher self-test", "global_batch": args.num_envs * world,
+                           "parallelism": f"dp{world}"}}), flush=True)
+        if use_dist:
+            dist.destroy_process_group()
+        return
 
     # ---- beside it: the same steps with the optional policy.encode_ahead() API (the frozen
     # trunks of batch k+1 issued before batch k's update is enqueued), same step count

@@ -1,0 +1,62 @@
+"""`python bench.py --gpus N` must start its N ranks itself when no launcher set WORLD_SIZE
+(the driver's multi-GPU command is the N=1 command with the number changed), keep working under
+torch.distributed.run, and print exactly ONE JSON line on stdout from rank 0 with n_gpus = N.
+Run here on CPU: bench.py's hidden --hostsim mode puts tests/hostsim.py behind the package and
+gloo behind torch.distributed, so the launcher, the rank set-up, the sharded update through
+GradientAllReducer and the max-over-ranks timing are the real code; nothing is measured."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ARGS = ["--steps", "2", "--warmup", "1", "--num-envs", "2", "--hw", "64", "--tokens", "7",
+        "--hostsim", "--no-cpu-baseline", "--no-f32-compare"]
+
+
+def _clean_env():
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT",
+                        "TORCHELASTIC_RUN_ID", "GROUP_RANK", "LOCAL_WORLD_SIZE")}
+    env["OMP_NUM_THREADS"] = "4"
+    return env
+
+
+def _one_json_line(stdout, n):
+    lines = [ln for ln in stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == n and d["steps"] == 2 and d["warmup"] == 1
+    assert d["config"]["parallelism"] == f"dp{n}" and d["config"]["global_batch"] == 2 * n
+    assert d["ms_per_step"] > 0 and d["scaling"] == "weak"
+    assert "hostsim" in d["data"] and d["value"] is None   # never mistaken for a measurement
+    return d
+
+
+def test_bench_gpus_2_launches_its_own_ranks():
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2"] + ARGS,
+                       env=_clean_env(), capture_output=True, text=True, timeout=600, cwd=REPO)
+    assert r.returncode == 0, r.stderr[-3000:]
+    _one_json_line(r.stdout, 2)
+    assert "without a launcher: starting 2 ranks" in r.stderr
+
+
+def test_bench_gpus_2_under_torch_distributed_run():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+                        "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+                        str(port), os.path.join(REPO, "bench.py"), "--gpus", "2"] + ARGS,
+                       env=_clean_env(), capture_output=True, text=True, timeout=600, cwd=REPO)
+    assert r.returncode == 0, r.stderr[-3000:]
+    _one_json_line(r.stdout, 2)
+    assert "without a launcher" not in r.stderr
+
+
+def test_bench_rejects_a_world_size_that_disagrees_with_gpus():
+    env = dict(_clean_env(), WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "4"] + ARGS,
+                       env=env, capture_output=True, text=True, timeout=120, cwd=REPO)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stderr + r.stdout)

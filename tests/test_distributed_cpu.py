@@ -59,6 +59,64 @@ def worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
+def unused_first_worker(rank, world, port, out):
+    """WaypointPolicy's layout: the unused head sits between used modules, so in reverse
+    parameter order it lands in an EARLY bucket.  From the second step on it must not hold the
+    other buckets back until finish(); a head that wakes up later must still be averaged."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    model = Tiny()
+    red = GradientAllReducer(model, bucket_bytes=64)  # about one bucket per tensor
+    x, tgt, w = make_data()
+    sl = shard_rows(x.size(1), rank, world)
+    early = []
+    for step in range(3):
+        model.zero_grad()
+        loss = il_loss(model, x[:, sl].reshape(-1, 12), tgt[:, sl], w[:, sl])
+        if step == 2:   # the head is used after all (same on every rank: static mode)
+            loss = loss + model.unused(x[0, sl, :3]).pow(2).mean() * (rank + 1)
+        loss.backward()
+        red.finish()
+        early.append(red.launched_before_finish)
+    if rank == 0:
+        torch.save({"early": early, "n_buckets": len(red.buckets),
+                    "grads": {n: p.grad for n, p in model.named_parameters() if p.grad is not None}},
+                   out)
+    dist.destroy_process_group()
+
+
+def test_unused_head_in_an_early_bucket_does_not_serialise_the_collectives(tmp_path):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "early.pt")
+    mp.spawn(unused_first_worker, args=(2, port, out), nprocs=2, join=True)
+    got = torch.load(out)
+    n = got["n_buckets"]
+    assert n >= 4
+    # step 0: the unused head's bucket (index 0 or 1 in reverse order) blocks the strict order
+    assert got["early"][0] < n - 1
+    # step 1: learned -- every bucket goes out from the hooks, none is left for finish()
+    assert got["early"][1] == n, got["early"]
+    # step 2: the head received a gradient after its bucket went out: reduced in finish()
+    torch.manual_seed(0)
+    model = Tiny()
+    x, tgt, w = make_data()
+    # reference: mean over the two ranks' losses = IL loss of the global batch + the rank-weighted extra
+    il_loss(model, x.reshape(-1, 12), tgt, w).backward()
+    extra = 0.0
+    for r in range(2):
+        sl = shard_rows(x.size(1), r, 2)
+        extra = extra + model.unused(x[0, sl, :3]).pow(2).mean() * (r + 1) / 2
+    extra.backward()
+    for name, p in model.named_parameters():
+        if p.grad is not None:
+            assert torch.allclose(got["grads"][name], p.grad, atol=1e-6), name
+    assert "unused.weight" in got["grads"]
+
+
 def test_two_rank_gradients_equal_single_process(tmp_path):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))

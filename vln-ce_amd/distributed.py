@@ -70,6 +70,15 @@ class GradientAllReducer:
         self._divergent = bool(divergent_unused)
         self._handles = []
         self._zeros = {}
+        # parameters that received no gradient in the previous step.  With a static graph (the
+        # default: the unused set is the same on every rank, e.g. WaypointPolicy's
+        # action_distribution under WDDPPO) they are not waited for again: their bucket's pending
+        # count starts without them, so strict bucket order no longer serialises every
+        # collective into finish() because bucket 0 holds an unused head (round-3 ADVICE).  One
+        # that does receive a gradient after its bucket went out is reduced in finish() (_late).
+        self._skip = frozenset()
+        self._late = []
+        self.launched_before_finish = 0  # buckets of the last step issued from the hooks (tests)
         # the hooks pin every AccumulateGrad node to the stream current here, which is what
         # orders gradients produced on side streams before the collective; the engine's
         # warning about that (intended) stream hand-over is noise
@@ -127,6 +136,13 @@ class GradientAllReducer:
 
     def _on_grad(self, p):
         b = self._bucket_of[p]
+        if p in self._skip:
+            # counted as unused when the step was armed.  Not launched yet: its gradient simply
+            # rides in the bucket.  Already launched (with zeros in its place): reduce it in
+            # finish() -- in static mode every rank sees the same thing and does the same.
+            if b.work is not None:
+                self._late.append(p)
+            return
         b.pending -= 1
         # Collectives are issued STRICTLY in bucket order: a complete bucket waits for every bucket
         # before it.  If the set of parameters that receive a gradient ever differs between ranks
@@ -140,9 +156,21 @@ class GradientAllReducer:
     def finish(self):
         """Call after loss.backward(): waits for every bucket (the gradients were averaged in
         place) and re-arms the hooks for the next step."""
+        self.launched_before_finish = self._next
         for b in self.buckets[self._next:]:  # held back by a parameter without a gradient
             self._launch(b)
         self._next = 0
+        if self._late:
+            late = [p.grad for p in self._late]
+            if self.comm is not None:
+                torch.cuda.current_stream(self.comm.device).wait_stream(self.comm)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                dist.all_reduce_coalesced(late, op=dist.ReduceOp.AVG if self.avg else dist.ReduceOp.SUM,
+                                          group=self.group)
+            if not self.avg:
+                torch._foreach_mul_(late, 1.0 / self.world)
+            self._late = []
         for b in self.buckets:
             if self.comm is None:
                 b.work.wait()
@@ -157,10 +185,14 @@ class GradientAllReducer:
                 for t, p, u in zip(b.tensors, b.params, used):
                     if p.grad is None and u > 0:   # used elsewhere: adopt the averaged gradient
                         p.grad = t.clone() if self.avg else t * (1.0 / self.world)
-            b.pending = len(b.params)
             b.work = None
             b.tensors = None
             b.flags = None
+        # re-arm: in static mode the parameters left without a gradient are not waited for again
+        if not self._divergent:
+            self._skip = frozenset(p for b in self.buckets for p in b.params if p.grad is None)
+        for b in self.buckets:
+            b.pending = sum(1 for p in b.params if p not in self._skip)
 
     def remove(self):
         for h in self._handles:
