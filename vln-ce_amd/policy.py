@@ -26,6 +26,12 @@ class CategoricalNet(nn.Module):
         if x.is_cuda and torch.cuda.is_current_stream_capturing():
             # (argument validation is a host sync: not inside a graph capture, streams.ActGraph)
             return CustomFixedCategorical(logits=logits, validate_args=False)
+        # Argument validation is a host sync (`(logits == logits).all()` read back), as in the
+        # reference.  Measured (profiles/r04_i_sync_probe.txt, r04_j_*): WITHOUT it a training step is
+        # 1.3-1.7 ms SLOWER -- the host then enqueues loss / backward / Adam while the trunks are
+        # still running, and the forward phase takes 9.7 instead of 8.1 ms on the GPU's own
+        # clock (launches arriving on the queue of a running graph slow its kernel-to-kernel
+        # dispatch).  So the sync stays where the reference has it.
         return CustomFixedCategorical(logits=logits)
 
 
