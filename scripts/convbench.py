@@ -91,7 +91,13 @@ def main():
     ap.add_argument("--pro", action="store_true",
                     help="train mode: also apply the previous layer's BatchNorm + ReLU in the operand "
                          "loader, as the trunks do (in_scale / in_shift / in_center / in_relu)")
+    ap.add_argument("--dual", default="", help="identity | bn: 1x1 stride-1 layers as residual block "
+                    "ends (second input added in the operand loader, block output written)")
+    ap.add_argument("--opt", default="", help="dispatch options, e.g. u3=2,s3=0 (vlnce_set_option)")
     args = ap.parse_args()
+    for kv in filter(None, args.opt.split(",")):
+        k_, v_ = kv.split("=")
+        ops.L().set_option(k_, int(v_))
     dev = "cuda:0"
     tot_t = tot_f = 0.0
     print(f"{'layer':22s} {'M':>8s} {'K':>6s} {'N':>5s} {'us':>9s} {'TF/s':>7s} x cnt")
@@ -110,6 +116,13 @@ def main():
         if args.pro and args.mode == "train" and cin % 32 == 0:
             kw.update(in_scale=torch.rand(cin, device=dev) + 0.5, in_shift=torch.randn(cin, device=dev),
                       in_center=torch.randn(cin, device=dev), in_relu=True)
+        if args.dual and k == 1 and s == 1 and "in_scale" in kw:
+            kw.update(x2=torch.randn_like(x), side_out=torch.empty_like(x))
+            if args.dual == "bn":
+                kw.update(in2_scale=torch.rand(cin, device=dev) + 0.5,
+                          in2_shift=torch.randn(cin, device=dev), in2_center=torch.randn(cin, device=dev))
+        elif args.dual:
+            continue
         if cin == 3:
             kw.update(in_scale=torch.full((3,), 1 / 255.0, device=dev),
                       in_shift=torch.zeros(3, device=dev))

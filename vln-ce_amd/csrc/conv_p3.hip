@@ -499,6 +499,14 @@ __global__ __launch_bounds__((WM * WN + P3_PRODUCERS) * 64) void conv_p3_kernel(
     const __amdgpu_buffer_rsrc_t rsrc_c = __builtin_amdgcn_make_buffer_rsrc(
         reinterpret_cast<char*>(p.C), 0, (int)p.c_bytes, 0x00020000);
 
+    // (Measured and dropped, round 4: a second A-fragment set so that the LDS reads of k-slab
+    // s + 1 are issued in front of the MFMAs of slab s -- branch-free steady loop, fragments
+    // carried as 128-bit integer vectors -- changes no 3x3 layer by more than 2 % on the same box
+    // (profiles/r04_t_*).  Bisection builds of this loop at 256 channels, 16x16 frames: 100 us as
+    // is, 96 without any hand-over wait, 84 without the B-fragment loads, 85 without the A reads,
+    // 69 with neither -- against 58 us of pure MFMA issue at the 1.9 GHz the launch runs at
+    // (profiles/r04_u_*): what the loop loses is the issue cost of its 9 memory instructions per
+    // 12 MFMAs (768 B of operands per MFMA at these per-wave tiles), not their latency.)
     bf16x8 fa[MT][3];
     bf16x8 b0[NT][3], b1[NT][3];
     f32x16 acc[MT][NT];
@@ -1608,7 +1616,11 @@ int p3_try_launch(const IgemmParams& p, hipStream_t stream) {
       const long rounds = (tiles + cus - 1) / cus;
       return (double)tiles / (double)(rounds * cus);
     };
-    const int bm = u3_env == 2 ? 64 : 128;
+    // 128-row tiles where they fill the CUs; else 64-row tiles for the long-K layers whose 128-row
+    // tiles would leave half of the CUs idle (the 1024 -> 256 block ends of layer 3 at num_envs 64:
+    // 70.5 us on conv_x3_kernel, 59.9 us here; profiles/r04_q_convbench_dual_u3.txt)
+    int bm = u3_env == 2 ? 64 : 128;
+    if (u3_env == 1 && eff(128) < 0.8 && p.K >= 512 && eff(64) >= 0.8) bm = 64;
     if (eff(bm) >= 0.8 || u3_env >= 2) {
       const int kind = !dual ? 0 : (p.in2_scale != nullptr ? 2 : 1);
       if (u3_waves == 4)   // one wave per SIMD, 64 x 256 tiles (a wave owns 64 x 64): experiment
