@@ -223,14 +223,15 @@ def conv_kernel_time(policy, obs, dev, repeats=3):
     os.environ["VLNCE_HIP_GRAPHS"] = "0"
     os.environ["VLNCE_SIDE_STREAMS"] = "0"
     orig_conv = ops.conv2d_nhwc
+    orig_conv_bn = ops.conv2d_bn_sums   # convolution that also adds its BatchNorm column sums
     events = []
 
     meta = []  # per launch: (algorithmic FLOPs, kernel path the library dispatched to)
 
-    def timed_conv(x, w, stride, pad, *a, **k):
+    def _timed(call, x, w, k):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        out = orig_conv(x, w, stride, pad, *a, **k)
+        out = call()
         e1.record()
         events.append((e0, e1))
         y = out[0] if isinstance(out, tuple) else out
@@ -241,6 +242,12 @@ def conv_kernel_time(policy, obs, dev, repeats=3):
             nbytes += 4.0 * x.numel() * (2 if k.get("side_out") is not None else 1)
         meta.append((2.0 * y.numel() * w[0].numel(), ops.L().conv2d_last_path(), nbytes))
         return out
+
+    def timed_conv(x, w, stride, pad, *a, **k):
+        return _timed(lambda: orig_conv(x, w, stride, pad, *a, **k), x, w, k)
+
+    def timed_conv_bn(x, w, stride, pad, acc, **k):
+        return _timed(lambda: orig_conv_bn(x, w, stride, pad, acc, **k), x, w, k)
 
     def trunks():
         with torch.no_grad():
@@ -267,6 +274,7 @@ def conv_kernel_time(policy, obs, dev, repeats=3):
         backlog_ms = min(3.0 * host_ms + 30.0, 2000.0)
         per_launch, totals, empties = None, [], []
         enc.ops.conv2d_nhwc = timed_conv
+        ops.conv2d_bn_sums = timed_conv_bn
         for _ in range(repeats):
             events.clear()
             meta.clear()
@@ -286,6 +294,7 @@ def conv_kernel_time(policy, obs, dev, repeats=3):
             totals.append(w0.elapsed_time(w1))
     finally:
         enc.ops.conv2d_nhwc = orig_conv
+        ops.conv2d_bn_sums = orig_conv_bn
         for k, v in saved.items():
             if v is None:
                 os.environ.pop(k, None)

@@ -30,7 +30,7 @@ typedef void* vlnce_stream_t;
 
 enum { VLNCE_ACT_NONE = 0, VLNCE_ACT_RELU = 1, VLNCE_ACT_SIGMOID = 2, VLNCE_ACT_TANH = 3 };
 
-int vlnce_version(void); /* major*100 + minor; 134 = this header */
+int vlnce_version(void); /* major*100 + minor; 136 = this header */
 const char* vlnce_last_error(void);
 
 /* Dispatch options: which of the library's equivalent kernels a launch is given to.  Explicit
@@ -107,6 +107,24 @@ typedef struct {
   const void* w_frag;
 } vlnce_prologue;
 
+/* Train-mode BatchNorm statistics taken BY the convolution (torch.nn.BatchNorm2d.forward in
+ * training mode on the convolution's output: resnet_encoders.py:136-139 leaves the frozen trunk's
+ * BatchNorm on batch statistics).  Every workgroup adds the {sum x, sum x^2} of
+ * its raw output columns to `acc` with fp64 device-scope atomics (per 32-row block: the block
+ * sum in fp32, x^2 as M2_block + sum^2 / rows evaluated in fp64 -- the same function of the
+ * accumulators as the tile-moment path below); vlnce_bn_finalize_sums, one workgroup, then turns
+ * the sums into the pending normalisation and the running statistics and leaves `acc` zero
+ * again.  Together they replace convolution + [coarsen] + finalize over thousands of tile
+ * moments (9-21 us behind every convolution of the train-mode trunk) by convolution + ~4 us.
+ * A kernel without this epilogue (fp32-MFMA kernel, split-K) writes its tile moments to
+ * `workspace` and the library reduces them into `acc` itself: the caller sees the same thing. */
+#define VLNCE_BN_SHARDS 16 /* copies of the sums: workgroup b adds to copy b % 16 (atomic contention) */
+typedef struct {
+  double* acc;            /* [VLNCE_BN_SHARDS][Cout][2] {sum x, sum x^2}; added to, not overwritten */
+  void* workspace;        /* vlnce_conv2d_bn_workspace_bytes(d) bytes, uninitialised               */
+  long workspace_bytes;
+} vlnce_bn_sums;
+
 typedef struct {
   const float* scale;     /* [Cout] per-channel multiplier or NULL (folded eval-BN gamma/sqrt(var+eps)) */
   const float* shift;     /* [Cout] per-channel add or NULL (bias / folded BN shift)                    */
@@ -118,7 +136,19 @@ typedef struct {
    * accumulator (before scale/shift): float2 {sum, M2 about the tile mean}.
    * Layout [tiles_m][Cout][2]; tiles_m from vlnce_conv2d_tiles_m(). NULL = off. */
   float* stat_partial;
+  /* train-mode BatchNorm statistics added by the convolution (see vlnce_bn_sums); excludes
+   * stat_partial, scale, shift, residual, act and accumulate.  NULL = off. */
+  const vlnce_bn_sums* bn;
 } vlnce_epilogue;
+
+long vlnce_conv2d_bn_workspace_bytes(const vlnce_conv_desc* d); /* vlnce_bn_sums.workspace */
+/* The sums of vlnce_bn_sums (all VLNCE_BN_SHARDS copies, M values per channel) -> scale_out =
+ * gamma * rstd, mean_out = batch mean [, shift_out = beta - mean * scale, rstd_out]; running
+ * statistics updated like torch (momentum, unbiased variance); `acc` is zero afterwards. */
+int vlnce_bn_finalize_sums(double* acc, int M, int C, const float* gamma, const float* beta,
+                           float eps, float momentum, float* running_mean, float* running_var,
+                           float* scale_out, float* shift_out, float* mean_out, float* rstd_out,
+                           vlnce_stream_t stream);
 
 int vlnce_conv2d_tiles_m(const vlnce_conv_desc* d);   /* rows of stat_partial  */
 int vlnce_conv2d_tile_rows(const vlnce_conv_desc* d); /* BM chosen for `d`      */

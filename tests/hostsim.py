@@ -36,10 +36,34 @@ class HostSim:
         M = g["N"] * g["Ho"] * g["Wo"]
         return (M + self.TILE_ROWS - 1) // self.TILE_ROWS, self.TILE_ROWS
 
+    def conv2d_bn_workspace_bytes(self, g):
+        return 16
+
+    def bn_finalize_sums(self, acc, M, gamma, beta, eps, momentum, running_mean, running_var,
+                         scale_out, mean_out, shift_out=None, rstd_out=None):
+        """vlnce_bn_finalize_sums: all copies of the sums -> pending normalisation, running
+        statistics like torch (momentum, unbiased variance); acc is zero afterwards."""
+        S, Q = acc[:, :, 0].sum(0), acc[:, :, 1].sum(0)
+        acc.zero_()
+        mean = S / M
+        m2 = (Q - S * mean).clamp_min(0.0)
+        rstd = 1.0 / torch.sqrt(m2 / M + eps)
+        g = gamma.double() if gamma is not None else 1.0
+        scale_out.copy_((g * rstd).float())
+        mean_out.copy_(mean.float())
+        if shift_out is not None:
+            b = beta.double() if beta is not None else 0.0
+            shift_out.copy_((b - mean * g * rstd).float())
+        if rstd_out is not None:
+            rstd_out.copy_(rstd.float())
+        if running_mean is not None:
+            running_mean.mul_(1 - momentum).add_(momentum * mean.float())
+            running_var.mul_(1 - momentum).add_(momentum * (m2 / max(M - 1, 1)).float())
+
     def conv2d_fwd(self, x, w, y, g, in_scale=None, in_shift=None, in_relu=0, scale=None,
                    shift=None, residual=None, ldr=0, act=0, accumulate=0, stat_partial=None,
                    in_center=None, x2=None, in2_scale=None, in2_shift=None, in2_center=None,
-                   side_out=None, w_split=None, w_frag=None):
+                   side_out=None, w_split=None, w_frag=None, bn=None):
         N, H, W, Cin, Cout = g["N"], g["H"], g["W"], g["Cin"], g["Cout"]
         xi = x.as_strided((N, H, W, Cin), (H * W * g["ldx"], W * g["ldx"], g["ldx"], 1))
         if in_scale is not None:
@@ -59,6 +83,11 @@ class HostSim:
         raw = F.conv2d(xi.permute(0, 3, 1, 2), wk, stride=g["stride"], padding=g["pad"])
         raw = raw.permute(0, 2, 3, 1).reshape(-1, Cout)
         M = raw.size(0)
+        if bn is not None:
+            # vlnce_bn_sums: {sum x, sum x^2} of the raw output per channel, ADDED to acc (copy 0)
+            acc = bn[0]
+            acc[0, :, 0] += raw.double().sum(0)
+            acc[0, :, 1] += (raw.double() ** 2).sum(0)
         if stat_partial is not None:
             tm, tr = self.conv2d_tiles(g)
             for t in range(tm):

@@ -60,7 +60,7 @@ def main():
     # the communication stream while the trunk's backward convolutions still run; from the second
     # step on every bucket must have been issued from the hooks (none left for finish())
     grads_t = []
-    for use in (False, True):
+    for use in (False, False, True):   # two runs without the reducer = the run-to-run floor
         case_t = dict(case, overrides={**case["overrides"], "RGB_ENCODER.trainable": True,
                                        "DEPTH_ENCODER.trainable": True})
         policy, _ = cases.build_policy(vlnce_amd, case_t, vlnce_amd.make_config,
@@ -83,18 +83,29 @@ def main():
                         if p.grad is not None})
         if red is not None:
             red.remove()
-    assert set(grads_t[0]) == set(grads_t[1]) and len(grads_t[0]) > 300
-    # (two separate runs of a trainable 50-layer trunk with batch-statistics BatchNorm at 6 frames:
-    # split-K atomics order differs run to run and is amplified down to the stem; the reducer
-    # itself -- AVG over one rank -- is the identity, which the frozen-encoder half above holds to
-    # 1e-4.  Here: no gradient lost or mangled.)
-    worst = 0.0
-    for n in grads_t[0]:
-        scale = grads_t[1][n].abs().max().item() + 1e-12
-        worst = max(worst, (grads_t[0][n] - grads_t[1][n]).abs().max().item() / scale)
-    print(f"trainable encoders: {len(grads_t[0])} gradients, worst relative difference between "
-          f"the run with and without the reducer {worst:.2e}", flush=True)
-    assert worst < 5e-2, worst
+    assert set(grads_t[0]) == set(grads_t[2]) and len(grads_t[0]) > 300
+
+    gmax = max(t.abs().max().item() for t in grads_t[0].values())
+
+    def worst(a, b):
+        # relative to the tensor's own scale, floored at 1e-3 of the largest gradient (text_k.bias
+        # has a mathematically zero gradient: its values are rounding noise)
+        w, name = 0.0, ""
+        for n in a:
+            d = (a[n] - b[n]).abs().max().item() / max(b[n].abs().max().item(), 1e-3 * gmax)
+            if d > w:
+                w, name = d, n
+        return w, name
+
+    floor, fname = worst(grads_t[0], grads_t[1])
+    got, gname = worst(grads_t[2], grads_t[0])
+    print(f"trainable encoders: {len(grads_t[0])} gradients; worst relative difference between two "
+          f"runs without the reducer {floor:.2e} ({fname}), with vs without {got:.2e} ({gname})",
+          flush=True)
+    # (a trainable 50-layer trunk with batch-statistics BatchNorm at 6 frames: split-K atomics
+    # order differs run to run and is amplified down to the stem; the reducer -- AVG over one rank
+    # -- must not add to that)
+    assert got <= 3 * floor + 1e-3, (got, floor)
     print("RCCL-SINGLE-RANK-OK", flush=True)
     dist.destroy_process_group()
 

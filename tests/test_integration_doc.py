@@ -52,7 +52,7 @@ def test_package_binding_matches_the_header():
 
     hdr = header_struct_fields()
     for cls, cname in ((_lib.ConvDesc, "vlnce_conv_desc"), (_lib.Prologue, "vlnce_prologue"),
-                       (_lib.Epilogue, "vlnce_epilogue")):
+                       (_lib.Epilogue, "vlnce_epilogue"), (_lib.BnSums, "vlnce_bn_sums")):
         assert [f for f, _ in cls._fields_] == hdr[cname], cname
 
 

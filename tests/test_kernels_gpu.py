@@ -950,3 +950,84 @@ def test_embedding_backward_matches_torch(hip):
     (out * wts.to(DEV)).sum().backward()
     close(w_hip.grad, w_ref.grad, 1e-5, what="embedding grad")
     assert w_hip.grad[0].abs().max().item() == 0.0   # the padding row gets no gradient
+
+
+# ------------------------------------------------------------------ BatchNorm sums added by the conv
+BN_CASES = [
+    # name,             N,  H,  W, Cin, Cout, k, s, p, extras
+    ("bn_1x1_64_256",   2, 16, 16,  64, 256, 1, 1, 0, dict()),
+    ("bn_3x3_64_64",    2, 16, 16,  64,  64, 3, 1, 1, dict(prologue=True)),
+    ("bn_3x3s2_128",    2, 16, 16, 128, 128, 3, 2, 1, dict()),
+    ("bn_1x1_rag",      1,  5,  7, 160,  96, 1, 1, 0, dict(prologue=True)),       # M = 35
+    ("bn_many_tiles",  40, 32, 32,  64, 256, 1, 1, 0, dict(prologue=True)),       # several tiles per workgroup
+    ("bn_two_coltiles", 3, 24, 24, 128, 512, 1, 1, 0, dict()),                    # the column tile changes
+    ("bn_dual",         3, 20, 12, 128, 256, 1, 1, 0, dict(prologue=True, dual=True)),
+    ("bn_stem_7x7",     2, 32, 32,   3,  64, 7, 2, 3, dict()),                    # fp32 kernel: moments + finalize behind
+    ("bn_split_k",      1,  4,  4, 512, 512, 3, 1, 1, dict()),                    # split-K: the same fall-back
+    ("bn_big_mean",     2, 16, 16,  64, 128, 1, 1, 0, dict(offset=30.0)),         # |mean| >> std
+]
+
+
+def _bn_case(hip, case, **opts):
+    name, N, H, W, Cin, Cout, k, s, pad, ex = case
+    x = rnd(N, H, W, Cin, seed=41) + ex.get("offset", 0.0)
+    w = rnd(Cout, k, k, Cin, seed=42) * (Cin * k * k) ** -0.5
+    bn = torch.nn.BatchNorm2d(Cout, momentum=0.1)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(Cout, generator=torch.Generator().manual_seed(43)) + 0.5)
+        bn.bias.copy_(rnd(Cout, seed=44))
+        bn.running_mean.copy_(rnd(Cout, seed=45))
+        bn.running_var.copy_(torch.rand(Cout, generator=torch.Generator().manual_seed(46)) + 0.5)
+    kw, xin = {}, x
+    if ex.get("prologue"):
+        isc, ish, ict = torch.rand(Cin) + 0.5, rnd(Cin, seed=47), rnd(Cin, seed=48)
+        kw = dict(in_scale=isc.to(DEV), in_shift=ish.to(DEV), in_center=ict.to(DEV), in_relu=True)
+        xin = (x - ict) * isc + ish
+        if ex.get("dual"):
+            x2 = rnd(N, H, W, Cin, seed=49)
+            kw.update(x2=x2.to(DEV), side_out=torch.empty(N, H, W, Cin, device=DEV))
+            xin = xin + x2
+        xin = torch.relu(xin)
+    raw = F.conv2d(xin.double().permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2), stride=s,
+                   padding=pad).permute(0, 2, 3, 1)
+    M = raw.numel() // Cout
+    mean = raw.reshape(M, Cout).mean(0)
+    var = raw.reshape(M, Cout).var(0, unbiased=False)
+    rm0, rv0 = bn.running_mean.clone(), bn.running_var.clone()
+    bn_g = torch.nn.BatchNorm2d(Cout, momentum=0.1).to(DEV)
+    bn_g.load_state_dict(bn.state_dict())
+    with hip.options(**opts):
+        for rep in range(2):   # the accumulators must be left clean: the second pass sees zeros again
+            y, (scale, beta, center) = ops.conv2d_bn_train(x.to(DEV), w.to(DEV), s, pad, bn_g, **kw)
+            torch.cuda.synchronize()
+            close(y, raw.float(), 1e-4, what=f"{name} raw output")
+            close(center, mean.float(), 2e-5, what=f"{name} batch mean")
+            want = bn.weight.double() / torch.sqrt(var + bn.eps)
+            assert ((scale.cpu().double() - want).abs() / want.abs()).max().item() < 3e-5, name
+            assert torch.equal(beta.cpu(), bn.bias.detach())
+            assert ops._bn_state(bn_g).abs().max().item() == 0.0, (name, rep)
+    unb = var * M / max(M - 1, 1)
+    for _ in range(2):
+        rm0 = 0.9 * rm0 + 0.1 * mean.float()
+        rv0 = 0.9 * rv0 + 0.1 * unb.float()
+    close(bn_g.running_mean, rm0, 2e-5, what=f"{name} running mean")
+    close(bn_g.running_var, rv0, 3e-5, what=f"{name} running var")
+    return hip.conv2d_last_path()
+
+
+@pytest.mark.parametrize("case", BN_CASES, ids=[c[0] for c in BN_CASES])
+def test_conv_bn_sums(hip, case):
+    """vlnce_bn_sums + vlnce_bn_finalize_sums: raw output, pending normalisation (scale, center), running statistics and
+    clean accumulators against an fp64 torch convolution + batch statistics, twice in a row."""
+    _bn_case(hip, case)
+
+
+@pytest.mark.parametrize("opts", [dict(u3=2), dict(u3=3), dict(s3=2), dict(p3=1, p3_tile=3),
+                                  dict(p3=0, u3=0, s3=0, x3_tile=1), dict(p3=0, u3=0, s3=0, x3_tile=4),
+                                  dict(conv_math=0)],
+                         ids=["u3_64", "u3_128", "s3", "p3_tile3", "x3_tile1", "x3_tile4", "f32_fallback"])
+def test_conv_bn_sums_every_kernel(hip, opts):
+    """the same through each convolution kernel (forced with the dispatch options) and through
+    the fall-back (fp32 kernel: tile moments reduced into the sums behind the convolution)."""
+    for case in BN_CASES:
+        _bn_case(hip, case, **opts)

@@ -39,9 +39,13 @@ class Frames(C.Structure):
                 ("Hs", _I), ("Ws", _I), ("C", _I), ("y0", _I), ("x0", _I), ("H", _I), ("W", _I)]
 
 
+class BnSums(C.Structure):
+    _fields_ = [("acc", _P), ("workspace", _P), ("workspace_bytes", _L)]
+
+
 class Epilogue(C.Structure):
     _fields_ = [("scale", _P), ("shift", _P), ("residual", _P), ("ldr", _I), ("act", _I),
-                ("accumulate", _I), ("stat_partial", _P)]
+                ("accumulate", _I), ("stat_partial", _P), ("bn", C.POINTER(BnSums))]
 
 
 _SIGNATURES = {
@@ -57,6 +61,8 @@ _SIGNATURES = {
     "vlnce_conv2d_pack_weights": (_I, [_P, _P, C.POINTER(ConvDesc), _P]),
     "vlnce_conv2d_tiles_m": (_I, [C.POINTER(ConvDesc)]),
     "vlnce_conv2d_tile_rows": (_I, [C.POINTER(ConvDesc)]),
+    "vlnce_conv2d_bn_workspace_bytes": (C.c_long, [C.POINTER(ConvDesc)]),
+    "vlnce_bn_finalize_sums": (_I, [_P, _I, _I, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P]),
     "vlnce_conv2d_fwd": (_I, [_P, _P, _P, C.POINTER(ConvDesc), C.POINTER(Prologue),
                               C.POINTER(Epilogue), _P]),
     "vlnce_gemm": (_I, [_P, _I, _I, _P, _I, _I, _P, _I, _I, _I, _I, C.POINTER(Epilogue), _P]),
@@ -186,7 +192,7 @@ class HipLib:
 
     name = "hip"
 
-    ABI = 134  # include/vlnce_hip.h
+    ABI = 136  # include/vlnce_hip.h
 
     def __init__(self, path=LIB_PATH):
         self.dll = load_cdll(path)
@@ -261,15 +267,33 @@ class HipLib:
     def conv2d_fwd(self, x, w, y, g, in_scale=None, in_shift=None, in_relu=0, scale=None,
                    shift=None, residual=None, ldr=0, act=0, accumulate=0, stat_partial=None,
                    in_center=None, x2=None, in2_scale=None, in2_shift=None, in2_center=None,
-                   side_out=None, w_split=None, w_frag=None):
+                   side_out=None, w_split=None, w_frag=None, bn=None):
+        """bn: train-mode BatchNorm statistics added by the launch (vlnce_bn_sums): (acc
+        [16, C, 2] f64, workspace uint8) -- finish them with bn_finalize_sums()."""
         d = self._desc(g)
         pro = Prologue(_ptr(in_scale), _ptr(in_shift), _ptr(in_center), int(in_relu), _ptr(x2),
                        _ptr(in2_scale), _ptr(in2_shift), _ptr(in2_center), _ptr(side_out),
                        _ptr(w_split), _ptr(w_frag))
+        bnp = None
+        if bn is not None:
+            acc, ws = bn
+            bnp = C.pointer(BnSums(_ptr(acc), _ptr(ws), ws.numel() * ws.element_size()))
         epi = Epilogue(_ptr(scale), _ptr(shift), _ptr(residual), int(ldr), int(act),
-                       int(accumulate), _ptr(stat_partial))
+                       int(accumulate), _ptr(stat_partial), bnp)
         self._check(self.dll.vlnce_conv2d_fwd(_ptr(x), _ptr(w), _ptr(y), C.byref(d), C.byref(pro),
                                               C.byref(epi), _stream()), "vlnce_conv2d_fwd")
+
+    def bn_finalize_sums(self, acc, M, gamma, beta, eps, momentum, running_mean, running_var,
+                         scale_out, mean_out, shift_out=None, rstd_out=None):
+        Cc = scale_out.numel()
+        self._check(self.dll.vlnce_bn_finalize_sums(
+            _ptr(acc), int(M), Cc, _ptr(gamma), _ptr(beta), float(eps), float(momentum),
+            _ptr(running_mean), _ptr(running_var), _ptr(scale_out), _ptr(shift_out),
+            _ptr(mean_out), _ptr(rstd_out), _stream()), "vlnce_bn_finalize_sums")
+
+    def conv2d_bn_workspace_bytes(self, g):
+        d = self._desc(g)
+        return int(self.dll.vlnce_conv2d_bn_workspace_bytes(C.byref(d)))
 
     def conv2d_split_weights(self, w, planes):
         self._check(self.dll.vlnce_conv2d_split_weights(_ptr(w), _ptr(planes), w.numel(),

@@ -20,7 +20,9 @@ extern "C" const char* vlnce_last_error(void) { return g_err; }
 // major*100 + minor; 1.x: round-1 ABI (centered normalisation vectors, dual-input prologue,
 // backward / data-path / returns entry points).  Struct layouts only ever grow at the end.
 // 134: vlnce_set_option / vlnce_get_option (the library no longer reads environment variables).
-extern "C" int vlnce_version(void) { return 134; }
+// 136: vlnce_epilogue.bn (train-mode BatchNorm column sums added by the convolution) +
+// vlnce_bn_finalize_sums.
+extern "C" int vlnce_version(void) { return 136; }
 
 // ---- dispatch options: one int per name, process-wide, relaxed atomics (a tuning / test knob,
 // not a synchronisation point: set them before the launches they are meant for)

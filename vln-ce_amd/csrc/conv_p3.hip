@@ -561,6 +561,8 @@ __global__ __launch_bounds__((WM * WN + P3_PRODUCERS) * 64) void conv_p3_kernel(
 #endif
     int h = 0;
     int vb[NT], vbn[NT];
+    WaveBn<NT> wbn;   // BatchNorm finished in this launch (p.bn): the wave's running column sums
+    wave_bn_reset(wbn);
     {
       int m0, n0;
       tile_of(0, m0, n0);
@@ -669,8 +671,11 @@ __global__ __launch_bounds__((WM * WN + P3_PRODUCERS) * 64) void conv_p3_kernel(
         }
       }
 
-      // -------------------------------------------------------------- statistics partials
-      if (p.stat_partial != nullptr) {
+      // -------------------------------------------------------------- statistics
+      if (p.bn.acc != nullptr) {
+        wave_bn_tile<MT, NT>(acc, wbn, p.bn.acc, n0 + wn * WTN, p.N, p.M - (m0 + wm * WTM), half, l31);
+        if (round == my_tiles - 1) wave_bn_flush(wbn, p.bn.acc, p.N, half, l31);  // in front of the stores
+      } else if (p.stat_partial != nullptr) {
         const int tile_m = m0 / BM;
         if (p.stat_rows == 32 && MT > 1) {
 #pragma unroll
@@ -1000,6 +1005,8 @@ __global__ __launch_bounds__(WAVES * 64) void conv_u3_kernel(IgemmParams p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   int c = 0, round = 0, ks3 = 0;
+  WaveBn<NT> wbn;   // BatchNorm finished in this launch (p.bn): the wave's running column sums
+  wave_bn_reset(wbn);
 #ifdef P3_DBG_TIME
   long long d_blk = 0, d_epi = 0, d_bar = 0, d_book = 0;
   const long long d_t0 = clock64(), d_w0 = wall_clock64();
@@ -1088,8 +1095,11 @@ __global__ __launch_bounds__(WAVES * 64) void conv_u3_kernel(IgemmParams p) {
     d_book += d_2 - d_1;
 #endif
     if (last_of_tile) {
-      // -------------------------------------------------------------- statistics partials
-      if (p.stat_partial != nullptr) {
+      // -------------------------------------------------------------- statistics
+      if (p.bn.acc != nullptr) {
+        wave_bn_tile<MT, NT>(acc, wbn, p.bn.acc, n0 + wave * NT * 32, p.N, p.M - m0, half, l31);
+        if (round == my_tiles - 1) wave_bn_flush(wbn, p.bn.acc, p.N, half, l31);  // in front of the stores
+      } else if (p.stat_partial != nullptr) {
         const int col0 = n0 + wave * NT * 32;
         if (p.stat_rows == 32 && MT > 1) {
 #pragma unroll
@@ -1320,9 +1330,14 @@ __global__ __launch_bounds__(512) void conv_s3_kernel(IgemmParams p) {
   constexpr int PB[6] = {0, 1, 2, 0, 1, 0};
   const int a_off = l31 * P3_ROW + half * 16;
 
-  // statistics partials of a finished tile (raw accumulators, 32-row blocks)
+  WaveBn<1> wbn;   // BatchNorm finished in this launch (p.bn): the wave's running column sums
+  wave_bn_reset(wbn);
+  // statistics of a finished tile (raw accumulators, 32-row blocks)
   auto stats = [&](const f32x16 (&a)[MT], int m0) {
-    if (p.stat_partial != nullptr) {
+    if (p.bn.acc != nullptr) {
+      wave_bn_tile<MT, 1>(reinterpret_cast<const f32x16(&)[MT][1]>(a), wbn, p.bn.acc, n0 + wave * 32,
+                          p.N, p.M - m0, half, l31);
+    } else if (p.stat_partial != nullptr) {
 #pragma unroll
       for (int i = 0; i < MT; ++i)
         wave_stats_block<1>(reinterpret_cast<const f32x16(&)[1]>(a[i]), p.stat_partial,
@@ -1423,9 +1438,11 @@ __global__ __launch_bounds__(512) void conv_s3_kernel(IgemmParams p) {
     const int m0 = (wg + (my_tiles - 1) * nwg) * BM;
     if ((my_tiles - 1) & 1) {
       stats(acc[1], m0);
+      if (p.bn.acc != nullptr) wave_bn_flush(wbn, p.bn.acc, p.N, half, l31);  // in front of the stores
       stores(acc[1], m0, 0, 32);
     } else {
       stats(acc[0], m0);
+      if (p.bn.acc != nullptr) wave_bn_flush(wbn, p.bn.acc, p.N, half, l31);
       stores(acc[0], m0, 0, 32);
     }
   }

@@ -1066,6 +1066,8 @@ __global__ __launch_bounds__((WM * WN + X3_PRODUCERS) * 64) void conv_x3_kernel(
     long long d_wait = 0;
 #endif
     Frag fa, fb;
+    WaveBn<NT> wbn;   // BatchNorm finished in this launch (p.bn): the wave's running column sums
+    wave_bn_reset(wbn);
     // the SIMD's VALU issue port is shared with the producer waves: the MFMAs must win it the
     // moment the matrix pipe frees up, the producers take the slots in between
     __builtin_amdgcn_s_setprio(3);
@@ -1123,8 +1125,11 @@ __global__ __launch_bounds__((WM * WN + X3_PRODUCERS) * 64) void conv_x3_kernel(
         __builtin_amdgcn_sched_barrier(0);
       }
 
-      // -------------------------------------------------------------- statistics partials
-      if (p.stat_partial != nullptr) {
+      // -------------------------------------------------------------- statistics
+      if (p.bn.acc != nullptr) {
+        wave_bn_tile<MT, NT>(acc, wbn, p.bn.acc, n0 + wn * WTN, p.N, p.M - (m0 + wm * WTM), half, l31);
+        if (round == my_tiles - 1) wave_bn_flush(wbn, p.bn.acc, p.N, half, l31);  // in front of the stores
+      } else if (p.stat_partial != nullptr) {
         const int tile_m = m0 / BM;
         if (p.stat_rows == 32 && MT > 1) {
           // one partial per 32x32 MFMA block row: exactly the 16 accumulator registers of a lane
@@ -1318,6 +1323,8 @@ void fill_epilogue(IgemmParams& p, const vlnce_epilogue* e) {
   p.act = e ? e->act : 0;
   p.accumulate = e ? e->accumulate : 0;
   p.stat_partial = e ? e->stat_partial : nullptr;
+  p.bn = vlnce_bn_sums{};
+  if (e && e->bn) p.bn = *e->bn;
 }
 
 bool aligned16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
@@ -1443,6 +1450,83 @@ extern "C" int vlnce_conv2d_split_weights(const float* w, void* planes, long cou
   return 0;
 }
 
+// {sum x, sum x^2} per channel (fp64, added by the convolution's workgroups) -> the pending
+// normalisation and the running statistics; leaves the sums zero for the next launch.  One
+// workgroup per 256 channels: ~2 us + a launch boundary behind the convolution instead of
+// finalize (+ coarsen) over thousands of tile moments.
+__global__ __launch_bounds__(256) void bn_sums_finalize_kernel(
+    double* __restrict__ acc, int M, int N, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float eps, float momentum, float* running_mean,
+    float* running_var, float* scale_out, float* shift_out, float* mean_out, float* rstd_out) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= N) return;
+  double S = 0.0, Q = 0.0;
+#pragma unroll
+  for (int k = 0; k < VLNCE_BN_SHARDS; ++k) {
+    double* q = acc + ((long)k * N + c) * 2;
+    S += q[0];
+    Q += q[1];
+    q[0] = 0.0;
+    q[1] = 0.0;
+  }
+  const double mean = S / (double)M;
+  double m2 = Q - S * mean;           // sum (x - mean)^2
+  if (m2 < 0.0) m2 = 0.0;
+  const double var = m2 / (double)M;  // biased, used for normalisation
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float g = gamma ? gamma[c] : 1.f;
+  const float sc = g * rstd;
+  scale_out[c] = sc;
+  if (shift_out) shift_out[c] = (beta ? beta[c] : 0.f) - (float)mean * sc;
+  if (mean_out) mean_out[c] = (float)mean;
+  if (rstd_out) rstd_out[c] = rstd;
+  if (running_mean) {
+    const double unbiased = M > 1 ? m2 / (double)(M - 1) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+  }
+}
+
+// tile moments {sum, M2 about the tile mean} of a kernel without the sums epilogue -> the same sums:
+// thread = (strip of 32 tiles, channel), channels fastest (coalesced 8-byte reads)
+__global__ __launch_bounds__(256) void bn_partials_to_sums_kernel(const float* __restrict__ partial,
+                                                                  int tiles_m, int tile_rows, int M,
+                                                                  int N, double* __restrict__ acc) {
+  const int c = blockIdx.y * 64 + (threadIdx.x & 63);
+  const int t0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 32;
+  if (c >= N || t0 >= tiles_m) return;
+  double S = 0.0, Q = 0.0;
+  for (int t = t0; t < min(t0 + 32, tiles_m); ++t) {
+    const float2 v = *reinterpret_cast<const float2*>(partial + ((long)t * N + c) * 2);
+    const int nt = min(tile_rows, M - t * tile_rows);
+    S += (double)v.x;
+    Q += (double)v.y + (double)v.x * (double)v.x / (double)nt;
+  }
+  double* q = acc + ((long)(blockIdx.x % VLNCE_BN_SHARDS) * N + c) * 2;
+  unsafeAtomicAdd(q, S);
+  unsafeAtomicAdd(q + 1, Q);
+}
+
+// vlnce_bn_sums.workspace: the tile moments of a convolution kernel WITHOUT the sums epilogue
+extern "C" long vlnce_conv2d_bn_workspace_bytes(const vlnce_conv_desc* d) {
+  if (!d || d->Cout <= 0) return 0;
+  return (((long)vlnce_conv2d_tiles_m(d) * d->Cout * 2 * 4) + 255) / 256 * 256;
+}
+
+extern "C" int vlnce_bn_finalize_sums(double* acc, int M, int C, const float* gamma, const float* beta,
+                                      float eps, float momentum, float* running_mean,
+                                      float* running_var, float* scale_out, float* shift_out,
+                                      float* mean_out, float* rstd_out, vlnce_stream_t stream) {
+  VLNCE_CHECK_ARG(acc && scale_out && M > 0 && C > 0, "bn_finalize_sums: bad argument");
+  VLNCE_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr),
+                  "bn_finalize_sums: running stats must come together");
+  hipLaunchKernelGGL(bn_sums_finalize_kernel, dim3(ceil_div(C, 256)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), acc, M, C, gamma, beta, eps, momentum,
+                     running_mean, running_var, scale_out, shift_out, mean_out, rstd_out);
+  VLNCE_CHECK_LAUNCH("bn_finalize_sums");
+  return 0;
+}
+
 // which kernel the calling thread's last vlnce_conv2d_fwd went to (bench.py prices the bf16-pipe
 // launches and the fp32-MFMA launches against their own peaks)
 static thread_local int g_last_path = -1;
@@ -1495,6 +1579,37 @@ extern "C" int vlnce_conv2d_fwd(const float* x, const float* w, float* y, const 
   VLNCE_CHECK_ARG((p.in_scale == nullptr) == (p.in_shift == nullptr),
                   "conv2d_fwd: in_scale and in_shift must come together");
   fill_epilogue(p, epi);
+  // ---- train-mode BatchNorm statistics added by the launch (vlnce_bn_sums).  The kernels
+  // without that epilogue (fp32-MFMA kernel, split-K) write tile moments into the workspace
+  // instead and a reduction kernel behind them adds those to the sums: same result for the caller.
+  const vlnce_bn_sums* const bnf = epi ? epi->bn : nullptr;
+  if (bnf != nullptr) {
+    VLNCE_CHECK_ARG(bnf->acc != nullptr, "conv2d_fwd: bn needs acc");
+    VLNCE_CHECK_ARG(!p.stat_partial && !p.scale && !p.shift && !p.residual && !p.act && !p.accumulate,
+                    "conv2d_fwd: bn excludes stat_partial / scale / shift / residual / act / accumulate");
+    VLNCE_CHECK_ARG(bnf->workspace && bnf->workspace_bytes >= vlnce_conv2d_bn_workspace_bytes(d) &&
+                        aligned16(bnf->workspace),
+                    "conv2d_fwd: bn workspace too small (vlnce_conv2d_bn_workspace_bytes)");
+  }
+  // hand the statistics to the tile-moment path (for a kernel without the sums epilogue) ...
+  auto bn_to_partials = [&]() {
+    if (bnf != nullptr) {
+      p.bn = vlnce_bn_sums{};
+      p.stat_partial = static_cast<float*>(bnf->workspace);
+    }
+  };
+  auto bn_sums_behind = [&](int rc) -> int { return rc; };   // the kernel added the sums itself
+  // ... and reduce the moments into the sums behind the convolution
+  auto bn_finalize_behind = [&](int rc) -> int {
+    if (rc != 0 || bnf == nullptr) return rc;
+    const int tiles = vlnce_conv2d_tiles_m(d);
+    hipLaunchKernelGGL(bn_partials_to_sums_kernel, dim3(ceil_div(tiles, 128), ceil_div(d->Cout, 64)),
+                       dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       static_cast<const float*>(bnf->workspace), tiles, stat_rows_for(d), (int)M,
+                       d->Cout, bnf->acc);
+    VLNCE_CHECK_LAUNCH("conv2d_fwd bn moments -> sums");
+    return 0;
+  };
   const bool v4 = (d->Cin % 4 == 0) && (p.lda % 4 == 0) && aligned16(x) && aligned16(w) &&
                   (!p.in_scale || (aligned16(p.in_scale) && aligned16(p.in_shift))) &&
                   (!p.in_center || aligned16(p.in_center));
@@ -1515,11 +1630,12 @@ extern "C" int vlnce_conv2d_fwd(const float* x, const float* w, float* y, const 
                     "conv2d_fwd: the dual-input prologue needs x2 + in_scale on a 1x1/stride-1/"
                     "pad-0 convolution with Cin %% 32 == 0 and 16-byte aligned operands");
     g_last_path = VLNCE_CONV_PATH_P3;
-    if (const int rc = p3_try_launch(p, s); rc >= 0) return rc;
+    if (const int rc = p3_try_launch(p, s); rc >= 0) return bn_sums_behind(rc);
     g_last_path = VLNCE_CONV_PATH_X3;
-    if (X3Plan t; x3_plan(p, &t)) return dispatch_x3<1>(p, t, s);
+    if (X3Plan t; x3_plan(p, &t)) return bn_sums_behind(dispatch_x3<1>(p, t, s));
     g_last_path = VLNCE_CONV_PATH_F32;
-    return dispatch_dual(p, s);
+    bn_to_partials();
+    return bn_finalize_behind(dispatch_dual(p, s));
   }
   if (v4 && buf_ok(p)) {
     // Small batches (act() at num_envs 1..8, eval BatchNorm folded into scale/shift): a late
@@ -1532,6 +1648,7 @@ extern "C" int vlnce_conv2d_fwd(const float* x, const float* w, float* y, const 
                        ? choose_splitk(p)
                        : 1;
     if (sk > 1) {
+      bn_to_partials();
       const float* scale = p.scale;
       const float* shift = p.shift;
       const float* residual = p.residual;
@@ -1549,6 +1666,7 @@ extern "C" int vlnce_conv2d_fwd(const float* x, const float* w, float* y, const 
                            0, s, y, p.ldc, (int)M, p.N, p.stat_rows, stat_partial);
         VLNCE_CHECK_LAUNCH("conv2d_fwd split-K statistics");
       }
+      if (bnf != nullptr) return bn_finalize_behind(0);
       if (scale) {
         VLNCE_CHECK_ARG(!residual || ldr == p.N, "conv2d_fwd: split-K needs a contiguous residual");
         return vlnce_scale_shift_act(y, scale, shift, nullptr, 0, residual, y, M, p.N, act, stream);
@@ -1562,16 +1680,18 @@ extern "C" int vlnce_conv2d_fwd(const float* x, const float* w, float* y, const 
       return 0;
     }
     g_last_path = VLNCE_CONV_PATH_P3;
-    if (const int rc = p3_try_launch(p, s); rc >= 0) return rc;
+    if (const int rc = p3_try_launch(p, s); rc >= 0) return bn_sums_behind(rc);
     g_last_path = VLNCE_CONV_PATH_X3;
-    if (X3Plan t; x3_plan(p, &t)) return dispatch_x3<0>(p, t, s);
+    if (X3Plan t; x3_plan(p, &t)) return bn_sums_behind(dispatch_x3<0>(p, t, s));
     g_last_path = VLNCE_CONV_PATH_F32;
-    return dispatch_tiles<A_BUF, B_BUF>(p, s);
+    bn_to_partials();
+    return bn_finalize_behind(dispatch_tiles<A_BUF, B_BUF>(p, s));
   }
-  if (v4) return dispatch_tiles<A_IM2COL_V4, B_NK_V4>(p, s);
-  if (d->KW == 7 && d->Cin == 3) return dispatch_stem<3>(p, s);
-  if (d->KW == 7 && d->Cin == 1) return dispatch_stem<1>(p, s);
-  return dispatch_tiles<A_IM2COL_S, B_NK_S>(p, s);
+  bn_to_partials();
+  if (v4) return bn_finalize_behind(dispatch_tiles<A_IM2COL_V4, B_NK_V4>(p, s));
+  if (d->KW == 7 && d->Cin == 3) return bn_finalize_behind(dispatch_stem<3>(p, s));
+  if (d->KW == 7 && d->Cin == 1) return bn_finalize_behind(dispatch_stem<1>(p, s));
+  return bn_finalize_behind(dispatch_tiles<A_IM2COL_S, B_NK_S>(p, s));
 }
 
 extern "C" int vlnce_gemm(const float* A, int lda, int transA, const float* B, int ldb, int transB,

@@ -44,6 +44,7 @@ struct IgemmParams {
   int act;
   int accumulate;
   float* stat_partial;
+  vlnce_bn_sums bn;  // bn.acc != nullptr: the launch adds its BatchNorm column sums to bn.acc
   int tiles_m, tiles_n;
   int splitk;  // > 1: blockIdx.y owns a K range and atomically adds into a pre-zeroed C
   int stat_rows;  // rows per statistics partial (vlnce_conv2d_tile_rows)
@@ -165,6 +166,87 @@ __device__ __forceinline__ void wave_stats_block(const f32x16 (&acc)[NT], float*
     }
   }
 }
+
+// ---- train-mode BatchNorm statistics added by the convolution (vlnce_bn_sums) -----------------
+// A wave's running {sum x, sum x^2} of its NT x 32 output columns over the tiles it has finished
+// for one column tile; flushed to IgemmParams::bn.acc with fp64 atomics when the column tile
+// changes and at the end of the launch.  Every lane of a half-wave pair holds the same values
+// (the block sums are completed with a shuffle across the halves); half 0 flushes.
+template <int NT>
+struct WaveBn {
+  double s[NT], q[NT];
+  int col0;   // first column of the wave's current column block, -1 = nothing accumulated
+};
+template <int NT>
+__device__ __forceinline__ void wave_bn_reset(WaveBn<NT>& w) {
+#pragma unroll
+  for (int j = 0; j < NT; ++j) w.s[j] = w.q[j] = 0.0;
+  w.col0 = -1;
+}
+// The sums are kept in VLNCE_BN_SHARDS copies, a workgroup adds to copy blockIdx.x % SHARDS: with
+// one copy the 256 workgroups of a launch queue up on each address (~12 ns per device-scope
+// atomic: 3-5 us at the very end of the kernel, where nothing hides it).
+template <int NT>
+__device__ __forceinline__ void wave_bn_flush(WaveBn<NT>& w, double* acc, int N, int half, int l31) {
+  acc += (long)(blockIdx.x % VLNCE_BN_SHARDS) * N * 2;
+  if (w.col0 >= 0 && half == 0) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int col = w.col0 + j * 32 + l31;
+      if (col < N) {
+        unsafeAtomicAdd(acc + 2 * col, w.s[j]);
+        unsafeAtomicAdd(acc + 2 * col + 1, w.q[j]);
+      }
+    }
+  }
+  wave_bn_reset(w);
+}
+// one 32-row MFMA block (NT 32x32 tiles side by side) of raw accumulators: rows_left = rows of it
+// that exist (<= 0: none)
+template <int NT>
+__device__ __forceinline__ void wave_bn_block(const f32x16 (&acc)[NT], WaveBn<NT>& w, int rows_left,
+                                              int half) {
+  const int rows_valid = min(32, rows_left);
+  if (rows_valid <= 0) return;   // (wave-uniform)
+  const double inv_n = 1.0 / (double)rows_valid;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      if ((r & 3) + 8 * (r >> 2) + 4 * half < rows_valid) s += acc[j][r];
+    s += __shfl_xor(s, 32, 64);
+    const float mean = s / (float)rows_valid;
+    float m2 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float d = acc[j][r] - mean;
+      if ((r & 3) + 8 * (r >> 2) + 4 * half < rows_valid) m2 += d * d;
+    }
+    m2 += __shfl_xor(m2, 32, 64);
+    w.s[j] += (double)s;
+    w.q[j] += (double)m2 + (double)s * (double)s * inv_n;
+  }
+}
+// a wave's MT x NT blocks of one finished tile: col0 = its first column, rows_left = rows of the
+// wave's sub-tile that exist
+template <int MT, int NT>
+__device__ __forceinline__ void wave_bn_tile(const f32x16 (&acc)[MT][NT], WaveBn<NT>& w, double* gacc,
+                                             int col0, int N, int rows_left, int half, int l31) {
+  if (w.col0 != col0) {
+    wave_bn_flush(w, gacc, N, half, l31);
+    w.col0 = col0;
+  }
+#pragma unroll
+  for (int i = 0; i < MT; ++i) wave_bn_block<NT>(acc[i], w, rows_left - i * 32, half);
+}
+// (Measured and dropped, round 4: finishing the statistics INSIDE the convolution -- ticket per
+// workgroup, the last one reads the sums back with atomic exchanges and writes the vectors -- costs
+// the launch three dependent device-scope round trips (atomics acknowledged, ticket returned,
+// exchanges returned: +12 us per launch, as much as the separate finalize launch it removed;
+// with a __threadfence() in front of the ticket +40 us: buffer_wbl2 / buffer_inv by every wave
+// behind a kernel that has just written up to 268 MB).  The convolution only ADDS; a one-workgroup
+// kernel behind it turns the sums into the vectors: profiles/r04_y_*.)
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 

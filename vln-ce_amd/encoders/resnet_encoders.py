@@ -270,10 +270,16 @@ class HipResNetTrunk(DropsGraphsOnApply, nn.Sequential):
                 pro.update(in2_scale=p2[0], in2_shift=p2[1], in2_center=p2[2])
         w, stride, pad = ((self._cache.stem_s2d(conv), 1, 0) if s2d else
                           (self._cache.conv(conv), conv.stride[0], conv.padding[0]))
-        y, stats = ops.conv2d_nhwc(x, w, stride, pad, want_stats=True, **pro)
         assert bn.momentum is not None
-        pend = ops.bn_finalize(stats, y.numel() // y.size(-1), bn.weight, bn.bias, bn.eps,
-                               bn.momentum, bn.running_mean, bn.running_var)
+        if os.environ.get("VLNCE_BN_FUSED", "1") == "0":   # A/B: tile moments + finalize launch(es)
+            y, stats = ops.conv2d_nhwc(x, w, stride, pad, want_stats=True, **pro)
+            pend = ops.bn_finalize(stats, y.numel() // y.size(-1), bn.weight, bn.bias, bn.eps,
+                                   bn.momentum, bn.running_mean, bn.running_var)
+            touched.append(bn.num_batches_tracked)
+            return y, pend
+        # raw output + batch statistics from the convolution itself (vlnce_bn_sums: fp64 atomic
+        # column sums) + a one-workgroup finalize behind it, instead of tile moments + finalize
+        y, pend = ops.conv2d_bn_train(x, w, stride, pad, bn, **pro)
         touched.append(bn.num_batches_tracked)
         return y, pend  # (scale, shift, center)
 

@@ -114,6 +114,56 @@ def conv2d_nhwc(x, w_ohwi, stride, pad, *, in_scale=None, in_shift=None, in_cent
     return (y, stats) if want_stats else y
 
 
+BN_SHARDS = 16   # VLNCE_BN_SHARDS of include/vlnce_hip.h
+_BN_STATE = {}   # id(BatchNorm module) -> (device, acc [BN_SHARDS,C,2] f64): zero between launches
+
+
+def _bn_state(bn):
+    """the persistent column sums (vlnce_bn_sums.acc) of one BatchNorm layer; bn_finalize_sums
+    leaves them zero.  Created on the first (eager) call of a layer, i.e. before any graph capture."""
+    w = bn.weight
+    hit = _BN_STATE.get(id(bn))
+    if hit is None or hit[0] != w.device or hit[1].size(1) != w.numel():
+        hit = (w.device, torch.zeros((BN_SHARDS, w.numel(), 2), device=w.device, dtype=torch.float64))
+        _BN_STATE[id(bn)] = hit
+    return hit[1]
+
+
+def conv2d_bn_sums(x, w_ohwi, stride, pad, acc, **pro):
+    """raw convolution output; the launch adds the output's per-channel {sum, sum of squares} to
+    `acc` (vlnce_bn_sums).  `pro`: the operand-loader arguments of conv2d_nhwc."""
+    assert x.is_contiguous() and w_ohwi.is_contiguous()
+    g = conv_geometry(x, w_ohwi, stride, pad)
+    y = torch.empty((g["N"], g["Ho"], g["Wo"], g["Cout"]), device=x.device, dtype=torch.float32)
+    lib = L()
+    ws = torch.empty(max(lib.conv2d_bn_workspace_bytes(g), 16), device=x.device, dtype=torch.uint8)
+    if pro.get("x2") is not None:
+        assert pro["x2"].is_contiguous() and pro["x2"].shape == x.shape
+    if "in_relu" in pro:
+        pro = dict(pro, in_relu=int(pro["in_relu"]))
+    lib.conv2d_fwd(x, w_ohwi, y, g, **pro, ldr=g["Cout"], w_split=split_weights(w_ohwi),
+                   w_frag=pack_weights(w_ohwi), bn=(acc, ws))
+    return y
+
+
+def conv2d_bn_train(x, w_ohwi, stride, pad, bn, **pro):
+    """Convolution + train-mode BatchNorm STATISTICS without a pass over tile moments: the
+    convolution adds its column sums (conv2d_bn_sums), a one-workgroup launch finishes them
+    (vlnce_bn_finalize_sums).  Returns the RAW output and the pending normalisation (scale =
+    gamma * rstd, shift = beta, center = batch mean) that the consumer's operand loader applies;
+    the running statistics of `bn` are updated like torch.  (resnet_encoders.py:136-139: the
+    frozen trunk's BatchNorm stays in training mode.)"""
+    assert bn.momentum is not None
+    acc = _bn_state(bn)
+    y = conv2d_bn_sums(x, w_ohwi, stride, pad, acc, **pro)
+    Cc = y.size(-1)
+    scale = torch.empty(Cc, device=x.device, dtype=torch.float32)
+    mean = torch.empty_like(scale)
+    L().bn_finalize_sums(acc, y.numel() // Cc, bn.weight.detach(), bn.bias.detach(), bn.eps,
+                         bn.momentum, bn.running_mean, bn.running_var, scale, mean)
+    return y, (scale, bn.bias.detach(), mean)
+
+
 def bn_finalize(stats, M, gamma, beta, eps, momentum, running_mean, running_var):
     """batch-statistics BatchNorm from the conv's tile moments; updates the running stats.
     Returns the apply triple (scale, shift, center) = (gamma*rstd, beta, mean): consumers
