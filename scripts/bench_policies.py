@@ -32,6 +32,25 @@ def timeit(fn, steps, warm=4):
     return (time.perf_counter() - t0) / steps
 
 
+def roofline_of(policy, obs):
+    """the `roofline` block of bench.py for this policy's trunks: per-launch HIP-event times of
+    every convolution of one eager forward (bench.conv_kernel_time), priced like the headline."""
+    c = bench.conv_kernel_time(policy, obs, dev)
+    if c["reason"] is not None:
+        return {"invalid_reason": c["reason"]}
+    ms, flop = c["conv_ms"], c["flop"]
+    bf = [v for k, v in c["by_path"].items() if k in (1, 2)]
+    bf_ms, bf_flop = sum(v["ms"] for v in bf), sum(v["flop"] for v in bf)
+    return {"bound": "mfma", "kernel": "conv2d fwd launches of the visual trunks",
+            "launches": c["n"], "kernel_ms_per_step": round(ms, 3),
+            "achieved": round(flop / (ms * 1e-3) / 1e12, 2), "peak": bench.FP32_MFMA_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": round(flop / (ms * 1e-3) / 1e12 / bench.FP32_MFMA_PEAK_TFLOPS, 4),
+            "bf16_pipe_frac": (round(6 * bf_flop / (bf_ms * 1e-3) / 1e12 / bench.BF16_MFMA_PEAK_TFLOPS, 4)
+                               if bf_ms else None),
+            "per_launch_floor_frac": round(c["floor_ms"] / ms, 4),
+            "algorithmic_GB": round(c["bytes"] / 1e9, 3), "traffic": None}
+
+
 def seq2seq(steps, n=32):
     torch.manual_seed(0)
     policy = vlnce_amd.build_model(vlnce_amd.make_config("Seq2SeqPolicy"),
@@ -45,9 +64,14 @@ def seq2seq(steps, n=32):
         state["nxt"] = policy.encode_ahead(obs)
         update_agent(policy, opt, cur, prev, masks, tgt, w, 512)
 
+    def plain():   # the loop the unchanged trainers issue
+        update_agent(policy, opt, obs, prev, masks, tgt, w, 512)
+
+    sp = timeit(plain, steps)
     s = timeit(step, steps)
     return {"config": f"Seq2Seq DAgger update, num_envs={n}, 256x256 RGB-D, 80 tokens",
-            "ms_per_step": round(1e3 * s, 3), "policy_steps_per_sec": round(n / s, 1)}
+            "ms_per_step": round(1e3 * sp, 3), "policy_steps_per_sec": round(n / sp, 1),
+            "encode_ahead_ms_per_step": round(1e3 * s, 3), "roofline": roofline_of(policy, obs)}
 
 
 def waypoint(steps, n=32, tokens=200):
@@ -91,7 +115,7 @@ def waypoint(steps, n=32, tokens=200):
     return {"config": f"WaypointPolicy WDDPPO minibatch update, num_envs={n}, 12+1 frames/env "
                       f"256x256 RGB-D ({frames} frames), {tokens} tokens",
             "ms_per_step": round(1e3 * s, 3), "policy_steps_per_sec": round(n / s, 1),
-            "frames_per_sec": round(frames / s, 1)}
+            "frames_per_sec": round(frames / s, 1), "roofline": roofline_of(policy, obs)}
 
 
 if __name__ == "__main__":

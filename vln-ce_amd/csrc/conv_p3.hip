@@ -498,6 +498,9 @@ __global__ __launch_bounds__((WM * WN + P3_PRODUCERS) * 64) void conv_p3_kernel(
         0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_c = __builtin_amdgcn_make_buffer_rsrc(
         reinterpret_cast<char*>(p.C), 0, (int)p.c_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_r = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(p.residual ? p.residual : p.C)), 0,
+        (int)p.c_bytes, 0x00020000);   // (ldr == ldc: the output's extent)
 
     // (Measured and dropped, round 4: a second A-fragment set so that the LDS reads of k-slab
     // s + 1 are issued in front of the MFMAs of slab s -- branch-free steady loop, fragments
@@ -693,19 +696,8 @@ __global__ __launch_bounds__((WM * WN + P3_PRODUCERS) * 64) void conv_p3_kernel(
       // one store = 2 rows x 32 columns = two full 128-byte lines; rows past M get an
       // out-of-range lane offset
       const int rows_left = p.M - (m0 + wm * WTM + 4 * half);
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int rw = i * 32 + (r & 3) + 8 * (r >> 2);
-          const int soff = rw * p.ldc * 4;
-#pragma unroll
-          for (int j = 0; j < NT; ++j) {
-            const float v = apply_act(acc[i][j][r] * e_sc[j] + e_sh[j], p.act);
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc_c,
-                                                  rw < rows_left ? e_voff[j] : BUF_OOB, soff, 0);
-          }
-        }
+      wave_epilogue<MT, NT>(acc, e_sc, e_sh, e_voff, rows_left, p.ldc, p.act, p.residual != nullptr,
+                            rsrc_c, rsrc_r, false);
     }
     __builtin_amdgcn_s_setprio(0);
 #ifdef P3_DBG_TIME
@@ -789,6 +781,9 @@ __global__ __launch_bounds__(WAVES * 64) void conv_u3_kernel(IgemmParams p) {
       0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_c = __builtin_amdgcn_make_buffer_rsrc(
       reinterpret_cast<char*>(p.C), 0, (int)p.c_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_r = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char*>(reinterpret_cast<const char*>(p.residual ? p.residual : p.C)), 0,
+      (int)p.c_bytes, 0x00020000);   // (ldr == ldc: the output's extent)
   const bool has_pro = p.in_scale != nullptr;
   const float relu_floor = p.in_relu ? 0.f : -__builtin_huge_valf();
   constexpr bool linear = LINEAR != 0;
@@ -1130,20 +1125,8 @@ __global__ __launch_bounds__(WAVES * 64) void conv_u3_kernel(IgemmParams p) {
         e_voff[j] = okc ? (int)((((long)(m0 + 4 * half)) * p.ldc + col) * 4) : BUF_OOB;
       }
       const int rows_left = p.M - (m0 + 4 * half);
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int rw = i * 32 + (r & 3) + 8 * (r >> 2);
-#pragma unroll
-          for (int j = 0; j < NT; ++j) {
-            const float v = apply_act(acc[i][j][r] * e_sc[j] + e_sh[j], p.act);
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc_c,
-                                                  rw < rows_left ? e_voff[j] : BUF_OOB,
-                                                  rw * p.ldc * 4, 0);
-            acc[i][j][r] = 0.f;
-          }
-        }
+      wave_epilogue<MT, NT>(acc, e_sc, e_sh, e_voff, rows_left, p.ldc, p.act, p.residual != nullptr,
+                            rsrc_c, rsrc_r, true);
       c = 0;
       ks3 = 0;
       if (++round < my_tiles) {
@@ -1527,12 +1510,12 @@ int launch_p3(const IgemmParams& p, int rows_alloc, hipStream_t stream) {
   static int attr_bytes = 0;  // per instantiation: the largest dynamic LDS size enabled so far
   if (smem_bytes > attr_bytes) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, x3_lds_max());
     if (e != hipSuccess) {
       vlnce_set_error("conv_p3: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
       return 2;
     }
-    attr_bytes = 163840;
+    attr_bytes = x3_lds_max();
   }
   IgemmParams q = p;
   q.tiles_m = ceil_div(p.M, BM);
@@ -1602,7 +1585,10 @@ int p3_try_launch(const IgemmParams& p, hipStream_t stream) {
   const int force = vlnce_opt(VLNCE_OPT_P3_TILE);  // tuning
   if (!mode_env || !conv_math() || !p.Bfrag) return -1;
   if (p.Cin % 32 != 0 || p.N % 32 != 0 || p.lda % 4 != 0 || p.splitk > 1) return -1;
-  if (p.residual || p.accumulate || p.c_bytes >= 0x7fffffffL || p.a_bytes >= 0x7fffffffL) return -1;
+  if (p.accumulate || p.c_bytes >= 0x7fffffffL || p.a_bytes >= 0x7fffffffL) return -1;
+  // residual (eval-mode block ends): added in the register epilogues of conv_p3 / conv_u3; it must
+  // have the output's raster
+  if (p.residual && (p.ldr != p.ldc || p.stat_partial || p.bn.acc)) return -1;
   if ((long)p.N * p.K * 6 >= 0x7fffffffL) return -1;
   const bool one = p.KH == 1 && p.KW == 1 && p.pad == 0;
   const bool dense = !one;
@@ -1617,7 +1603,7 @@ int p3_try_launch(const IgemmParams& p, hipStream_t stream) {
   // short-K wide 1x1 (the bottleneck expansions): conv_s3_kernel.  option "s3": 0 = off, 1 = default
   // (where the 64-row tiles give every CU at least four), 2 = every eligible shape (tests)
   const int s3_env = vlnce_opt(VLNCE_OPT_S3);
-  if (!dense && !dual && s3_env && p.stride == 1 && (p.Cin == 64 || p.Cin == 128) && p.K == p.Cin &&
+  if (!dense && !dual && !p.residual && s3_env && p.stride == 1 && (p.Cin == 64 || p.Cin == 128) && p.K == p.Cin &&
       p.N % 256 == 0 && p.N / 256 <= 8 && (p.stat_partial == nullptr || p.stat_rows == 32) &&
       (p.act == VLNCE_ACT_NONE || p.act == VLNCE_ACT_RELU) &&
       (s3_env == 2 || (long)ceil_div(p.M, 64) * (p.N / 256) >= 4L * x3_cus()))
@@ -1666,7 +1652,7 @@ int p3_try_launch(const IgemmParams& p, hipStream_t stream) {
     const P3Tile& c = cand[ci];
     if (forced ? ci != force - 1 : c.bn > bn) continue;  // (narrower tiles only to fill the CUs)
     const int rows = p3_rows_for(p, c.bm, dense);
-    if (2L * rows * P3_ROW + (dense ? 0 : 2L * c.bn * 192) + 16 > 163840) continue;
+    if (2L * rows * P3_ROW + (dense ? 0 : 2L * c.bn * 192) + 16 > x3_lds_max()) continue;
     const long tiles = (long)ceil_div(p.M, c.bm) * ceil_div(p.N, c.bn);
     const long rounds = (tiles + cus - 1) / cus;
     const double eff = (double)tiles / (double)(rounds * cus);

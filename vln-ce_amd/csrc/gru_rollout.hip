@@ -384,8 +384,29 @@ int dispatch_rollout(GruRolloutParams& p, int H, bool bwd, hipStream_t s) {
 
 }  // namespace
 
+// The H / 16 workgroups of a rollout launch hand each other the state every step: all of them must
+// be RESIDENT at once (up to 122 KB of LDS each, i.e. one per CU).  That is a property of the
+// device, checked here once per device: a part with less LDS per workgroup or fewer CUs than
+// workgroups reports "unsupported" and the host takes the per-step kernels instead of a launch
+// that would spin until its poll bound traps (round-3 ADVICE).
+static bool rollout_device_ok(int H) {
+  static int lds_max[16], cus[16];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return false;
+  if (cus[dev] == 0) {
+    int l = 0, c = 0;
+    if (hipDeviceGetAttribute(&l, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess ||
+        hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+      return false;
+    lds_max[dev] = l;
+    cus[dev] = c > 0 ? c : -1;
+  }
+  return lds_max[dev] >= 128 * 1024 && cus[dev] >= H / 16;
+}
+
 extern "C" int vlnce_gru_rollout_supported(int N, int H) {
-  return N > 0 && N <= RO_MAXN && (H == 64 || H == 128 || H == 256 || H == 512);
+  return N > 0 && N <= RO_MAXN && (H == 64 || H == 128 || H == 256 || H == 512) &&
+         rollout_device_ok(H);
 }
 
 extern "C" long vlnce_gru_rollout_workspace_bytes(int N, int H) {

@@ -1060,6 +1060,9 @@ __global__ __launch_bounds__((WM * WN + X3_PRODUCERS) * 64) void conv_x3_kernel(
     };
     const __amdgpu_buffer_rsrc_t rsrc_c = __builtin_amdgcn_make_buffer_rsrc(
         reinterpret_cast<char*>(p.C), 0, (int)p.c_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_r = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(p.residual ? p.residual : p.C)), 0,
+        (int)p.c_bytes, 0x00020000);   // (ldr == ldc: the output's extent)
 
 #ifdef X3_DBG_TIME
     const long long d_c0 = clock64(), d_w0 = wall_clock64();
@@ -1149,19 +1152,8 @@ __global__ __launch_bounds__((WM * WN + X3_PRODUCERS) * 64) void conv_x3_kernel(
       // the buffer (the row bound is folded into the descriptor's extent) only for the last
       // tile row, where the lane offset is sent out of range instead
       const int rows_left = p.M - (m0 + wm * WTM + 4 * half);
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int rw = i * 32 + (r & 3) + 8 * (r >> 2);
-          const int soff = rw * p.ldc * 4;
-#pragma unroll
-          for (int j = 0; j < NT; ++j) {
-            const float v = apply_act(acc[i][j][r] * e_sc[j] + e_sh[j], p.act);
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc_c,
-                                                  rw < rows_left ? e_voff[j] : BUF_OOB, soff, 0);
-          }
-        }
+      wave_epilogue<MT, NT>(acc, e_sc, e_sh, e_voff, rows_left, p.ldc, p.act, p.residual != nullptr,
+                            rsrc_c, rsrc_r, false);
     }
     __builtin_amdgcn_s_setprio(0);
 #ifdef X3_DBG_TIME
@@ -1371,7 +1363,8 @@ struct X3Plan {
 };
 bool x3_plan(const IgemmParams& p, X3Plan* out) {
   if (!conv_math() || !p.Bsplit || !buf_ok(p) || p.splitk > 1) return false;
-  if (p.residual || p.accumulate || p.c_bytes >= 0x7fffffffL) return false;
+  if (p.accumulate || p.c_bytes >= 0x7fffffffL) return false;
+  if (p.residual && (p.ldr != p.ldc || p.stat_partial || p.bn.acc)) return false;  // (register epilogue)
   const int force = vlnce_opt(VLNCE_OPT_X3_TILE);  // tuning
   const X3Plan cand[4] = {{128, 128}, {64, 128}, {128, 64}, {64, 64}};
   if (force >= 1 && force <= 4) {

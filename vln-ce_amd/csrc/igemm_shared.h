@@ -248,6 +248,60 @@ __device__ __forceinline__ void wave_bn_tile(const f32x16 (&acc)[MT][NT], WaveBn
 // behind a kernel that has just written up to 268 MB).  The convolution only ADDS; a one-workgroup
 // kernel behind it turns the sums into the vectors: profiles/r04_y_*.)
 
+// Register epilogue of the bf16-plane kernels for a wave's MT x NT blocks of 32 x 32 outputs:
+// y = act(acc * scale[col] + shift[col] [+ residual[row, col]]), one store = 2 rows x 32 columns.
+// e_voff[j]: lane byte offset of (first row of the wave tile + 4 * half, column of block j), or
+// BUF_OOB; rows_left: rows of the wave tile that exist, counted from row 4 * half.
+// The residual (eval-mode block ends: relu(bn(conv) + identity), torchvision BasicBlock /
+// Bottleneck.forward) has the raster of the output (ldr == ldc is a dispatch condition), so its
+// loads use the stores' offsets; they are fetched per 32-row block.
+template <int MT, int NT>
+__device__ __forceinline__ void wave_epilogue(f32x16 (&acc)[MT][NT], const float (&e_sc)[NT],
+                                              const float (&e_sh)[NT], const int (&e_voff)[NT],
+                                              int rows_left, int ldc, int act, bool has_res,
+                                              __amdgpu_buffer_rsrc_t rsrc_c,
+                                              __amdgpu_buffer_rsrc_t rsrc_r, bool clear) {
+  if (has_res) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      float rv[NT][16];   // (one block at a time: a second set spills in the 128-register kernels)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rw = i * 32 + (r & 3) + 8 * (r >> 2);
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          rv[j][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                         rsrc_r, rw < rows_left ? e_voff[j] : BUF_OOB, rw * ldc * 4, 0));
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rw = i * 32 + (r & 3) + 8 * (r >> 2);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const float v = apply_act(acc[i][j][r] * e_sc[j] + e_sh[j] + rv[j][r], act);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc_c,
+                                                rw < rows_left ? e_voff[j] : BUF_OOB, rw * ldc * 4, 0);
+          if (clear) acc[i][j][r] = 0.f;
+        }
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int rw = i * 32 + (r & 3) + 8 * (r >> 2);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const float v = apply_act(acc[i][j][r] * e_sc[j] + e_sh[j], act);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc_c,
+                                              rw < rows_left ? e_voff[j] : BUF_OOB, rw * ldc * 4, 0);
+        if (clear) acc[i][j][r] = 0.f;
+      }
+    }
+}
+
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ int x3_peek(const int* flag) {
@@ -278,6 +332,18 @@ static inline int x3_cus() {
     return n >= 8 ? (n / 8) * 8 : 8;
   }();
   return cus;
+}
+
+// dynamic LDS a workgroup of this device may ask for (163840 on gfx950: one workgroup per CU)
+static inline int x3_lds_max() {
+  static const int v = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess || n <= 0)
+      n = 65536;
+    return n;
+  }();
+  return v;
 }
 
 // convolution arithmetic: 1 = fp32 operands split into three bf16 planes, six products on the

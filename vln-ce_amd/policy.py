@@ -1,6 +1,7 @@
 """Policy base classes of the plugin surface (reference: models/policy.py:10-58
 and habitat-lab v0.1.7 rl/ppo/policy.py + utils/common.py)."""
 import abc
+import os
 
 import torch
 import torch.nn as nn
@@ -92,12 +93,13 @@ class ILPolicy(DropsGraphsOnApply, Policy):
         return self._step(observations, rnn_states, prev_actions, masks)[0]
 
     def act(self, observations, rnn_states, prev_actions, masks, deterministic=False):
-        graph = self.__dict__.get("_act_graph")
-        if graph is None:
-            graph = ActGraph(self)
-            object.__setattr__(self, "_act_graph", graph)  # (not a sub-module, not in state_dict)
-        if graph.usable(observations, rnn_states):
-            return graph(observations, rnn_states, prev_actions, masks, deterministic)
+        if os.environ.get("VLNCE_ACT_GRAPH", "0") == "1":   # opt-in: the whole call as one HIP graph
+            graph = self.__dict__.get("_act_graph")
+            if graph is None:
+                graph = ActGraph(self)
+                object.__setattr__(self, "_act_graph", graph)  # (not a sub-module, not in state_dict)
+            if graph.usable(observations, rnn_states):
+                return graph(observations, rnn_states, prev_actions, masks, deterministic)
         return self._act_eager(observations, rnn_states, prev_actions, masks, deterministic)
 
     def _act_eager(self, observations, rnn_states, prev_actions, masks, deterministic):
