@@ -249,6 +249,18 @@ def conv_kernel_time(policy, obs, dev, repeats=3):
     def timed_conv_bn(x, w, stride, pad, acc, **k):
         return _timed(lambda: orig_conv_bn(x, w, stride, pad, acc, **k), x, w, k)
 
+    orig_stem7 = ops.stem7   # the 7x7 RGB stem from the frames (one of the conv launches)
+
+    def timed_stem7(fr, wf, Cout, *a, **k):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        y = orig_stem7(fr, wf, Cout, *a, **k)
+        e1.record()
+        events.append((e0, e1))
+        frame_bytes = fr["images"] * fr["H"] * fr["W"] * 3 * fr["x"].element_size()
+        meta.append((2.0 * y.numel() * 147, 2, frame_bytes + 4.0 * y.numel() + 4.0 * Cout * 147))
+        return y
+
     def trunks():
         with torch.no_grad():
             policy.net.rgb_encoder.trunk_features(obs)
@@ -275,6 +287,7 @@ def conv_kernel_time(policy, obs, dev, repeats=3):
         per_launch, totals, empties = None, [], []
         enc.ops.conv2d_nhwc = timed_conv
         ops.conv2d_bn_sums = timed_conv_bn
+        ops.stem7 = timed_stem7
         for _ in range(repeats):
             events.clear()
             meta.clear()
@@ -295,6 +308,7 @@ def conv_kernel_time(policy, obs, dev, repeats=3):
     finally:
         enc.ops.conv2d_nhwc = orig_conv
         ops.conv2d_bn_sums = orig_conv_bn
+        ops.stem7 = orig_stem7
         for k, v in saved.items():
             if v is None:
                 os.environ.pop(k, None)

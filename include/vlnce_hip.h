@@ -30,7 +30,7 @@ typedef void* vlnce_stream_t;
 
 enum { VLNCE_ACT_NONE = 0, VLNCE_ACT_RELU = 1, VLNCE_ACT_SIGMOID = 2, VLNCE_ACT_TANH = 3 };
 
-int vlnce_version(void); /* major*100 + minor; 136 = this header */
+int vlnce_version(void); /* major*100 + minor; 137 = this header */
 const char* vlnce_last_error(void);
 
 /* Dispatch options: which of the library's equivalent kernels a launch is given to.  Explicit
@@ -299,6 +299,18 @@ typedef struct {
  * n*(F+1) + f as torch.cat([frames, history.unsqueeze(1)], 1).flatten(0, 1) orders them. */
 int vlnce_frames_s2d(const vlnce_frames* frames, float* y, int pad_lo, int pad_hi,
                      const float* scale, const float* shift, vlnce_stream_t stream);
+/* RGB stem in one launch, from the frames: y[img, ho, wo, :] = conv 7x7 / stride 2 / pad 3 of
+ * (frame * in_scale[c] + in_shift[c]) (zero outside the frame) with `Cout` = 32 | 64 filters --
+ * torchvision ResNet.conv1 behind the encoder's /255 (+ ImageNet mean/std),
+ * resnet_encoders.py:131-139,171-199 -- on the bf16 matrix pipe (three exact bf16 planes per
+ * operand, six plane products, fp32 accumulation).  w_frag: the filters as B fragments
+ * [Cout/32][11 k-slabs][3 planes][64 lanes][8 bf16], k' = kh * 24 + kw * 3 + c (21 of every 24 used,
+ * the rest and k' >= 168 zero), lane (l, h) = output channel 32 nb + l, k' = 16 ks + 8 h + [0, 8).
+ * epi: NULL, {scale, shift, act} (eval: folded BatchNorm + ReLU) or {bn} (train: raw output, the
+ * launch adds its column sums to bn->acc; workspace unused). */
+int vlnce_stem7_fwd(const vlnce_frames* frames, const float* in_scale, const float* in_shift,
+                    const void* w_frag, float* y, int Cout, const vlnce_epilogue* epi,
+                    vlnce_stream_t stream);
 /* depth stem input: F.avg_pool2d(x, 2) of every frame, y [N*(F+..), H/2, W/2, C] fp32 */
 int vlnce_frames_avgpool2(const vlnce_frames* frames, float* y, vlnce_stream_t stream);
 /* the frames as fp32 [N*(F+..), H, W, C] (x*scale+shift when given): stems that cannot take the

@@ -357,6 +357,28 @@ class HostSim:
         v = self._frames_f32(fr)
         self.space_to_depth2(v, y, v.size(0), fr["H"], fr["W"], fr["C"], pad_lo, pad_hi, scale, shift)
 
+    def stem7_fwd(self, fr, in_scale, in_shift, w_frag, y, scale=None, shift=None, act=0, bn=None):
+        """vlnce_stem7_fwd: conv 7x7 / stride 2 / pad 3 of (frame * in_scale + in_shift), the
+        filters given as B fragments [Cout/32][11][3][64 lanes][8 bf16] (k' = kh*24 + kw*3 + c)."""
+        v = self._frames_f32(fr)
+        if in_scale is not None:
+            v = v * in_scale + in_shift
+        Cout = y.size(-1)
+        pl = w_frag.view(torch.bfloat16).view(Cout // 32, 11, 3, 2, 32, 8).float().sum(2)  # nb ks half l31 e
+        w = pl.permute(0, 3, 1, 2, 4).reshape(Cout, 176)[:, :168].reshape(Cout, 7, 24)[:, :, :21]
+        w = w.reshape(Cout, 7, 7, 3).permute(0, 3, 1, 2)
+        raw = F.conv2d(v.permute(0, 3, 1, 2), w, stride=2, padding=3).permute(0, 2, 3, 1)
+        if bn is not None:
+            flat = raw.reshape(-1, Cout).double()
+            bn[0, :, 0] += flat.sum(0)
+            bn[0, :, 1] += (flat ** 2).sum(0)
+        out = raw
+        if scale is not None:
+            out = out * scale
+        if shift is not None:
+            out = out + shift
+        y.copy_(_act(out, act))
+
     def frames_avgpool2(self, fr, y):
         v = self._frames_f32(fr)
         y.copy_(F.avg_pool2d(v.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1))

@@ -1031,3 +1031,61 @@ def test_conv_bn_sums_every_kernel(hip, opts):
     the fall-back (fp32 kernel: tile moments reduced into the sums behind the convolution)."""
     for case in BN_CASES:
         _bn_case(hip, case, **opts)
+
+
+# ------------------------------------------------------------------ RGB stem from the frames
+STEM7_CASES = [
+    # name,          N, F, Hs, Ws, crop (y0, x0, H, W) | None, Cout, dtype, extra frame, mode
+    ("u8_64",        3, 1, 64, 64, None,             64, torch.uint8,   False, "bn"),
+    ("f32_ragged",   2, 1, 50, 38, None,             64, torch.float32, False, "eval"),
+    ("u8_crop",      2, 1, 72, 96, (4, 10, 64, 80),  64, torch.uint8,   False, "eval"),
+    ("pano_extra",   2, 3, 32, 48, None,             64, torch.float32, True,  "bn"),
+    ("cout32",       2, 1, 70, 66, None,             32, torch.uint8,   False, "bn"),
+    ("many_tiles",  20, 1, 128, 128, None,           64, torch.uint8,   False, "bn"),   # several tiles per workgroup
+]
+
+
+@pytest.mark.parametrize("case", STEM7_CASES, ids=[c[0] for c in STEM7_CASES])
+def test_stem7_from_frames(hip, case):
+    """vlnce_stem7_fwd (7x7 / stride 2 / pad 3 on the bf16 pipe, straight from uint8 / fp32
+    frames, crop window, frame stack + masked extra frame, input transform) against the CPU
+    contract (tests/hostsim.py: F.conv2d on the transformed frames): raw output + BatchNorm
+    column sums, or the folded-BatchNorm + ReLU epilogue."""
+    name, N, F_, Hs, Ws, crop, Cout, dtype, extra, mode = case
+    g = torch.Generator().manual_seed(61)
+    shape = (N, F_, Hs, Ws, 3) if F_ > 1 or extra else (N, Hs, Ws, 3)
+    x = torch.randint(0, 256, shape, generator=g)
+    x = x.to(dtype) if dtype == torch.uint8 else x.float() + torch.rand(shape, generator=g)
+    if crop is not None:
+        y0, x0, H, W = crop
+        x = x[..., y0:y0 + H, x0:x0 + W, :]
+    x2 = mask = None
+    if extra:
+        x2 = torch.randint(0, 256, (N,) + tuple(x.shape[-3:]), generator=g).to(x.dtype)
+        mask = torch.tensor([1, 0][:N], dtype=torch.uint8)
+    w = rnd(Cout, 7, 7, 3, seed=62) * 147 ** -0.5
+    isc = torch.tensor([1 / 58.4, 1 / 57.1, 1 / 57.4])
+    ish = torch.tensor([-2.12, -2.04, -1.80])
+    esc, esh = torch.rand(Cout, generator=g) + 0.5, rnd(Cout, seed=63)
+
+    def run(lib, dev):
+        to = (lambda t: t.to(dev)) if dev != "cpu" else (lambda t: t)
+        xs = (to(x), to(x2), to(mask)) if extra else to(x)
+        fr = ops.frames(xs)
+        wf = ops.stem7_pack_weights(to(w))
+        yv = torch.empty((fr["images"], (fr["H"] - 1) // 2 + 1, (fr["W"] - 1) // 2 + 1, Cout), device=dev)
+        acc = torch.zeros((ops.BN_SHARDS, Cout, 2), device=dev, dtype=torch.float64)
+        if mode == "bn":
+            lib.stem7_fwd(fr, to(isc), to(ish), wf, yv, bn=acc)
+        else:
+            lib.stem7_fwd(fr, to(isc), to(ish), wf, yv, scale=to(esc), shift=to(esh), act=ops.ACT_RELU)
+        return yv, acc.sum(0)
+
+    want, wacc = run(SIM, "cpu")
+    got, gacc = run(hip, DEV)
+    torch.cuda.synchronize()
+    close(got, want, 1e-4, what=f"{name} output")
+    if mode == "bn":
+        M = want.numel() // Cout
+        close((gacc[:, 0] / M).float(), (wacc[:, 0] / M).float(), 2e-5, what=f"{name} sum")
+        close((gacc[:, 1] / M).float(), (wacc[:, 1] / M).float(), 3e-5, what=f"{name} sum of squares")

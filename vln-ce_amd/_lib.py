@@ -85,6 +85,7 @@ _SIGNATURES = {
     "vlnce_space_to_depth2": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
     "vlnce_frames_s2d": (_I, [C.POINTER(Frames), _P, _I, _I, _P, _P, _P]),
     "vlnce_frames_avgpool2": (_I, [C.POINTER(Frames), _P, _P]),
+    "vlnce_stem7_fwd": (_I, [C.POINTER(Frames), _P, _P, _P, _P, _I, C.POINTER(Epilogue), _P]),
     "vlnce_frames_f32": (_I, [C.POINTER(Frames), _P, _P, _P, _P]),
     "vlnce_frames_gather": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "vlnce_frames_resize_area": (_I, [_P] + [_I] * 11 + [_P, _P]),
@@ -192,7 +193,7 @@ class HipLib:
 
     name = "hip"
 
-    ABI = 136  # include/vlnce_hip.h
+    ABI = 137  # include/vlnce_hip.h
 
     def __init__(self, path=LIB_PATH):
         self.dll = load_cdll(path)
@@ -421,6 +422,18 @@ class HipLib:
         d = self._frames(fr)
         self._check(self.dll.vlnce_frames_s2d(C.byref(d), _ptr(y), pad_lo, pad_hi, _ptr(scale),
                                               _ptr(shift), _stream()), "vlnce_frames_s2d")
+
+    def stem7_fwd(self, fr, in_scale, in_shift, w_frag, y, scale=None, shift=None, act=0, bn=None):
+        """RGB stem (7x7 / stride 2 / pad 3) straight from the frame descriptor; epilogue =
+        scale / shift / act, or bn = the column-sum accumulator of vlnce_bn_sums."""
+        d = self._frames(fr)
+        bnp = None
+        if bn is not None:
+            bnp = C.pointer(BnSums(_ptr(bn), None, 0))
+        epi = Epilogue(_ptr(scale), _ptr(shift), None, 0, int(act), 0, None, bnp)
+        self._check(self.dll.vlnce_stem7_fwd(C.byref(d), _ptr(in_scale), _ptr(in_shift),
+                                             _ptr(w_frag), _ptr(y), y.size(-1), C.byref(epi),
+                                             _stream()), "vlnce_stem7_fwd")
 
     def frames_avgpool2(self, fr, y):
         d = self._frames(fr)

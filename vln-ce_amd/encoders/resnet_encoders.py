@@ -61,6 +61,15 @@ class _WeightCache:
             self._packed[("s2d", id(conv))] = hit
         return hit[1]
 
+    def stem7(self, conv):
+        """the 7x7 stem filters as the B fragments of vlnce_stem7_fwd (ops.stem7_pack_weights)"""
+        k = self._key(conv.weight)
+        hit = self._packed.get(("stem7", id(conv)))
+        if hit is None or hit[0] != k:
+            hit = (k, ops.stem7_pack_weights(self.conv(conv)))
+            self._packed[("stem7", id(conv))] = hit
+        return hit[1]
+
     def bn_eval(self, bn, gen=0):
         # `gen` counts train-mode forwards: the HIP kernels update the running statistics
         # through raw pointers, which torch's version counters do not see
@@ -368,17 +377,36 @@ class HipResNetTrunk(DropsGraphsOnApply, nn.Sequential):
             fr = ops.frames(x)  # crop window / frame stack / uint8 -> read by the ingest kernel
             s2d = _stem_is_s2d(kids[0], fr["H"], fr["W"])
             pro = self.input_scale
-            if s2d:  # /255 (+mean/std) applied while regrouping, before the zero border
-                x = ops.frames_s2d(fr, 2, 1, self.input_scale[0], self.input_scale[1])
-                pro = None
+            stem7 = (s2d and fr["C"] == 3 and kids[0].out_channels in (32, 64)
+                     and os.environ.get("VLNCE_STEM7", "1") != "0")
+            if stem7:
+                # the 7x7 / stride-2 stem straight from the frames on the bf16 matrix pipe
+                # (vlnce_stem7_fwd): no regrouped copy of the frames, no fp32-MFMA convolution
+                wf = self._cache.stem7(kids[0])
+                if train:
+                    bn = kids[1]
+                    acc = ops._bn_state(bn)
+                    raw = ops.stem7(fr, wf, kids[0].out_channels, pro[0], pro[1], bn_acc=acc)
+                    pend = ops.bn_finalize_sums(acc, raw.numel() // raw.size(-1), bn)
+                    touched.append(bn.num_batches_tracked)
+                    x = ops.maxpool3x3s2(raw, pend[0], pend[1], in_relu=True, in_center=pend[2])
+                else:
+                    sc, sh = self._cache.bn_eval(kids[1], self._bn_gen)
+                    x = ops.stem7(fr, wf, kids[0].out_channels, pro[0], pro[1], scale=sc, shift=sh,
+                                  act=ops.ACT_RELU)
+                    x = ops.maxpool3x3s2(x)
             else:
-                x = ops.frames_f32(fr)
-            if train:
-                raw, pend = self._conv_stats(x, kids[0], kids[1], touched, prologue=pro, s2d=s2d)
-                x = ops.maxpool3x3s2(raw, pend[0], pend[1], in_relu=True, in_center=pend[2])
-            else:
-                x = self._conv_bn_eval(x, kids[0], kids[1], True, prologue=pro, s2d=s2d)
-                x = ops.maxpool3x3s2(x)
+                if s2d:  # /255 (+mean/std) applied while regrouping, before the zero border
+                    x = ops.frames_s2d(fr, 2, 1, self.input_scale[0], self.input_scale[1])
+                    pro = None
+                else:
+                    x = ops.frames_f32(fr)
+                if train:
+                    raw, pend = self._conv_stats(x, kids[0], kids[1], touched, prologue=pro, s2d=s2d)
+                    x = ops.maxpool3x3s2(raw, pend[0], pend[1], in_relu=True, in_center=pend[2])
+                else:
+                    x = self._conv_bn_eval(x, kids[0], kids[1], True, prologue=pro, s2d=s2d)
+                    x = ops.maxpool3x3s2(x)
             pending = None
             for stage in kids[4:8]:
                 for blk in stage:

@@ -9,6 +9,7 @@ All tensors are fp32; images are channels-last [N,H,W,C].
 import os
 
 import torch
+import torch.nn.functional as F
 from torch.autograd import Function
 
 from . import _lib
@@ -146,6 +147,17 @@ def conv2d_bn_sums(x, w_ohwi, stride, pad, acc, **pro):
     return y
 
 
+def bn_finalize_sums(acc, M, bn):
+    """the column sums in `acc` -> pending normalisation (scale, shift = beta, center = mean);
+    running statistics of `bn` updated like torch; acc is zero afterwards."""
+    Cc = bn.weight.numel()
+    scale = torch.empty(Cc, device=acc.device, dtype=torch.float32)
+    mean = torch.empty_like(scale)
+    L().bn_finalize_sums(acc, M, bn.weight.detach(), bn.bias.detach(), bn.eps, bn.momentum,
+                         bn.running_mean, bn.running_var, scale, mean)
+    return scale, bn.bias.detach(), mean
+
+
 def conv2d_bn_train(x, w_ohwi, stride, pad, bn, **pro):
     """Convolution + train-mode BatchNorm STATISTICS without a pass over tile moments: the
     convolution adds its column sums (conv2d_bn_sums), a one-workgroup launch finishes them
@@ -156,12 +168,7 @@ def conv2d_bn_train(x, w_ohwi, stride, pad, bn, **pro):
     assert bn.momentum is not None
     acc = _bn_state(bn)
     y = conv2d_bn_sums(x, w_ohwi, stride, pad, acc, **pro)
-    Cc = y.size(-1)
-    scale = torch.empty(Cc, device=x.device, dtype=torch.float32)
-    mean = torch.empty_like(scale)
-    L().bn_finalize_sums(acc, y.numel() // Cc, bn.weight.detach(), bn.bias.detach(), bn.eps,
-                         bn.momentum, bn.running_mean, bn.running_var, scale, mean)
-    return y, (scale, bn.bias.detach(), mean)
+    return y, bn_finalize_sums(acc, y.numel() // y.size(-1), bn)
 
 
 def bn_finalize(stats, M, gamma, beta, eps, momentum, running_mean, running_var):
@@ -366,6 +373,35 @@ def frames_s2d(fr, pad_lo, pad_hi, scale=None, shift=None):
     y = torch.empty((fr["images"], fr["H"] // 2 + pad_lo + pad_hi, fr["W"] // 2 + pad_lo + pad_hi,
                      4 * fr["C"]), device=fr["x"].device, dtype=torch.float32)
     L().frames_s2d(fr, y, pad_lo, pad_hi, scale, shift)
+    return y
+
+
+def stem7_pack_weights(w_ohwi):
+    """[Cout, 7, 7, 3] -> the B fragments vlnce_stem7_fwd reads: three exact bf16 planes (round to
+    nearest) of the filters laid out [Cout/32][11 k-slabs][3][64 lanes][8], k' = kh * 24 + kw * 3 + c."""
+    Cout = w_ohwi.size(0)
+    assert tuple(w_ohwi.shape[1:]) == (7, 7, 3) and Cout % 32 == 0
+    wk = torch.zeros((Cout, 7, 24), device=w_ohwi.device, dtype=torch.float32)
+    wk[:, :, :21] = w_ohwi.detach().float().reshape(Cout, 7, 21)
+    wk = F.pad(wk.reshape(Cout, 168), (0, 8))                      # [Cout, 176]
+    planes, r = [], wk
+    for _ in range(3):
+        hb = r.to(torch.bfloat16)
+        planes.append(hb)
+        r = r - hb.float()
+    pl = torch.stack(planes, 0)                                    # [3, Cout, 176]
+    # [3, nb, l31, ks, half, e] -> [nb, ks, 3, half, l31, e]  (lane = half * 32 + l31)
+    frag = pl.view(3, Cout // 32, 32, 11, 2, 8).permute(1, 3, 0, 4, 2, 5).contiguous()
+    return frag.view(torch.int16)
+
+
+def stem7(fr, w_frag, Cout, in_scale=None, in_shift=None, *, scale=None, shift=None, act=ACT_NONE,
+          bn_acc=None):
+    """The 7x7 / stride-2 / pad-3 RGB stem in one launch from the frame descriptor
+    (vlnce_stem7_fwd); raw output + BatchNorm column sums when bn_acc is given."""
+    Ho, Wo = (fr["H"] - 1) // 2 + 1, (fr["W"] - 1) // 2 + 1
+    y = torch.empty((fr["images"], Ho, Wo, Cout), device=fr["x"].device, dtype=torch.float32)
+    L().stem7_fwd(fr, in_scale, in_shift, w_frag, y, scale=scale, shift=shift, act=act, bn=bn_acc)
     return y
 
 
