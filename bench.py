@@ -21,9 +21,9 @@ backward and Adam, over 4 distinct resident batches in rotation.  Beside it
 trunks of batch k+1 issued on side HIP streams before batch k's update is enqueued.
 
 The JSON line also carries `roofline` (dominant kernel = the implicit-GEMM convolution:
-conv_p3_kernel / conv_x3_kernel, fp32 operands split exactly into three bf16 planes and
-multiplied as six plane products on the bf16 matrix pipe, plus the fp32-MFMA igemm_kernel for
-the stems and the small layers; every launch timed with HIP events on the launch stream and
+conv_p3 / conv_u3 / conv_s3 / conv_x3 / stem7 kernels, fp32 operands split exactly into three bf16
+planes and multiplied as six plane products on the bf16 matrix pipe, plus the fp32-MFMA igemm_kernel
+for the depth stem and the small layers; every launch timed with HIP events on the launch stream and
 attributed to the kernel the library dispatched it to; `frac` prices the ALGORITHMIC fp32 FLOPs
 against the fp32 MFMA peak, `bf16_pipe.frac` the hardware FLOPs of the bf16-plane launches
 against the bf16 MFMA peak) and, on rank 0 at N=1, `cpu_baseline` (the CPU oracle restatement of the reference
@@ -187,14 +187,18 @@ def f32_mfma_compare(args):
 
 def pmc_traffic(n_conv):
     """HBM bytes per conv launch from the committed rocprofv3 PMC passes of this same
-    workload (profiles/r03_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate
+    workload (profiles/r04_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate
     passes of `bench.py --pmc-step`, gfx950 corrections applied as MI355X_MICROARCH.md
     prescribes).  None when the file is absent or was taken for a different launch count."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
-                        "r03_pmc_traffic.json")
-    try:
-        rec = json.load(open(path))
-    except OSError:
+    prof = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    rec = None
+    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json"):   # newest collection first
+        try:
+            rec = json.load(open(os.path.join(prof, name)))
+            break
+        except OSError:
+            continue
+    if rec is None:
         return None
     if rec.get("conv_launches_per_step") != n_conv:
         return None
@@ -678,12 +682,16 @@ def main():
                                    "KxK: A transformed once per workgroup into an LDS patch, B "
                                    "fragments from L2), conv_u3_kernel (wide 1x1: no producer "
                                    "waves, the matrix waves transform the next K-chunk between "
-                                   "their MFMAs) and conv_x3_kernel (the other 1x1 / strided: "
-                                   "im2col K-tiles through LDS, 8 producer + 8 matrix waves); all "
-                                   "three: fp32 operands split exactly into 3 bf16 planes, 6 x "
-                                   "v_mfma_f32_32x32x16_bf16 per 32x32x16 block, fp32 accumulate; "
-                                   "igemm_kernel (v_mfma_f32_32x32x2_f32) for the stems and the "
-                                   "handful-of-tiles layers",
+                                   "their MFMAs), conv_s3_kernel (short-K 1x1 expansions: whole K "
+                                   "resident, tile n+1's loads under tile n's stores), "
+                                   "conv_x3_kernel (the other 1x1 / strided: im2col K-tiles through "
+                                   "LDS, 8 producer + 8 matrix waves) and stem7_kernel (the 7x7/s2 "
+                                   "RGB stem straight from the frames); all five: fp32 operands "
+                                   "split exactly into 3 bf16 planes, 6 x "
+                                   "v_mfma_f32_32x32x16_bf16 per 32x32x16 block, fp32 accumulate, "
+                                   "train-mode BatchNorm column sums taken in the epilogue; "
+                                   "igemm_kernel (v_mfma_f32_32x32x2_f32) for the depth stem and "
+                                   "the handful-of-tiles layers",
                          "achieved": round(achieved, 2) if ok else None,
                          "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4) if ok else None,

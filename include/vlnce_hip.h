@@ -30,7 +30,7 @@ typedef void* vlnce_stream_t;
 
 enum { VLNCE_ACT_NONE = 0, VLNCE_ACT_RELU = 1, VLNCE_ACT_SIGMOID = 2, VLNCE_ACT_TANH = 3 };
 
-int vlnce_version(void); /* major*100 + minor; 137 = this header */
+int vlnce_version(void); /* major*100 + minor; 138 = this header */
 const char* vlnce_last_error(void);
 
 /* Dispatch options: which of the library's equivalent kernels a launch is given to.  Explicit
@@ -367,6 +367,22 @@ int vlnce_maxpool3x3s2_bwd(const float* dy, const uint8_t* argmax, float* dx, in
                            int C, int Ho, int Wo, vlnce_stream_t stream);
 int vlnce_adaptive_avgpool_bwd(const float* dy, float* dx, int N, int H, int W, int C, int OH,
                                int OW, vlnce_stream_t stream);
+
+/* ---------------------------------------------------------------- categorical action head
+ * habitat-lab CategoricalNet (built at models/policy.py:19-21; the distribution is utils.py:269-289):
+ *   z = x W^T + b;  torch.distributions.Categorical(logits=z) keeps  z - logsumexp(z, -1)  and its
+ *   argument validation raises when that holds a NaN.
+ * fwd: x [M,K] (row stride ldx), w [A,K], b [A] or NULL, A <= 16  ->  logits_out [M,A] (normalised);
+ *      *nan_count (device int, or NULL) is incremented once per row that holds a NaN -- the host
+ *      reads it where the reference's validation reads its own flag.
+ * bwd: logits = what fwd returned, dlogits = gradient w.r.t. it;  dx [M,K], dw [A,K], db [A]
+ *      (each may be NULL; db needs dw).  One launch (plus a zero-fill when M > 1024, where the rows
+ *      of dw are reduced by several workgroups). */
+int vlnce_action_head_fwd(const float* x, int ldx, const float* w, const float* b, int M, int K,
+                          int A, float* logits_out, int* nan_count, vlnce_stream_t stream);
+int vlnce_action_head_bwd(const float* x, int ldx, const float* w, const float* logits,
+                          const float* dlogits, int M, int K, int A, float* dx, float* dw,
+                          float* db, vlnce_stream_t stream);
 
 /* ---------------------------------------------------------------- attention
  * One query per batch row against P keys:  logits[i] = <q, K[i]>;

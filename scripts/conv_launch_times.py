@@ -23,33 +23,56 @@ torch.manual_seed(0)
 pol = vlnce_amd.build_model(vlnce_amd.make_config("CMAPolicy"), *vlnce_amd.make_spaces(256, 256)).to(dev)
 obs = {"rgb": torch.randint(0, 256, (a.n, 256, 256, 3), device=dev).float(),
        "depth": torch.rand(a.n, 256, 256, 1, device=dev)}
-orig = ops.conv2d_nhwc
+orig, orig_bn, orig_stem = ops.conv2d_nhwc, ops.conv2d_bn_sums, ops.stem7
+PATHS = {0: "igemm", 1: "x3", 2: "p3/u3/s3", 9: "stem7"}
 rec = []
 
 
-def timed(x, w, s, p, **k):
+def _rec(call, M, K, N, d):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    out = orig(x, w, s, p, **k)
+    out = call()
     e1.record()
-    M = x.shape[0] * ((x.shape[1] + 2 * p - w.shape[1]) // s + 1) * ((x.shape[2] + 2 * p - w.shape[2]) // s + 1)
-    rec.append((M, w.shape[1] * w.shape[2] * w.shape[3], w.shape[0], "dual" if k.get("x2") is not None else "", e0, e1))
+    rec.append((M, K, N, d, ops.L().conv2d_last_path(), e0, e1))
     return out
+
+
+def _mkn(x, w, s, p):
+    M = x.shape[0] * ((x.shape[1] + 2 * p - w.shape[1]) // s + 1) * ((x.shape[2] + 2 * p - w.shape[2]) // s + 1)
+    return M, w.shape[1] * w.shape[2] * w.shape[3], w.shape[0]
+
+
+def timed(x, w, s, p, **k):
+    return _rec(lambda: orig(x, w, s, p, **k), *_mkn(x, w, s, p), "dual" if k.get("x2") is not None else "")
+
+
+def timed_bn(x, w, s, p, acc, **k):   # the convolution that also adds its BatchNorm column sums
+    return _rec(lambda: orig_bn(x, w, s, p, acc, **k), *_mkn(x, w, s, p),
+                "dual" if k.get("x2") is not None else "")
+
+
+def timed_stem(fr, wf, Cout, *a_, **k):   # the 7x7 / stride-2 RGB stem from the frames
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    y = orig_stem(fr, wf, Cout, *a_, **k)
+    e1.record()
+    rec.append((y.numel() // Cout, 147, Cout, "", 9, e0, e1))
+    return y
 
 
 best = {}
 for it in range(4):
     rec.clear()
-    ops.conv2d_nhwc = timed
+    ops.conv2d_nhwc, ops.conv2d_bn_sums, ops.stem7 = timed, timed_bn, timed_stem
     with torch.no_grad():
         torch.cuda._sleep(int(2.0e8))
         for enc in (pol.net.rgb_encoder, pol.net.depth_encoder):
             enc.trunk_features(obs)
-    ops.conv2d_nhwc = orig
+    ops.conv2d_nhwc, ops.conv2d_bn_sums, ops.stem7 = orig, orig_bn, orig_stem
     torch.cuda.synchronize()
-    for i, (M, K, N, d, e0, e1) in enumerate(rec):
+    for i, (M, K, N, d, path, e0, e1) in enumerate(rec):
         t = e0.elapsed_time(e1) * 1e3
-        best[i] = (M, K, N, d, min(t, best[i][4]) if i in best else t)
+        best[i] = (M, K, N, d + " " + PATHS.get(path, str(path)), min(t, best[i][4]) if i in best else t)
 grp = collections.OrderedDict()
 for i in sorted(best):
     M, K, N, d, t = best[i]
@@ -59,4 +82,4 @@ for i in sorted(best):
 tot = sum(v[1] for v in grp.values())
 print(f"{len(best)} launches, {tot/1e3:.3f} ms")
 for (M, K, N, d), (c, t) in sorted(grp.items(), key=lambda kv: -kv[1][1]):
-    print(f"M {M:8d} K {K:5d} N {N:5d} {d:5s} x{c:2d}  {t:8.1f} us  {100*t/tot:5.1f}%  {2.0*M*K*N*c/t/1e6:7.1f} TF/s")
+    print(f"M {M:8d} K {K:5d} N {N:5d} {d:13s} x{c:2d}  {t:8.1f} us  {100*t/tot:5.1f}%  {2.0*M*K*N*c/t/1e6:7.1f} TF/s")

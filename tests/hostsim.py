@@ -408,6 +408,25 @@ class HostSim:
         y.copy_(x.reshape(B, P, Cc).mean(1))
 
     # ---- attention
+    # ---- categorical action head
+    def action_head_fwd(self, x, ldx, w, b, M, K, A, logits_out, nan_count=None):
+        z = _mat(x, M, K, ldx) @ w.t()
+        if b is not None:
+            z = z + b
+        n = z - z.logsumexp(dim=-1, keepdim=True)
+        logits_out.copy_(n)
+        if nan_count is not None:
+            nan_count += int((n != n).any(dim=1).sum())
+
+    def action_head_bwd(self, x, ldx, w, logits, dlogits, M, K, A, dx=None, dw=None, db=None):
+        dz = dlogits - logits.exp() * dlogits.sum(dim=1, keepdim=True)
+        if dx is not None:
+            dx.copy_(dz @ w)
+        if dw is not None:
+            dw.copy_(dz.t() @ _mat(x, M, K, ldx))
+        if db is not None:
+            db.copy_(dz.sum(0))
+
     @staticmethod
     def _kv(t, B, P, D, ld):
         return t.as_strided((B, P, D), (P * ld, ld, 1))

@@ -348,3 +348,41 @@ def test_moving_a_policy_drops_its_captured_graphs():
     assert [p._version for p in policy.parameters()] == versions  # (why the keys cannot see it)
     assert all(len(h.entries) == 0 for h in holders)
     assert len(policy.net._tail.sightings) == 0 and policy._act_graph._tracked is None
+
+
+def test_categorical_net_matches_torch_categorical_and_raises_like_it(sim, monkeypatch):
+    """policy.CategoricalNet builds the distribution from the fused action head (normalised logits,
+    NaN count) -- same logits / log_prob / entropy / gradients as torch's Categorical(logits=...)
+    and the reference's ValueError when the parameter holds a NaN (utils.py:269-289)."""
+    from vlnce_amd.policy import CategoricalNet
+    # (this module switches argument validation off for speed; torch's default is on)
+    monkeypatch.setattr(torch.distributions.Distribution, "_validate_args", True)
+    torch.manual_seed(3)
+    net = CategoricalNet(32, 4)
+    torch.nn.init.normal_(net.linear.weight, std=0.3)
+    x = torch.randn(6, 32, requires_grad=True)
+    d = net(x)
+    ref = torch.distributions.Categorical(logits=torch.nn.functional.linear(x, net.linear.weight,
+                                                                            net.linear.bias))
+    assert torch.allclose(d.logits, ref.logits, atol=1e-6)
+    assert torch.allclose(d.probs, ref.probs, atol=1e-6)
+    a = torch.tensor([[0], [3], [1], [2], [2], [0]])
+    assert d.log_probs(a).shape == (6, 1)
+    assert torch.allclose(d.log_probs(a).squeeze(-1), ref.log_prob(a.squeeze(-1)), atol=1e-6)
+    assert torch.allclose(d.entropy(), ref.entropy(), atol=1e-6)
+    assert d.sample().shape == (6, 1) and d.mode().shape == (6, 1)
+    gx, gw = torch.autograd.grad(d.logits[:, 1].sum(), (x, net.linear.weight))
+    rx, rw = torch.autograd.grad(ref.logits[:, 1].sum(), (x, net.linear.weight))
+    assert torch.allclose(gx, rx, atol=1e-6) and torch.allclose(gw, rw, atol=1e-6)
+    with pytest.raises(ValueError):                      # sample outside the support: torch's check
+        d.log_probs(torch.full((6, 1), 7))
+    bad = x.detach().clone()
+    bad[4, 0] = float("nan")
+    with pytest.raises(ValueError, match="logits"):
+        net(bad)
+    with pytest.raises(ValueError):                      # the reference construction raises too
+        torch.distributions.Categorical(logits=torch.nn.functional.linear(
+            bad, net.linear.weight, net.linear.bias))
+    assert float(net(x.detach()).logits.exp().sum(-1).mean()) == pytest.approx(1.0, abs=1e-6)
+    monkeypatch.setattr(torch.distributions.Distribution, "_validate_args", False)
+    assert bool(torch.isnan(net(bad).logits[4]).all())   # validation off: no read-back, no raise

@@ -306,6 +306,45 @@ def test_attention_autograd_matches_torch(hip):
     close(q.grad, q2.grad, what="d q")
 
 
+# ------------------------------------------------------------------ categorical action head
+@pytest.mark.parametrize("cfg", [(64, 512, 4), (1, 512, 4), (7, 512, 6), (64, 514, 6), (300, 96, 16),
+                                 (2500, 512, 4), (5, 33, 1)])
+def test_action_head_fwd_bwd_match_torch(hip, cfg):
+    """vlnce_action_head_fwd / _bwd against Categorical(logits=Linear(x)).logits and its autograd
+    (fp64 reference, tolerance 1e-4 of the largest value); M > 1024 takes the atomic dW path."""
+    M, K, A = cfg
+    x, w, b = rnd(M, K, seed=1), rnd(A, K, seed=2, scale=0.2), rnd(A, seed=3)
+    g = rnd(M, A, seed=4)
+    xd, wd, bd = (t.to(DEV).requires_grad_() for t in (x, w, b))
+    n, cnt = ops.action_head(xd, wd, bd)
+    (n * g.to(DEV)).sum().backward()
+    assert int(cnt.item()) == 0
+    xr, wr, br = (t.double().requires_grad_() for t in (x, w, b))
+    ref = torch.distributions.Categorical(logits=xr @ wr.t() + br).logits
+    (ref * g.double()).sum().backward()
+    close(n, ref, what="normalised logits")
+    for got, want, what in ((xd.grad, xr.grad, "dx"), (wd.grad, wr.grad, "dW"), (bd.grad, br.grad, "db")):
+        close(got, want, what=what)
+
+
+def test_action_head_counts_nan_rows_and_strided_input(hip):
+    M, K, A = 9, 512, 4
+    big = rnd(M, K + 64, seed=5).to(DEV)
+    x = big[:, :K]                       # row stride K + 64
+    w, b = rnd(A, K, seed=6).to(DEV), rnd(A, seed=7).to(DEV)
+    n, cnt = ops.action_head(x, w, b)
+    close(n, torch.log_softmax(x @ w.t() + b, -1), what="strided rows")
+    assert int(cnt.item()) == 0
+    bad = x.clone()
+    bad[2, 5] = float("nan")
+    bad[7, 0] = float("inf")             # inf - inf in the normalisation: NaN, as in the reference
+    n, cnt = ops.action_head(bad, w, b)
+    assert int(cnt.item()) == 2 and bool(torch.isnan(n[2]).all()) and bool(torch.isnan(n[7]).any())
+    cnt.zero_()
+    n, cnt = ops.action_head(bad, w, None, count_nans=False)
+    assert cnt is None
+
+
 def test_rowzero_mask(hip):
     x = rnd(4, 30, 256, seed=1)
     x[1, 20:] = 0

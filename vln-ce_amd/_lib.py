@@ -94,6 +94,8 @@ _SIGNATURES = {
     "vlnce_attn_bwd": (_I, [_P, _P, _P, _I, _P, _I, _P, _I, _F, _P, _P, _P, _I, _P, _I,
                             _I, _I, _I, _I, _P]),
     "vlnce_rowzero_mask": (_I, [_P, _I, _L, _I, _P, _P]),
+    "vlnce_action_head_fwd": (_I, [_P, _I, _P, _P, _I, _I, _I, _P, _P, _P]),
+    "vlnce_action_head_bwd": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P]),
     "vlnce_gru_gates_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "vlnce_gru_gates_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "vlnce_lstm_gates_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
@@ -193,7 +195,7 @@ class HipLib:
 
     name = "hip"
 
-    ABI = 137  # include/vlnce_hip.h
+    ABI = 138  # include/vlnce_hip.h
 
     def __init__(self, path=LIB_PATH):
         self.dll = load_cdll(path)
@@ -466,6 +468,17 @@ class HipLib:
     def mean_rows(self, x, y, B, P, Cc):
         self._check(self.dll.vlnce_mean_rows(_ptr(x), _ptr(y), B, P, Cc, _stream()),
                     "vlnce_mean_rows")
+
+    # ---- categorical action head
+    def action_head_fwd(self, x, ldx, w, b, M, K, A, logits_out, nan_count=None):
+        self._check(self.dll.vlnce_action_head_fwd(_ptr(x), ldx, _ptr(w), _ptr(b), M, K, A,
+                                                   _ptr(logits_out), _ptr(nan_count), _stream()),
+                    "vlnce_action_head_fwd")
+
+    def action_head_bwd(self, x, ldx, w, logits, dlogits, M, K, A, dx=None, dw=None, db=None):
+        self._check(self.dll.vlnce_action_head_bwd(_ptr(x), ldx, _ptr(w), _ptr(logits),
+                                                   _ptr(dlogits), M, K, A, _ptr(dx), _ptr(dw),
+                                                   _ptr(db), _stream()), "vlnce_action_head_bwd")
 
     # ---- attention
     def attn_fwd(self, q, K, ldk, V, ldv, mask, mask_mode, scale, out, attn_out, B, P, Dk, Dv):

@@ -23,7 +23,8 @@ extern "C" const char* vlnce_last_error(void) { return g_err; }
 // 136: vlnce_epilogue.bn (train-mode BatchNorm column sums added by the convolution) +
 // vlnce_bn_finalize_sums.
 // 137: vlnce_stem7_fwd.
-extern "C" int vlnce_version(void) { return 137; }
+// 138: vlnce_action_head_fwd / _bwd.
+extern "C" int vlnce_version(void) { return 138; }
 
 // ---- dispatch options: one int per name, process-wide, relaxed atomics (a tuning / test knob,
 // not a synchronisation point: set them before the launches they are meant for)

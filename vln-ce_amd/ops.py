@@ -521,6 +521,57 @@ def linear(x, weight, bias=None, act=ACT_NONE):
     return y if x.dim() == 2 else y.view(*lead, weight.size(0))
 
 
+# ----------------------------------------------------------------- categorical action head
+class ActionHeadFn(Function):
+    """normalised logits of Categorical(logits = x W^T + b), i.e. z - logsumexp(z, -1), in one
+    launch; the whole backward (dx, dW, db) in one launch (vlnce_action_head_fwd / _bwd).
+    `nan_count` (int32 [1] or None) counts the rows holding a NaN."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, nan_count):
+        x, ldx = _rows2d(_f32c(x) if x.dtype != torch.float32 else x)
+        M, K = x.shape
+        A = weight.size(0)
+        w = weight if weight.is_contiguous() else weight.contiguous()
+        out = torch.empty((M, A), device=x.device, dtype=torch.float32)
+        L().action_head_fwd(x, ldx, w, bias, M, K, A, out, nan_count)
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, w, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, dn):
+        x, w, out = ctx.saved_tensors
+        M, K = x.shape
+        A = w.size(0)
+        ldx = x.stride(0) if M > 1 else K
+        dn = _f32c(dn)
+        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        need_b = ctx.has_bias and ctx.needs_input_grad[2]
+        dx = torch.empty((M, K), device=dn.device, dtype=torch.float32) if need_x else None
+        dw = (torch.empty((A, K), device=dn.device, dtype=torch.float32)
+              if need_w or need_b else None)
+        db = torch.empty((A,), device=dn.device, dtype=torch.float32) if need_b else None
+        L().action_head_bwd(x, ldx, w, out, dn, M, K, A, dx, dw, db)
+        return dx, (dw if need_w else None), db, None
+
+
+_NAN_COUNT = {}
+
+
+def action_head(x, weight, bias=None, count_nans=True):
+    """(normalised logits [..., A], nan counter).  The counter is one persistent int32 per device,
+    zero between calls: the caller that reads it non-zero resets it (`.zero_()`) before raising."""
+    cnt = None
+    if count_nans:
+        cnt = _NAN_COUNT.get(x.device)
+        if cnt is None:
+            cnt = _NAN_COUNT[x.device] = torch.zeros(1, device=x.device, dtype=torch.int32)
+    lead = x.shape[:-1]
+    y = ActionHeadFn.apply(x.reshape(-1, x.size(-1)) if x.dim() != 2 else x, weight, bias, cnt)
+    return (y if x.dim() == 2 else y.view(*lead, weight.size(0))), cnt
+
+
 # ----------------------------------------------------------------- attention
 class AttnFn(Function):
     """out[B,Dv] = softmax(mask(q K^T) * scale) V ; K [B,P,Dk], V [B,P,Dv] (views allowed)."""

@@ -23,17 +23,29 @@ class CategoricalNet(nn.Module):
         nn.init.constant_(self.linear.bias, 0)
 
     def forward(self, x):
-        logits = ops.linear(x, self.linear.weight, self.linear.bias)
-        if x.is_cuda and torch.cuda.is_current_stream_capturing():
-            # (argument validation is a host sync: not inside a graph capture, streams.ActGraph)
-            return CustomFixedCategorical(logits=logits, validate_args=False)
-        # Argument validation is a host sync (`(logits == logits).all()` read back), as in the
-        # reference.  Measured (profiles/r04_i_sync_probe.txt, r04_j_*): WITHOUT it a training step is
-        # 1.3-1.7 ms SLOWER -- the host then enqueues loss / backward / Adam while the trunks are
-        # still running, and the forward phase takes 9.7 instead of 8.1 ms on the GPU's own
-        # clock (launches arriving on the queue of a running graph slow its kernel-to-kernel
-        # dispatch).  So the sync stays where the reference has it.
-        return CustomFixedCategorical(logits=logits)
+        """Categorical(logits=Linear(x)) as the reference builds it (models/policy.py:19-21,
+        utils.py:269-289) with the linear layer, the normalisation `z - logsumexp(z)` and the NaN
+        test of the argument validation in ONE launch (ops.action_head; ~16 host-paced launches as
+        torch ops), and the whole backward in one more."""
+        capturing = x.is_cuda and torch.cuda.is_current_stream_capturing()
+        if os.environ.get("VLNCE_ACTION_HEAD", "1") == "0":   # A/B: the head as separate torch ops
+            logits = ops.linear(x, self.linear.weight, self.linear.bias)
+            return CustomFixedCategorical(logits=logits, validate_args=False if capturing else None)
+        validate = torch.distributions.Distribution._validate_args and not capturing
+        # (argument validation is a host sync: not inside a graph capture, streams.ActGraph)
+        logits, nans = ops.action_head(x, self.linear.weight, self.linear.bias, count_nans=validate)
+        # The validation's host read-back stays where the reference has it.  Measured
+        # (profiles/r04_i_sync_probe.txt, r04_j_*): WITHOUT it a training step is 1.3-1.7 ms SLOWER
+        # -- the host then enqueues loss / backward / Adam while the trunks are still running, and
+        # the forward phase takes 9.7 instead of 8.1 ms on the GPU's own clock (launches arriving
+        # on the queue of a running graph slow its kernel-to-kernel dispatch).
+        if validate and int(nans.item()) != 0:
+            nans.zero_()
+            raise ValueError(
+                f"Expected parameter logits (Tensor of shape {tuple(logits.shape)}) of distribution "
+                "CustomFixedCategorical to satisfy the constraint IndependentConstraint(Real(), 1), "
+                f"but found invalid values:\n{logits}")
+        return CustomFixedCategorical.from_normalized(logits)
 
 
 class CriticHead(nn.Module):

@@ -184,6 +184,21 @@ class CustomFixedCategorical(torch.distributions.Categorical):
     """Categorical whose samples, modes and log-probabilities keep a trailing unit dimension
     (reference utils.py:269-289; `log_probs` is the habitat-lab spelling)."""
 
+    @classmethod
+    def from_normalized(cls, logits):
+        """The distribution over ALREADY normalised logits (z - logsumexp(z), what
+        torch.distributions.Categorical.__init__ computes first): no launches, no host sync.  The
+        caller has validated the parameter (policy.CategoricalNet); sample / log_prob arguments are
+        validated as torch's default says."""
+        self = cls.__new__(cls)
+        self.logits = logits
+        self._param = logits
+        self._num_events = logits.size(-1)
+        batch_shape = logits.shape[:-1] if logits.dim() > 1 else torch.Size()
+        torch.distributions.Distribution.__init__(self, batch_shape, validate_args=False)
+        self._validate_args = torch.distributions.Distribution._validate_args
+        return self
+
     def sample(self, sample_shape=torch.Size()):
         return super().sample(sample_shape)[..., None]
 
