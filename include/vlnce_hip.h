@@ -30,7 +30,7 @@ typedef void* vlnce_stream_t;
 
 enum { VLNCE_ACT_NONE = 0, VLNCE_ACT_RELU = 1, VLNCE_ACT_SIGMOID = 2, VLNCE_ACT_TANH = 3 };
 
-int vlnce_version(void); /* major*100 + minor; 138 = this header */
+int vlnce_version(void); /* major*100 + minor; 139 = this header */
 const char* vlnce_last_error(void);
 
 /* Dispatch options: which of the library's equivalent kernels a launch is given to.  Explicit
@@ -399,6 +399,28 @@ int vlnce_attn_bwd(const float* dout, const float* q, const float* K, int ldk,
                    const float* V, int ldv, const uint8_t* mask, int mask_mode, float scale,
                    const float* attn, float* dq, float* dK, int lddk, float* dV, int lddv,
                    int B, int P, int Dk, int Dv, vlnce_stream_t stream);
+
+/* The same attention with K / V / mask SHARED by groups of queries: query row b attends over block
+ * kv_index[b] (0 <= kv_index[b] < U) of K [U,P,Dk], V [U,P,Dv], mask [U,P].  A sequence-mode batch
+ * (T*N rows: a cached-feature DAgger batch, dagger_trainer.py:39-114) repeats every episode's
+ * instruction T times; the instruction encoder runs once per DISTINCT instruction and the text
+ * attention (cma_policy.py:260) reads the distinct blocks in place instead of a T-fold expanded
+ * copy.  bwd: dq [B,Dk]; dK [B,P,Dk] / dV [B,P,Dv] are PER QUERY ROW (as vlnce_attn_bwd writes
+ * them) -- vlnce_segment_sum reduces them to the U blocks. */
+int vlnce_attn_fwd_shared(const float* q, const float* K, int ldk, const float* V, int ldv,
+                          const uint8_t* mask, int mask_mode, float scale, const int64_t* kv_index,
+                          float* out, float* attn_out, int B, int P, int Dk, int Dv,
+                          vlnce_stream_t stream);
+int vlnce_attn_bwd_shared(const float* dout, const float* q, const float* K, int ldk,
+                          const float* V, int ldv, const uint8_t* mask, int mask_mode, float scale,
+                          const int64_t* kv_index, const float* attn, float* dq, float* dK,
+                          int lddk, float* dV, int lddv, int B, int P, int Dk, int Dv,
+                          vlnce_stream_t stream);
+/* out[u, :] = sum of the rows b of x [B, row_elems] with index[b] == u, added in row order
+ * (deterministic; the backward of a row gather `x_u.index_select(0, index)`).  row_elems % 4 == 0,
+ * U <= 65535. */
+int vlnce_segment_sum(const float* x, const int64_t* index, int B, int U, long row_elems,
+                      float* out, vlnce_stream_t stream);
 /* mask[b,i] = all_c(x[b,i,c] == 0)   (text_mask, cma_policy.py:260) */
 int vlnce_rowzero_mask(const float* x, int ld, long rows, int C, uint8_t* mask,
                        vlnce_stream_t stream);

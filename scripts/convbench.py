@@ -93,6 +93,9 @@ def main():
                          "loader, as the trunks do (in_scale / in_shift / in_center / in_relu)")
     ap.add_argument("--dual", default="", help="identity | bn: 1x1 stride-1 layers as residual block "
                     "ends (second input added in the operand loader, block output written)")
+    ap.add_argument("--backlog", action="store_true",
+                    help="issue each timed round behind a spin kernel: GPU-paced times for launches "
+                         "shorter than the host's issue cost")
     ap.add_argument("--opt", default="", help="dispatch options, e.g. u3=2,s3=0 (vlnce_set_option)")
     args = ap.parse_args()
     for kv in filter(None, args.opt.split(",")):
@@ -131,6 +134,8 @@ def main():
         us = 1e30
         for _ in range(args.rounds):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            if args.backlog:
+                torch.cuda._sleep(int(4e7))
             e0.record()
             for _ in range(args.iters):
                 ops.conv2d_nhwc(x, w, s, pad, **kw)

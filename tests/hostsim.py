@@ -431,9 +431,14 @@ class HostSim:
     def _kv(t, B, P, D, ld):
         return t.as_strided((B, P, D), (P * ld, ld, 1))
 
-    def attn_fwd(self, q, K, ldk, V, ldv, mask, mask_mode, scale, out, attn_out, B, P, Dk, Dv):
-        k = self._kv(K, B, P, Dk, ldk)
-        v = self._kv(V, B, P, Dv, ldv)
+    def attn_fwd(self, q, K, ldk, V, ldv, mask, mask_mode, scale, out, attn_out, B, P, Dk, Dv,
+                 kv_index=None):
+        U = B if kv_index is None else int(kv_index.max()) + 1
+        k = self._kv(K, U, P, Dk, ldk)
+        v = self._kv(V, U, P, Dv, ldv)
+        if kv_index is not None:   # K / V / mask blocks shared by groups of queries
+            k, v = k[kv_index], v[kv_index]
+            mask = mask[kv_index] if mask is not None else None
         logits = torch.einsum("bd,bpd->bp", q, k)
         if mask is not None and mask_mode == 1:
             logits = logits - mask.float() * 1e8
@@ -445,9 +450,13 @@ class HostSim:
         out.copy_(torch.einsum("bp,bpd->bd", a, v))
 
     def attn_bwd(self, dout, q, K, ldk, V, ldv, mask, mask_mode, scale, attn, dq, dK, lddk, dV,
-                 lddv, B, P, Dk, Dv):
-        k = self._kv(K, B, P, Dk, ldk)
-        v = self._kv(V, B, P, Dv, ldv)
+                 lddv, B, P, Dk, Dv, kv_index=None):
+        U = B if kv_index is None else int(kv_index.max()) + 1
+        k = self._kv(K, U, P, Dk, ldk)
+        v = self._kv(V, U, P, Dv, ldv)
+        if kv_index is not None:
+            k, v = k[kv_index], v[kv_index]
+            mask = mask[kv_index] if mask is not None else None
         da = torch.einsum("bd,bpd->bp", dout, v)
         dl = attn * (da - (attn * da).sum(1, keepdim=True)) * scale
         if mask is not None and mask_mode == 2:
@@ -458,6 +467,9 @@ class HostSim:
             self._kv(dK, B, P, Dk, lddk).copy_(dl.unsqueeze(2) * q.unsqueeze(1))
         if dq is not None:
             dq.copy_(torch.einsum("bp,bpd->bd", dl, k))
+
+    def segment_sum(self, x, index, B, U, row_elems, out):
+        out.view(U, row_elems).zero_().index_add_(0, index, x.reshape(B, row_elems))
 
     def rowzero_mask(self, x, ld, rows, Cc, mask):
         mask.view(-1).copy_((_mat(x, rows, Cc, ld) == 0).all(1).to(torch.uint8))

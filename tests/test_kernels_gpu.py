@@ -345,6 +345,44 @@ def test_action_head_counts_nan_rows_and_strided_input(hip):
     assert cnt is None
 
 
+@pytest.mark.parametrize("cfg", [(12, 3, 40, 128, 256, 1), (500, 5, 200, 128, 256, 1), (7, 7, 9, 64, 32, 0),
+                                 (9, 2, 33, 128, 128, 2)])
+def test_attention_shared_blocks_and_segment_sum(hip, cfg):
+    """ops.attention(index=...): K / V / mask blocks shared by groups of queries
+    (vlnce_attn_fwd_shared / _bwd_shared + vlnce_segment_sum) against the same attention over the
+    expanded K[index] / V[index] through torch autograd (fp64)."""
+    B, U, P, Dk, Dv, mode = cfg
+    q, K, V = rnd(B, Dk, seed=1), rnd(U, P, Dk, seed=2), rnd(U, P, Dv, seed=3)
+    idx = (torch.arange(B) * 7 + 3) % U
+    mask = None
+    if mode:
+        mask = torch.zeros(U, P, dtype=torch.uint8)
+        for u in range(U):
+            mask[u, max(1, P - 3 - u):] = 1
+    g = rnd(B, Dv, seed=4)
+    scale = Dk ** -0.5
+    qd, Kd, Vd = (t.to(DEV).requires_grad_() for t in (q, K, V))
+    out = ops.attention(qd, Kd, Vd, None if mask is None else mask.to(DEV), mode or 1, scale,
+                        index=idx.to(DEV))
+    (out * g.to(DEV)).sum().backward()
+    qr, Kr, Vr = (t.double().requires_grad_() for t in (q, K, V))
+    logits = torch.einsum("bd,bpd->bp", qr, Kr[idx])
+    if mode == 1:
+        logits = logits - mask[idx].double() * 1e8
+    if mode == 2:
+        logits = logits * mask[idx].double()
+    ref = torch.einsum("bp,bpd->bd", torch.softmax(logits * scale, 1), Vr[idx])
+    (ref * g.double()).sum().backward()
+    close(out, ref, what="out")
+    for got, want, what in ((qd.grad, qr.grad, "dq"), (Kd.grad, Kr.grad, "dK"), (Vd.grad, Vr.grad, "dV")):
+        close(got, want, what=what)
+    x = rnd(B, 520, seed=5)
+    got = torch.empty(U, 520, device=DEV)
+    ops.L().segment_sum(x.to(DEV), idx.to(DEV), B, U, 520, got)
+    want = torch.zeros(U, 520, dtype=torch.float64).index_add_(0, idx, x.double())
+    close(got, want, what="segment_sum")
+
+
 def test_rowzero_mask(hip):
     x = rnd(4, 30, 256, seed=1)
     x[1, 20:] = 0

@@ -54,6 +54,23 @@ def test_hip_policy_matches_reference_golden(name):
     compare(outs, gold, atol=1e-4, rtol=1e-4)
 
 
+def test_distinct_instruction_path_matches_reference_golden():
+    """cma_cached_feats with the de-duplication threshold lowered: the instruction encoder runs once
+    per distinct instruction, the text attention reads the distinct K / V blocks in place
+    (vlnce_attn_fwd_shared / _bwd_shared, vlnce_segment_sum); outputs and gradients against the
+    reference's golden vectors, 1e-4."""
+    name = "cma_cached_feats"
+    case = cases.CASES[name]
+    obs, prev, masks, extra, gold = cases.load_case(os.path.join(GOLD, name + ".npz"))
+    policy, _ = cases.build_policy(vlnce_amd, case, vlnce_amd.make_config, vlnce_amd.make_spaces,
+                                   tp.synth_state_dict)
+    policy.to(DEV)
+    policy.net.instruction_encoder.DEDUP_MIN_ROWS = 4
+    outs = cases.run_case(policy, case, to_dev(obs), to_dev(prev), to_dev(masks), to_dev(extra),
+                          hip_update, vlnce_amd.AuxLosses, ppo_fn=hip_ppo)
+    compare(outs, gold, atol=1e-4, rtol=1e-4)
+
+
 def synth_batch(N, hw, L, seed=1, ragged=False):
     g = torch.Generator().manual_seed(seed)
     obs = {"rgb": torch.randint(0, 256, (N, hw, hw, 3), generator=g).float(),

@@ -94,6 +94,10 @@ _SIGNATURES = {
     "vlnce_attn_bwd": (_I, [_P, _P, _P, _I, _P, _I, _P, _I, _F, _P, _P, _P, _I, _P, _I,
                             _I, _I, _I, _I, _P]),
     "vlnce_rowzero_mask": (_I, [_P, _I, _L, _I, _P, _P]),
+    "vlnce_attn_fwd_shared": (_I, [_P, _P, _I, _P, _I, _P, _I, _F, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "vlnce_attn_bwd_shared": (_I, [_P, _P, _P, _I, _P, _I, _P, _I, _F, _P, _P, _P, _P, _I, _P, _I,
+                                   _I, _I, _I, _I, _P]),
+    "vlnce_segment_sum": (_I, [_P, _P, _I, _I, _L, _P, _P]),
     "vlnce_action_head_fwd": (_I, [_P, _I, _P, _P, _I, _I, _I, _P, _P, _P]),
     "vlnce_action_head_bwd": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P]),
     "vlnce_gru_gates_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
@@ -195,7 +199,7 @@ class HipLib:
 
     name = "hip"
 
-    ABI = 138  # include/vlnce_hip.h
+    ABI = 139  # include/vlnce_hip.h
 
     def __init__(self, path=LIB_PATH):
         self.dll = load_cdll(path)
@@ -481,13 +485,29 @@ class HipLib:
                                                    _ptr(db), _stream()), "vlnce_action_head_bwd")
 
     # ---- attention
-    def attn_fwd(self, q, K, ldk, V, ldv, mask, mask_mode, scale, out, attn_out, B, P, Dk, Dv):
+    def attn_fwd(self, q, K, ldk, V, ldv, mask, mask_mode, scale, out, attn_out, B, P, Dk, Dv,
+                 kv_index=None):
+        if kv_index is not None:
+            self._check(self.dll.vlnce_attn_fwd_shared(
+                _ptr(q), _ptr(K), ldk, _ptr(V), ldv, _ptr(mask), mask_mode, scale, _ptr(kv_index),
+                _ptr(out), _ptr(attn_out), B, P, Dk, Dv, _stream()), "vlnce_attn_fwd_shared")
+            return
         self._check(self.dll.vlnce_attn_fwd(_ptr(q), _ptr(K), ldk, _ptr(V), ldv, _ptr(mask),
                                             mask_mode, scale, _ptr(out), _ptr(attn_out), B, P, Dk,
                                             Dv, _stream()), "vlnce_attn_fwd")
 
+    def segment_sum(self, x, index, B, U, row_elems, out):
+        self._check(self.dll.vlnce_segment_sum(_ptr(x), _ptr(index), B, U, row_elems, _ptr(out),
+                                               _stream()), "vlnce_segment_sum")
+
     def attn_bwd(self, dout, q, K, ldk, V, ldv, mask, mask_mode, scale, attn, dq, dK, lddk, dV,
-                 lddv, B, P, Dk, Dv):
+                 lddv, B, P, Dk, Dv, kv_index=None):
+        if kv_index is not None:
+            self._check(self.dll.vlnce_attn_bwd_shared(
+                _ptr(dout), _ptr(q), _ptr(K), ldk, _ptr(V), ldv, _ptr(mask), mask_mode, scale,
+                _ptr(kv_index), _ptr(attn), _ptr(dq), _ptr(dK), lddk, _ptr(dV), lddv, B, P, Dk, Dv,
+                _stream()), "vlnce_attn_bwd_shared")
+            return
         self._check(self.dll.vlnce_attn_bwd(_ptr(dout), _ptr(q), _ptr(K), ldk, _ptr(V), ldv,
                                             _ptr(mask), mask_mode, scale, _ptr(attn), _ptr(dq),
                                             _ptr(dK), lddk, _ptr(dV), lddv, B, P, Dk, Dv,

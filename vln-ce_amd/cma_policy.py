@@ -45,16 +45,24 @@ class _CMATail(nn.Module):
     (no host syncs, static shapes) so that it can be captured as a HIP graph.  It shares
     the parent's sub-modules; it is NOT registered as a child of the parent."""
 
-    def __init__(self, net):
+    def __init__(self, net, rgb_frozen=0, dep_frozen=0):
+        """`rgb_frozen` / `dep_frozen`: leading channels of the rgb / depth rows that carry no
+        gradient (a frozen trunk's or cached features; the trailing 64 are the trainable spatial
+        embeddings) -- the input gradients of rgb_kv / depth_kv are computed for the rest only."""
         super().__init__()
+        self._rgb_frozen, self._dep_frozen = int(rgb_frozen), int(dep_frozen)
         for name in ("rgb_linear", "depth_linear", "state_encoder", "rgb_kv", "depth_kv", "state_q",
                      "text_k", "text_q", "second_state_compress", "second_state_encoder"):
             setattr(self, name, getattr(net, name))
         self._hidden_size = net._hidden_size
         self._scale_f = net._scale_f
 
-    def forward(self, ins, dep, rgb, act, rnn_states, masks):
-        B, L, Ci = ins.shape
+    def forward(self, ins, dep, rgb, act, rnn_states, masks, ins_index=None):
+        """`ins_index` (int64 [B]) given: `ins` holds the U DISTINCT instructions of a
+        sequence-mode batch and row b attends over ins[ins_index[b]] -- text_k, the padding mask and
+        the attention's K / V are then U blocks instead of B copies."""
+        B = dep.size(0)
+        L, Ci = ins.shape[1:]
         P_d, C_d = dep.shape[1:]
         C_r = rgb.shape[2]
         half = self._hidden_size // 2
@@ -72,10 +80,13 @@ class _CMATail(nn.Module):
         text_state_k = ops.linear(ins, self.text_k.weight.view(half, Ci), self.text_k.bias)
         text_mask = ops.rowzero_mask(ins.detach())  # (instruction_embedding == 0).all(dim=1)
         # softmax((q.k - 1e8 mask) * scale) . v over [B, P, C] rows (cma_policy.py:207-217)
-        text_embedding = ops.attention(text_state_q, text_state_k, ins, text_mask, 1, scale)
+        text_embedding = ops.attention(text_state_q, text_state_k, ins, text_mask, 1, scale,
+                                       index=ins_index)
 
-        rgb_kv = ops.linear(rgb, self.rgb_kv.weight.view(-1, C_r), self.rgb_kv.bias)
-        depth_kv = ops.linear(dep, self.depth_kv.weight.view(-1, C_d), self.depth_kv.bias)
+        rgb_kv = ops.linear(rgb, self.rgb_kv.weight.view(-1, C_r), self.rgb_kv.bias,
+                            dx_from=self._rgb_frozen)
+        depth_kv = ops.linear(dep, self.depth_kv.weight.view(-1, C_d), self.depth_kv.bias,
+                              dx_from=self._dep_frozen)
         text_q = ops.linear(text_embedding, self.text_q.weight, self.text_q.bias)
         rgb_embedding = ops.attention(text_q, rgb_kv[..., :half], rgb_kv[..., half:], None, 1, scale)
         depth_embedding = ops.attention(text_q, depth_kv[..., :half], depth_kv[..., half:], None, 1,
@@ -130,7 +141,7 @@ class CMANet(Net):
         self._output_size = hidden_size
         self._branches = BranchStreams()
         # kept out of the module tree (shares our sub-modules): see _CMATail
-        object.__setattr__(self, "_tail", GraphedTail(lambda: _CMATail(self)))
+        object.__setattr__(self, "_tail", GraphedTail(lambda *static: _CMATail(self, *static)))
         self.progress_monitor = nn.Linear(self.output_size, 1)
         if model_config.PROGRESS_MONITOR.use:
             nn.init.kaiming_normal_(self.progress_monitor.weight, nonlinearity="tanh")
@@ -154,10 +165,27 @@ class CMANet(Net):
         """softmax((q.k - 1e8 mask) * scale) . v  over [B, P, C] rows (cma_policy.py:207-217)."""
         return ops.attention(q, k, v, mask, 1, self._scale_f)
 
+    def _frozen_cols(self, enc, cached_key, observations):
+        """leading channels of an encoder's [B, C, h, w] output that cannot need a gradient: the
+        trunk's own channels when the trunk is frozen or its features came in precomputed
+        (the channels behind them are the encoder's trainable spatial embeddings)."""
+        if any(getattr(self.model_config, "ablate_" + k) for k in ("rgb", "depth")):
+            return 0
+        if not hasattr(enc, "spatial_embeddings") or not getattr(enc, "spatial_output", False):
+            return 0
+        if cached_key in observations:
+            if getattr(observations[cached_key], "requires_grad", False):
+                return 0
+        elif any(p.requires_grad for p in enc.trunk_parameters()):
+            return 0
+        return enc.output_shape[0] - enc.spatial_embeddings.embedding_dim
+
     def forward(self, observations, rnn_states, prev_actions, masks):
         # three independent encoders: RGB trunk on this stream, instruction RNN + depth trunk on
         # a side stream (net_parts.encode_three_branches); then everything as [B, rows, C]
-        ins, dep, rgb = encode_three_branches(self, observations, rnn_states.device)
+        ins, dep, rgb = encode_three_branches(self, observations, rnn_states.device,
+                                              distinct_instructions=True)
+        ins, ins_index = ins   # [U, 2H, L] distinct instructions + row map, or ([B, 2H, L], None)
         ins, dep, rgb = apply_ablations(self.model_config, ins.permute(0, 2, 1),  # [B, L, 2H]
                                         rows_of(dep),                             # [B, P, 192]
                                         rows_of(rgb))                             # [B, 16, 2112]
@@ -171,7 +199,12 @@ class CMANet(Net):
             pad = bucket_rows(ins.size(1)) - ins.size(1)
             if pad:
                 ins = F.pad(ins, (0, 0, 0, pad))
+        extra = () if ins_index is None else (ins_index,)
         x, rnn_states_out = self._tail(ins.contiguous(), dep.contiguous(), rgb.contiguous(), act,
-                                       rnn_states.contiguous(), masks_u8)
+                                       rnn_states.contiguous(), masks_u8, *extra,
+                                       static=(self._frozen_cols(self.rgb_encoder, "rgb_features",
+                                                                 observations),
+                                               self._frozen_cols(self.depth_encoder, "depth_features",
+                                                                 observations)))
         register_progress_loss(self, x, observations)
         return x, rnn_states_out

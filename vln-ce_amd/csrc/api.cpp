@@ -24,7 +24,8 @@ extern "C" const char* vlnce_last_error(void) { return g_err; }
 // vlnce_bn_finalize_sums.
 // 137: vlnce_stem7_fwd.
 // 138: vlnce_action_head_fwd / _bwd.
-extern "C" int vlnce_version(void) { return 138; }
+// 139: vlnce_attn_fwd_shared / _bwd_shared, vlnce_segment_sum.
+extern "C" int vlnce_version(void) { return 139; }
 
 // ---- dispatch options: one int per name, process-wide, relaxed atomics (a tuning / test knob,
 // not a synchronisation point: set them before the launches they are meant for)

@@ -23,14 +23,15 @@ __device__ __forceinline__ float block_reduce(float v, float* sbuf, bool is_max)
 __global__ __launch_bounds__(256) void attn_fwd_kernel(
     const float* __restrict__ q, const float* __restrict__ K, int ldk, const float* __restrict__ V,
     int ldv, const uint8_t* __restrict__ mask, int mask_mode, float scale, float* __restrict__ out,
-    float* __restrict__ attn_out, int P, int Dk, int Dv) {
+    float* __restrict__ attn_out, int P, int Dk, int Dv, const long long* __restrict__ kv_index) {
   __shared__ float logits[MAXP];
   __shared__ float sbuf[4];
   const int b = blockIdx.x;
+  const long kb = kv_index ? (long)kv_index[b] : (long)b;   // the K / V / mask block of this query
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* qb = q + (long)b * Dk;
-  const float* Kb = K + (long)b * P * ldk;
-  const float* Vb = V + (long)b * P * ldv;
+  const float* Kb = K + kb * P * ldk;
+  const float* Vb = V + kb * P * ldv;
   const bool vec = ((Dk & 3) == 0) && ((ldk & 3) == 0) &&
                    ((reinterpret_cast<uintptr_t>(K) | reinterpret_cast<uintptr_t>(q)) & 15) == 0;
   for (int i = wave; i < P; i += 4) {
@@ -48,7 +49,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(
     s = wave_sum(s);
     if (lane == 0) {
       if (mask != nullptr) {
-        const float mk = (float)mask[(long)b * P + i];
+        const float mk = (float)mask[kb * P + i];
         if (mask_mode == 1) s = s - mk * 1e8f;
         if (mask_mode == 2) s = s * mk;
       }
@@ -85,15 +86,17 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(
     const float* __restrict__ dout, const float* __restrict__ q, const float* __restrict__ K,
     int ldk, const float* __restrict__ V, int ldv, const uint8_t* __restrict__ mask, int mask_mode,
     float scale, const float* __restrict__ attn, float* __restrict__ dq, float* __restrict__ dK,
-    int lddk, float* __restrict__ dV, int lddv, int P, int Dk, int Dv) {
+    int lddk, float* __restrict__ dV, int lddv, int P, int Dk, int Dv,
+    const long long* __restrict__ kv_index) {
   __shared__ float dl[MAXP];  // d(attn) then d(logit)
   __shared__ float sbuf[4];
   const int b = blockIdx.x;
+  const long kb = kv_index ? (long)kv_index[b] : (long)b;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* dob = dout + (long)b * Dv;
   const float* ab = attn + (long)b * P;
-  const float* Vb = V + (long)b * P * ldv;
-  const float* Kb = K + (long)b * P * ldk;
+  const float* Vb = V + kb * P * ldv;
+  const float* Kb = K + kb * P * ldk;
   const float* qb = q + (long)b * Dk;
   // d attn[i] = <dout, V[i]>,  dV[i] = attn[i] * dout
   for (int i = wave; i < P; i += 4) {
@@ -114,7 +117,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(
   __syncthreads();
   for (int i = tid; i < P; i += 256) {
     float g = ab[i] * (dl[i] - dot) * scale;
-    if (mask != nullptr && mask_mode == 2) g *= (float)mask[(long)b * P + i];
+    if (mask != nullptr && mask_mode == 2) g *= (float)mask[kb * P + i];
     dl[i] = g;
   }
   __syncthreads();
@@ -129,6 +132,36 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(
     }
     if (dq) dq[(long)b * Dk + c] = acc;
   }
+}
+
+// out[u, :] = sum over the rows b with index[b] == u of x[b, :], in row order (deterministic).
+// One workgroup per (1024-float strip, u): the index test is wave-uniform, only matching rows are read.
+__global__ __launch_bounds__(256) void segment_sum_kernel(const float* __restrict__ x,
+                                                          const long long* __restrict__ index, int B,
+                                                          long row_elems, float* __restrict__ out) {
+  const long u = blockIdx.y;
+  const long c = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (c >= row_elems) return;
+  const bool v4 = c + 4 <= row_elems;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int b = 0; b < B; ++b) {
+    if (index[b] != u) continue;
+    const float* r = x + (long)b * row_elems + c;
+    if (v4) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(r);
+      acc.x += v.x;
+      acc.y += v.y;
+      acc.z += v.z;
+      acc.w += v.w;
+    } else {
+      for (int e = 0; c + e < row_elems; ++e) acc[e] += r[e];
+    }
+  }
+  float* o = out + u * row_elems + c;
+  if (v4)
+    *reinterpret_cast<f32x4*>(o) = acc;
+  else
+    for (int e = 0; c + e < row_elems; ++e) o[e] = acc[e];
 }
 
 __global__ __launch_bounds__(256) void rowzero_mask_kernel(const float* __restrict__ x, int ld,
@@ -155,8 +188,24 @@ extern "C" int vlnce_attn_fwd(const float* q, const float* K, int ldk, const flo
                   MAXP);
   VLNCE_CHECK_ARG(mask_mode >= 0 && mask_mode <= 2, "attn_fwd: bad mask_mode");
   hipLaunchKernelGGL(attn_fwd_kernel, dim3(B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                     q, K, ldk, V, ldv, mask, mask_mode, scale, out, attn_out, P, Dk, Dv);
+                     q, K, ldk, V, ldv, mask, mask_mode, scale, out, attn_out, P, Dk, Dv,
+                     (const long long*)nullptr);
   VLNCE_CHECK_LAUNCH("attn_fwd");
+  return 0;
+}
+
+extern "C" int vlnce_attn_fwd_shared(const float* q, const float* K, int ldk, const float* V,
+                                     int ldv, const uint8_t* mask, int mask_mode, float scale,
+                                     const int64_t* kv_index, float* out, float* attn_out, int B,
+                                     int P, int Dk, int Dv, vlnce_stream_t stream) {
+  VLNCE_CHECK_ARG(q && K && V && out && kv_index, "attn_fwd_shared: null argument");
+  VLNCE_CHECK_ARG(B > 0 && P > 0 && P <= MAXP && Dk > 0 && Dv > 0,
+                  "attn_fwd_shared: bad shape (P<=%d)", MAXP);
+  VLNCE_CHECK_ARG(mask_mode >= 0 && mask_mode <= 2, "attn_fwd_shared: bad mask_mode");
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3(B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     q, K, ldk, V, ldv, mask, mask_mode, scale, out, attn_out, P, Dk, Dv,
+                     reinterpret_cast<const long long*>(kv_index));
+  VLNCE_CHECK_LAUNCH("attn_fwd_shared");
   return 0;
 }
 
@@ -169,8 +218,36 @@ extern "C" int vlnce_attn_bwd(const float* dout, const float* q, const float* K,
   VLNCE_CHECK_ARG(B > 0 && P > 0 && P <= MAXP, "attn_bwd: bad shape");
   hipLaunchKernelGGL(attn_bwd_kernel, dim3(B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                      dout, q, K, ldk, V, ldv, mask, mask_mode, scale, attn, dq, dK, lddk, dV, lddv,
-                     P, Dk, Dv);
+                     P, Dk, Dv, (const long long*)nullptr);
   VLNCE_CHECK_LAUNCH("attn_bwd");
+  return 0;
+}
+
+extern "C" int vlnce_attn_bwd_shared(const float* dout, const float* q, const float* K, int ldk,
+                                     const float* V, int ldv, const uint8_t* mask, int mask_mode,
+                                     float scale, const int64_t* kv_index, const float* attn,
+                                     float* dq, float* dK, int lddk, float* dV, int lddv, int B,
+                                     int P, int Dk, int Dv, vlnce_stream_t stream) {
+  VLNCE_CHECK_ARG(dout && q && K && V && attn && kv_index, "attn_bwd_shared: null argument");
+  VLNCE_CHECK_ARG(B > 0 && P > 0 && P <= MAXP, "attn_bwd_shared: bad shape");
+  hipLaunchKernelGGL(attn_bwd_kernel, dim3(B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     dout, q, K, ldk, V, ldv, mask, mask_mode, scale, attn, dq, dK, lddk, dV, lddv,
+                     P, Dk, Dv, reinterpret_cast<const long long*>(kv_index));
+  VLNCE_CHECK_LAUNCH("attn_bwd_shared");
+  return 0;
+}
+
+extern "C" int vlnce_segment_sum(const float* x, const int64_t* index, int B, int U, long row_elems,
+                                 float* out, vlnce_stream_t stream) {
+  VLNCE_CHECK_ARG(x && index && out, "segment_sum: null argument");
+  VLNCE_CHECK_ARG(B > 0 && U > 0 && U <= 65535 && row_elems > 0, "segment_sum: bad shape");
+  VLNCE_CHECK_ARG(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15) == 0 &&
+                      row_elems % 4 == 0,
+                  "segment_sum: rows must be 16-byte aligned multiples of 4 floats");
+  hipLaunchKernelGGL(segment_sum_kernel, dim3(ceil_div(row_elems, 1024), U), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), x,
+                     reinterpret_cast<const long long*>(index), B, row_elems, out);
+  VLNCE_CHECK_LAUNCH("segment_sum");
   return 0;
 }
 

@@ -1295,11 +1295,20 @@ int dispatch_stem(const IgemmParams& p, hipStream_t s) {
 }
 
 // split-K factor for a plain GEMM with few output tiles and a long reduction
-int choose_splitk(const IgemmParams& p) {
+int choose_splitk(const IgemmParams& p, bool long_reduction_form = false) {
   const bool off = vlnce_opt(VLNCE_OPT_IGEMM_NO_SPLITK) != 0;  // diagnostic switch
   if (off) return 1;
   const long tiles = (long)ceil_div(p.M, 64) * ceil_div(p.N, 64);
   const int KT = ceil_div(p.K, BK);
+  // dW = dz^T x of a sequence-mode batch (reduction over T*N*P rows, e.g. 512 x 2112 x 8000 for
+  // rgb_kv at 500 rows x 16 positions): a few hundred tiles with one workgroup per CU walk a
+  // 250-step K loop with nothing to hide its latency behind -- four workgroups per CU as in
+  // vlnce_conv2d_wgrad (364 -> ~190 us there)
+  if (long_reduction_form && KT >= 64 && tiles >= 128 && tiles < 1024) {
+    long s = (1024 + tiles - 1) / tiles;
+    if (s > KT / 4) s = KT / 4;
+    return s < 2 ? 1 : (int)s;
+  }
   if (tiles >= 128 || KT < 8) return 1;
   long s = (256 + tiles - 1) / tiles;
   if (s > KT / 2) s = KT / 2;
@@ -1723,7 +1732,7 @@ extern "C" int vlnce_gemm(const float* A, int lda, int transA, const float* B, i
   // the same thing minus the zero-fill -- the recurrent dgrad of a T-step rollout,
   // dh += dgates W_hh with 5 x 512 outputs and K = 1536, is 8 workgroups otherwise.
   const bool plain = !p.scale && !p.residual && !(p.accumulate && p.act);
-  if (plain) p.splitk = choose_splitk(p);
+  if (plain) p.splitk = choose_splitk(p, transA != 0);
   const float* bias2 = nullptr;
   int act2 = 0;
   if (p.splitk > 1) {

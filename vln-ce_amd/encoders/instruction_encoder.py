@@ -76,8 +76,12 @@ class InstructionEncoder(nn.Module):
     # Sequence-mode batches (T*N rows: 5 episodes x ~100 steps, or a DD-PPO minibatch) are larger.
     DEDUP_MIN_ROWS = 128
 
-    def forward(self, observations):
-        """Sequence-mode batches ([T*N, 200] tokens: a cached-feature DAgger batch,
+    def forward(self, observations, distinct=False):
+        """`distinct=True` returns (output, inverse): when the batch was encoded once per distinct
+        instruction, `output` holds the U distinct rows and `inverse` [B] the row of every batch
+        element (None when every row was encoded -- then output is per batch element).
+
+        Sequence-mode batches ([T*N, 200] tokens: a cached-feature DAgger batch,
         dagger_trainer.py:39-114, or a DD-PPO minibatch, rollout_storage.py:154-276) repeat every
         episode's instruction T times (and pad with all-ones rows); the recurrence is run once per
         DISTINCT token row and the result gathered back -- same values, T-fold less LSTM work.
@@ -96,7 +100,10 @@ class InstructionEncoder(nn.Module):
                                        (lengths, lmin, lmax))
                     # [U, C, L] / [U, H] -> rows; the stacked bidirectional final state is [2, U, H]
                     dim = 1 if (cfg.final_state_only and out.dim() == 3) else 0
-                    return out.index_select(dim, inverse)
+                    if distinct and dim == 0:
+                        return out, inverse
+                    out = out.index_select(dim, inverse)
+                    return (out, None) if distinct else out
             feats = ops.embedding(tokens, self.embedding_layer.weight,
                                   self.embedding_layer.padding_idx)
             lengths = nonzero_row[tokens].sum(dim=1)
@@ -104,10 +111,13 @@ class InstructionEncoder(nn.Module):
                 # inside a graph capture (streams.ActGraph): no host sync -- the recurrence runs
                 # at the static padded length with the lengths on the device (steps past a row's
                 # length keep its state and emit zeros: the same values, more padding)
-                return self._encode(feats, (lengths, 1, tokens.size(1)))
+                out = self._encode(feats, (lengths, 1, tokens.size(1)))
+                return (out, None) if distinct else out
             lmin, lmax = (int(v) for v in torch.stack([lengths.min(), lengths.max()]).tolist())
-            return self._encode(feats, (lengths, lmin, lmax))
-        return self._encode(observations["rxr_instruction"])
+            out = self._encode(feats, (lengths, lmin, lmax))
+            return (out, None) if distinct else out
+        out = self._encode(observations["rxr_instruction"])
+        return (out, None) if distinct else out
 
     @staticmethod
     def _distinct_rows(tokens, nonzero_row):

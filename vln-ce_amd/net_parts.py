@@ -41,11 +41,18 @@ def relu_fc(n_in, n_out, *front):
     return torch.nn.Sequential(*front, torch.nn.Linear(n_in, n_out), torch.nn.ReLU(True))
 
 
-def encode_three_branches(net, observations, device):
+def encode_three_branches(net, observations, device, distinct_instructions=False):
     """RGB encoder on the caller's stream; instruction encoder (one host sync for the lengths,
     as upstream) and depth encoder on a side stream, overlapping the RGB trunk's long MFMA
-    kernels.  Returns (instruction, depth, rgb) with the side-stream results joined."""
+    kernels.  Returns (instruction, depth, rgb) with the side-stream results joined; with
+    `distinct_instructions` the first is InstructionEncoder.forward(..., distinct=True)'s pair."""
     branches = net._branches
+
+    def instruction():
+        if distinct_instructions:
+            return net.instruction_encoder(observations, distinct=True)
+        return net.instruction_encoder(observations)
+
     fork = branches.fork(device)
     if not torch.is_grad_enabled():
         # act() at a handful of environments: every branch is a chain of latency-bound launches
@@ -55,7 +62,7 @@ def encode_three_branches(net, observations, device):
         # own stream (the one a run-ahead depth trunk would use), then RGB, then the instruction.
         dep, join_dep = branches.run(fork, 2, device, lambda: net.depth_encoder(observations))
         rgb = net.rgb_encoder(observations)
-        ins, join_ins = branches.run(fork, 0, device, lambda: net.instruction_encoder(observations))
+        ins, join_ins = branches.run(fork, 0, device, instruction)
     else:
         # training step: both side branches share side stream 0 (the instruction encoder's ~1 ms
         # then the depth trunk's ~1.9 ms, beside the RGB trunk's ~6.8 ms on the caller's stream).
@@ -66,7 +73,7 @@ def encode_three_branches(net, observations, device):
         # (profiles/r04_b_*): side branches first 11.1 ms/step, depth trunk first on its own
         # stream 10.3-10.9, this order 10.2-10.7.
         rgb = net.rgb_encoder(observations)
-        ins, join_ins = branches.run(fork, 0, device, lambda: net.instruction_encoder(observations))
+        ins, join_ins = branches.run(fork, 0, device, instruction)
         dep, join_dep = branches.run(fork, 0, device, lambda: net.depth_encoder(observations))
     join_ins()
     join_dep()

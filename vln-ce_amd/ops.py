@@ -473,10 +473,14 @@ def rowzero_mask(x3):
 
 # ----------------------------------------------------------------- linear / 1x1 conv
 class LinearFn(Function):
-    """y = act(x W^T + b).  x [M,K] (row stride >= K), W [N,K], b [N] | None."""
+    """y = act(x W^T + b).  x [M,K] (row stride >= K), W [N,K], b [N] | None.
+    dx_from > 0: only columns [dx_from, K) of the input gradient are wanted (the leading columns
+    of x are a frozen trunk's features, the rest trainable spatial embeddings concatenated to
+    them, resnet_encoders.py:199-204): dx is returned with the leading columns ZERO and the GEMM
+    runs on the trailing ones only."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, act):
+    def forward(ctx, x, weight, bias, act, dx_from=0):
         x, ldx = _rows2d(x)
         M, K = x.shape
         N = weight.size(0)
@@ -485,6 +489,7 @@ class LinearFn(Function):
         L().gemm(x, ldx, 0, w, K, 0, y, N, M, N, K, shift=bias, act=act)
         ctx.act = act
         ctx.has_bias = bias is not None
+        ctx.dx_from = int(dx_from) if 0 < int(dx_from) < K and int(dx_from) % 4 == 0 else 0
         ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
         return y
 
@@ -502,9 +507,15 @@ class LinearFn(Function):
             dz = dz2
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = torch.empty((M, K), device=dz.device, dtype=torch.float32)
-            # dx[M,K] = dz[M,N] * W[N,K]   (B stored [K'=N, N'=K])
-            lib.gemm(dz, N, 0, w, K, 1, dx, K, M, K, N)
+            c0 = ctx.dx_from
+            if c0:
+                dx = torch.zeros((M, K), device=dz.device, dtype=torch.float32)
+                # dx[:, c0:] += dz[M,N] * W[:, c0:]   (the zero-fill doubles as the split-K one)
+                lib.gemm(dz, N, 0, w[:, c0:], K, 1, dx[:, c0:], K, M, K - c0, N, accumulate=1)
+            else:
+                dx = torch.empty((M, K), device=dz.device, dtype=torch.float32)
+                # dx[M,K] = dz[M,N] * W[N,K]   (B stored [K'=N, N'=K])
+                lib.gemm(dz, N, 0, w, K, 1, dx, K, M, K, N)
         if ctx.needs_input_grad[1]:
             dw = torch.empty((N, K), device=dz.device, dtype=torch.float32)
             # dW[N,K] = dz^T[N,M] * x[M,K]
@@ -512,12 +523,12 @@ class LinearFn(Function):
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = torch.empty((N,), device=dz.device, dtype=torch.float32)
             lib.colsum(dz, N, M, N, db, 0)
-        return dx, dw, db, None
+        return dx, dw, db, None, None
 
 
-def linear(x, weight, bias=None, act=ACT_NONE):
+def linear(x, weight, bias=None, act=ACT_NONE, dx_from=0):
     lead = x.shape[:-1]
-    y = LinearFn.apply(x.reshape(-1, x.size(-1)) if x.dim() != 2 else x, weight, bias, act)
+    y = LinearFn.apply(x.reshape(-1, x.size(-1)) if x.dim() != 2 else x, weight, bias, act, dx_from)
     return y if x.dim() == 2 else y.view(*lead, weight.size(0))
 
 
@@ -574,12 +585,16 @@ def action_head(x, weight, bias=None, count_nans=True):
 
 # ----------------------------------------------------------------- attention
 class AttnFn(Function):
-    """out[B,Dv] = softmax(mask(q K^T) * scale) V ; K [B,P,Dk], V [B,P,Dv] (views allowed)."""
+    """out[B,Dv] = softmax(mask(q K^T) * scale) V ; K [B,P,Dk], V [B,P,Dv] (views allowed).
+    With `index` (int64 [B]): K [U,P,Dk], V [U,P,Dv], mask [U,P] are shared by groups of queries,
+    query row b attends over block index[b] (vlnce_attn_fwd_shared); the gradients of K and V are
+    the per-query gradients summed per block (vlnce_segment_sum)."""
 
     @staticmethod
-    def forward(ctx, q, K, V, mask, mask_mode, scale):
+    def forward(ctx, q, K, V, mask, mask_mode, scale, index=None):
         q = _f32c(q)
-        B, P, Dk = K.shape
+        U, P, Dk = K.shape
+        B = q.size(0)
         Dv = V.size(2)
 
         def ld_of(t):
@@ -589,30 +604,44 @@ class AttnFn(Function):
 
         K, ldk = ld_of(K)
         V, ldv = ld_of(V)
+        if index is None:
+            assert U == B, (U, B)
+        else:
+            index = index.contiguous()
+            assert index.dtype == torch.int64 and index.numel() == B
         out = torch.empty((B, Dv), device=q.device, dtype=torch.float32)
         attn = torch.empty((B, P), device=q.device, dtype=torch.float32)
         mm = 0 if mask is None else int(mask_mode)
-        L().attn_fwd(q, K, ldk, V, ldv, mask, mm, float(scale), out, attn, B, P, Dk, Dv)
-        ctx.save_for_backward(q, K, V, attn, mask)
+        L().attn_fwd(q, K, ldk, V, ldv, mask, mm, float(scale), out, attn, B, P, Dk, Dv,
+                     kv_index=index)
+        ctx.save_for_backward(q, K, V, attn, mask, index)
         ctx.cfg = (mm, float(scale), ldk, ldv)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        q, K, V, attn, mask = ctx.saved_tensors
+        q, K, V, attn, mask, index = ctx.saved_tensors
         mm, scale, ldk, ldv = ctx.cfg
-        B, P, Dk = K.shape
+        U, P, Dk = K.shape
+        B = q.size(0)
         Dv = V.size(2)
         dout = _f32c(dout)
         dq = torch.empty((B, Dk), device=q.device, dtype=torch.float32)
         dK = torch.empty((B, P, Dk), device=q.device, dtype=torch.float32)
         dV = torch.empty((B, P, Dv), device=q.device, dtype=torch.float32)
-        L().attn_bwd(dout, q, K, ldk, V, ldv, mask, mm, scale, attn, dq, dK, Dk, dV, Dv, B, P, Dk, Dv)
-        return dq, dK, dV, None, None, None
+        L().attn_bwd(dout, q, K, ldk, V, ldv, mask, mm, scale, attn, dq, dK, Dk, dV, Dv, B, P, Dk, Dv,
+                     kv_index=index)
+        if index is not None:
+            dKu = torch.empty((U, P, Dk), device=q.device, dtype=torch.float32)
+            dVu = torch.empty((U, P, Dv), device=q.device, dtype=torch.float32)
+            L().segment_sum(dK, index, B, U, P * Dk, dKu)
+            L().segment_sum(dV, index, B, U, P * Dv, dVu)
+            dK, dV = dKu, dVu
+        return dq, dK, dV, None, None, None, None
 
 
-def attention(q, K, V, mask=None, mask_mode=1, scale=1.0):
-    return AttnFn.apply(q, K, V, mask, mask_mode, scale)
+def attention(q, K, V, mask=None, mask_mode=1, scale=1.0, index=None):
+    return AttnFn.apply(q, K, V, mask, mask_mode, scale, index)
 
 
 # ----------------------------------------------------------------- row utilities

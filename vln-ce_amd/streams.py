@@ -241,17 +241,29 @@ class GraphedTail:
         # make_graphed_callables patches the module's forward in place, so every captured
         # signature gets its own (cheap: it only references the shared sub-modules) instance
         self.make_module = make_module
-        self.module = make_module()
+        self.modules = {}             # static configuration -> eager instance
         self.entries = OrderedDict()  # signature -> graphed callable; LRU over CAPTURED graphs
         self.sightings = OrderedDict()  # signature -> times seen before capture (bounded, no graphs)
 
-    def __call__(self, *tensors):
+    @property
+    def module(self):
+        return self._eager(())
+
+    def _eager(self, static):
+        m = self.modules.get(static)
+        if m is None:
+            m = self.modules[static] = self.make_module(*static)
+        return m
+
+    def __call__(self, *tensors, static=()):
+        """`static`: hashable configuration handed to make_module(*static) -- part of the graph key
+        (values the tail's Python control flow depends on that are not visible in the tensors)."""
         t0 = tensors[0]
         if (not t0.is_cuda or os.environ.get("VLNCE_HIP_GRAPHS", "1") == "0"
                 or torch.cuda.is_current_stream_capturing()):
-            return self.module(*tensors)
+            return self._eager(static)(*tensors)
         key = tuple((tuple(t.shape), t.dtype, t.requires_grad) for t in tensors) + (
-            torch.is_grad_enabled(),)
+            torch.is_grad_enabled(), static)
         ent = self.entries.get(key)
         if ent is None:
             # first sightings are counted apart from the captured graphs: a stream of new
@@ -261,10 +273,10 @@ class GraphedTail:
                 while len(self.sightings) >= 8 * self.MAX_GRAPHS:
                     self.sightings.popitem(last=False)
                 self.sightings[key] = seen
-                return self.module(*tensors)
+                return self._eager(static)(*tensors)
             sample = tuple(t.detach().clone().requires_grad_(t.requires_grad) for t in tensors)
             with capture_guard():
-                ent = torch.cuda.make_graphed_callables(self.make_module(), sample,
+                ent = torch.cuda.make_graphed_callables(self.make_module(*static), sample,
                                                         allow_unused_input=True)
             while len(self.entries) >= self.MAX_GRAPHS:
                 self.entries.popitem(last=False)  # least recently used captured graph
