@@ -30,7 +30,7 @@ typedef void* vlnce_stream_t;
 
 enum { VLNCE_ACT_NONE = 0, VLNCE_ACT_RELU = 1, VLNCE_ACT_SIGMOID = 2, VLNCE_ACT_TANH = 3 };
 
-int vlnce_version(void); /* major*100 + minor; 139 = this header */
+int vlnce_version(void); /* major*100 + minor; 140 = this header */
 const char* vlnce_last_error(void);
 
 /* Dispatch options: which of the library's equivalent kernels a launch is given to.  Explicit
@@ -51,6 +51,7 @@ const char* vlnce_last_error(void);
  *   "igemm_no_splitk"  0        1: no split-K
  *   "wgrad_tile"       64       64 or 128 (vlnce_conv2d_wgrad)
  *   "rollout_one_xcd"  0        1: all workgroups of vlnce_gru_rollout_* on one XCD
+ *   "m3"               1        conv_m3_kernel (small launches): 0 off, 1 default rule, 2 / 3 every layer it covers
  * Set options between launches, not concurrently with them (relaxed atomics).  Unknown names
  * return non-zero. */
 int vlnce_set_option(const char* name, int value);
@@ -174,6 +175,7 @@ int vlnce_conv2d_pack_weights(const float* w_ohwi, void* frag, const vlnce_conv_
 #define VLNCE_CONV_PATH_F32 0 /* igemm_kernel, v_mfma_f32_32x32x2_f32 (incl. split-K)            */
 #define VLNCE_CONV_PATH_X3 1  /* conv_x3_kernel, bf16 planes, im2col K-tiles through LDS          */
 #define VLNCE_CONV_PATH_P3 2  /* conv_p3_kernel, bf16 planes, patch-resident A / fragment-order B */
+#define VLNCE_CONV_PATH_M3 3  /* conv_m3_kernel, bf16 planes, small launches: no LDS staging, 4-way k split */
 int vlnce_conv2d_last_path(void);
 
 int vlnce_conv2d_fwd(const float* x, const float* w_ohwi, float* y,

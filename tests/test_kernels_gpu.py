@@ -882,6 +882,7 @@ def _conv_cases_under(hip, cases, want_path=None, **opts):
     (vlnce_set_option: in-process, restored afterwards); `want_path`: the kernel family at
     least one of the cases must really have been given to (vlnce_conv2d_last_path)."""
     seen = set()
+    opts.setdefault("m3", 0)   # (conv_m3_kernel would take every unit-test shape: they are all small)
     with hip.options(**opts):
         for case in cases:
             try:
@@ -960,7 +961,18 @@ P3_CASES = [
 
 @pytest.mark.parametrize("case", P3_CASES, ids=[c[0] for c in P3_CASES])
 def test_conv_p3(hip, case):
-    test_conv2d_fwd(hip, case)
+    with hip.options(m3=0):   # the persistent kernels' own default dispatch
+        test_conv2d_fwd(hip, case)
+
+
+def test_conv_m3_every_eligible_case(hip):
+    """conv_m3_kernel (small launches: A fragments straight from global memory, four-way k split
+    through LDS or four row blocks per workgroup) over every conv case it covers (option "m3" = 2):
+    3x3 / 5x5 / 1x1, strides 1 and 2, padding 0..2, ragged M, tiles across image borders, prologue
+    with centre and ReLU, epilogue scale / shift / ReLU / residual, statistics partials of 32 and
+    16 rows, N = 32 (one column block) to 768."""
+    _conv_cases_under(hip, CONV_CASES + P3_CASES, want_path=3, m3=2)
+    _conv_cases_under(hip, CONV_CASES + P3_CASES, want_path=3, m3=3)   # two row blocks per workgroup
 
 
 @pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6])
@@ -1099,10 +1111,13 @@ def test_conv_bn_sums(hip, case):
     _bn_case(hip, case)
 
 
-@pytest.mark.parametrize("opts", [dict(u3=2), dict(u3=3), dict(s3=2), dict(p3=1, p3_tile=3),
-                                  dict(p3=0, u3=0, s3=0, x3_tile=1), dict(p3=0, u3=0, s3=0, x3_tile=4),
-                                  dict(conv_math=0)],
-                         ids=["u3_64", "u3_128", "s3", "p3_tile3", "x3_tile1", "x3_tile4", "f32_fallback"])
+@pytest.mark.parametrize("opts", [dict(m3=0, u3=2), dict(m3=0, u3=3), dict(m3=0, s3=2),
+                                  dict(m3=0, p3=1, p3_tile=3),
+                                  dict(m3=0, p3=0, u3=0, s3=0, x3_tile=1),
+                                  dict(m3=0, p3=0, u3=0, s3=0, x3_tile=4),
+                                  dict(conv_math=0), dict(m3=2)],
+                         ids=["u3_64", "u3_128", "s3", "p3_tile3", "x3_tile1", "x3_tile4", "f32_fallback",
+                              "m3"])
 def test_conv_bn_sums_every_kernel(hip, opts):
     """the same through each convolution kernel (forced with the dispatch options) and through
     the fall-back (fp32 kernel: tile moments reduced into the sums behind the convolution)."""

@@ -199,7 +199,7 @@ class HipLib:
 
     name = "hip"
 
-    ABI = 139  # include/vlnce_hip.h
+    ABI = 140  # include/vlnce_hip.h
 
     def __init__(self, path=LIB_PATH):
         self.dll = load_cdll(path)
@@ -213,7 +213,7 @@ class HipLib:
     # ---- dispatch options (vlnce_set_option): the library itself never reads the environment;
     # the VLNCE_* variables of INTEGRATION.md section 8 are translated here, once, at load
     OPTION_NAMES = ("conv_math", "p3", "p3_tile", "s3", "u3", "u3_waves", "x3_tile", "igemm_tile",
-                    "igemm_nobuf", "igemm_no_splitk", "wgrad_tile", "rollout_one_xcd")
+                    "igemm_nobuf", "igemm_no_splitk", "wgrad_tile", "rollout_one_xcd", "m3")
 
     def _options_from_env(self):
         for name in self.OPTION_NAMES:

@@ -25,7 +25,8 @@ extern "C" const char* vlnce_last_error(void) { return g_err; }
 // 137: vlnce_stem7_fwd.
 // 138: vlnce_action_head_fwd / _bwd.
 // 139: vlnce_attn_fwd_shared / _bwd_shared, vlnce_segment_sum.
-extern "C" int vlnce_version(void) { return 139; }
+// 140: option "m3" (conv_m3_kernel).
+extern "C" int vlnce_version(void) { return 140; }
 
 // ---- dispatch options: one int per name, process-wide, relaxed atomics (a tuning / test knob,
 // not a synchronisation point: set them before the launches they are meant for)
@@ -38,9 +39,10 @@ const OptDef kOpts[VLNCE_OPT_COUNT] = {
     {"conv_math", 1},   {"p3", 2},          {"p3_tile", 0},         {"s3", 1},
     {"u3", 1},          {"u3_waves", 8},    {"x3_tile", 0},         {"igemm_tile", 0},
     {"igemm_nobuf", 0}, {"igemm_no_splitk", 0}, {"wgrad_tile", 64}, {"rollout_one_xcd", 0},
+    {"m3", 1},
 };
 std::atomic<int> g_opt[VLNCE_OPT_COUNT] = {
-    {1}, {2}, {0}, {1}, {1}, {8}, {0}, {0}, {0}, {0}, {64}, {0},
+    {1}, {2}, {0}, {1}, {1}, {8}, {0}, {0}, {0}, {0}, {64}, {0}, {1},
 };
 int opt_index(const char* name) {
   if (name)

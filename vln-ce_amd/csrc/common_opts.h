@@ -19,6 +19,7 @@ enum {
   VLNCE_OPT_IGEMM_NO_SPLITK,  // 1 = no split-K
   VLNCE_OPT_WGRAD_TILE,       // 64 (default) or 128
   VLNCE_OPT_ROLLOUT_ONE_XCD,  // 1 = the GRU rollout's workgroups on one XCD
+  VLNCE_OPT_M3,               // conv_m3_kernel: 0 off, 1 the small launches (default), 2 every layer it covers
   VLNCE_OPT_COUNT
 };
 int vlnce_opt(int id);

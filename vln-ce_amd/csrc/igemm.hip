@@ -1640,6 +1640,10 @@ extern "C" int vlnce_conv2d_fwd(const float* x, const float* w, float* y, const 
     return bn_finalize_behind(dispatch_dual(p, s));
   }
   if (v4 && buf_ok(p)) {
+    // small launches (the depth trunk, any layer at a few environments): conv_m3_kernel
+    g_last_path = VLNCE_CONV_PATH_M3;
+    if (const int rc = m3_try_launch(p, s); rc >= 0) return bn_sums_behind(rc);
+    g_last_path = VLNCE_CONV_PATH_F32;
     // Small batches (act() at num_envs 1..8, eval BatchNorm folded into scale/shift): a late
     // ResNet layer is a handful of 64x64 tiles with a reduction of up to 144 K-tiles -- one
     // workgroup walking them alone is pure latency (20-50 us per layer).  Split the reduction

@@ -354,5 +354,6 @@ static inline int conv_math() { return vlnce_opt(VLNCE_OPT_CONV_MATH) != 0; }
 // conv_p3.hip: the patch-resident bf16-plane convolution.  Returns -1 when the problem is not
 // one it covers (the caller falls through to conv_x3_kernel / igemm_kernel), else a C-ABI status.
 int p3_try_launch(const IgemmParams& p, hipStream_t stream);
+int m3_try_launch(const IgemmParams& p, hipStream_t stream);   // conv_m3.hip
 
 }  // namespace vlnce_detail
