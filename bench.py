@@ -21,7 +21,7 @@ backward and Adam, over 4 distinct resident batches in rotation.  Beside it
 trunks of batch k+1 issued on side HIP streams before batch k's update is enqueued.
 
 The JSON line also carries `roofline` (dominant kernel = the implicit-GEMM convolution:
-conv_p3 / conv_u3 / conv_s3 / conv_x3 / stem7 kernels, fp32 operands split exactly into three bf16
+conv_p3 / conv_u3 / conv_s3 / conv_x3 / conv_m3 / stem7 kernels, fp32 operands split exactly into three bf16
 planes and multiplied as six plane products on the bf16 matrix pipe, plus the fp32-MFMA igemm_kernel
 for the depth stem and the small layers; every launch timed with HIP events on the launch stream and
 attributed to the kernel the library dispatched it to; `frac` prices the ALGORITHMIC fp32 FLOPs
@@ -644,7 +644,7 @@ def main():
         ok = conv["reason"] is None
         achieved = conv_flop / (conv_ms * 1e-3) / 1e12 if ok else None
         # per kernel family, from the library's own dispatch record (vlnce_conv2d_last_path)
-        fam = {0: "fp32_mfma", 1: "bf16_planes_x3", 2: "bf16_planes_p3"}
+        fam = {0: "fp32_mfma", 1: "bf16_planes_x3", 2: "bf16_planes_p3", 3: "bf16_planes_m3"}
         paths = {fam.get(k, str(k)): v for k, v in conv["by_path"].items()}
         bf = [v for k, v in paths.items() if k.startswith("bf16")]
         bf_ms, bf_flop = sum(v["ms"] for v in bf), sum(v["flop"] for v in bf)
@@ -685,8 +685,11 @@ def main():
                                    "their MFMAs), conv_s3_kernel (short-K 1x1 expansions: whole K "
                                    "resident, tile n+1's loads under tile n's stores), "
                                    "conv_x3_kernel (the other 1x1 / strided: im2col K-tiles through "
-                                   "LDS, 8 producer + 8 matrix waves) and stem7_kernel (the 7x7/s2 "
-                                   "RGB stem straight from the frames); all five: fp32 operands "
+                                   "LDS, 8 producer + 8 matrix waves), conv_m3_kernel (small "
+                                   "launches -- the depth trunk: A fragments straight from global "
+                                   "memory, reduction split over a workgroup's waves) and "
+                                   "stem7_kernel (the 7x7/s2 RGB stem straight from the frames); "
+                                   "all six: fp32 operands "
                                    "split exactly into 3 bf16 planes, 6 x "
                                    "v_mfma_f32_32x32x16_bf16 per 32x32x16 block, fp32 accumulate, "
                                    "train-mode BatchNorm column sums taken in the epilogue; "

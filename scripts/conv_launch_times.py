@@ -24,7 +24,7 @@ pol = vlnce_amd.build_model(vlnce_amd.make_config("CMAPolicy"), *vlnce_amd.make_
 obs = {"rgb": torch.randint(0, 256, (a.n, 256, 256, 3), device=dev).float(),
        "depth": torch.rand(a.n, 256, 256, 1, device=dev)}
 orig, orig_bn, orig_stem = ops.conv2d_nhwc, ops.conv2d_bn_sums, ops.stem7
-PATHS = {0: "igemm", 1: "x3", 2: "p3/u3/s3", 9: "stem7"}
+PATHS = {0: "igemm", 1: "x3", 2: "p3/u3/s3", 3: "m3", 9: "stem7"}
 rec = []
 
 

@@ -9,7 +9,7 @@ import re
 import sys
 
 CONV = ("conv_p3_kernel", "conv_u3_kernel", "conv_s3_kernel", "conv_x3_kernel", "igemm_kernel",
-        "stem7_kernel")
+        "stem7_kernel", "conv_m3_kernel")
 
 
 def segments(path):
@@ -42,7 +42,7 @@ fb, wb = fkb * 1024 / f_frac, wkb * 1024 / w_frac
 out = {
     "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over "
               "`python bench.py --pmc-step`, segment 2 = the two visual trunks' forward (N=64, "
-              "256x256): conv_p3 / conv_u3 / conv_s3 / conv_x3 / stem7 / igemm dispatches only (" + sys.argv[4] + ")",
+              "256x256): conv_p3 / conv_u3 / conv_s3 / conv_x3 / conv_m3 / stem7 / igemm dispatches only (" + sys.argv[4] + ")",
     "calibration": {"note": "256 MiB device copy in the same run (segment 1): FETCH_SIZE reports this "
                             "fraction of the bytes read (gfx950: 1/2), WRITE_SIZE this fraction of "
                             "the bytes written",
