@@ -239,7 +239,7 @@ struct Stem7Params {
 // instructions / output stores, which a workgroup runs one after the other: 79 + 100 + 77 us of
 // the 258 us launch at num_envs 64, profiles/r04_zh_*) drift apart and overlap.
 template <int NB, int WAVES>   // NB = Cout / 32 (1 or 2)
-__global__ __launch_bounds__(WAVES * 64) void stem7_kernel(Stem7Params p) {
+__global__ __launch_bounds__(WAVES * 64, 8 / WAVES) void stem7_kernel(Stem7Params p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int NTHR = WAVES * 64;
   constexpr int TH = 2 * WAVES / NB;              // output rows of a tile
@@ -340,6 +340,32 @@ __global__ __launch_bounds__(WAVES * 64) void stem7_kernel(Stem7Params p) {
   int par = 0;
   constexpr int PA[6] = {2, 1, 0, 1, 0, 0};  // smallest products first
   constexpr int PB[6] = {0, 1, 2, 0, 1, 0};
+  // The 16 stores of a finished tile are issued UNDER the next tile's matrix instructions
+  // (conv_s3_kernel's recipe: a second accumulator set, one or two stores behind each k-slab's six
+  // MFMAs, fire-and-forget): a tile used to be [patch build | 66 MFMAs | 16 stores] back to back,
+  // with the CU's two workgroups in phase.  prv = the previous tile's raw accumulators, p_* where
+  // its stores go (p_rows < 0: there is no previous tile, every store takes the out-of-range offset).
+  f32x16 prv;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) prv[r] = 0.f;
+  long p_base = 0;
+  int p_oy0 = 0x40000000, p_cols_left = 0;
+  const long row_b = (long)p.Wo * p.Cout * 4;
+  const int lane_off = (4 * half * p.Cout + col) * 4;
+  auto store_prev = [&](int first, int count) {
+#pragma unroll
+    for (int r = first; r < first + count; ++r) {
+      const int row = r >> 3, cpart = (r & 3) + 8 * ((r >> 2) & 1);
+      const float lin = prv[r] * e_sc + e_sh;
+      const float v = relu_out ? (lin > 0.f ? lin : 0.f) : lin;
+      const bool ok = p_oy0 + row < p.Ho && cpart < p_cols_left;
+#ifndef S7_DBG_NOSTORE
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc_y,
+                                            ok ? lane_off + cpart * p.Cout * 4 : BUF_OOB,
+                                            (int)(p_base + row * row_b), 0);
+#endif
+    }
+  };
   for (; tile < ntiles; tile += gridDim.x, par ^= 1) {
     const char* buf = xsm + par * PBUF;
     // the next tile's patch (fetched a tile ago) goes into the other buffer FIRST -- its LDS
@@ -351,9 +377,10 @@ __global__ __launch_bounds__(WAVES * 64) void stem7_kernel(Stem7Params p) {
     // this lane's pixel of the wave's 32: (dy, dx) inside the tile
     const int dy = 2 * wm + (l31 >> 4), dx = l31 & 15;
     const char* abase = buf + (2 * dy) * S7_ROWB + dx * 12;
-    f32x16 acc, acc1;   // even / odd k-slabs: two independent accumulation chains
+    f32x16 acc;   // (one accumulation chain: the second set of 16 registers holds the previous
+                  // tile's results for the deferred stores; two waves per SIMD interleave their chains)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = acc1[r] = 0.f;
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     // A fragments one k-slab ahead (two register sets, the loop is fully unrolled): left to the
     // compiler every slab was [6 LDS reads, s_waitcnt lgkmcnt(0), 6 MFMAs]
     auto readA = [&](u32x4 (&fa)[3], int ks) {
@@ -387,16 +414,26 @@ __global__ __launch_bounds__(WAVES * 64) void stem7_kernel(Stem7Params p) {
 #pragma unroll
       for (int q = 0; q < 6; ++q) {
         if (ks & 1)
-          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f1[PA[q]]),
-                                                         bres[ks][PB[q]], acc1, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f1[PA[q]]),
+                                                        bres[ks][PB[q]], acc, 0, 0, 0);
         else
           acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f0[PA[q]]),
                                                         bres[ks][PB[q]], acc, 0, 0, 0);
       }
+      // the previous tile's stores: two behind each of the first five slabs, one behind the rest
+      if (ks < 5) {
+        store_prev(2 * ks, 2);
+        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);  // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);  // VMEM write
+        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+        __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);
+      } else {
+        store_prev(10 + (ks - 5), 1);
+        __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+        __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] += acc1[r];
     // ---- epilogue: MFMA row index pi = (r & 3) + 8 (r >> 2) + 4 half -> pixel (2 wm + pi / 16, pi % 16)
     const int img = (int)(tile / per_img), rem = (int)(tile - (long)img * per_img);
     const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
@@ -430,27 +467,15 @@ __global__ __launch_bounds__(WAVES * 64) void stem7_kernel(Stem7Params p) {
     }
     // stores: pixel pi -> output row pi >> 4 = r >> 3 (wave-uniform per register), column
     // (r & 3) + 8 ((r >> 2) & 1) + 4 half: one buffer store per register with the lane part in
-    // the vector offset, the tile / row part in the scalar offset and the rest an immediate
-    {
-      const long row_b = (long)p.Wo * p.Cout * 4;
-      const long base = (((long)img * p.Ho + oy0) * p.Wo + ox0) * p.Cout * 4;   // < 2^31 (launcher)
-      const int lane_off = (4 * half * p.Cout + col) * 4;
-      const int cols_left = p.Wo - ox0 - 4 * half;   // columns this lane's first pixel may still use
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = r >> 3, cpart = (r & 3) + 8 * ((r >> 2) & 1);
-        const float lin = acc[r] * e_sc + e_sh;
-        const float v = relu_out ? (lin > 0.f ? lin : 0.f) : lin;
-        const bool ok = oy0 + row < p.Ho && cpart < cols_left;
-#ifndef S7_DBG_NOSTORE
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc_y,
-                                              ok ? lane_off + cpart * p.Cout * 4 : BUF_OOB,
-                                              (int)(base + row * row_b), 0);
-#endif
-      }
-    }
+    // the vector offset, the tile / row part in the scalar offset and the rest an immediate --
+    // issued under the NEXT tile's matrix instructions (store_prev)
+    prv = acc;
+    p_base = (((long)img * p.Ho + oy0) * p.Wo + ox0) * p.Cout * 4;   // < 2^31 (launcher)
+    p_oy0 = oy0;
+    p_cols_left = p.Wo - ox0 - 4 * half;   // columns this lane's first pixel may still use
     __syncthreads();   // the next tile's patch is complete; this tile's buffer is free again
   }
+  store_prev(0, 16);   // the last tile's stores have nothing left to hide under
   if (p.bn_acc != nullptr && half == 0) {
     double* q = p.bn_acc + ((long)(blockIdx.x % VLNCE_BN_SHARDS) * p.Cout + col) * 2;
     unsafeAtomicAdd(q, bn_s);

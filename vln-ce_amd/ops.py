@@ -1006,11 +1006,15 @@ class RNNSeqFn(Function):
         res = [None, None, None, None]
         for d in range(dirs):
             dG = dgh[d] if kind == 1 else dgi[d]
-            zero = torch.zeros((1, B, H), device=dev, dtype=torch.float32)
-            # state entering step t: previous output in processing order (zeros at the start)
-            hprev = torch.cat([outs[d][1:], zero] if d == 1 else [zero, outs[d][:-1]], dim=0)
+            # dW_hh = dG^T H_prev, H_prev = the state entering each step = the previous output in
+            # processing order: outs shifted by one step (zeros at the start: that step adds
+            # nothing, and outputs past a row's length are zeros), i.e. two views, no copy
             dw = torch.empty((GH, H), device=dev, dtype=torch.float32)
-            lib.gemm(dG, GH, 1, hprev, H, 1, dw, H, GH, H, Lm * B)  # dW_hh = dG^T H_prev
+            if Lm > 1:
+                dG_s, h_s = (dG[:-1], outs[d][1:]) if d == 1 else (dG[1:], outs[d][:-1])
+                lib.gemm(dG_s, GH, 1, h_s, H, 1, dw, H, GH, H, (Lm - 1) * B)
+            else:
+                dw.zero_()
             db = torch.empty((GH,), device=dev, dtype=torch.float32)
             lib.colsum(dG, GH, Lm * B, GH, db, 0)
             res += [dgi[d], dw, db]
