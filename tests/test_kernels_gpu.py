@@ -306,6 +306,32 @@ def test_attention_autograd_matches_torch(hip):
     close(q.grad, q2.grad, what="d q")
 
 
+def test_large_linear_runs_on_the_bf16_plane_kernels(hip):
+    """ops.linear with >= 2048 rows and >= 1 GFLOP (sequence-mode batches: rgb_kv at 500 x 16
+    rows, the Waypoint tail at 416 frames) goes through vlnce_conv2d_fwd as a 1x1 convolution --
+    forward with bias + ReLU, and the input gradient as dz (W^T)^T; values and all three gradients
+    against fp64 at 1e-4.  Rows with a stride (a column slice of a wider matrix) included."""
+    M, K, N = 4000, 544, 288     # 4000 = 4 x 1000 pixel rows; 2 M N K = 1.25 GFLOP
+    wide = rnd(M, K + 32, seed=1)
+    w, b, g = rnd(N, K, seed=2, scale=0.1), rnd(N, seed=3), rnd(M, N, seed=4)
+    for act in (ops.ACT_NONE, ops.ACT_RELU):
+        xd = wide.to(DEV).requires_grad_()
+        wd, bd = w.to(DEV).requires_grad_(), b.to(DEV).requires_grad_()
+        hip.set_option("m3", hip.get_option("m3"))   # (touch the dispatch record)
+        y = ops.linear(xd[:, :K], wd, bd, act)
+        assert hip.conv2d_last_path() in (1, 2, 3)       # a bf16-plane kernel took it
+        (y * g.to(DEV)).sum().backward()
+        xr = wide.double().requires_grad_()
+        wr, br = w.double().requires_grad_(), b.double().requires_grad_()
+        ref = xr[:, :K] @ wr.t() + br
+        ref = torch.relu(ref) if act == ops.ACT_RELU else ref
+        (ref * g.double()).sum().backward()
+        close(y, ref, what="y")
+        close(xd.grad, xr.grad, what="dx")
+        close(wd.grad, wr.grad, what="dW")
+        close(bd.grad, br.grad, what="db")
+
+
 # ------------------------------------------------------------------ categorical action head
 @pytest.mark.parametrize("cfg", [(64, 512, 4), (1, 512, 4), (7, 512, 6), (64, 514, 6), (300, 96, 16),
                                  (2500, 512, 4), (5, 33, 1)])

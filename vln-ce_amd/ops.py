@@ -472,6 +472,27 @@ def rowzero_mask(x3):
 
 
 # ----------------------------------------------------------------- linear / 1x1 conv
+def _planes_gemm(x, ldx, w, y, bias=None, act=ACT_NONE):
+    """y[M,N] = act(x[M,K] w[N,K]^T + bias) through the convolution entry point (a 1x1 convolution
+    over M pixels: the bf16-plane kernels, fp32-class arithmetic at 1.5-2.5x the fp32-MFMA GEMM's
+    rate) when the product is large enough to pay for splitting the weights (two small launches per
+    call: a trainable layer's weights change every step).  False: not taken, use lib.gemm."""
+    M, K = x.shape
+    N = w.size(0)
+    if (not x.is_cuda or M < 2048 or K % 32 or N % 32 or 2.0 * M * N * K < 1e9
+            or os.environ.get("VLNCE_LINEAR_PLANES", "1") == "0"):
+        return False
+    Wd = next((d for d in range(min(M, 1024), 0, -1) if M % d == 0), 1)   # rows of <= 1024 pixels
+    if M // Wd > 32767:
+        return False
+    g = dict(N=1, H=M // Wd, W=Wd, Cin=K, Cout=N, KH=1, KW=1, stride=1, pad=0, Ho=M // Wd, Wo=Wd,
+             ldx=ldx, ldy=N)
+    w4 = w.view(N, 1, 1, K)
+    L().conv2d_fwd(x, w4, y, g, shift=bias, ldr=N, act=act, w_split=split_weights(w4),
+                   w_frag=pack_weights(w4))
+    return True
+
+
 class LinearFn(Function):
     """y = act(x W^T + b).  x [M,K] (row stride >= K), W [N,K], b [N] | None.
     dx_from > 0: only columns [dx_from, K) of the input gradient are wanted (the leading columns
@@ -486,7 +507,8 @@ class LinearFn(Function):
         N = weight.size(0)
         w = weight if weight.is_contiguous() else weight.contiguous()
         y = torch.empty((M, N), device=x.device, dtype=torch.float32)
-        L().gemm(x, ldx, 0, w, K, 0, y, N, M, N, K, shift=bias, act=act)
+        if not _planes_gemm(x, ldx, w, y, bias, act):
+            L().gemm(x, ldx, 0, w, K, 0, y, N, M, N, K, shift=bias, act=act)
         ctx.act = act
         ctx.has_bias = bias is not None
         ctx.dx_from = int(dx_from) if 0 < int(dx_from) < K and int(dx_from) % 4 == 0 else 0
@@ -514,8 +536,10 @@ class LinearFn(Function):
                 lib.gemm(dz, N, 0, w[:, c0:], K, 1, dx[:, c0:], K, M, K - c0, N, accumulate=1)
             else:
                 dx = torch.empty((M, K), device=dz.device, dtype=torch.float32)
-                # dx[M,K] = dz[M,N] * W[N,K]   (B stored [K'=N, N'=K])
-                lib.gemm(dz, N, 0, w, K, 1, dx, K, M, K, N)
+                # dx[M,K] = dz[M,N] * W[N,K]   (B stored [K'=N, N'=K]); large: as dz (W^T)^T on the
+                # bf16-plane kernels (one transpose of the weights)
+                if not (M >= 2048 and _planes_gemm(dz, N, w.t().contiguous(), dx)):
+                    lib.gemm(dz, N, 0, w, K, 1, dx, K, M, K, N)
         if ctx.needs_input_grad[1]:
             dw = torch.empty((N, K), device=dz.device, dtype=torch.float32)
             # dW[N,K] = dz^T[N,M] * x[M,K]
