@@ -306,6 +306,23 @@ def test_attention_autograd_matches_torch(hip):
     close(q.grad, q2.grad, what="d q")
 
 
+@pytest.mark.parametrize("M", [64, 1000])
+def test_linear_input_gradient_for_the_trailing_columns_only(hip, M):
+    """ops.linear(dx_from=c0): the input gradient is computed for columns [c0, K) only and the
+    leading ones (a frozen trunk's features) come back zero; weight / bias gradients are the full
+    ones.  Against fp64 autograd."""
+    K, N, c0 = 2112, 320, 2048
+    x, w, b, g = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.05), rnd(N, seed=3), rnd(M, N, seed=4)
+    xd, wd, bd = (t.to(DEV).requires_grad_() for t in (x, w, b))
+    (ops.linear(xd, wd, bd, dx_from=c0) * g.to(DEV)).sum().backward()
+    xr, wr, br = (t.double().requires_grad_() for t in (x, w, b))
+    ((xr @ wr.t() + br) * g.double()).sum().backward()
+    assert float(xd.grad[:, :c0].abs().max()) == 0.0
+    close(xd.grad[:, c0:], xr.grad[:, c0:], what="dx trailing columns")
+    close(wd.grad, wr.grad, what="dW")
+    close(bd.grad, br.grad, what="db")
+
+
 def test_large_linear_runs_on_the_bf16_plane_kernels(hip):
     """ops.linear with >= 2048 rows and >= 1 GFLOP (sequence-mode batches: rgb_kv at 500 x 16
     rows, the Waypoint tail at 416 frames) goes through vlnce_conv2d_fwd as a 1x1 convolution --
