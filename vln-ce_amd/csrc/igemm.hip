@@ -1304,7 +1304,7 @@ int choose_splitk(const IgemmParams& p, bool long_reduction_form = false) {
   // rgb_kv at 500 rows x 16 positions): a few hundred tiles with one workgroup per CU walk a
   // 250-step K loop with nothing to hide its latency behind -- four workgroups per CU as in
   // vlnce_conv2d_wgrad (364 -> ~190 us there)
-  if (long_reduction_form && KT >= 64 && tiles >= 128 && tiles < 1024) {
+  if (long_reduction_form && KT >= 32 && tiles >= 128 && tiles < 1024) {
     long s = (1024 + tiles - 1) / tiles;
     if (s > KT / 4) s = KT / 4;
     return s < 2 ? 1 : (int)s;
