@@ -98,14 +98,28 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(
   const float* Vb = V + kb * P * ldv;
   const float* Kb = K + kb * P * ldk;
   const float* qb = q + (long)b * Dk;
-  // d attn[i] = <dout, V[i]>,  dV[i] = attn[i] * dout
+  // d attn[i] = <dout, V[i]>,  dV[i] = attn[i] * dout   (a wave per key row; 16-byte accesses where
+  // the rows allow it: the kernel is a chain of P row reads and writes, 4-byte ones were 47 us for
+  // the text attention of a 64-environment step)
+  const bool vec_v = ((Dv & 3) == 0) && ((ldv & 3) == 0) && (dV == nullptr || (lddv & 3) == 0) &&
+                     ((reinterpret_cast<uintptr_t>(V) | reinterpret_cast<uintptr_t>(dout) |
+                       reinterpret_cast<uintptr_t>(dV)) & 15) == 0;
   for (int i = wave; i < P; i += 4) {
     const float a = ab[i];
     float s = 0.f;
-    for (int c = lane; c < Dv; c += 64) {
-      const float g = dob[c];
-      s += g * Vb[(long)i * ldv + c];
-      if (dV) dV[((long)b * P + i) * lddv + c] = a * g;
+    if (vec_v) {
+      for (int c = lane * 4; c < Dv; c += 256) {
+        const f32x4 g = *reinterpret_cast<const f32x4*>(dob + c);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(Vb + (long)i * ldv + c);
+        s += g.x * v.x + g.y * v.y + g.z * v.z + g.w * v.w;
+        if (dV) *reinterpret_cast<f32x4*>(dV + ((long)b * P + i) * lddv + c) = f32x4{a * g.x, a * g.y, a * g.z, a * g.w};
+      }
+    } else {
+      for (int c = lane; c < Dv; c += 64) {
+        const float g = dob[c];
+        s += g * Vb[(long)i * ldv + c];
+        if (dV) dV[((long)b * P + i) * lddv + c] = a * g;
+      }
     }
     s = wave_sum(s);
     if (lane == 0) dl[i] = s;
@@ -122,6 +136,49 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(
   }
   __syncthreads();
   // dK[i] = dl[i] * q ; dq = sum_i dl[i] * K[i]
+  const bool vec_k = ((Dk & 3) == 0) && ((ldk & 3) == 0) && (dK == nullptr || (lddk & 3) == 0) &&
+                     Dk <= 1024 &&
+                     ((reinterpret_cast<uintptr_t>(K) | reinterpret_cast<uintptr_t>(q) |
+                       reinterpret_cast<uintptr_t>(dK) | reinterpret_cast<uintptr_t>(dq)) & 15) == 0;
+  if (vec_k) {
+    // a wave per key row, 16 bytes per lane; the waves' partial dq meet in LDS (the logits' array
+    // is free: dl has been read into registers per row)
+    __shared__ f32x4 dq_part[4][256];   // [wave][Dk / 4 <= 256]
+    f32x4 acc[4];                       // Dk <= 1024: up to 4 strips of 256 columns per wave
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = wave; i < P; i += 4) {
+      const float g = dl[i];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int c = lane * 4 + t * 256;
+        if (c < Dk) {
+          const f32x4 kv = *reinterpret_cast<const f32x4*>(Kb + (long)i * ldk + c);
+          acc[t].x += g * kv.x;
+          acc[t].y += g * kv.y;
+          acc[t].z += g * kv.z;
+          acc[t].w += g * kv.w;
+          if (dK) {
+            const f32x4 qv = *reinterpret_cast<const f32x4*>(qb + c);
+            *reinterpret_cast<f32x4*>(dK + ((long)b * P + i) * lddk + c) =
+                f32x4{g * qv.x, g * qv.y, g * qv.z, g * qv.w};
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      if (lane * 4 + t * 256 < Dk) dq_part[wave][lane + t * 64] = acc[t];
+    __syncthreads();
+    if (dq)
+      for (int c4 = tid; c4 * 4 < Dk; c4 += 256) {
+        const f32x4 a0 = dq_part[0][c4], a1 = dq_part[1][c4], a2 = dq_part[2][c4], a3 = dq_part[3][c4];
+        *reinterpret_cast<f32x4*>(dq + (long)b * Dk + c4 * 4) =
+            f32x4{(a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y),
+                  (a0.z + a1.z) + (a2.z + a3.z), (a0.w + a1.w) + (a2.w + a3.w)};
+      }
+    return;
+  }
   for (int c = tid; c < Dk; c += 256) {
     const float qc = qb[c];
     float acc = 0.f;
