@@ -413,3 +413,47 @@ def test_distinct_instruction_path_matches_reference_golden(sim):
                           vlnce_amd.AuxLosses, ppo_fn=product_ppo)
     assert seen and seen[0] is not None and int(seen[0].max()) + 1 < obs["instruction"].size(0)
     compare(outs, gold, atol=1e-4, rtol=1e-4)
+
+
+def test_linear_dx_from_and_frozen_feature_columns(sim):
+    """ops.linear(dx_from=c0) returns the input gradient of the trailing columns only (leading ones
+    zero) with the full weight / bias gradients; CMANet._frozen_cols says how many leading channels
+    of an encoder's output cannot need a gradient: the trunk's channels when it is frozen or its
+    features came in precomputed, none when the trunk trains or an ablation multiplies the rows."""
+    from vlnce_amd import ops
+    torch.manual_seed(0)
+    x = torch.randn(6, 40, requires_grad=True)
+    w = torch.randn(12, 40, requires_grad=True)
+    b = torch.randn(12, requires_grad=True)
+    g = torch.randn(6, 12)
+    (ops.linear(x, w, b, dx_from=32) * g).sum().backward()
+    got = (x.grad.clone(), w.grad.clone(), b.grad.clone())
+    x.grad = w.grad = b.grad = None
+    (torch.nn.functional.linear(x, w, b) * g).sum().backward()
+    assert torch.equal(got[0][:, :32], torch.zeros(6, 32))
+    assert torch.allclose(got[0][:, 32:], x.grad[:, 32:], atol=1e-5)
+    assert torch.allclose(got[1], w.grad, atol=1e-5) and torch.allclose(got[2], b.grad, atol=1e-5)
+    # dx_from that is not a multiple of 4 (alignment of the column slice) or out of range: ignored
+    x.grad = None
+    (ops.linear(x, w, b, dx_from=30) * g).sum().backward()
+    assert float(x.grad[:, :30].abs().min()) > 0.0
+
+    case = cases.CASES["cma_update_64"]
+    policy, _ = cases.build_policy(vlnce_amd, case, vlnce_amd.make_config, vlnce_amd.make_spaces,
+                                   tp.synth_state_dict)
+    net = policy.net
+    rgb_c = net.rgb_encoder.output_shape[0] - 64
+    dep_c = net.depth_encoder.output_shape[0] - 64
+    assert net._frozen_cols(net.rgb_encoder, "rgb_features", {}) == rgb_c > 0
+    assert net._frozen_cols(net.depth_encoder, "depth_features", {}) == dep_c > 0
+    for p in net.rgb_encoder.trunk_parameters():
+        p.requires_grad_(True)
+    assert net._frozen_cols(net.rgb_encoder, "rgb_features", {}) == 0
+    feats = torch.zeros(2, rgb_c, 4, 4)
+    assert net._frozen_cols(net.rgb_encoder, "rgb_features", {"rgb_features": feats}) == rgb_c
+    assert net._frozen_cols(net.rgb_encoder, "rgb_features",
+                            {"rgb_features": feats.requires_grad_()}) == 0
+    net.model_config.defrost()
+    net.model_config.ablate_depth = True
+    net.model_config.freeze()
+    assert net._frozen_cols(net.depth_encoder, "depth_features", {}) == 0
