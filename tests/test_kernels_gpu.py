@@ -324,7 +324,7 @@ def test_linear_input_gradient_for_the_trailing_columns_only(hip, M):
 
 
 def test_large_linear_runs_on_the_bf16_plane_kernels(hip):
-    """ops.linear with >= 2048 rows and >= 1 GFLOP (sequence-mode batches: rgb_kv at 500 x 16
+    """ops.linear with >= 1024 rows and >= 1 GFLOP (sequence-mode batches: rgb_kv at 500 x 16
     rows, the Waypoint tail at 416 frames) goes through vlnce_conv2d_fwd as a 1x1 convolution --
     forward with bias + ReLU, and the input gradient as dz (W^T)^T; values and all three gradients
     against fp64 at 1e-4.  Rows with a stride (a column slice of a wider matrix) included."""

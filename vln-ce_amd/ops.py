@@ -475,11 +475,12 @@ def rowzero_mask(x3):
 def _planes_gemm(x, ldx, w, y, bias=None, act=ACT_NONE):
     """y[M,N] = act(x[M,K] w[N,K]^T + bias) through the convolution entry point (a 1x1 convolution
     over M pixels: the bf16-plane kernels, fp32-class arithmetic at 1.5-2.5x the fp32-MFMA GEMM's
-    rate) when the product is large enough to pay for splitting the weights (two small launches per
-    call: a trainable layer's weights change every step).  False: not taken, use lib.gemm."""
+    rate) when the product is large enough (>= 1024 rows and >= 1 GFLOP: rgb_kv of a 64-environment
+    step, 1024 x 2112 -> 512, is 60 us on the fp32-MFMA GEMM) to pay for splitting the weights (two
+    small launches per call: a trainable layer's weights change every step).  False: not taken, use lib.gemm."""
     M, K = x.shape
     N = w.size(0)
-    if (not x.is_cuda or M < 2048 or K % 32 or N % 32 or 2.0 * M * N * K < 1e9
+    if (not x.is_cuda or M < 1024 or K % 32 or N % 32 or 2.0 * M * N * K < 1e9
             or os.environ.get("VLNCE_LINEAR_PLANES", "1") == "0"):
         return False
     Wd = next((d for d in range(min(M, 1024), 0, -1) if M % d == 0), 1)   # rows of <= 1024 pixels
@@ -538,7 +539,7 @@ class LinearFn(Function):
                 dx = torch.empty((M, K), device=dz.device, dtype=torch.float32)
                 # dx[M,K] = dz[M,N] * W[N,K]   (B stored [K'=N, N'=K]); large: as dz (W^T)^T on the
                 # bf16-plane kernels (one transpose of the weights)
-                if not (M >= 2048 and _planes_gemm(dz, N, w.t().contiguous(), dx)):
+                if not (M >= 1024 and _planes_gemm(dz, N, w.t().contiguous(), dx)):
                     lib.gemm(dz, N, 0, w, K, 1, dx, K, M, K, N)
         if ctx.needs_input_grad[1]:
             dw = torch.empty((N, K), device=dz.device, dtype=torch.float32)
