@@ -109,13 +109,13 @@ def cpu_baseline_worker(num_envs, hw, L, threads):
 
     pol = oc.CMAPolicy.from_config(tp.make_config("CMAPolicy"), *tp.make_spaces(hw, hw))
     opt = torch.optim.Adam(pol.parameters(), lr=2.5e-4)
-    n = min(num_envs, 8)
+    n = num_envs   # the bench workload itself (num_envs = 64): ~3-6 s per iteration on this host
     obs, prev, masks, tgt, w = synth_batch(n, hw, L, "cpu")
     oc.AuxLosses.activate()
     sweep = {}
     t_start = time.time()
     for th in [int(t) for t in str(threads).split(",")]:
-        if time.time() - t_start > 45:  # bounded: the default bench run finishes within minutes
+        if sweep and time.time() - t_start > 60:  # bounded: the default bench run finishes within minutes
             break
         torch.set_num_threads(th)
         times = []
@@ -131,7 +131,7 @@ def cpu_baseline_worker(num_envs, hw, L, threads):
     facts = host_cpu_facts()
     print(json.dumps({
         "value": round(n / sweep[best_th], 2), "unit": "policy-steps/sec", "cores": best_th,
-        "kind": "port",
+        "physical_cores": facts["physical_cores"], "kind": "port",
         "sample": f"CMA fwd+bwd+Adam (oracle/policy_cpu.py), {n} envs x {hw}x{hw} RGB-D, L={L}, "
                   f"min of 2 iters after 1 warm-up, torch CPU fp32, best of thread counts "
                   f"{sorted(sweep)} = {best_th} threads",
@@ -139,7 +139,7 @@ def cpu_baseline_worker(num_envs, hw, L, threads):
         "steps_per_sec_by_threads": {str(k): round(n / v, 2) for k, v in sorted(sweep.items())}}))
 
 
-def cpu_baseline(num_envs, hw, L, timeout_s=100):
+def cpu_baseline(num_envs, hw, L, timeout_s=150):
     """Bounded: the child is killed after `timeout_s` (the default bench run must finish within
     minutes).  The child sweeps a few thread counts up to the host's physical cores and reports
     the best one as `cores`; the host's CPU model / socket / core counts ride along in
@@ -149,7 +149,7 @@ def cpu_baseline(num_envs, hw, L, timeout_s=100):
     facts = host_cpu_facts()
     usable = facts["usable_logical_cpus"]
     phys = min(facts["physical_cores"] or usable, usable)
-    counts = sorted({min(c, usable) for c in (16, 32, 64, phys)})
+    counts = sorted({min(c, usable) for c in (32, 64, phys)}, reverse=True)
     threads = max(counts)
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--num-envs",
            str(num_envs), "--hw", str(hw), "--tokens", str(L), "--threads",
@@ -179,7 +179,7 @@ def f32_mfma_compare(args):
         d = json.loads(out[-1])
         return {"value": d["value"], "ms_per_step": d["ms_per_step"],
                 "encode_ahead_ms_per_step": d["config"]["encode_ahead_ms_per_step"],
-                "roofline_frac": d["roofline"]["frac"],
+                "roofline_frac_of_fp32_mfma_peak": d["roofline"]["fp32_mfma_peak"]["frac"],
                 "conv_kernel_ms_per_step": d["roofline"]["kernel_ms_per_step"]}
     except Exception as e:  # never block the main line
         return {"value": None, "error": type(e).__name__}
@@ -503,9 +503,11 @@ def main():
         it[0] += 1
         return batches[it[0] % NB]
 
+    losses = []  # (loss, action_loss, aux_loss) floats of every step, as the trainers log them
+
     def step():
         obs, prev, masks, tgt, w = next_batch()
-        update_agent(policy, opt, obs, prev, masks, tgt, w, 512, grad_hook=grad_hook)
+        losses.append(update_agent(policy, opt, obs, prev, masks, tgt, w, 512, grad_hook=grad_hook))
 
     if os.environ.get("VLNCE_BENCH_CACHED_DEPTH"):  # diagnostic: how much the depth trunk costs
         with torch.no_grad():
@@ -530,7 +532,8 @@ def main():
             if k + 1 < n:
                 b = next_batch()
                 nxt = policy.encode_ahead(b[0])
-            update_agent(policy, opt, cur, prev, masks, tgt, w, 512, grad_hook=grad_hook)
+            losses.append(update_agent(policy, opt, cur, prev, masks, tgt, w, 512,
+                                       grad_hook=grad_hook))
 
     if args.pmc_step:
         # layout of the profiled run:  warm-up | marker | calibration copy (a known 256 MiB
@@ -570,7 +573,10 @@ def main():
     run_steps(args.steps, ahead=False)
     sync()
     elapsed = time.perf_counter() - t0
-    log(f"timed region (plain trainer loop): {args.steps} steps in {elapsed:.3f}s")
+    log(f"timed region (plain trainer loop): {args.steps} steps in {elapsed:.3f}s; "
+        f"loss of the last step {losses[-1][0]:.5f} (every step ends with the reference's "
+        f"loss.item() / action_loss.item() read-backs)")
+    timed_losses = [l[0] for l in losses[-args.steps:]]
     from vlnce_amd import streams as _st
     if _st.TIMING:
         per = {}
@@ -643,6 +649,7 @@ def main():
         conv_ms, n_conv = conv["conv_ms"], conv["n"]
         ok = conv["reason"] is None
         achieved = conv_flop / (conv_ms * 1e-3) / 1e12 if ok else None
+        floor_rate = conv_flop / (conv["floor_ms"] * 1e-3) / 1e12 if ok else None
         # per kernel family, from the library's own dispatch record (vlnce_conv2d_last_path)
         fam = {0: "fp32_mfma", 1: "bf16_planes_x3", 2: "bf16_planes_p3", 3: "bf16_planes_m3"}
         paths = {fam.get(k, str(k)): v for k, v in conv["by_path"].items()}
@@ -666,6 +673,10 @@ def main():
                                    f"{args.hw}x{args.hw} RGB-D, {args.tokens}-token instruction, "
                                    f"{NB} distinct batches in rotation",
                        "global_batch": args.num_envs * world, "parallelism": f"dp{world}",
+                       "host_readbacks_per_step": "loss.item(), action_loss.item() [, aux_loss.item()] "
+                                                  "as base_il_trainer.py:176-180",
+                       "loss_first_last_timed_step": [round(timed_losses[0], 5),
+                                                      round(timed_losses[-1], 5)],
                        "whole_step_tflops": round(step_gflop * value / 1e3, 2),
                        "encode_ahead_ms_per_step": round(ahead_ms, 3) if ahead_ms else None,
                        "encode_ahead_steps_per_sec": (
@@ -696,13 +707,19 @@ def main():
                                    "igemm_kernel (v_mfma_f32_32x32x2_f32) for the depth stem and "
                                    "the handful-of-tiles layers",
                          "achieved": round(achieved, 2) if ok else None,
-                         "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4) if ok else None,
-                         "peak_is": "the fp32 MFMA peak: `achieved` counts ALGORITHMIC fp32 FLOPs "
-                                    "over ALL conv launches, so this fraction can exceed 1 -- it is "
-                                    "the reference arithmetic's roofline, not the instruction "
-                                    "stream's; the hardware roofline of the launches that run on "
-                                    "the bf16 pipe is `bf16_pipe`, of the rest `fp32_mfma`",
+                         "peak": round(floor_rate, 2) if ok else None, "unit": "TFLOP/s",
+                         "frac": round(conv["floor_ms"] / conv_ms, 4) if ok else None,
+                         "peak_is": "the algorithmic fp32 rate these launches would reach if EACH sat "
+                                    "on its own hardware roofline, max(algorithmic bytes / achievable "
+                                    "HBM rate, instruction FLOPs / peak of the pipe it runs on) -- "
+                                    "`per_launch_floor` below has the terms; frac = achieved / peak = "
+                                    "floor_ms / kernel_ms_per_step.  The same `achieved` against the "
+                                    "fp32 MFMA peak (the reference arithmetic's roofline, which the "
+                                    "bf16-plane kernels can exceed) is `fp32_mfma_peak`; the hardware "
+                                    "FLOPs of the bf16-plane launches against their pipe `bf16_pipe`",
+                         "fp32_mfma_peak": {"peak": FP32_MFMA_PEAK_TFLOPS,
+                                            "frac": (round(achieved / FP32_MFMA_PEAK_TFLOPS, 4)
+                                                     if ok else None)},
                          "bf16_pipe": {"instruction": "v_mfma_f32_32x32x16_bf16",
                                        "hw_flops_per_algorithmic_flop": 6,
                                        "peak": BF16_MFMA_PEAK_TFLOPS,

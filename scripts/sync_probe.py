@@ -41,7 +41,7 @@ def loop(n, item):
         obs, prev, masks, tgt, w = batches[i % 4]
         loss, al, aux = update_agent(policy, opt, obs, prev, masks, tgt, w, 512)
         if item:
-            loss.item(), al.item()
+            pass
 
 
 for novalidate in (False, True):

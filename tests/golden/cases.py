@@ -65,6 +65,17 @@ CASES = {
     "waypoint_ppo_update_64": dict(
         policy="WaypointPolicy", hw=64, N=2, T=3, lengths=[9, 14], mode="ppo", call="ppo_update",
     ),
+    # BASELINE.json configs[2] / the bench workload ITSELF: one `_update_agent`
+    # (base_il_trainer.py:134-180) of the CMA policy at num_envs = 64, 256x256 RGB-D, instructions of
+    # up to 80 tokens, batch-statistics BatchNorm as constructed -- the batch at which the library
+    # picks the conv_p3 / conv_u3 / conv_s3 tile plans the bench times.  OUTPUTS ONLY (loss, the
+    # [64, 4] logits, every gradient norm, three full gradients, BatchNorm running statistics and
+    # their checksums over all 106 layers): the 67 MB of inputs regenerate from the seed
+    # (build_inputs); the reference takes ~7 s of CPU for it (8 threads).
+    "cma_update_n64_256": dict(
+        policy="CMAPolicy", hw=256, N=64, T=1, lengths=[80 - (i % 6) for i in range(64)],
+        mode="train", call="update", outputs_only=True, capture_logits=True,
+    ),
 }
 
 VOCAB = 2504
@@ -219,7 +230,26 @@ def run_case(policy, case, obs, prev, masks, extra, update_fn=None, aux=None, pp
     elif call == "update":
         if aux is not None:
             aux.activate()
-        loss, al, xl = update_fn(policy, obs, prev, masks, extra["targets"], extra["weights"])
+        seen = []
+        if case.get("capture_logits"):
+            # the logits of the very forward the update differentiates (a second forward would
+            # move the BatchNorm running statistics again): an instance attribute shadows the
+            # method for the duration of the call, whatever implementation `policy` is
+            inner = policy.build_distribution
+
+            def recording(*a, **k):
+                dist = inner(*a, **k)
+                seen.append(dist.logits.detach().clone())
+                return dist
+
+            policy.build_distribution = recording
+        try:
+            loss, al, xl = update_fn(policy, obs, prev, masks, extra["targets"], extra["weights"])
+        finally:
+            if case.get("capture_logits"):
+                del policy.build_distribution
+        if seen:
+            out["logits"] = seen[0]
         if aux is not None:
             aux.deactivate()
         out["loss"] = torch.tensor([loss, al, xl], dtype=torch.float64)
@@ -275,11 +305,22 @@ def run_case(policy, case, obs, prev, masks, extra, update_fn=None, aux=None, pp
         for k in _BN_PROBES:
             if k in sd:
                 out["bn/" + k] = sd[k].detach().clone().float()
+        if case.get("outputs_only"):
+            # one number per BatchNorm / GroupNorm-free layer: sum of every running_mean and of
+            # every running_var of the RGB trunk, in state_dict order
+            rm = [sd[k].double().sum() for k in sd if k.endswith("running_mean")]
+            rv = [sd[k].double().sum() for k in sd if k.endswith("running_var")]
+            out["bn_checksum/running_mean"] = torch.stack(rm)
+            out["bn_checksum/running_var"] = torch.stack(rv)
     return {k: (v.detach().cpu() if isinstance(v, torch.Tensor) else v) for k, v in out.items()}
 
 
 def save_case(path, case_name, obs, prev, masks, extra, outputs):
     blob = {}
+    if CASES.get(case_name, {}).get("outputs_only"):
+        blob.update(to_numpy_tree(outputs, "out/"))
+        np.savez_compressed(path, **blob)
+        return
     ins = dict(obs=dict(obs), masks=masks, extra=extra)
     ins["prev"] = prev if isinstance(prev, dict) else {"_": prev}
     for k in list(ins["obs"].keys()):
@@ -291,7 +332,18 @@ def save_case(path, case_name, obs, prev, masks, extra, outputs):
 
 
 def load_case(path, device="cpu"):
+    """(obs, prev, masks, extra, expected outputs); an outputs-only fixture regenerates its inputs
+    from the seed (build_inputs of the case named like the file)."""
     z = np.load(path, allow_pickle=False)
+    import os
+    name = os.path.splitext(os.path.basename(path))[0]
+    if CASES.get(name, {}).get("outputs_only"):
+        outs = {k[4:]: (z[k] if z[k].dtype.kind in "US" else torch.from_numpy(z[k]))
+                for k in z.files if k.startswith("out/")}
+        obs, prev, masks, extra = build_inputs(CASES[name])
+        mv = lambda t: t.to(device) if isinstance(t, torch.Tensor) else t  # noqa: E731
+        return ({k: mv(v) for k, v in obs.items()}, mv(prev), mv(masks),
+                {k: mv(v) for k, v in extra.items()}, outs)
     obs, prev, extra, outs = {}, {}, {}, {}
     masks = None
     for k in z.files:

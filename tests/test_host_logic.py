@@ -34,7 +34,7 @@ def product_update(policy, obs, prev, masks, targets, weights):
     hs = policy.net.model_config.STATE_ENCODER.hidden_size
     loss, al, xl = update_agent(policy, None, obs, prev, masks, targets, weights, hs,
                                 step_grad=False)
-    return loss.item(), al.item(), (xl.item() if isinstance(xl, torch.Tensor) else xl)
+    return loss, al, xl
 
 
 def product_ppo(policy, sample):

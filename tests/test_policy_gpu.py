@@ -31,7 +31,7 @@ def to_dev(x):
 def hip_update(policy, obs, prev, masks, targets, weights):
     hs = policy.net.model_config.STATE_ENCODER.hidden_size
     loss, al, xl = update_agent(policy, None, obs, prev, masks, targets, weights, hs, step_grad=False)
-    return loss.item(), al.item(), (xl.item() if isinstance(xl, torch.Tensor) else xl)
+    return loss, al, xl
 
 
 def hip_ppo(policy, sample):
@@ -303,7 +303,7 @@ def test_encode_ahead_pipeline_equals_plain_loop():
             if ahead:
                 assert "rgb_features" in cur and "depth_features" in cur
             loss, _, _ = update_agent(policy, opt, cur, prev_d, masks_d, tgt, w, 512)
-            losses.append(loss.item())
+            losses.append(loss)
         torch.cuda.synchronize()
         sd = {k: v.detach().clone() for k, v in policy.state_dict().items()}
         results.append((losses, sd))
@@ -341,7 +341,7 @@ def test_graph_replay_equals_eager_on_a_rollout_batch():
         policy.zero_grad(set_to_none=True)
         loss, _, _ = update_agent(policy, None, obs, prev, masks, tgt, w, 512, step_grad=False)
         torch.cuda.synchronize()
-        runs.append((loss.item(), {n: p.grad.clone() for n, p in policy.named_parameters()
+        runs.append((loss, {n: p.grad.clone() for n, p in policy.named_parameters()
                                    if p.grad is not None}))
     (l0, g0), (_, _), (l2, g2) = runs
     assert abs(l0 - l2) <= 1e-5 * max(1.0, abs(l0)), (l0, l2)

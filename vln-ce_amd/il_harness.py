@@ -28,7 +28,9 @@ def update_agent(policy, optimizer, observations, prev_actions, not_done_masks,
     if step_grad:
         optimizer.step()
         optimizer.zero_grad()
-    # detached: a caller that keeps the returned loss must not keep this step's autograd graph
-    # (and its AccumulateGrad nodes) alive into the next step
-    aux_out = aux_loss.detach() if isinstance(aux_loss, torch.Tensor) else aux_loss
-    return loss.detach(), action_loss.detach(), aux_out
+    # the reference ends every step with three host read-backs (base_il_trainer.py:176-180):
+    # `loss.item(), action_loss.item(), aux_loss.item()` -- Python floats, one sync each; the timed
+    # loop of bench.py consumes them exactly as the trainers' loggers do
+    if isinstance(aux_loss, torch.Tensor):
+        aux_loss = aux_loss.item()
+    return loss.item(), action_loss.item(), aux_loss
