@@ -19,7 +19,8 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 torch.distributions.Distribution.set_default_validate_args(False)
-IL_CASES = [n for n, c in cases.CASES.items() if c["policy"] in vlnce_amd.baseline_registry._policies]
+IL_CASES = [n for n, c in cases.CASES.items()
+            if c["policy"] in vlnce_amd.baseline_registry._policies and not c.get("outputs_only")]
 
 
 def to_dev(x):
@@ -52,6 +53,99 @@ def test_hip_policy_matches_reference_golden(name):
     outs = cases.run_case(policy, case, to_dev(obs), to_dev(prev), to_dev(masks), to_dev(extra),
                           hip_update, vlnce_amd.AuxLosses, ppo_fn=hip_ppo)
     compare(outs, gold, atol=1e-4, rtol=1e-4)
+
+
+class _PinnedReLU(torch.nn.Module):
+    """relu(z) whose BACKWARD uses a given 0/1 pattern instead of (z > 0): the sub-gradient side of
+    the units whose pre-activation is within rounding noise of zero is taken from the other
+    implementation.  Keeps the pre-activation for the report."""
+
+    class Fn(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, z, mask):
+            ctx.save_for_backward(mask)
+            return z.clamp_min(0)
+
+        @staticmethod
+        def backward(ctx, g):
+            return g * ctx.saved_tensors[0], None
+
+    def __init__(self, mask):
+        super().__init__()
+        self.mask, self.z = mask, None
+
+    def forward(self, z):
+        self.z = z.detach().clone()
+        return self.Fn.apply(z, self.mask)
+
+
+def test_bench_workload_num_envs_64_matches_reference_golden():
+    """The bench workload itself -- `_update_agent` (base_il_trainer.py:134-180) of the CMA policy at
+    num_envs = 64, 256x256 RGB-D, <= 80 tokens, batch-statistics BatchNorm -- against
+    tests/golden/cma_update_n64_256.npz, written by the REAL reference classes.  This is the batch at
+    which the library dispatches the conv_p3 / conv_u3 / conv_s3 tile plans the bench times.
+
+    1e-4 (north_star) on everything the forward produces: loss, the [64, 4] logits, the probed
+    BatchNorm running statistics and the per-layer checksums of all of them.
+    Gradients: 57 344 ReLU units sit between the trunks and the loss (rgb_linear, depth_linear,
+    second_state_compress at 64 rows); a handful of them have a pre-activation within fp32 rounding
+    noise of zero (|z| ~ 1e-5), where the two implementations may land on different sides and the
+    reference's own gradient is a coin toss (one such unit moves a whole batch row's upstream
+    gradient by 10 %, profiles/r05_a_*).  So every parameter gradient is compared, at 1e-4, with the
+    oracle (pinned to that same golden at 2e-5 in the CPU tier) evaluated with the HIP forward's
+    side on exactly those units -- and the test asserts that they are few and all knife-edge."""
+    name = "cma_update_n64_256"
+    case = cases.CASES[name]
+    obs, prev, masks, extra, gold = cases.load_case(os.path.join(GOLD, name + ".npz"))
+    policy, _ = cases.build_policy(vlnce_amd, case, vlnce_amd.make_config, vlnce_amd.make_spaces,
+                                   tp.synth_state_dict)
+    policy.to(DEV)
+    from vlnce_amd import ops
+    relu_outs = []
+    orig_linear = ops.linear
+
+    def recording_linear(x, w, b=None, act=ops.ACT_NONE, **k):
+        y = orig_linear(x, w, b, act, **k)
+        if act == ops.ACT_RELU:
+            relu_outs.append(y.detach())
+        return y
+
+    ops.linear = recording_linear
+    try:
+        outs = cases.run_case(policy, case, to_dev(obs), to_dev(prev), to_dev(masks), to_dev(extra),
+                              hip_update, vlnce_amd.AuxLosses, ppo_fn=hip_ppo)
+    finally:
+        ops.linear = orig_linear
+    fwd_keys = [k for k in gold if k in ("loss", "logits") or k.startswith("bn")]
+    assert len(fwd_keys) >= 9
+    compare({k: outs[k] for k in fwd_keys}, {k: gold[k] for k in fwd_keys}, atol=1e-4, rtol=1e-4)
+    assert list(gold["grad_names"]) == list(outs["grad_names"])
+    # rgb_linear, depth_linear, second_state_compress in _CMATail.forward's order
+    assert [tuple(t.shape) for t in relu_outs] == [(64, 256), (64, 128), (64, 512)]
+    ref, _ = cases.build_policy(oc, case, tp.make_config, tp.make_spaces, tp.synth_state_dict)
+    pins = [_PinnedReLU((t > 0).float().cpu()) for t in relu_outs]
+    ref.net.rgb_linear[3], ref.net.depth_linear[2], ref.net.second_state_compress[1] = pins
+    oc.AuxLosses.activate()
+    oc.il_update(ref, None, obs, prev, masks, extra["targets"], extra["weights"], 512,
+                 step_grad=False)
+    oc.AuxLosses.deactivate()
+    flips = 0
+    for pin in pins:
+        other_side = (pin.z > 0).float() != pin.mask
+        flips += int(other_side.sum())
+        assert float(pin.z[other_side].abs().max() if other_side.any() else 0.0) < 2e-4
+    assert flips <= 16, flips
+    refp = dict(ref.named_parameters())
+    worst = ("", 0.0)
+    for n, p in policy.named_parameters():
+        if p.grad is None:
+            assert refp[n].grad is None, n
+            continue
+        g, r = p.grad.cpu().double(), refp[n].grad.double()
+        ratio = ((g - r).abs() / (1e-4 + 1e-4 * r.abs())).max().item()
+        if ratio > worst[1]:
+            worst = (n, ratio)
+    assert worst[1] <= 1.0, (worst, flips)
 
 
 def test_distinct_instruction_path_matches_reference_golden():
