@@ -2,8 +2,6 @@
 cma_policy.py:24-309; arXiv 2004.02857).  Same module / parameter names; the
 arithmetic runs on the HIP kernels with visual and text features kept as
 [B, positions, channels] rows (the reference's [B, C, P] tensors permuted)."""
-import os
-
 import numpy as np
 import torch
 import torch.nn as nn
@@ -45,81 +43,59 @@ def nchw_flat_weight(linear, c, p):
 class _CMATail(nn.Module):
     """The part of CMANet.forward downstream of the encoders, as a tensor-only callable
     (no host syncs, static shapes) so that it can be captured as a HIP graph.  It shares
-    the parent's sub-modules; it is NOT registered as a child of the parent.
+    the parent's sub-modules; it is NOT registered as a child of the parent."""
 
-    `part` = "all": the whole tail (forward-only calls: one graph).  In a training step the tail
-    is captured as TWO graphs, "front" (everything that does not read the instruction: the two
-    projections, the first state encoder, state_q, rgb_kv / depth_kv) and "back" (text_k, the
-    three attentions, text_q, the compression, the second state encoder).  Backward then replays
-    back's graph FIRST, which ends with the instruction's gradient, and autograd runs the
-    instruction encoder's BPTT (on the side stream its forward used) next to front's backward
-    graph (the long rgb_kv / depth_kv weight-gradient GEMMs, the first state encoder) instead of
-    behind the whole tail."""
-
-    def __init__(self, net, rgb_frozen=0, dep_frozen=0, part="all"):
+    def __init__(self, net, rgb_frozen=0, dep_frozen=0):
         """`rgb_frozen` / `dep_frozen`: leading channels of the rgb / depth rows that carry no
         gradient (a frozen trunk's or cached features; the trailing 64 are the trainable spatial
         embeddings) -- the input gradients of rgb_kv / depth_kv are computed for the rest only."""
         super().__init__()
         self._rgb_frozen, self._dep_frozen = int(rgb_frozen), int(dep_frozen)
-        self._part = part
         for name in ("rgb_linear", "depth_linear", "state_encoder", "rgb_kv", "depth_kv", "state_q",
                      "text_k", "text_q", "second_state_compress", "second_state_encoder"):
             setattr(self, name, getattr(net, name))
         self._hidden_size = net._hidden_size
         self._scale_f = net._scale_f
 
-    def front(self, dep, rgb, act, rnn_states, masks):
+    def forward(self, ins, dep, rgb, act, rnn_states, masks, ins_index=None):
+        """`ins_index` (int64 [B]) given: `ins` holds the U DISTINCT instructions of a
+        sequence-mode batch and row b attends over ins[ins_index[b]] -- text_k, the padding mask and
+        the attention's K / V are then U blocks instead of B copies."""
         B = dep.size(0)
+        L, Ci = ins.shape[1:]
         P_d, C_d = dep.shape[1:]
         C_r = rgb.shape[2]
+        half = self._hidden_size // 2
+        scale = self._scale_f
         rgb_in = ops.linear(ops.mean_rows(rgb), self.rgb_linear[2].weight,
                             self.rgb_linear[2].bias, ops.ACT_RELU)
         depth_in = ops.linear(dep.reshape(B, P_d * C_d),
                               nchw_flat_weight(self.depth_linear[1], C_d, P_d),
                               self.depth_linear[1].bias, ops.ACT_RELU)
         state_in = torch.cat([rgb_in, depth_in, act], dim=1)
-        state, h1 = self.state_encoder(state_in, rnn_states, masks)
-        text_state_q = ops.linear(state, self.state_q.weight, self.state_q.bias)
-        rgb_kv = ops.linear(rgb, self.rgb_kv.weight.view(-1, C_r), self.rgb_kv.bias,
-                            dx_from=self._rgb_frozen)
-        depth_kv = ops.linear(dep, self.depth_kv.weight.view(-1, C_d), self.depth_kv.bias,
-                              dx_from=self._dep_frozen)
-        return state, h1, text_state_q, rgb_kv, depth_kv
+        n1 = self.state_encoder.num_recurrent_layers
+        state, h1 = self.state_encoder(state_in, rnn_states[:, 0:n1], masks)
 
-    def back(self, ins, state, text_state_q, rgb_kv, depth_kv, act, rnn_states, masks,
-             ins_index=None):
-        """`ins_index` (int64 [B]) given: `ins` holds the U DISTINCT instructions of a
-        sequence-mode batch and row b attends over ins[ins_index[b]] -- text_k, the padding mask and
-        the attention's K / V are then U blocks instead of B copies."""
-        Ci = ins.shape[2]
-        half = self._hidden_size // 2
-        scale = self._scale_f
+        text_state_q = ops.linear(state, self.state_q.weight, self.state_q.bias)
         text_state_k = ops.linear(ins, self.text_k.weight.view(half, Ci), self.text_k.bias)
         text_mask = ops.rowzero_mask(ins.detach())  # (instruction_embedding == 0).all(dim=1)
         # softmax((q.k - 1e8 mask) * scale) . v over [B, P, C] rows (cma_policy.py:207-217)
         text_embedding = ops.attention(text_state_q, text_state_k, ins, text_mask, 1, scale,
                                        index=ins_index)
+
+        rgb_kv = ops.linear(rgb, self.rgb_kv.weight.view(-1, C_r), self.rgb_kv.bias,
+                            dx_from=self._rgb_frozen)
+        depth_kv = ops.linear(dep, self.depth_kv.weight.view(-1, C_d), self.depth_kv.bias,
+                              dx_from=self._dep_frozen)
         text_q = ops.linear(text_embedding, self.text_q.weight, self.text_q.bias)
         rgb_embedding = ops.attention(text_q, rgb_kv[..., :half], rgb_kv[..., half:], None, 1, scale)
         depth_embedding = ops.attention(text_q, depth_kv[..., :half], depth_kv[..., half:], None, 1,
                                         scale)
+
         x = torch.cat([state, text_embedding, rgb_embedding, depth_embedding, act], dim=1)
         x = ops.linear(x, self.second_state_compress[0].weight,
                        self.second_state_compress[0].bias, ops.ACT_RELU)
-        return self.second_state_encoder(x, rnn_states, masks)
-
-    def forward(self, *t):
-        if self._part == "front":
-            return self.front(*t)
-        if self._part == "back":
-            return self.back(*t)
-        ins, dep, rgb, act, rnn_states, masks = t[:6]
-        n1 = self.state_encoder.num_recurrent_layers
-        state, h1, text_state_q, rgb_kv, depth_kv = self.front(dep, rgb, act, rnn_states[:, 0:n1],
-                                                               masks)
-        x, h2 = self.back(ins, state, text_state_q, rgb_kv, depth_kv, act, rnn_states[:, n1:], masks,
-                          *t[6:])
+        x, h2 = self.second_state_encoder(x, rnn_states[:, n1:], masks)
         return x, torch.cat([h1, h2], dim=1)
 
 
@@ -166,10 +142,6 @@ class CMANet(Net):
         self._branches = BranchStreams()
         # kept out of the module tree (shares our sub-modules): see _CMATail
         object.__setattr__(self, "_tail", GraphedTail(lambda *static: _CMATail(self, *static)))
-        object.__setattr__(self, "_tail_front",
-                           GraphedTail(lambda *static: _CMATail(self, *static, part="front")))
-        object.__setattr__(self, "_tail_back",
-                           GraphedTail(lambda *static: _CMATail(self, part="back")))
         self.progress_monitor = nn.Linear(self.output_size, 1)
         if model_config.PROGRESS_MONITOR.use:
             nn.init.kaiming_normal_(self.progress_monitor.weight, nonlinearity="tanh")
@@ -228,22 +200,11 @@ class CMANet(Net):
             if pad:
                 ins = F.pad(ins, (0, 0, 0, pad))
         extra = () if ins_index is None else (ins_index,)
-        static = (self._frozen_cols(self.rgb_encoder, "rgb_features", observations),
-                  self._frozen_cols(self.depth_encoder, "depth_features", observations))
-        ins, dep, rgb = ins.contiguous(), dep.contiguous(), rgb.contiguous()
-        rnn_states = rnn_states.contiguous()
-        if (torch.is_grad_enabled() and ins.is_cuda and ins.requires_grad
-                and os.environ.get("VLNCE_TAIL_SPLIT", "1") != "0"):
-            # training step: two graphs, so that the instruction encoder's backward starts when
-            # the back half's backward graph ends and runs beside the front half's (see _CMATail)
-            n1 = self.state_encoder.num_recurrent_layers
-            state, h1, text_state_q, rgb_kv, depth_kv = self._tail_front(
-                dep, rgb, act, rnn_states[:, 0:n1].contiguous(), masks_u8, static=static)
-            x, h2 = self._tail_back(ins, state, text_state_q, rgb_kv, depth_kv, act,
-                                    rnn_states[:, n1:].contiguous(), masks_u8, *extra)
-            rnn_states_out = torch.cat([h1, h2], dim=1)
-        else:
-            x, rnn_states_out = self._tail(ins, dep, rgb, act, rnn_states, masks_u8, *extra,
-                                           static=static)
+        x, rnn_states_out = self._tail(ins.contiguous(), dep.contiguous(), rgb.contiguous(), act,
+                                       rnn_states.contiguous(), masks_u8, *extra,
+                                       static=(self._frozen_cols(self.rgb_encoder, "rgb_features",
+                                                                 observations),
+                                               self._frozen_cols(self.depth_encoder, "depth_features",
+                                                                 observations)))
         register_progress_loss(self, x, observations)
         return x, rnn_states_out

@@ -377,12 +377,12 @@ class ActGraph:
 
 class DropsGraphsOnApply:
     """Mixin (in front of nn.Module in the bases) for modules that hold captured HIP graphs in
-    `_graphs` / `_tail` (`_tail_front`, `_tail_back`) / `_act_graph`.  nn.Module._apply -- .to(), .cuda(), .float(), .half() --
+    `_graphs` / `_tail` / `_act_graph`.  nn.Module._apply -- .to(), .cuda(), .float(), .half() --
     gives the parameters new storage WITHOUT bumping their version counters, which are what the
     graph keys carry; a graph captured before the move would replay on the old pointers.  The
     captured graphs are dropped instead; the next calls run eagerly and capture again."""
 
-    _graph_holders = ("_graphs", "_tail", "_tail_front", "_tail_back", "_act_graph")
+    _graph_holders = ("_graphs", "_tail", "_act_graph")
 
     def _apply(self, fn, *args, **kwargs):
         out = super()._apply(fn, *args, **kwargs)
