@@ -30,7 +30,7 @@ typedef void* vlnce_stream_t;
 
 enum { VLNCE_ACT_NONE = 0, VLNCE_ACT_RELU = 1, VLNCE_ACT_SIGMOID = 2, VLNCE_ACT_TANH = 3 };
 
-int vlnce_version(void); /* major*100 + minor; 140 = this header */
+int vlnce_version(void); /* major*100 + minor; 141 = this header */
 const char* vlnce_last_error(void);
 
 /* Dispatch options: which of the library's equivalent kernels a launch is given to.  Explicit
@@ -477,6 +477,37 @@ int vlnce_rnn_seq_bwd(int kind, int dirs, const float* const* w_hh_t, const int*
                       const float* const* aux_save, const float* const* dout,
                       const float* const* dh_final, float* const* dgi, float* const* dgh,
                       int B, int L, int H, vlnce_stream_t stream);
+/* Second-generation entry points (ABI 141): the same two kernels, self-contained -- the launch
+ * writes the zeros past each row's length itself (no pre-zeroed buffers), the forward also stores
+ * the outputs in the CONSUMER's layout (`seq`, may be NULL: element (t, b, direction d, unit u) at
+ * seq[t * seq_st + b * seq_sb + d * H + u]; [B, L, dirs*H] rows = the reference's
+ * pad_packed_sequence output permuted, instruction_encoder.py:88-94, with seq_st = dirs*H,
+ * seq_sb = L*dirs*H) next to the time-major copy `out_tm[d]` [L,B,H] the backward needs, BPTT takes
+ * the output gradient in that same addressing (`dseq`, may be NULL; regrouped into `dout_ws` by a
+ * small launch of the same call) and W_hh as the module stores it ([G*H, H], no transposed copy).
+ * dgi / dgh [L,B,G*H] are written everywhere. */
+int vlnce_rnn_seq_fwd2(int kind, int dirs, const float* const* gi, const float* const* w_hh,
+                       const float* const* b_hh, const int* lengths, float* const* out_tm,
+                       float* seq, long seq_st, long seq_sb, float* const* h_final,
+                       float* const* gates_save, float* const* aux_save, int B, int L, int H,
+                       vlnce_stream_t stream);
+int vlnce_rnn_seq_bwd2(int kind, int dirs, const float* const* w_hh, const int* lengths,
+                       const float* const* out_tm, const float* const* gates_save,
+                       const float* const* aux_save, const float* dseq, long dseq_st, long dseq_sb,
+                       float* dout_ws /* dirs*L*B*H floats, needed with dseq */,
+                       const float* const* dh_final, float* const* dgi, float* const* dgh,
+                       int B, int L, int H, vlnce_stream_t stream);
+/* Every parameter gradient of the recurrent layer, and the gradient of its input rows, from what
+ * BPTT left in dgi / dgh, behind ONE call (torch: the autograd of nn.LSTM / nn.GRU's weight_ih,
+ * weight_hh, bias_ih, bias_hh): dw_hh[d] [G*H,H] = dGh^T Hprev, db_hh[d] = colsum dGh (dGh = dgh
+ * for a GRU, dgi for an LSTM), dw_ih[d] [G*H,E] = dgi^T X, db_ih[d] = colsum dgi (skipped when
+ * db_ih[d] == db_hh[d]: an LSTM's two bias gradients are equal), dx_tm [L*B, E] (may be NULL) =
+ * sum_d dgi[d] W_ih[d].  x_tm: the time-major input rows [L*B, E] (row stride ldx). */
+int vlnce_rnn_seq_wgrad(int kind, int dirs, const float* const* dgi, const float* const* dgh,
+                        const float* const* out_tm, const float* x_tm, int ldx, int E,
+                        const float* const* w_ih, float* const* dw_ih, float* const* dw_hh,
+                        float* const* db_ih, float* const* db_hh, float* dx_tm, int B, int L, int H,
+                        vlnce_stream_t stream);
 
 /* ---------------------------------------------------------------- utilities */
 /* y[b, c] = mean_p x[b, p, c]   (AdaptiveAvgPool1d(1) of rgb_linear, cma_policy.py:104) */

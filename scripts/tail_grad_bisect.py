@@ -32,7 +32,7 @@ masks = (torch.rand(N, 1, generator=g) > 0.1).to(torch.uint8)
 tgt = torch.randint(0, 4, (1, N), generator=g)
 w = torch.rand(1, N, generator=g) + 0.5
 
-NAMES = ["linear", "attention", "gru_cell", "mean_rows", "mask_rows", "rnn_seq", "embedding", "action_head"]
+NAMES = ["linear", "attention", "gru_cell", "mean_rows", "mask_rows", "rnn_layer", "embedding", "action_head"]
 orig = {n: getattr(ops, n) for n in NAMES}
 
 

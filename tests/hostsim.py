@@ -688,6 +688,51 @@ class HostSim:
                     dgh[d][idx] = dpre_h[active]
                 dh = torch.where(a, dpre_h @ W + keep, dh)
 
+    # second-generation entry points (ABI 141): same contracts, self-zeroing, consumer-layout outputs
+    def rnn_seq_fwd2(self, kind, dirs, gi, w_hh, b_hh, lengths, out_tm, seq, seq_st, seq_sb, h_final,
+                     gates_save, aux_save, B, Lm, H):
+        for o in out_tm:
+            o.zero_()
+        self.rnn_seq_fwd(kind, dirs, gi, w_hh, b_hh, lengths, out_tm, h_final, gates_save, aux_save,
+                         B, Lm, H)
+        if seq is not None:
+            for d in range(dirs):
+                view = torch.as_strided(seq, (Lm, B, H), (seq_st, seq_sb, 1), seq.storage_offset() + d * H)
+                view.copy_(out_tm[d])
+
+    def rnn_seq_bwd2(self, kind, dirs, w_hh, lengths, out_tm, gates_save, aux_save, dseq, dseq_st,
+                     dseq_sb, dout_ws, dh_final, dgi, dgh, B, Lm, H):
+        dout = None
+        if dseq is not None:
+            dout = [torch.as_strided(dseq, (Lm, B, H), (dseq_st, dseq_sb, 1), dseq.storage_offset() + d * H)
+                    for d in range(dirs)]
+        for t in list(dgi) + (list(dgh) if dgh is not None else []):
+            t.zero_()
+        self.rnn_seq_bwd(kind, dirs, [w.t() for w in w_hh], lengths, out_tm, gates_save, aux_save,
+                         dout, dh_final, dgi, dgh, B, Lm, H)
+
+    def rnn_seq_wgrad(self, kind, dirs, dgi, dgh, out_tm, x_tm, ldx, E, w_ih, dw_ih, dw_hh, db_ih,
+                      db_hh, dx_tm, B, Lm, H):
+        GH = dgi[0].shape[-1]
+        x = x_tm.reshape(Lm * B, -1)[:, :E]
+        if dx_tm is not None:
+            dx_tm.zero_()
+        for d in range(dirs):
+            dG = (dgh[d] if kind == 1 else dgi[d]).reshape(Lm, B, GH)
+            hprev = torch.zeros(Lm, B, H)
+            if Lm > 1:
+                if d == 1:
+                    hprev[:-1] = out_tm[d][1:]
+                else:
+                    hprev[1:] = out_tm[d][:-1]
+            dw_hh[d].copy_(dG.reshape(-1, GH).t() @ hprev.reshape(-1, H))
+            db_hh[d].copy_(dG.reshape(-1, GH).sum(0))
+            g = dgi[d].reshape(-1, GH)
+            dw_ih[d].copy_(g.t() @ x)
+            db_ih[d].copy_(g.sum(0))
+            if dx_tm is not None:
+                dx_tm += g @ w_ih[d]
+
     def mask_rows(self, x, mask, out, B, H):
         out.copy_(x.view(B, H) * mask.view(B, 1).float())
 

@@ -570,6 +570,45 @@ def test_instruction_encoder_matches_torch_packed_rnn(hip, rnn_type, bidir, fina
         close(ph.grad, pr.grad, 5e-4, what=f"d {n}")
 
 
+@pytest.mark.parametrize("rnn_type,bidir", [("LSTM", True), ("GRU", True), ("GRU", False)])
+def test_rnn_layer_fn_input_gradient_and_sliced_output_gradient(hip, rnn_type, bidir):
+    """ops.RNNLayerFn (vlnce_rnn_seq_fwd2 / _bwd2 / _wgrad) against torch's packed nn.LSTM / nn.GRU:
+    outputs in the consumer's [B, L, dirs*H] rows with zeros past each length (from an uninitialised
+    buffer), final states, the gradient of the time-major INPUT rows and of every parameter, with
+    the output gradient arriving as a slice of a longer padded buffer (what F.pad's backward hands
+    over when the tail pads the instruction to a bucket of 8 tokens)."""
+    B, Lm, E, H = 19, 13, 50, 128
+    dirs = 2 if bidir else 1
+    gen = torch.Generator().manual_seed(11)
+    lengths = torch.randint(1, Lm + 1, (B,), generator=gen)
+    lengths[3] = Lm
+    rnn = (torch.nn.LSTM if rnn_type == "LSTM" else torch.nn.GRU)(E, H, bidirectional=bidir)
+    x = rnd(Lm, B, E, seed=12)
+    xr = x.clone().requires_grad_(True)
+    packed = torch.nn.utils.rnn.pack_padded_sequence(xr, lengths, enforce_sorted=False)
+    out_p, hn = rnn(packed)
+    hn = hn[0] if rnn_type == "LSTM" else hn
+    out_r, _ = torch.nn.utils.rnn.pad_packed_sequence(out_p, total_length=Lm)   # [L, B, dirs*H]
+    wseq, wfin = rnd(B, Lm + 3, dirs * H, seed=13), rnd(dirs, B, H, seed=14)
+    ((out_r.transpose(0, 1) * wseq[:, :Lm]).sum() + (hn * wfin).sum()).backward()
+
+    xh = x.to(DEV).reshape(Lm * B, E).requires_grad_(True)
+    prm = {n: p.detach().to(DEV).requires_grad_(True) for n, p in rnn.named_parameters()}
+    quads = [tuple(prm[n + sfx] for n in ("weight_ih_l0", "bias_ih_l0", "weight_hh_l0", "bias_hh_l0"))
+             for sfx in (["", "_reverse"] if bidir else [""])]
+    seq, fin = ops.rnn_layer(0 if rnn_type == "LSTM" else 1, lengths.to(DEV).to(torch.int32), xh, B, Lm,
+                             quads, True)
+    close(seq, out_r.transpose(0, 1), 2e-4, what="seq")
+    for d in range(dirs):
+        close(fin[d], hn[d], 2e-4, what=f"final state {d}")
+    padded = torch.nn.functional.pad(seq, (0, 0, 0, 3))     # backward: a [:, :Lm] slice of [B, Lm+3, C]
+    loss = (padded * wseq.to(DEV)).sum() + sum((fin[d] * wfin[d].to(DEV)).sum() for d in range(dirs))
+    loss.backward()
+    close(xh.grad.view(Lm, B, E), xr.grad, 5e-4, what="d input rows")
+    for n, p in rnn.named_parameters():
+        close(prm[n].grad, p.grad, 5e-4, what=f"d {n}")
+
+
 def test_fused_bn_consumers(hip):
     """max-pool with the stem's BatchNorm+ReLU applied on the fly, and the dual-input block-end pass."""
     x = rnd(2, 18, 22, 64, seed=1)

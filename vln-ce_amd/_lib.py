@@ -116,6 +116,9 @@ _SIGNATURES = {
     "vlnce_rnn_seq_supported": (_I, [_I, _I]),
     "vlnce_rnn_seq_fwd": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "vlnce_rnn_seq_bwd": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "vlnce_rnn_seq_fwd2": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _L, _L, _P, _P, _P, _I, _I, _I, _P]),
+    "vlnce_rnn_seq_bwd2": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _L, _L, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "vlnce_rnn_seq_wgrad": (_I, [_I, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "vlnce_group_norm_small": (_I, [_P, _I, _I, _I, _I, _P, _P, _F, _P, _I, _P, _P]),
     "vlnce_gru_rollout_supported": (_I, [_I, _I]),
     "vlnce_gru_rollout_workspace_bytes": (C.c_long, [_I, _I]),
@@ -199,7 +202,7 @@ class HipLib:
 
     name = "hip"
 
-    ABI = 140  # include/vlnce_hip.h
+    ABI = 141  # include/vlnce_hip.h
 
     def __init__(self, path=LIB_PATH):
         self.dll = load_cdll(path)
@@ -607,6 +610,30 @@ class HipLib:
             kind, dirs, pa(w_hh_t, dirs), _ptr(lengths), pa(out, dirs), pa(gates_save, dirs),
             pa(aux_save, dirs), pa(dout, dirs), pa(dh_final, dirs), pa(dgi, dirs), pa(dgh, dirs),
             B, Lm, H, _stream()), "vlnce_rnn_seq_bwd")
+
+    def rnn_seq_fwd2(self, kind, dirs, gi, w_hh, b_hh, lengths, out_tm, seq, seq_st, seq_sb, h_final,
+                     gates_save, aux_save, B, Lm, H):
+        pa = self._parr
+        self._check(self.dll.vlnce_rnn_seq_fwd2(
+            kind, dirs, pa(gi, dirs), pa(w_hh, dirs), pa(b_hh, dirs), _ptr(lengths), pa(out_tm, dirs),
+            _ptr(seq), seq_st, seq_sb, pa(h_final, dirs), pa(gates_save, dirs), pa(aux_save, dirs),
+            B, Lm, H, _stream()), "vlnce_rnn_seq_fwd2")
+
+    def rnn_seq_bwd2(self, kind, dirs, w_hh, lengths, out_tm, gates_save, aux_save, dseq, dseq_st,
+                     dseq_sb, dout_ws, dh_final, dgi, dgh, B, Lm, H):
+        pa = self._parr
+        self._check(self.dll.vlnce_rnn_seq_bwd2(
+            kind, dirs, pa(w_hh, dirs), _ptr(lengths), pa(out_tm, dirs), pa(gates_save, dirs),
+            pa(aux_save, dirs), _ptr(dseq), dseq_st, dseq_sb, _ptr(dout_ws), pa(dh_final, dirs),
+            pa(dgi, dirs), pa(dgh, dirs), B, Lm, H, _stream()), "vlnce_rnn_seq_bwd2")
+
+    def rnn_seq_wgrad(self, kind, dirs, dgi, dgh, out_tm, x_tm, ldx, E, w_ih, dw_ih, dw_hh, db_ih,
+                      db_hh, dx_tm, B, Lm, H):
+        pa = self._parr
+        self._check(self.dll.vlnce_rnn_seq_wgrad(
+            kind, dirs, pa(dgi, dirs), pa(dgh, dirs), pa(out_tm, dirs), _ptr(x_tm), ldx, E,
+            pa(w_ih, dirs), pa(dw_ih, dirs), pa(dw_hh, dirs), pa(db_ih, dirs), pa(db_hh, dirs),
+            _ptr(dx_tm), B, Lm, H, _stream()), "vlnce_rnn_seq_wgrad")
 
     def group_norm_small(self, x, N, HW, Cc, groups, gamma, beta, eps, residual, act, y):
         self._check(self.dll.vlnce_group_norm_small(

@@ -34,7 +34,52 @@ struct RnnSeqParams {
   float* dgh[2];            // GRU only: [L,B,G*H] grads wrt (h W_hh^T + b_hh) (pre-zeroed)
   const int* lengths;       // [B]
   int B, L;
+  // round 5 (vlnce_rnn_seq_fwd2 / _bwd2); all zero for the first-generation entry points
+  float* seq[2];            // fwd: optional second copy of the outputs in the CONSUMER's layout,
+                            // element (t, b, u) of direction d at seq[d][t * seq_st + b * seq_sb + u]
+  long seq_st, seq_sb;
+  int self_zero;            // 1: the launch itself writes the zeros past each row's length
+                            //    (out / seq in the forward, dgi / dgh in the backward)
+  int w_plain;              // bwd: w_hh[d] is W_hh [G*H, H] as the module stores it, not its transpose
 };
+
+// dout_tm[d][t][b][u] = dseq[t * st + b * sb + d * H + u]: the output gradient from the consumer's
+// row layout into the time-major layout BPTT reads.  (Reading it strided inside rnn_seq_bwd_kernel
+// costs four loop-invariant offset registers, which spills the LSTM / H = 128 instance: 254 VGPRs.)
+__global__ __launch_bounds__(256) void dseq_to_time_major_kernel(const float* __restrict__ dseq, long st,
+                                                                 long sb, float* __restrict__ dst, int dirs,
+                                                                 int L, int B, int H) {
+  const int h4 = H / 4;
+  const long n = (long)dirs * L * B * h4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int u4 = (int)(i % h4);
+    long r = i / h4;
+    const int b = (int)(r % B);
+    r /= B;
+    const int t = (int)(r % L);
+    const int d = (int)(r / L);
+    const float* src = dseq + (long)t * st + (long)b * sb + d * H + 4 * u4;
+    f32x4 v = {src[0], src[1], src[2], src[3]};
+    *reinterpret_cast<f32x4*>(dst + i * 4) = v;
+  }
+}
+
+// zeros of the rows [len[b], L) of a [L, B, width]-addressed array for the 16 samples of a tile
+template <int NT>
+__device__ __forceinline__ void zero_tails(float* __restrict__ base, long st, long sb, int width,
+                                           const int* __restrict__ lengths, int b0, int B, int L,
+                                           int tid) {
+  for (int r = 0; r < 16; ++r) {
+    const int b = b0 + r;
+    if (b >= B) break;
+    const int lb = min(max(lengths[b], 0), L);
+    const int n = (L - lb) * width;
+    for (int i = tid; i < n; i += NT) {
+      const int q = i / width;
+      base[(long)(lb + q) * st + (long)b * sb + (i - q * width)] = 0.f;
+    }
+  }
+}
 
 // Gate non-linearities on the hardware exp2 / rcp (v_exp_f32, v_rcp_f32; absolute error < 3e-7,
 // tests at 1e-5): libm's expf / tanhf are ~25 / ~50 VALU instructions each and a step evaluates
@@ -120,6 +165,10 @@ __global__ __launch_bounds__(NW * 64) void rnn_seq_fwd_kernel(RnnSeqParams p) {
   const float* __restrict__ gi = p.gi[d];
   const float* __restrict__ W = p.w_hh[d];
   const int B = p.B, L = p.L;
+  if (p.self_zero) {  // (stores only: they drain under the weight split below)
+    zero_tails<NW * 64>(p.out[d], (long)B * H, H, H, p.lengths, b0, B, L, tid);
+    if (p.seq[d]) zero_tails<NW * 64>(p.seq[d], p.seq_st, p.seq_sb, H, p.lengths, b0, B, L, tid);
+  }
 
   int len[4];
 #pragma unroll
@@ -281,6 +330,7 @@ __global__ __launch_bounds__(NW * 64) void rnn_seq_fwd_kernel(RnnSeqParams p) {
         if (active) {
           hreg[nt][r] = hnew;
           p.out[d][((long)tt * B + b) * H + u] = hnew;
+          if (p.seq[d]) p.seq[d][(long)tt * p.seq_st + (long)b * p.seq_sb + u] = hnew;
         }
         unsigned short hw[3];
         split_scalar(hreg[nt][r], hw);
@@ -330,8 +380,12 @@ __global__ __launch_bounds__(NW * 64) void rnn_seq_bwd_kernel(RnnSeqParams p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, quad = lane >> 4;
   const bool reverse = d == 1;
-  const float* __restrict__ WT = p.w_hh[d];  // [H, G*H]: WT[n][k] = W_hh[k][n]
+  const float* __restrict__ WT = p.w_hh[d];  // [H, G*H]: WT[n][k] = W_hh[k][n]  (w_plain: W_hh itself)
   const int B = p.B, L = p.L;
+  if (p.self_zero) {
+    zero_tails<NW * 64>(p.dgi[d], (long)B * GH, GH, GH, p.lengths, b0, B, L, tid);
+    if (KIND == 1) zero_tails<NW * 64>(p.dgh[d], (long)B * GH, GH, GH, p.lengths, b0, B, L, tid);
+  }
 
   int len[4];
 #pragma unroll
@@ -349,9 +403,20 @@ __global__ __launch_bounds__(NW * 64) void rnn_seq_bwd_kernel(RnnSeqParams p) {
     const int n = wave * (H / NW) + nt * 16 + l15;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      const float* w8 = WT + (long)n * GH + 32 * ks + 8 * quad;
-      wt[nt][ks] = split_planes(*reinterpret_cast<const f32x4*>(w8),
-                                *reinterpret_cast<const f32x4*>(w8 + 4));
+      f32x4 lo4, hi4;
+      if (p.w_plain) {  // W_hh [G*H, H] as stored: WT[n][k] = W[k][n], eight strided 4-byte loads
+        const float* wk = WT + (long)(32 * ks + 8 * quad) * H + n;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          lo4[i] = wk[(long)i * H];
+          hi4[i] = wk[(long)(i + 4) * H];
+        }
+      } else {
+        const float* w8 = WT + (long)n * GH + 32 * ks + 8 * quad;
+        lo4 = *reinterpret_cast<const f32x4*>(w8);
+        hi4 = *reinterpret_cast<const f32x4*>(w8 + 4);
+      }
+      wt[nt][ks] = split_planes(lo4, hi4);
       if (KL > 0 && nt == 0 && ks >= KS - KL) {
 #pragma unroll
         for (int q = 0; q < 3; ++q) w_lds[ks - (KS - KL)][q][tid] = wt[nt][ks].p[q];
@@ -645,5 +710,140 @@ extern "C" int vlnce_rnn_seq_bwd(int kind, int dirs, const float* const* w_hh_t,
   const int rc = kind == 0 ? launch_bwd<0>(p, H, dirs, s) : launch_bwd<1>(p, H, dirs, s);
   VLNCE_CHECK_ARG(rc == 0, "rnn_seq_bwd: no kernel for H=%d", H);
   VLNCE_CHECK_LAUNCH("rnn_seq_bwd");
+  return 0;
+}
+
+
+// ---- round 5: the same two kernels behind self-contained entry points (no zero-fills, no
+// transposed weight copies, no layout copies around them) and the parameter gradients of the whole
+// recurrent layer behind ONE call.  The instruction encoder's backward runs eagerly on a side
+// stream behind the tail's backward graph; what it cost was the host issuing ~45 launches
+// (fills, transposes, contiguous copies, 6 GEMMs with their split-K zero-fills, 4 column sums).
+extern "C" int vlnce_rnn_seq_fwd2(int kind, int dirs, const float* const* gi,
+                                  const float* const* w_hh, const float* const* b_hh,
+                                  const int* lengths, float* const* out_tm, float* seq,
+                                  long seq_st, long seq_sb, float* const* h_final,
+                                  float* const* gates_save, float* const* aux_save, int B, int L,
+                                  int H, vlnce_stream_t stream) {
+  VLNCE_CHECK_ARG(gi && w_hh && b_hh && lengths && out_tm && h_final, "rnn_seq_fwd2: null argument");
+  VLNCE_CHECK_ARG(dirs == 1 || dirs == 2, "rnn_seq_fwd2: dirs must be 1 or 2");
+  VLNCE_CHECK_ARG(vlnce_rnn_seq_supported(kind, H), "rnn_seq_fwd2: unsupported kind/H (%d,%d)", kind, H);
+  VLNCE_CHECK_ARG(B > 0 && L > 0, "rnn_seq_fwd2: bad shape");
+  VLNCE_CHECK_ARG(!seq || (seq_st > 0 && seq_sb > 0), "rnn_seq_fwd2: seq needs its strides");
+  RnnSeqParams p{};
+  for (int d = 0; d < dirs; ++d) {
+    p.gi[d] = gi[d];
+    p.w_hh[d] = w_hh[d];
+    p.b_hh[d] = b_hh[d];
+    p.out[d] = out_tm[d];
+    p.seq[d] = seq ? seq + (long)d * H : nullptr;
+    p.h_final[d] = h_final[d];
+    p.gates[d] = gates_save ? gates_save[d] : nullptr;
+    p.aux[d] = aux_save ? aux_save[d] : nullptr;
+    VLNCE_CHECK_ARG((p.gates[d] == nullptr) == (p.aux[d] == nullptr),
+                    "rnn_seq_fwd2: gates_save and aux_save come together");
+  }
+  p.seq_st = seq_st;
+  p.seq_sb = seq_sb;
+  p.self_zero = 1;
+  p.lengths = lengths;
+  p.B = B;
+  p.L = L;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int rc = kind == 0 ? launch_fwd<0>(p, H, dirs, s) : launch_fwd<1>(p, H, dirs, s);
+  VLNCE_CHECK_ARG(rc == 0, "rnn_seq_fwd2: no kernel for H=%d", H);
+  VLNCE_CHECK_LAUNCH("rnn_seq_fwd2");
+  return 0;
+}
+
+extern "C" int vlnce_rnn_seq_bwd2(int kind, int dirs, const float* const* w_hh, const int* lengths,
+                                  const float* const* out_tm, const float* const* gates_save,
+                                  const float* const* aux_save, const float* dseq, long dseq_st,
+                                  long dseq_sb, float* dout_ws, const float* const* dh_final,
+                                  float* const* dgi, float* const* dgh, int B, int L, int H,
+                                  vlnce_stream_t stream) {
+  VLNCE_CHECK_ARG(w_hh && lengths && out_tm && gates_save && aux_save && dgi,
+                  "rnn_seq_bwd2: null argument");
+  VLNCE_CHECK_ARG(dirs == 1 || dirs == 2, "rnn_seq_bwd2: dirs must be 1 or 2");
+  VLNCE_CHECK_ARG(vlnce_rnn_seq_supported(kind, H), "rnn_seq_bwd2: unsupported kind/H (%d,%d)", kind, H);
+  VLNCE_CHECK_ARG(kind == 0 || dgh, "rnn_seq_bwd2: GRU needs dgh");
+  VLNCE_CHECK_ARG(!dseq || (dseq_st > 0 && dseq_sb > 0), "rnn_seq_bwd2: dseq needs its strides");
+  VLNCE_CHECK_ARG(!dseq || dout_ws, "rnn_seq_bwd2: dseq needs the dirs*L*B*H workspace");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dseq) {
+    const long n4 = (long)dirs * L * B * (H / 4);
+    const int grid = (int)((n4 + 255) / 256 > 2048 ? 2048 : (n4 + 255) / 256);
+    hipLaunchKernelGGL(dseq_to_time_major_kernel, dim3(grid), dim3(256), 0, s, dseq, dseq_st, dseq_sb,
+                       dout_ws, dirs, L, B, H);
+    VLNCE_CHECK_LAUNCH("rnn_seq_bwd2 (output gradient to time-major)");
+  }
+  RnnSeqParams p{};
+  for (int d = 0; d < dirs; ++d) {
+    p.w_hh[d] = w_hh[d];
+    p.out[d] = const_cast<float*>(out_tm[d]);
+    p.gates[d] = const_cast<float*>(gates_save[d]);
+    p.aux[d] = const_cast<float*>(aux_save[d]);
+    p.dout[d] = dseq ? dout_ws + (long)d * L * B * H : nullptr;
+    p.dh_final[d] = dh_final ? dh_final[d] : nullptr;
+    p.dgi[d] = dgi[d];
+    p.dgh[d] = dgh ? dgh[d] : nullptr;
+  }
+  p.self_zero = 1;
+  p.w_plain = 1;
+  p.lengths = lengths;
+  p.B = B;
+  p.L = L;
+  const int rc = kind == 0 ? launch_bwd<0>(p, H, dirs, s) : launch_bwd<1>(p, H, dirs, s);
+  VLNCE_CHECK_ARG(rc == 0, "rnn_seq_bwd2: no kernel for H=%d", H);
+  VLNCE_CHECK_LAUNCH("rnn_seq_bwd2");
+  return 0;
+}
+
+// Parameter gradients of the recurrent layer (and the gradient of its input rows) from what BPTT
+// left in dgi / dgh:  dW_hh[d] = dGh^T Hprev (Hprev = the time-major outputs shifted by one step in
+// processing order: outputs past a row's length are zeros, so the shift is two views),
+// db_hh[d] = colsum dGh, dW_ih[d] = dgi^T X, db_ih[d] = colsum dgi (LSTM: dGh = dgi, so db_ih ==
+// db_hh and the caller may pass the same pointer), dX = sum_d dgi[d] W_ih[d].
+extern "C" int vlnce_rnn_seq_wgrad(int kind, int dirs, const float* const* dgi,
+                                   const float* const* dgh, const float* const* out_tm,
+                                   const float* x_tm, int ldx, int E, const float* const* w_ih,
+                                   float* const* dw_ih, float* const* dw_hh, float* const* db_ih,
+                                   float* const* db_hh, float* dx_tm, int B, int L, int H,
+                                   vlnce_stream_t stream) {
+  VLNCE_CHECK_ARG(dgi && out_tm && x_tm && dw_ih && dw_hh && db_ih && db_hh,
+                  "rnn_seq_wgrad: null argument");
+  VLNCE_CHECK_ARG(dirs == 1 || dirs == 2, "rnn_seq_wgrad: dirs must be 1 or 2");
+  VLNCE_CHECK_ARG(kind == 0 || dgh, "rnn_seq_wgrad: GRU needs dgh");
+  VLNCE_CHECK_ARG(!dx_tm || w_ih, "rnn_seq_wgrad: dx_tm needs w_ih");
+  const int GH = (kind == 0 ? 4 : 3) * H;
+  const long rows = (long)L * B;
+  VLNCE_CHECK_ARG(B > 0 && L > 0 && E > 0 && ldx >= E && rows < 0x7fffffffL, "rnn_seq_wgrad: bad shape");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  for (int d = 0; d < dirs; ++d) {
+    const float* dGh = kind == 1 ? dgh[d] : dgi[d];
+    if (L > 1) {
+      // forward direction: step t's previous state is the output of t - 1; reverse: of t + 1
+      const float* dG_s = d == 1 ? dGh : dGh + (long)B * GH;
+      const float* h_s = d == 1 ? out_tm[d] + (long)B * H : out_tm[d];
+      int rc = vlnce_gemm(dG_s, GH, 1, h_s, H, 1, dw_hh[d], H, GH, H, (int)((long)(L - 1) * B), nullptr, stream);
+      if (rc != 0) return rc;
+    } else {
+      vlnce_zero(dw_hh[d], GH, H, H, s);
+    }
+    int rc = vlnce_colsum(dGh, GH, (int)rows, GH, db_hh[d], 0, stream);
+    if (rc != 0) return rc;
+    rc = vlnce_gemm(dgi[d], GH, 1, x_tm, ldx, 1, dw_ih[d], E, GH, E, (int)rows, nullptr, stream);
+    if (rc != 0) return rc;
+    if (db_ih[d] != db_hh[d]) {
+      rc = vlnce_colsum(dgi[d], GH, (int)rows, GH, db_ih[d], 0, stream);
+      if (rc != 0) return rc;
+    }
+    if (dx_tm) {
+      vlnce_epilogue e{};
+      e.accumulate = d > 0;
+      rc = vlnce_gemm(dgi[d], GH, 0, w_ih[d], E, 1, dx_tm, E, (int)rows, E, GH, &e, stream);
+      if (rc != 0) return rc;
+    }
+  }
   return 0;
 }

@@ -95,29 +95,37 @@ class InstructionEncoder(nn.Module):
             if tokens.size(0) >= self.DEDUP_MIN_ROWS and os.environ.get("VLNCE_INSTR_DEDUP", "1") != "0":
                 uniq, inverse, lengths, lmin, lmax = self._distinct_rows(tokens, nonzero_row)
                 if uniq is not None and uniq.size(0) < tokens.size(0):
-                    out = self._encode(ops.embedding(uniq, self.embedding_layer.weight,
-                                                     self.embedding_layer.padding_idx),
-                                       (lengths, lmin, lmax))
+                    out = self._encode(self._embed_tm(uniq, lmax), (lengths, lmin, lmax),
+                                       time_major=True)
                     # [U, C, L] / [U, H] -> rows; the stacked bidirectional final state is [2, U, H]
                     dim = 1 if (cfg.final_state_only and out.dim() == 3) else 0
                     if distinct and dim == 0:
                         return out, inverse
                     out = out.index_select(dim, inverse)
                     return (out, None) if distinct else out
-            feats = ops.embedding(tokens, self.embedding_layer.weight,
-                                  self.embedding_layer.padding_idx)
             lengths = nonzero_row[tokens].sum(dim=1)
             if tokens.is_cuda and torch.cuda.is_current_stream_capturing():
                 # inside a graph capture (streams.ActGraph): no host sync -- the recurrence runs
                 # at the static padded length with the lengths on the device (steps past a row's
                 # length keep its state and emit zeros: the same values, more padding)
-                out = self._encode(feats, (lengths, 1, tokens.size(1)))
+                out = self._encode(self._embed_tm(tokens, tokens.size(1)),
+                                   (lengths, 1, tokens.size(1)), time_major=True)
                 return (out, None) if distinct else out
             lmin, lmax = (int(v) for v in torch.stack([lengths.min(), lengths.max()]).tolist())
-            out = self._encode(feats, (lengths, lmin, lmax))
+            if lmin <= 0:
+                raise RuntimeError("Length of all samples has to be greater than 0, "
+                                   "but found an element in 'lengths' that is <= 0")
+            out = self._encode(self._embed_tm(tokens, lmax), (lengths, lmin, lmax), time_major=True)
             return (out, None) if distinct else out
         out = self._encode(observations["rxr_instruction"])
         return (out, None) if distinct else out
+
+    def _embed_tm(self, tokens, lmax):
+        """embedding of the first `lmax` tokens of every row, TIME-MAJOR [lmax, B, E]: the rows the
+        recurrent layer's input GEMM reads (no [B, 200, E] table lookup followed by a transposed
+        copy; the embedding's backward scatters the time-major gradient rows as they are)."""
+        tok_tm = tokens[:, :lmax].t().contiguous()
+        return ops.embedding(tok_tm, self.embedding_layer.weight, self.embedding_layer.padding_idx)
 
     @staticmethod
     def _distinct_rows(tokens, nonzero_row):
@@ -150,7 +158,7 @@ class InstructionEncoder(nn.Module):
             return None, None, None, 0, 0
         return cand[:n_uniq], inverse, lengths[:n_uniq], int(lmin), int(lmax)
 
-    def _encode(self, feats, length_info=None):
+    def _encode(self, feats, length_info=None, time_major=False):
         cfg = self.config
         if length_info is None:
             # :79-80 (rxr features) a step counts iff its feature vector is not all-zero;
@@ -166,39 +174,47 @@ class InstructionEncoder(nn.Module):
         if lmin <= 0:
             raise RuntimeError("Length of all samples has to be greater than 0, "
                                "but found an element in 'lengths' that is <= 0")
-        B, E = feats.size(0), feats.size(2)
         H = cfg.hidden_size
         rnn = self.encoder_rnn
-        x_tm = feats[:, :lmax].transpose(0, 1).reshape(lmax * B, E)
+        if time_major:   # feats is already [lmax, B, E] (the token path embeds tokens[:, :lmax].t())
+            B, E = feats.size(1), feats.size(2)
+            x_tm = feats.reshape(lmax * B, E)
+        else:
+            B, E = feats.size(0), feats.size(2)
+            x_tm = feats[:, :lmax].transpose(0, 1).reshape(lmax * B, E)
         same_len = lmin == lmax
-        active = None
-        if not same_len:
-            active = (torch.arange(lmax, device=feats.device)[:, None] < lengths[None, :]).to(
-                torch.uint8).contiguous()
         dirs = [("", False)] + ([("_reverse", True)] if cfg.bidirectional else [])
         kind = 0 if cfg.rnn_type == "LSTM" else 1
+        seqs, finals = [], []
+        if ops.L().rnn_seq_supported(kind, H) and rnn.bias_hh_l0 is not None:
+            # the whole layer -- input projections, the recurrence of both directions in one
+            # persistent launch, the outputs in the consumer's [B, L, dirs*H] rows -- as one
+            # autograd node whose backward is two library calls (ops.RNNLayerFn)
+            need_grad = torch.is_grad_enabled() and (
+                x_tm.requires_grad or any(p.requires_grad for p in rnn.parameters()))
+            quads = [tuple(getattr(rnn, n + sfx) for n in ("weight_ih_l0", "bias_ih_l0",
+                                                           "weight_hh_l0", "bias_hh_l0"))
+                     for sfx, _ in dirs]
+            seq, finals = ops.rnn_layer(kind, lengths.to(torch.int32).contiguous(), x_tm, B, lmax,
+                                        quads, need_grad)
+            if cfg.final_state_only:
+                return finals[0] if len(finals) == 1 else torch.stack(finals, 0)
+            return seq.permute(0, 2, 1)  # logical [B, H*dirs, Lmax]; memory stays [B, L, C]
+        active = None
+        if not same_len:
+            active = (torch.arange(lmax, device=x_tm.device)[:, None] < lengths[None, :]).to(
+                torch.uint8).contiguous()
         gis = []
         for sfx, _ in dirs:
             gis.append(ops.linear(x_tm, getattr(rnn, "weight_ih_l0" + sfx),
                                   getattr(rnn, "bias_ih_l0" + sfx)).view(lmax, B, -1))
-        seqs, finals = [], []
-        if ops.L().rnn_seq_supported(kind, H):
-            # whole recurrence (both directions) in one persistent launch
-            need_grad = torch.is_grad_enabled() and (
-                gis[0].requires_grad or rnn.weight_hh_l0.requires_grad)
-            trips = [(gis[i], getattr(rnn, "weight_hh_l0" + sfx), getattr(rnn, "bias_hh_l0" + sfx))
-                     for i, (sfx, _) in enumerate(dirs)]
-            outs_tm, finals = ops.rnn_seq(kind, lengths.to(torch.int32).contiguous(), trips,
-                                          need_grad)
-            seqs = [o.transpose(0, 1) for o in outs_tm]  # [B, L, H] views
-        else:
-            for i, (sfx, rev) in enumerate(dirs):
-                outs, h_last = self._direction(gis[i], same_len, active,
-                                               getattr(rnn, "weight_hh_l0" + sfx),
-                                               getattr(rnn, "bias_hh_l0" + sfx), rev)
-                finals.append(h_last)
-                if not cfg.final_state_only:
-                    seqs.append(torch.stack(outs, dim=1))  # [B, L, H]
+        for i, (sfx, rev) in enumerate(dirs):
+            outs, h_last = self._direction(gis[i], same_len, active,
+                                           getattr(rnn, "weight_hh_l0" + sfx),
+                                           getattr(rnn, "bias_hh_l0" + sfx), rev)
+            finals.append(h_last)
+            if not cfg.final_state_only:
+                seqs.append(torch.stack(outs, dim=1))  # [B, L, H]
         if cfg.final_state_only:
             # final_state.squeeze(0): [1,B,H] -> [B,H]; a bidirectional [2,B,H] is left as is (App. B-10)
             return finals[0] if len(finals) == 1 else torch.stack(finals, 0)

@@ -980,75 +980,96 @@ class MaskedRNNSeqFn(Function):
 
 
 # ----------------------------------------------------------------- packed-sequence RNN
-class RNNSeqFn(Function):
-    """Whole packed (bi)directional LSTM/GRU recurrence in one launch (+ one for BPTT).
+class RNNLayerFn(Function):
+    """A whole packed (bi)directional LSTM / GRU layer over time-major input rows as ONE autograd
+    node (instruction_encoder.py:27-32,80-94: pack_padded_sequence -> nn.LSTM/GRU ->
+    pad_packed_sequence), built for a short HOST path: the backward is two library calls
+    (vlnce_rnn_seq_bwd2, vlnce_rnn_seq_wgrad) where the chain linear -> RNNSeqFn -> cat issued
+    ~45 launches from Python, eagerly, behind the tail's backward graph.
 
-    forward(kind, save, lengths_i32, dirs, gi_0, w_hh_0, b_hh_0[, gi_1, w_hh_1, b_hh_1])
-      gi_d [L,B,G*H] time-major input projections (x W_ih^T + b_ih)
-    returns out_0[, out_1] ([L,B,H], zeros past each length) then hfin_0[, hfin_1] ([B,H]).
-    """
+    forward(kind, save, lengths_i32, dirs, B, L, x_tm [L*B, E], then per direction
+            w_ih [G*H,E], b_ih, w_hh [G*H,H], b_hh)
+    returns seq [B, L, dirs*H] (zeros past each length: the consumer's row layout, written by
+    the kernel itself) then hfin_0[, hfin_1] ([B,H])."""
 
     @staticmethod
-    def forward(ctx, kind, save, lengths, dirs, *t):
-        gis = [_f32c(t[3 * d]) for d in range(dirs)]
-        whh = [_f32c(t[3 * d + 1]) for d in range(dirs)]
-        bhh = [_f32c(t[3 * d + 2]) for d in range(dirs)]
-        Lm, B, GH = gis[0].shape
-        H = whh[0].size(1)
-        dev = gis[0].device
-        outs = [torch.zeros((Lm, B, H), device=dev, dtype=torch.float32) for _ in range(dirs)]
-        hfin = [torch.empty((B, H), device=dev, dtype=torch.float32) for _ in range(dirs)]
+    def forward(ctx, kind, save, lengths, dirs, B, Lm, x_tm, *params):
+        x_tm, ldx = _rows2d(_f32c(x_tm) if x_tm.dtype != torch.float32 else x_tm)
+        E = x_tm.size(1)
+        w_ih = [_f32c(params[4 * d]) for d in range(dirs)]
+        b_ih = [params[4 * d + 1] for d in range(dirs)]
+        w_hh = [_f32c(params[4 * d + 2]) for d in range(dirs)]
+        b_hh = [_f32c(params[4 * d + 3]) for d in range(dirs)]
+        GH, H = w_hh[0].shape
+        dev = x_tm.device
+        lib = L()
+        rows = Lm * B
+        gis = []
+        for d in range(dirs):
+            gi = torch.empty((rows, GH), device=dev, dtype=torch.float32)
+            if not _planes_gemm(x_tm, ldx, w_ih[d], gi, b_ih[d]):
+                lib.gemm(x_tm, ldx, 0, w_ih[d], E, 0, gi, GH, rows, GH, E, shift=b_ih[d])
+            gis.append(gi.view(Lm, B, GH))
+
+        def new(*shape):
+            return torch.empty(shape, device=dev, dtype=torch.float32)
+
+        out_tm = [new(Lm, B, H) for _ in range(dirs)]
+        seq = new(B, Lm, dirs * H)
+        hfin = [new(B, H) for _ in range(dirs)]
         gates = aux = None
         if save:
-            gates = [torch.empty((Lm, B, GH), device=dev, dtype=torch.float32) for _ in range(dirs)]
-            aux = [torch.empty((Lm, B, H), device=dev, dtype=torch.float32) for _ in range(dirs)]
-        L().rnn_seq_fwd(kind, dirs, gis, whh, bhh, lengths, outs, hfin, gates, aux, B, Lm, H)
-        ctx.cfg = (kind, dirs, Lm, B, H, GH)
+            gates = [new(Lm, B, GH) for _ in range(dirs)]
+            aux = [new(Lm, B, H) for _ in range(dirs)]
+        lib.rnn_seq_fwd2(kind, dirs, gis, w_hh, b_hh, lengths, out_tm, seq, dirs * H, Lm * dirs * H,
+                         hfin, gates, aux, B, Lm, H)
+        ctx.cfg = (kind, dirs, Lm, B, H, GH, E, ldx)
+        ctx.set_materialize_grads(False)   # unused outputs (the final states) arrive as None, not zeros
         if save:
-            ctx.save_for_backward(lengths, *whh, *outs, *gates, *aux)
-        return (*outs, *hfin)
+            ctx.save_for_backward(lengths, x_tm, *w_ih, *w_hh, *out_tm, *gates, *aux)
+        return (seq, *hfin)
 
     @staticmethod
-    def backward(ctx, *grads):
-        kind, dirs, Lm, B, H, GH = ctx.cfg
+    def backward(ctx, dseq, *dhf):
+        kind, dirs, Lm, B, H, GH, E, ldx = ctx.cfg
         sv = ctx.saved_tensors
-        lengths = sv[0]
-        whh = sv[1:1 + dirs]
-        outs = sv[1 + dirs:1 + 2 * dirs]
-        gates = sv[1 + 2 * dirs:1 + 3 * dirs]
-        aux = sv[1 + 3 * dirs:1 + 4 * dirs]
-        dev = outs[0].device
-        douts = [(_f32c(g) if g is not None else None) for g in grads[:dirs]]
-        dhf = [(_f32c(g) if g is not None else None) for g in grads[dirs:2 * dirs]]
-        whh_t = [w.t().contiguous() for w in whh]
-        dgi = [torch.zeros((Lm, B, GH), device=dev, dtype=torch.float32) for _ in range(dirs)]
-        dgh = None
-        if kind == 1:
-            dgh = [torch.zeros((Lm, B, GH), device=dev, dtype=torch.float32) for _ in range(dirs)]
+        lengths, x_tm = sv[0], sv[1]
+        w_ih, w_hh = sv[2:2 + dirs], sv[2 + dirs:2 + 2 * dirs]
+        out_tm = sv[2 + 2 * dirs:2 + 3 * dirs]
+        gates = sv[2 + 3 * dirs:2 + 4 * dirs]
+        aux = sv[2 + 4 * dirs:2 + 5 * dirs]
+        dev = x_tm.device
+        st = sb = 0
+        if dseq is not None:
+            if dseq.dtype != torch.float32 or dseq.stride(2) != 1:
+                dseq = _f32c(dseq)
+            sb, st = dseq.stride(0), dseq.stride(1)
+        dhf = [(_f32c(g) if g is not None else None) for g in dhf[:dirs]]
+
+        def new(*shape):
+            return torch.empty(shape, device=dev, dtype=torch.float32)
+
+        dgi = [new(Lm, B, GH) for _ in range(dirs)]
+        dgh = [new(Lm, B, GH) for _ in range(dirs)] if kind == 1 else None
         lib = L()
-        lib.rnn_seq_bwd(kind, dirs, whh_t, lengths, list(outs), list(gates), list(aux), douts, dhf,
-                        dgi, dgh, B, Lm, H)
-        res = [None, None, None, None]
+        ws = new(dirs, Lm, B, H) if dseq is not None else None
+        lib.rnn_seq_bwd2(kind, dirs, list(w_hh), lengths, list(out_tm), list(gates), list(aux), dseq,
+                         st, sb, ws, dhf, dgi, dgh, B, Lm, H)
+        dw_ih = [new(GH, E) for _ in range(dirs)]
+        dw_hh = [new(GH, H) for _ in range(dirs)]
+        db_ih = [new(GH) for _ in range(dirs)]
+        db_hh = [new(GH) for _ in range(dirs)]
+        dx = new(Lm * B, E) if ctx.needs_input_grad[6] else None
+        lib.rnn_seq_wgrad(kind, dirs, dgi, dgh, list(out_tm), x_tm, ldx, E, list(w_ih), dw_ih, dw_hh,
+                          db_ih, db_hh, dx, B, Lm, H)
+        res = [None, None, None, None, None, None, dx]
         for d in range(dirs):
-            dG = dgh[d] if kind == 1 else dgi[d]
-            # dW_hh = dG^T H_prev, H_prev = the state entering each step = the previous output in
-            # processing order: outs shifted by one step (zeros at the start: that step adds
-            # nothing, and outputs past a row's length are zeros), i.e. two views, no copy
-            dw = torch.empty((GH, H), device=dev, dtype=torch.float32)
-            if Lm > 1:
-                dG_s, h_s = (dG[:-1], outs[d][1:]) if d == 1 else (dG[1:], outs[d][:-1])
-                lib.gemm(dG_s, GH, 1, h_s, H, 1, dw, H, GH, H, (Lm - 1) * B)
-            else:
-                dw.zero_()
-            db = torch.empty((GH,), device=dev, dtype=torch.float32)
-            lib.colsum(dG, GH, Lm * B, GH, db, 0)
-            res += [dgi[d], dw, db]
+            res += [dw_ih[d], db_ih[d], dw_hh[d], db_hh[d]]
         return tuple(res)
 
 
-def rnn_seq(kind, lengths_i32, per_direction, need_grad):
-    """per_direction: list of (gi [L,B,G*H], w_hh, b_hh).  Returns ([out_d], [hfin_d])."""
-    dirs = len(per_direction)
-    flat = [t for trip in per_direction for t in trip]
-    res = RNNSeqFn.apply(kind, bool(need_grad), lengths_i32, dirs, *flat)
-    return list(res[:dirs]), list(res[dirs:])
+def rnn_layer(kind, lengths_i32, x_tm, B, Lm, per_direction, need_grad):
+    """per_direction: list of (w_ih, b_ih, w_hh, b_hh).  Returns (seq [B, L, dirs*H], [hfin_d])."""
+    flat = [t for quad in per_direction for t in quad]
+    res = RNNLayerFn.apply(kind, bool(need_grad), lengths_i32, len(per_direction), B, Lm, x_tm, *flat)
+    return res[0], list(res[1:])
