@@ -6,8 +6,15 @@ Weights are not stored: they are regenerated from state_dict key names by
 oracle.thirdparty.synth_state_dict (seeded, construction-order independent).
 Inputs ARE stored in the .npz next to the expected outputs.
 """
+import os
+
 import numpy as np
 import torch
+
+# a synthetic stand-in for data/datasets/R2R_VLNCE_v1-3_preprocessed/embeddings.json.gz (320 words x
+# 50 dims, PAD row 0 = zeros, UNK row 1 = the mean row), written by make_goldens_embeddings.py
+EMBEDDINGS_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "embeddings_synth.json.gz")
+EMBEDDINGS_VOCAB = 320
 
 CASES = {
     # BASELINE.json configs[0]: the reference's own CPU-runnable case
@@ -65,6 +72,24 @@ CASES = {
     "waypoint_ppo_update_64": dict(
         policy="WaypointPolicy", hw=64, N=2, T=3, lengths=[9, 14], mode="ppo", call="ppo_update",
     ),
+    # The upstream DEFAULT instruction embedding (config/default.py:225-232,
+    # instruction_encoder.py:36-41,52-61): the table is read from embeddings.json.gz and FROZEN
+    # (no embedding gradient, no state to optimise); the second case fine-tunes it.  The table keeps
+    # the file's values (synth_state_dict's embedding is not loaded over it).
+    "cma_pretrained_embeddings_64": dict(
+        policy="CMAPolicy", hw=64, N=3, T=2, lengths=[7, 12, 4], mode="train", call="update",
+        vocab=EMBEDDINGS_VOCAB, pretrained_embeddings=True,
+        overrides={"INSTRUCTION_ENCODER.use_pretrained_embeddings": True,
+                   "INSTRUCTION_ENCODER.embedding_file": EMBEDDINGS_FILE,
+                   "INSTRUCTION_ENCODER.fine_tune_embeddings": False},
+    ),
+    "seq2seq_finetuned_embeddings_64": dict(
+        policy="Seq2SeqPolicy", hw=64, N=2, T=2, lengths=[9, 5], mode="train", call="update",
+        vocab=EMBEDDINGS_VOCAB, pretrained_embeddings=True,
+        overrides={"INSTRUCTION_ENCODER.use_pretrained_embeddings": True,
+                   "INSTRUCTION_ENCODER.embedding_file": EMBEDDINGS_FILE,
+                   "INSTRUCTION_ENCODER.fine_tune_embeddings": True},
+    ),
     # BASELINE.json configs[2] / the bench workload ITSELF: one `_update_agent`
     # (base_il_trainer.py:134-180) of the CMA policy at num_envs = 64, 256x256 RGB-D, instructions of
     # up to 80 tokens, batch-statistics BatchNorm as constructed -- the batch at which the library
@@ -96,7 +121,7 @@ def build_inputs(case):
     obs = {}
     tok = torch.zeros(N, 200, dtype=torch.long)
     for i, L in enumerate(c["lengths"]):
-        tok[i, :L] = torch.randint(1, VOCAB, (L,), generator=g)
+        tok[i, :L] = torch.randint(1, c.get("vocab", VOCAB), (L,), generator=g)
     obs["instruction"] = tok.repeat(T, 1)  # time-major rows: row = t*N + n
     if c.get("rxr"):
         feats = torch.zeros(N, 32, 768)
@@ -181,7 +206,11 @@ def build_policy(ns, case, make_config, make_spaces, synth_state_dict):
         rgb_space, _ = make_spaces(r, r, pano=pano)
         obs_space.spaces["rgb"] = rgb_space.spaces["rgb"]
     policy = getattr(ns, case["policy"]).from_config(cfg, obs_space, act_space)
-    policy.load_state_dict(synth_state_dict(policy))
+    sd = synth_state_dict(policy)
+    if case.get("pretrained_embeddings"):  # the table read from the embeddings file stays
+        sd["net.instruction_encoder.embedding_layer.weight"] = \
+            policy.net.instruction_encoder.embedding_layer.weight.detach().clone()
+    policy.load_state_dict(sd)
     if case["mode"] == "eval":
         policy.eval()
     elif case["mode"] == "ppo":  # agent.train(); visual encoders .eval()
@@ -264,6 +293,12 @@ def run_case(policy, case, obs, prev, masks, extra, update_fn=None, aux=None, pp
         if hasattr(policy.net, "state_q"):
             out["grad_state_q_w"] = policy.net.state_q.weight.grad
         out["grad_ins_w_hh"] = policy.net.instruction_encoder.encoder_rnn.weight_hh_l0.grad
+        if case.get("pretrained_embeddings"):
+            emb = policy.net.instruction_encoder.embedding_layer.weight
+            out["embedding_requires_grad"] = torch.tensor(int(emb.requires_grad))
+            out["embedding_table_checksum"] = emb.detach().double().sum().reshape(1)
+            if emb.grad is not None:
+                out["grad_embedding"] = emb.grad
     elif call == "waypoint":
         with torch.no_grad():
             pa = {k: v.clone() for k, v in prev.items()}

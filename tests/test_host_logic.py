@@ -56,6 +56,47 @@ def test_host_logic_matches_golden(sim, name):
     compare(outs, gold, atol=1e-4, rtol=1e-4)
 
 
+@pytest.mark.parametrize("fine_tune", [False, True])
+def test_pretrained_embeddings_default_path(monkeypatch, fine_tune):
+    """The upstream default instruction embedding (use_pretrained_embeddings=True,
+    fine_tune_embeddings=False; config/default.py:225-232, instruction_encoder.py:36-61): the table
+    comes from the embeddings file under the reference's state_dict key, is frozen unless
+    fine-tuned, has no padding_idx -- and a frozen table costs NO backward work: the recurrent
+    layer is not asked for the gradient of its input rows and no embedding-backward launch is
+    made.  (Values against the reference: the two `*_embeddings_64` goldens.)"""
+    calls = []
+
+    class Recording(hostsim.HostSim):
+        def rnn_seq_wgrad(self, *a):
+            calls.append(("rnn_seq_wgrad", a[13] is not None))   # a[13] = dx_tm
+            return super().rnn_seq_wgrad(*a)
+
+        def embedding_bwd(self, *a, **k):
+            calls.append(("embedding_bwd", True))
+            return super().embedding_bwd(*a, **k)
+
+    monkeypatch.setattr(_lib, "_LIB", Recording())
+    cfg = vlnce_amd.make_config("CMAPolicy", **{
+        "INSTRUCTION_ENCODER.use_pretrained_embeddings": True,
+        "INSTRUCTION_ENCODER.embedding_file": cases.EMBEDDINGS_FILE,
+        "INSTRUCTION_ENCODER.fine_tune_embeddings": fine_tune})
+    policy = vlnce_amd.build_model(cfg, *vlnce_amd.make_spaces(64, 64))
+    emb = policy.net.instruction_encoder.embedding_layer
+    assert "net.instruction_encoder.embedding_layer.weight" in policy.state_dict()
+    assert tuple(emb.weight.shape) == (cases.EMBEDDINGS_VOCAB, 50) and emb.padding_idx is None
+    assert emb.weight.requires_grad == fine_tune
+    assert float(emb.weight.detach()[0].abs().sum()) == 0.0 and float(emb.weight.detach()[1].abs().sum()) > 0.0
+    case = dict(cases.CASES["cma_pretrained_embeddings_64"])
+    obs, prev, masks, extra = cases.build_inputs(case)
+    vlnce_amd.AuxLosses.activate()
+    product_update(policy, obs, prev, masks, extra["targets"], extra["weights"])
+    vlnce_amd.AuxLosses.deactivate()
+    assert ("rnn_seq_wgrad", fine_tune) in calls and ("rnn_seq_wgrad", not fine_tune) not in calls
+    assert fine_tune or ("embedding_bwd", True) not in calls   # (CPU tensors scatter through torch)
+    assert (emb.weight.grad is not None) == fine_tune
+    assert policy.net.instruction_encoder.encoder_rnn.weight_ih_l0.grad is not None
+
+
 def test_no_cpu_fallback_without_library(monkeypatch):
     monkeypatch.setattr(_lib, "_LIB", None)
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libvlnce_hip.so")
