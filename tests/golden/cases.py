@@ -72,6 +72,16 @@ CASES = {
     "waypoint_ppo_update_64": dict(
         policy="WaypointPolicy", hw=64, N=2, T=3, lengths=[9, 14], mode="ppo", call="ppo_update",
     ),
+    # the heading-prediction-network configs (r2r_waypoint/5-hpn-_c.yaml: no distance head, offset
+    # predicted; 6-hpn-__.yaml: neither -- waypoint_policy.py:93-134 then fixes the distance / offset)
+    "waypoint_hpn_c_64": dict(
+        policy="WaypointPolicy", hw=64, N=2, T=1, lengths=[8, 11], mode="eval", call="waypoint",
+        overrides={"WAYPOINT.predict_distance": False},
+    ),
+    "waypoint_hpn_64": dict(
+        policy="WaypointPolicy", hw=64, N=2, T=1, lengths=[5, 13], mode="eval", call="waypoint",
+        overrides={"WAYPOINT.predict_distance": False, "WAYPOINT.predict_offset": False},
+    ),
     # The upstream DEFAULT instruction embedding (config/default.py:225-232,
     # instruction_encoder.py:36-41,52-61): the table is read from embeddings.json.gz and FROZEN
     # (no embedding gradient, no state to optimise); the second case fine-tunes it.  The table keeps
