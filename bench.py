@@ -398,14 +398,190 @@ def self_launch(n):
     return subprocess.call(cmd, env=env)
 
 
+def exchange_fields(ex):
+    """`allreduce_ms` / `allreduce_hidden_frac` of the JSON line (world > 1 or --force-dist): the
+    bucket collectives of the last timed step on rank 0 and the share of them that ran before
+    backward had ended (GradientAllReducer.stats)."""
+    if not ex:
+        return {}
+    return {"allreduce_ms": round(ex["allreduce_ms"], 3),
+            "allreduce_hidden_frac": (round(ex["hidden_frac"], 4) if ex["hidden_frac"] is not None
+                                      else None),
+            "allreduce": {"buckets": ex["buckets"], "issued_from_backward_hooks": ex["issued_from_hooks"],
+                          "exposed_ms": round(ex["exposed_ms"], 3),
+                          "what": "rank 0, last timed step; hidden = ran under backward"}}
+
+
+def synth_pano_batch(n, hw, tokens, device, seed=1):
+    """WaypointPolicy inputs (ddppo_waypoint_trainer.py:283-306 after ObsStack): 12 panorama
+    frames + the history frame per env, angle features, a `tokens`-token instruction."""
+    g = torch.Generator().manual_seed(seed)
+    obs = {"rgb": torch.randint(0, 256, (n, 12, hw, hw, 3), generator=g).float(),
+           "depth": torch.rand(n, 12, hw, hw, 1, generator=g),
+           "rgb_history": torch.randint(0, 256, (n, hw, hw, 3), generator=g).float(),
+           "depth_history": torch.rand(n, hw, hw, 1, generator=g),
+           "angle_features": torch.randn(n, 12, 4, generator=g),
+           "instruction": torch.zeros(n, 200, dtype=torch.long)}
+    obs["instruction"][:, :tokens] = torch.randint(1, 2504, (n, tokens), generator=g)
+    prev = {"pano": torch.randint(0, 12, (n, 1), generator=g),
+            "offset": (torch.rand(n, 1, generator=g) - 0.5) * 0.4,
+            "distance": 0.25 + torch.rand(n, 1, generator=g) * 2.0}
+    extra = {"pano_action": torch.randint(0, 12, (n, 1), generator=g),
+             "value_preds": torch.randn(n, 1, generator=g) * 0.5,
+             "adv": torch.randn(n, 1, generator=g)}
+    mv = lambda t: t.to(device)  # noqa: E731
+    return ({k: mv(v) for k, v in obs.items()}, {k: mv(v) for k, v in prev.items()},
+            {k: mv(v) for k, v in extra.items()})
+
+
+def secondary_policy_bench(args, dev, rank, world, sim, use_dist, dev_sync):
+    """`--policy seq2seq | waypoint`: BASELINE.json configs[1] / configs[4] under the same launcher,
+    rank set-up, barrier + max-over-ranks timing and GradientAllReducer as the headline.  One step =
+    one `_update_agent` (Seq2Seq; base_il_trainer.py:134-180) or one WDDPPO minibatch update
+    (ddppo_alg.py:53-141: evaluate_actions, the clipped losses, backward, gradient exchange,
+    clipping, Adam; encoders in eval mode as ddppo_waypoint_trainer.py:528-530 puts them; the
+    policy's unused `action_distribution` head never receives a gradient, :370), every step
+    ending with the host read-backs the reference makes."""
+    import vlnce_amd
+    from vlnce_amd.il_harness import update_agent
+    from vlnce_amd.ppo_harness import PPOConfig, wddppo_minibatch_update
+
+    torch.manual_seed(0)
+    n, hw, L = args.num_envs, args.hw, args.tokens
+    way = args.policy == "waypoint"
+    name = "WaypointPolicy" if way else "Seq2SeqPolicy"
+    policy = vlnce_amd.build_model(vlnce_amd.make_config(name),
+                                   *vlnce_amd.make_spaces(hw, hw, pano=way)).to(dev)
+    if way:
+        policy.train()
+        policy.net.rgb_encoder.eval()
+        policy.net.depth_encoder.eval()
+        opt = torch.optim.Adam([p for p in policy.parameters() if p.requires_grad], lr=2.5e-4)
+    else:
+        opt = torch.optim.Adam(policy.parameters(), lr=2.5e-4)
+    reducer = grad_hook = None
+    if use_dist:
+        from vlnce_amd.distributed import GradientAllReducer
+
+        reducer = GradientAllReducer(policy, timing=True)
+        grad_hook = reducer.finish
+    vlnce_amd.AuxLosses.activate()
+    NB = 2 if way else 4   # distinct resident batches in rotation (a waypoint batch is 330 MB)
+    it = [0]
+    if way:
+        hid = policy.net.model_config.STATE_ENCODER.hidden_size
+        samples = []
+        for i in range(NB):
+            obs, prev, ex = synth_pano_batch(n, hw, L, dev, seed=1 + rank + 101 * i)
+            masks = torch.ones(n, 1, dtype=torch.uint8, device=dev)
+            h0 = torch.zeros(n, policy.net.num_recurrent_layers, hid, device=dev)
+            with torch.no_grad():   # action components inside the truncated-normal supports
+                out = policy.act(obs, h0, {k: v.clone() for k, v in prev.items()}, masks,
+                                 deterministic=True)
+            actions = {k: v.clone() for k, v in out[2].items()}
+            actions["pano"] = ex["pano_action"]
+            samples.append((obs, h0, actions, prev, ex["value_preds"], ex["value_preds"] + 0.3,
+                            masks, torch.full((n, 1), -2.0, device=dev), ex["adv"]))
+
+        def step():
+            it[0] += 1
+            s = list(samples[it[0] % NB])
+            s[3] = {k: v.clone() for k, v in s[3].items()}   # the policy mutates prev_actions
+            stats = wddppo_minibatch_update(policy, opt, tuple(s), PPOConfig(), grad_hook=grad_hook)
+            return [v.item() for v in stats]   # ddppo_alg.py:133-140 accumulates six .item()s
+        frames = 13
+    else:
+        batches = [synth_batch(n, hw, L, dev, seed=1 + rank + 101 * i) for i in range(NB)]
+
+        def step():
+            it[0] += 1
+            obs, prev, masks, tgt, w = batches[it[0] % NB]
+            return update_agent(policy, opt, obs, prev, masks, tgt, w, 512, grad_hook=grad_hook)
+        frames = 1
+
+    def sync():
+        if use_dist:
+            dist.barrier()
+        dev_sync()
+
+    log(f"{name} built, starting warm-up")
+    for i in range(args.warmup):
+        t0 = time.perf_counter()
+        step()
+        dev_sync()
+        log(f"warm-up step {i}: {1e3 * (time.perf_counter() - t0):.1f} ms")
+    sync()
+    t0 = time.perf_counter()
+    last = None
+    for _ in range(args.steps):
+        last = step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    exchange = None
+    if use_dist:
+        exchange = reducer.stats()
+        tmax = torch.tensor([elapsed], device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = tmax.item()
+    log(f"timed region: {args.steps} steps in {elapsed:.3f}s; last step's read-backs {last}")
+    roof = None
+    if rank == 0 and not sim and not way:
+        c = conv_kernel_time(policy, batches[0][0], dev)
+        if c["reason"] is None:
+            roof = {"bound": "mfma", "kernel": "conv2d fwd launches of the visual trunks",
+                    "achieved": round(c["flop"] / (c["conv_ms"] * 1e-3) / 1e12, 2),
+                    "peak": round(c["flop"] / (c["floor_ms"] * 1e-3) / 1e12, 2), "unit": "TFLOP/s",
+                    "frac": round(c["floor_ms"] / c["conv_ms"], 4),
+                    "peak_is": "per-launch max(HBM, MFMA) floor, as in the headline line",
+                    "launches_per_step": c["n"], "kernel_ms_per_step": round(c["conv_ms"], 3),
+                    "traffic": None}
+    if rank == 0:
+        ms = 1e3 * elapsed / args.steps
+        line = {
+            "metric": "policy-steps/sec (fwd+bwd)",
+            "value": None if sim else round(n * world * args.steps / elapsed, 1),
+            "unit": "policy-steps/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32",
+            "data": ("hostsim: CPU simulator of the C ABI (tests/hostsim.py) over gloo -- a test of "
+                     "the launcher and the rank logic, NOT a measurement") if sim else "synthetic",
+            "config": {"workload": (
+                f"WaypointPolicy WDDPPO minibatch update (evaluate_actions + losses + backward + "
+                f"clip + Adam), encoders in eval mode, num_envs={n}/GPU x 13 frames "
+                f"{hw}x{hw} RGB-D, {L}-token instruction" if way else
+                f"Seq2Seq policy DAgger update (fwd+bwd+Adam), num_envs={n}/GPU, {hw}x{hw} RGB-D, "
+                f"{L}-token instruction") + f", {NB} distinct batches in rotation",
+                "global_batch": n * world, "parallelism": f"dp{world}",
+                "frames_per_sec": None if sim else round(frames * n * world * args.steps / elapsed, 1)},
+            **exchange_fields(exchange)}
+        if roof:
+            line["roofline"] = roof
+        final = json.dumps(line)
+    if use_dist:
+        dist.destroy_process_group()
+    if rank == 0:
+        sys.stdout.flush()
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        print(final, flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--num-envs", type=int, default=64)
+    ap.add_argument("--policy", choices=["cma", "seq2seq", "waypoint"], default="cma",
+                    help="cma (default) = the headline workload (BASELINE.json configs[2]/[3]); "
+                         "seq2seq = configs[1] (DAgger update, num_envs 32); waypoint = configs[4] "
+                         "(WaypointPolicy WDDPPO minibatch update, num_envs 32 x 13 frames, 200 tokens): "
+                         "the same rank logic, timing and gradient all-reducer, a shorter JSON line")
+    ap.add_argument("--num-envs", type=int, default=None, help="per GPU; default 64 (cma) / 32")
     ap.add_argument("--hw", type=int, default=256)
-    ap.add_argument("--tokens", type=int, default=80)
+    ap.add_argument("--tokens", type=int, default=None, help="default 80 (cma, seq2seq) / 200 (waypoint)")
     ap.add_argument("--bn", choices=["train", "eval"], default="train",
                     help="train = as constructed by the reference (batch statistics)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -430,6 +606,10 @@ def main():
     # no roofline.  Never a measurement.
     ap.add_argument("--hostsim", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.num_envs is None:
+        args.num_envs = 64 if args.policy == "cma" else 32
+    if args.tokens is None:
+        args.tokens = 200 if args.policy == "waypoint" else 80
     if args.cpu_baseline_only:
         cpu_baseline_worker(args.num_envs, args.hw, args.tokens, args.threads)
         return
@@ -472,6 +652,9 @@ def main():
     from vlnce_amd import ops
     from vlnce_amd.il_harness import update_agent
 
+    if args.policy != "cma":
+        secondary_policy_bench(args, dev, rank, world, sim, use_dist, dev_sync)
+        return
     torch.manual_seed(0)
     over = {}
     if args.trainable_encoders:
@@ -488,7 +671,7 @@ def main():
     if use_dist:
         from vlnce_amd.distributed import GradientAllReducer
 
-        reducer = GradientAllReducer(policy)
+        reducer = GradientAllReducer(policy, timing=True)
         grad_hook = reducer.finish
     vlnce_amd.AuxLosses.activate()
     # NB distinct resident batches, used in rotation: one batch fed every step would stay warm in
@@ -584,7 +767,9 @@ def main():
             per.setdefault(idx, []).append(e0.elapsed_time(e1))
         log("side-stream branch durations (ms, mean over the timed launches): "
             + ", ".join(f"stream{idx}: {sum(v) / len(v):.2f} x{len(v)}" for idx, v in sorted(per.items())))
+    exchange = None
     if use_dist:
+        exchange = reducer.stats()   # the last timed step's gradient exchange on this rank
         tmax = torch.tensor([elapsed], device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = tmax.item()
@@ -599,7 +784,7 @@ def main():
                 "data": "hostsim: CPU simulator of the C ABI (tests/hostsim.py) over gloo -- a test "
                         "of the launcher and the rank logic, NOT a measurement",
                 "config": {"workload": "launcher self-test", "global_batch": args.num_envs * world,
-                           "parallelism": f"dp{world}"}}), flush=True)
+                           "parallelism": f"dp{world}"}, **exchange_fields(exchange)}), flush=True)
         if use_dist:
             dist.destroy_process_group()
         return
@@ -775,6 +960,7 @@ def main():
                          "invalid_reason": conv["reason"],
                          "traffic": pmc_traffic(n_conv)},
         }
+        line.update(exchange_fields(exchange))
         if world == 1 and not args.no_f32_compare and "VLNCE_CONV_MATH" not in os.environ:
             line["config"]["fp32_mfma_only"] = f32_mfma_compare(args)
         if world == 1 and not args.no_cpu_baseline:

@@ -31,6 +31,10 @@ def _one_json_line(stdout, n):
     assert d["config"]["parallelism"] == f"dp{n}" and d["config"]["global_batch"] == 2 * n
     assert d["ms_per_step"] > 0 and d["scaling"] == "weak"
     assert "hostsim" in d["data"] and d["value"] is None   # never mistaken for a measurement
+    # the gradient exchange of the last step: total time of the bucket collectives and the share of
+    # it that ran before backward had ended (GradientAllReducer.stats)
+    assert d["allreduce_ms"] > 0 and 0.0 <= d["allreduce_hidden_frac"] <= 1.0
+    assert d["allreduce"]["buckets"] >= 1
     return d
 
 
@@ -60,3 +64,17 @@ def test_bench_rejects_a_world_size_that_disagrees_with_gpus():
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "4"] + ARGS,
                        env=env, capture_output=True, text=True, timeout=120, cwd=REPO)
     assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stderr + r.stdout)
+
+
+def test_bench_policy_waypoint_and_seq2seq_run_data_parallel():
+    """BASELINE.json configs[4] (WaypointPolicy DD-PPO, `--policy waypoint`: evaluate_actions +
+    WDDPPO minibatch update with the never-used `action_distribution` head in the reducer's first
+    bucket, ddppo_waypoint_trainer.py:370) and configs[1] (`--policy seq2seq`) launch under
+    `--gpus 2` like the headline and print the same one line."""
+    for pol, workload in (("waypoint", "WaypointPolicy WDDPPO minibatch update"),
+                          ("seq2seq", "Seq2Seq policy DAgger update")):
+        r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--policy", pol]
+                           + ARGS, env=_clean_env(), capture_output=True, text=True, timeout=900, cwd=REPO)
+        assert r.returncode == 0, r.stderr[-3000:]
+        d = _one_json_line(r.stdout, 2)
+        assert workload in d["config"]["workload"]

@@ -20,6 +20,7 @@ Semantics preserved (base_il_trainer.py:159-165): the IL loss is normalised
 per episode and then .mean()'d over episodes, so equal-sized shards + gradient
 averaging reproduce the single-process gradient exactly.
 """
+import time
 import warnings
 
 import torch
@@ -35,7 +36,14 @@ class GradientAllReducer:
     .grad tensors themselves (ncclGroupStart/End underneath, no flatten / unflatten copies and,
     on RCCL, ReduceOp.AVG so there is no scaling pass either)."""
 
-    def __init__(self, module, bucket_bytes=8 << 20, process_group=None, divergent_unused=False):
+    def __init__(self, module, bucket_bytes=8 << 20, process_group=None, divergent_unused=False,
+                 timing=False):
+        """timing=True: every bucket's collective is bracketed by events (host clock without a
+        communication stream), finish() stamps the end of backward, and stats() reports how much
+        of the exchange ran under backward (bench.py: `allreduce_ms`, `allreduce_hidden_frac`)."""
+        self.timing = bool(timing)
+        self._stamps = []   # per bucket of the last step: (start, end) events or host times
+        self._bwd_end = None
         self.group = process_group
         self.world = dist.get_world_size(process_group)
         # gloo (CPU tests) has no AVG: sum, then one fused multiply
@@ -125,14 +133,21 @@ class GradientAllReducer:
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             if self.comm is None:
+                if self.timing:
+                    self._stamps.append([time.perf_counter(), None, b])
                 b.work = dist.all_reduce_coalesced(b.tensors, op=op, group=self.group,
                                                    async_op=True)
                 return
             self.comm.wait_stream(torch.cuda.current_stream(self.comm.device))
             with torch.cuda.stream(self.comm):
+                if self.timing:
+                    t0 = torch.cuda.Event(enable_timing=True)
+                    t0.record(self.comm)
                 dist.all_reduce_coalesced(b.tensors, op=op, group=self.group, async_op=False)
-                b.work = torch.cuda.Event()
+                b.work = torch.cuda.Event(enable_timing=self.timing)
                 b.work.record(self.comm)
+                if self.timing:
+                    self._stamps.append([t0, b.work, b])
 
     def _on_grad(self, p):
         b = self._bucket_of[p]
@@ -157,6 +172,15 @@ class GradientAllReducer:
         """Call after loss.backward(): waits for every bucket (the gradients were averaged in
         place) and re-arms the hooks for the next step."""
         self.launched_before_finish = self._next
+        if self.timing:
+            if self.comm is None:
+                self._bwd_end = time.perf_counter()
+            else:
+                self._bwd_end = torch.cuda.Event(enable_timing=True)
+                self._bwd_end.record(torch.cuda.current_stream(self.comm.device))
+            self._done_stamps = self._stamps   # this step's buckets (those launched below join it)
+            self._stamps = []
+            stamps_of_step = self._done_stamps
         for b in self.buckets[self._next:]:  # held back by a parameter without a gradient
             self._launch(b)
         self._next = 0
@@ -171,9 +195,16 @@ class GradientAllReducer:
             if not self.avg:
                 torch._foreach_mul_(late, 1.0 / self.world)
             self._late = []
+        if self.timing:
+            stamps_of_step.extend(self._stamps)
+            self._stamps = []
         for b in self.buckets:
             if self.comm is None:
                 b.work.wait()
+                if self.timing:
+                    for st in stamps_of_step:
+                        if st[2] is b and st[1] is None:
+                            st[1] = time.perf_counter()
             else:
                 torch.cuda.current_stream(self.comm.device).wait_event(b.work)
             if not self.avg:
@@ -193,6 +224,25 @@ class GradientAllReducer:
             self._skip = frozenset(p for b in self.buckets for p in b.params if p.grad is None)
         for b in self.buckets:
             b.pending = sum(1 for p in b.params if p not in self._skip)
+
+    def stats(self):
+        """Exchange of the LAST finished step (call after a device synchronisation): total time of
+        the bucket collectives, the part of it that ran after backward had ended (`exposed_ms`:
+        from the backward-end stamp finish() takes to the end of the last collective), and
+        hidden_frac = 1 - exposed / total.  None without timing=True or before the first step."""
+        st = getattr(self, "_done_stamps", None)
+        if not self.timing or not st or self._bwd_end is None:
+            return None
+        if self.comm is None:
+            total = sum(e - s for s, e, _ in st) * 1e3
+            exposed = max(0.0, max(e for _, e, _ in st) - self._bwd_end) * 1e3
+        else:
+            total = sum(s.elapsed_time(e) for s, e, _ in st)
+            exposed = max(0.0, max(self._bwd_end.elapsed_time(e) for _, e, _ in st))
+        exposed = min(exposed, total)
+        return {"allreduce_ms": total, "exposed_ms": exposed, "buckets": len(st),
+                "issued_from_hooks": self.launched_before_finish,
+                "hidden_frac": (1.0 - exposed / total) if total > 0 else None}
 
     def remove(self):
         for h in self._handles:
