@@ -194,6 +194,20 @@ int vlnce_gemm(const float* A, int lda, int transA, const float* B, int ldb, int
                float* C, int ldc, int M, int N, int K,
                const vlnce_epilogue* epi, vlnce_stream_t stream);
 
+/* Skinny linear layers (M <= 128 rows = one row per environment; N % 4 == 0, K % 4 == 0; rows of x,
+ * w, dy, y 16-byte aligned), ABI 141: y = act(x W^T + b) in ONE launch and the whole backward --
+ * dx [M,K] = dz W, dw [N,K] = dz^T x, db [N] = colsum dz with dz = dy * act'(y) -- in ONE launch
+ * (each of dx / dw / db may be NULL), exact fp32 MFMA, no atomics, no pre-zeroed outputs.
+ * Replace nn.Linear / the nn.GRU projections of the nets at one row per environment and their
+ * autograd (cma_policy.py:103-131,140-177; seq2seq_policy.py:109-121; waypoint_predictors.py:76-180),
+ * which through vlnce_gemm are 3 launches forward and 5 backward per layer. */
+int vlnce_linear_rows_supported(int M, int N, int K);
+int vlnce_linear_rows_fwd(const float* x, int ldx, const float* w, int ldw, const float* bias,
+                          int act, float* y, int ldy, int M, int N, int K, vlnce_stream_t stream);
+int vlnce_linear_rows_bwd(const float* x, int ldx, const float* w, int ldw, const float* dy,
+                          int lddy, const float* y, int ldy, int act, float* dx, float* dw,
+                          float* db, int M, int N, int K, vlnce_stream_t stream);
+
 /* column sums: out[n] (+)= sum_m X[m,n]  (bias gradients) */
 int vlnce_colsum(const float* x, int ldx, int M, int N, float* out, int accumulate,
                  vlnce_stream_t stream);

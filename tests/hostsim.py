@@ -688,6 +688,42 @@ class HostSim:
                     dgh[d][idx] = dpre_h[active]
                 dh = torch.where(a, dpre_h @ W + keep, dh)
 
+    # ---- skinny linear layers (contract of csrc/linear_rows.hip)
+    def linear_rows_supported(self, M, N, K):
+        return 1 <= M <= 128 and N % 4 == 0 and K % 4 == 0 and K >= 4
+
+    @staticmethod
+    def _act_grad(g, y, act):
+        if act == 1:
+            return g * (y > 0)
+        if act == 2:
+            return g * y * (1 - y)
+        if act == 3:
+            return g * (1 - y * y)
+        return g
+
+    def linear_rows_fwd(self, x, ldx, w, ldw, bias, act, y, ldy, M, N, K):
+        xv = torch.as_strided(x, (M, K), (ldx, 1), x.storage_offset())
+        wv = torch.as_strided(w, (N, K), (ldw, 1), w.storage_offset())
+        v = xv @ wv.t()
+        if bias is not None:
+            v = v + bias
+        v = {0: lambda t: t, 1: torch.relu, 2: torch.sigmoid, 3: torch.tanh}[act](v)
+        torch.as_strided(y, (M, N), (ldy, 1), y.storage_offset()).copy_(v)
+
+    def linear_rows_bwd(self, x, ldx, w, ldw, dy, lddy, y, ldy, act, dx, dw, db, M, N, K):
+        xv = torch.as_strided(x, (M, K), (ldx, 1), x.storage_offset())
+        wv = torch.as_strided(w, (N, K), (ldw, 1), w.storage_offset())
+        dz = torch.as_strided(dy, (M, N), (lddy, 1), dy.storage_offset())
+        if act != 0:
+            dz = self._act_grad(dz, torch.as_strided(y, (M, N), (ldy, 1), y.storage_offset()), act)
+        if dx is not None:
+            dx.copy_(dz @ wv)
+        if dw is not None:
+            dw.copy_(dz.t() @ xv)
+        if db is not None:
+            db.copy_(dz.sum(0))
+
     # second-generation entry points (ABI 141): same contracts, self-zeroing, consumer-layout outputs
     def rnn_seq_fwd2(self, kind, dirs, gi, w_hh, b_hh, lengths, out_tm, seq, seq_st, seq_sb, h_final,
                      gates_save, aux_save, B, Lm, H):

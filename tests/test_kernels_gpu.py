@@ -570,6 +570,65 @@ def test_instruction_encoder_matches_torch_packed_rnn(hip, rnn_type, bidir, fina
         close(ph.grad, pr.grad, 5e-4, what=f"d {n}")
 
 
+LINEAR_ROWS_CASES = [
+    # M,   N,    K,   act, bias, strided x
+    (64, 256, 2112, 1, True, False),    # rgb_linear of a 64-environment CMA step
+    (64, 128, 3072, 1, True, False),    # depth_linear
+    (64, 1536, 416, 0, True, False),    # first state encoder, input gates
+    (64, 512, 1184, 1, True, True),     # second_state_compress, x a column window of a wider matrix
+    (32, 768, 512, 3, True, False),
+    (128, 64, 256, 2, False, False),
+    (100, 36, 52, 1, True, False),      # ragged everywhere: rows, a 4-column strip tail, K % 16 != 0
+    (5, 16, 4, 0, True, False),
+    (1, 4, 2052, 3, True, False),
+    (17, 260, 1028, 0, False, True),
+]
+
+
+@pytest.mark.parametrize("M,N,K,act,bias,strided", LINEAR_ROWS_CASES)
+def test_linear_rows_fwd_bwd_match_torch(hip, M, N, K, act, bias, strided):
+    """vlnce_linear_rows_fwd / _bwd (one launch per direction of a <= 128-row linear layer) against
+    torch: y = act(x W^T + b), and dx, dW, db through the activation's derivative."""
+    x_full = rnd(M, K + (8 if strided else 0), seed=1)
+    x = x_full[:, 4:4 + K] if strided else x_full
+    w, b = rnd(N, K, seed=2) * (K ** -0.5), (rnd(N, seed=3) if bias else None)
+    gy = rnd(M, N, seed=4)
+    fn = {0: lambda t: t, 1: torch.relu, 2: torch.sigmoid, 3: torch.tanh}[act]
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True) if bias else None
+    yr = fn(xr @ wr.t() + (br if bias else 0))
+    yr.backward(gy)
+    xh = x_full.to(DEV)
+    xh = (xh[:, 4:4 + K] if strided else xh).requires_grad_(True)
+    wh = w.to(DEV).requires_grad_(True)
+    bh = b.to(DEV).requires_grad_(True) if bias else None
+    lib = ops.L()
+    assert lib.linear_rows_supported(M, N, K)
+    calls = []
+    orig = lib.linear_rows_fwd, lib.linear_rows_bwd
+    lib.linear_rows_fwd = lambda *a: (calls.append("fwd"), orig[0](*a))[1]
+    lib.linear_rows_bwd = lambda *a: (calls.append("bwd"), orig[1](*a))[1]
+    try:
+        yh = ops.linear(xh, wh, bh, act)
+        yh.backward(gy.to(DEV))
+    finally:
+        del lib.linear_rows_fwd, lib.linear_rows_bwd
+    assert calls == ["fwd", "bwd"], calls   # this layer did run on the skinny-linear kernels
+    close(yh, yr, 2e-5, what="y")
+    close(xh.grad, xr.grad, 2e-5, what="dx")
+    close(wh.grad, wr.grad, 2e-5, what="dW")
+    if bias:
+        close(bh.grad, br.grad, 2e-5, what="db")
+    # parameters only (a frozen input) and input only (frozen parameters)
+    y2 = ops.linear(xh.detach(), wh, bh, act)
+    wh.grad = None
+    y2.backward(gy.to(DEV))
+    close(wh.grad, wr.grad, 2e-5, what="dW, no dx")
+    x3 = xh.detach().requires_grad_(True)
+    ops.linear(x3, wh.detach(), None if not bias else bh.detach(), act).backward(gy.to(DEV))
+    close(x3.grad, xr.grad, 2e-5, what="dx, no dW")
+
+
 @pytest.mark.parametrize("rnn_type,bidir", [("LSTM", True), ("GRU", True), ("GRU", False)])
 def test_rnn_layer_fn_input_gradient_and_sliced_output_gradient(hip, rnn_type, bidir):
     """ops.RNNLayerFn (vlnce_rnn_seq_fwd2 / _bwd2 / _wgrad) against torch's packed nn.LSTM / nn.GRU:

@@ -116,6 +116,9 @@ _SIGNATURES = {
     "vlnce_rnn_seq_supported": (_I, [_I, _I]),
     "vlnce_rnn_seq_fwd": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "vlnce_rnn_seq_bwd": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "vlnce_linear_rows_supported": (_I, [_I, _I, _I]),
+    "vlnce_linear_rows_fwd": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P]),
+    "vlnce_linear_rows_bwd": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _P, _P, _P, _I, _I, _I, _P]),
     "vlnce_rnn_seq_fwd2": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _L, _L, _P, _P, _P, _I, _I, _I, _P]),
     "vlnce_rnn_seq_bwd2": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _L, _L, _P, _P, _P, _P, _I, _I, _I, _P]),
     "vlnce_rnn_seq_wgrad": (_I, [_I, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
@@ -610,6 +613,18 @@ class HipLib:
             kind, dirs, pa(w_hh_t, dirs), _ptr(lengths), pa(out, dirs), pa(gates_save, dirs),
             pa(aux_save, dirs), pa(dout, dirs), pa(dh_final, dirs), pa(dgi, dirs), pa(dgh, dirs),
             B, Lm, H, _stream()), "vlnce_rnn_seq_bwd")
+
+    def linear_rows_supported(self, M, N, K):
+        return bool(self.dll.vlnce_linear_rows_supported(M, N, K))
+
+    def linear_rows_fwd(self, x, ldx, w, ldw, bias, act, y, ldy, M, N, K):
+        self._check(self.dll.vlnce_linear_rows_fwd(_ptr(x), ldx, _ptr(w), ldw, _ptr(bias), act, _ptr(y),
+                                                   ldy, M, N, K, _stream()), "vlnce_linear_rows_fwd")
+
+    def linear_rows_bwd(self, x, ldx, w, ldw, dy, lddy, y, ldy, act, dx, dw, db, M, N, K):
+        self._check(self.dll.vlnce_linear_rows_bwd(_ptr(x), ldx, _ptr(w), ldw, _ptr(dy), lddy, _ptr(y),
+                                                   ldy, act, _ptr(dx), _ptr(dw), _ptr(db), M, N, K,
+                                                   _stream()), "vlnce_linear_rows_bwd")
 
     def rnn_seq_fwd2(self, kind, dirs, gi, w_hh, b_hh, lengths, out_tm, seq, seq_st, seq_sb, h_final,
                      gates_save, aux_save, B, Lm, H):

@@ -1,6 +1,8 @@
 """Pieces the Seq2Seq, CMA and waypoint nets share: construction of the visual encoders from
 `config.MODEL`, the three-branch encoder pass on side HIP streams, ablation switches, the
 previous-action index and the progress-monitor auxiliary loss."""
+import os
+
 import torch
 
 from . import ops
@@ -74,7 +76,8 @@ def encode_three_branches(net, observations, device, distinct_instructions=False
         # stream 10.3-10.9, this order 10.2-10.7.
         rgb = net.rgb_encoder(observations)
         ins, join_ins = branches.run(fork, 0, device, instruction)
-        dep, join_dep = branches.run(fork, 0, device, lambda: net.depth_encoder(observations))
+        dep, join_dep = branches.run(fork, 2 if os.environ.get("VLNCE_DEPTH_OWN_STREAM") == "1" else 0,
+                                     device, lambda: net.depth_encoder(observations))
     join_ins()
     join_dep()
     return ins, dep, rgb

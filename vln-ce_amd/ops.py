@@ -508,7 +508,14 @@ class LinearFn(Function):
         N = weight.size(0)
         w = weight if weight.is_contiguous() else weight.contiguous()
         y = torch.empty((M, N), device=x.device, dtype=torch.float32)
-        if not _planes_gemm(x, ldx, w, y, bias, act):
+        ctx.rows = _linear_rows_ok(x, ldx, w, M, N, K)
+        # one row per environment: one launch, bias and activation included.  (Reductions past
+        # 2048 -- rgb_linear, depth_linear: 16 / 8 column strips -- are as fast split over K by the
+        # general GEMM's three launches, profiles/r05_f_linear_rows_per_layer.txt; their backward
+        # is not.)
+        if ctx.rows and K <= 2048:
+            L().linear_rows_fwd(x, ldx, w, K, bias, act, y, N, M, N, K)
+        elif not _planes_gemm(x, ldx, w, y, bias, act):
             L().gemm(x, ldx, 0, w, K, 0, y, N, M, N, K, shift=bias, act=act)
         ctx.act = act
         ctx.has_bias = bias is not None
@@ -524,11 +531,21 @@ class LinearFn(Function):
         N = w.size(0)
         ldx = x.stride(0) if M > 1 else K
         dz = _f32c(dy)
+        dx = dw = db = None
+        if ctx.rows and not ctx.dx_from and dz.data_ptr() % 16 == 0:
+            # dx, dW, db and the activation's derivative in one launch (vlnce_linear_rows_bwd)
+            def new(*shape):
+                return torch.empty(shape, device=dz.device, dtype=torch.float32)
+
+            dx = new(M, K) if ctx.needs_input_grad[0] else None
+            dw = new(N, K) if ctx.needs_input_grad[1] else None
+            db = new(N) if ctx.has_bias and ctx.needs_input_grad[2] else None
+            lib.linear_rows_bwd(x, ldx, w, K, dz, N, y, N, ctx.act, dx, dw, db, M, N, K)
+            return dx, dw, db, None, None
         if ctx.act != ACT_NONE:
             dz2 = torch.empty_like(dz)
             lib.act_bwd(dz, y, dz2, dz.numel(), ctx.act)
             dz = dz2
-        dx = dw = db = None
         if ctx.needs_input_grad[0]:
             c0 = ctx.dx_from
             if c0:
@@ -549,6 +566,14 @@ class LinearFn(Function):
             db = torch.empty((N,), device=dz.device, dtype=torch.float32)
             lib.colsum(dz, N, M, N, db, 0)
         return dx, dw, db, None, None
+
+
+def _linear_rows_ok(x, ldx, w, M, N, K):
+    """True where the skinny-linear kernels apply (csrc/linear_rows.hip): at most 128 rows, N and K
+    multiples of 4, 16-byte aligned rows.  VLNCE_LINEAR_ROWS=0 keeps the general GEMM (A/B)."""
+    return (M <= 128 and N % 4 == 0 and K % 4 == 0 and K >= 4 and ldx % 4 == 0
+            and x.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0
+            and os.environ.get("VLNCE_LINEAR_ROWS", "1") != "0")
 
 
 def linear(x, weight, bias=None, act=ACT_NONE, dx_from=0):

@@ -15,7 +15,7 @@ from .encoders.instruction_encoder import InstructionEncoder
 from .net_parts import build_depth_encoder, build_rgb_encoder, relu_fc
 from .policy import Net
 from .rnn_state_encoder import build_rnn_state_encoder
-from .streams import GraphedTail
+from .streams import BranchStreams, GraphedTail
 from .utils import (CustomFixedCategorical, DotProductAttention, MultiHeadDotProductAttention,
                     TemperatureTanh)
 
@@ -179,6 +179,7 @@ class WaypointPredictionNet(Net):
         self._build_component_heads(hs + pano_width)
         # kept out of the module tree (it shares our sub-modules): see _WaypointTail
         object.__setattr__(self, "_tail", GraphedTail(lambda: _WaypointTail(self)))
+        self._branches = BranchStreams()
         self.train()
 
     # ---- class index -> metres / radians (waypoint_predictors.py:184-215)
@@ -254,11 +255,18 @@ class WaypointPredictionNet(Net):
         hs = self._hidden_size
         half = hs // 2
 
-        ins = self.instruction_encoder(observations).permute(0, 2, 1)  # [B, L, C]
+        # the instruction encoder (200-token RxR-length instructions: a 200-step recurrence on a
+        # handful of workgroups, ~0.7 ms, and one host sync for the lengths) on a side stream under
+        # the two trunks' 2 x 13 x B frames; autograd runs its backward on that stream too
+        fork = self._branches.fork(rnn_states.device)
+        ins, join_ins = self._branches.run(fork, 0, rnn_states.device,
+                                           lambda: self.instruction_encoder(observations))
         rgb, rgb_hist = self._encode_frames(self.rgb_encoder, "rgb", observations["rgb"],
                                             observations["rgb_history"], masks)
         dep, dep_hist = self._encode_frames(self.depth_encoder, "depth", observations["depth"],
                                             observations["depth_history"], masks)
+        join_ins()
+        ins = ins.permute(0, 2, 1)  # [B, L, C]
         B = rgb.shape[0]
 
         if len(prev_actions["pano"].shape) == 1:  # :380-382, mutates the caller's dict
