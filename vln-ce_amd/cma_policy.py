@@ -88,9 +88,8 @@ class _CMATail(nn.Module):
         depth_kv = ops.linear(dep, self.depth_kv.weight.view(-1, C_d), self.depth_kv.bias,
                               dx_from=self._dep_frozen)
         text_q = ops.linear(text_embedding, self.text_q.weight, self.text_q.bias)
-        rgb_embedding = ops.attention(text_q, rgb_kv[..., :half], rgb_kv[..., half:], None, 1, scale)
-        depth_embedding = ops.attention(text_q, depth_kv[..., :half], depth_kv[..., half:], None, 1,
-                                        scale)
+        rgb_embedding = ops.attention_kv(text_q, rgb_kv, half, None, 1, scale)
+        depth_embedding = ops.attention_kv(text_q, depth_kv, half, None, 1, scale)
 
         x = torch.cat([state, text_embedding, rgb_embedding, depth_embedding, act], dim=1)
         x = ops.linear(x, self.second_state_compress[0].weight,

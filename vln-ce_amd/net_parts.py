@@ -1,8 +1,6 @@
 """Pieces the Seq2Seq, CMA and waypoint nets share: construction of the visual encoders from
 `config.MODEL`, the three-branch encoder pass on side HIP streams, ablation switches, the
 previous-action index and the progress-monitor auxiliary loss."""
-import os
-
 import torch
 
 from . import ops
@@ -66,18 +64,18 @@ def encode_three_branches(net, observations, device, distinct_instructions=False
         rgb = net.rgb_encoder(observations)
         ins, join_ins = branches.run(fork, 0, device, instruction)
     else:
-        # training step: both side branches share side stream 0 (the instruction encoder's ~1 ms
-        # then the depth trunk's ~1.9 ms, beside the RGB trunk's ~6.8 ms on the caller's stream).
-        # Measured with GPU event stamps (profiles/r04_d_overlap_probe2_event_stamps.txt): the side
-        # work does run under the RGB trunk (instruction encoder done at 1.0 ms, depth trunk at
-        # 6.6 ms, RGB trunk 6.8 -> 7.6 ms); a rocprofv3 kernel trace shows the two queues
-        # serialised, which is the profiler, not the run.  Issue orders tried and dropped
-        # (profiles/r04_b_*): side branches first 11.1 ms/step, depth trunk first on its own
-        # stream 10.3-10.9, this order 10.2-10.7.
+        # training step: RGB trunk on the caller's stream, the instruction encoder (~1 ms, one host
+        # sync for the lengths) on side stream 0 and the depth trunk on side stream 2.  Every one
+        # of the depth trunk's ~200 small launches waits for a boundary between the RGB trunk's
+        # one-workgroup-per-CU kernels, so it takes ~6 ms beside the RGB trunk (1.4 ms alone) and
+        # must not also wait behind the instruction encoder: on a shared side stream it ended
+        # 0.2 ms AFTER the RGB trunk (profiles/r05_d_*; 9.71 -> 9.57 ms/step with its own stream,
+        # r05_g_depth_trunk_stream_and_order.txt; issuing it before the RGB trunk delays that
+        # one by as much as it gains).  GPU event stamps, not the tracer, are the evidence for
+        # overlap on this runtime (profiles/r04_d_overlap_probe2_event_stamps.txt).
         rgb = net.rgb_encoder(observations)
         ins, join_ins = branches.run(fork, 0, device, instruction)
-        dep, join_dep = branches.run(fork, 2 if os.environ.get("VLNCE_DEPTH_OWN_STREAM") == "1" else 0,
-                                     device, lambda: net.depth_encoder(observations))
+        dep, join_dep = branches.run(fork, 2, device, lambda: net.depth_encoder(observations))
     join_ins()
     join_dep()
     return ins, dep, rgb

@@ -694,6 +694,49 @@ def attention(q, K, V, mask=None, mask_mode=1, scale=1.0, index=None):
     return AttnFn.apply(q, K, V, mask, mask_mode, scale, index)
 
 
+class AttnKVFn(Function):
+    """AttnFn over ONE projection that holds keys and values side by side, kv [B, P, Dk + Dv]
+    (the rgb_kv / depth_kv 1x1 convolutions of cma_policy.py:258-274 and
+    waypoint_predictors.py:462-490, torch.split there): the kernels read K and V in place through
+    their row stride, and the backward writes dK and dV into the two column ranges of one d_kv --
+    slicing kv in Python cost, per attention, two zero-fills, two strided copies and an add in the
+    backward graph (the autograd of the two slices)."""
+
+    @staticmethod
+    def forward(ctx, q, kv, dk, mask, mask_mode, scale):
+        q = _f32c(q)
+        if kv.stride(2) != 1 or kv.stride(0) != kv.size(1) * kv.stride(1) or kv.dtype != torch.float32:
+            kv = _f32c(kv)
+        B, P, D = kv.shape
+        dv = D - dk
+        ld = kv.stride(1)
+        out = torch.empty((B, dv), device=q.device, dtype=torch.float32)
+        attn = torch.empty((B, P), device=q.device, dtype=torch.float32)
+        mm = 0 if mask is None else int(mask_mode)
+        L().attn_fwd(q, kv[..., :dk], ld, kv[..., dk:], ld, mask, mm, float(scale), out, attn, B, P, dk, dv,
+                     kv_index=None)
+        ctx.save_for_backward(q, kv, attn, mask)
+        ctx.cfg = (mm, float(scale), dk, dv, ld)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, kv, attn, mask = ctx.saved_tensors
+        mm, scale, dk, dv, ld = ctx.cfg
+        B, P, D = kv.shape
+        dout = _f32c(dout)
+        dq = torch.empty((B, dk), device=q.device, dtype=torch.float32)
+        dkv = torch.empty((B, P, D), device=q.device, dtype=torch.float32)
+        L().attn_bwd(dout, q, kv[..., :dk], ld, kv[..., dk:], ld, mask, mm, scale, attn, dq,
+                     dkv[..., :dk], D, dkv[..., dk:], D, B, P, dk, dv, kv_index=None)
+        return dq, dkv, None, None, None, None
+
+
+def attention_kv(q, kv, dk, mask=None, mask_mode=1, scale=1.0):
+    """softmax(mask(q K^T) * scale) V with K = kv[..., :dk], V = kv[..., dk:]."""
+    return AttnKVFn.apply(q, kv, dk, mask, mask_mode, scale)
+
+
 # ----------------------------------------------------------------- row utilities
 class EmbeddingFn(Function):
     """F.embedding with the backward as one atomic scatter-add launch (vlnce_embedding_bwd)."""

@@ -85,10 +85,10 @@ class _WaypointTail(nn.Module):
                             n.rgb_kv_spatial.bias)
         dep_kv = ops.linear(dep.reshape(B * P, Pd, Cd), n.depth_kv_spatial.weight.view(-1, Cd),
                             n.depth_kv_spatial.bias)
-        att_rgb = ops.attention(tq, rgb_kv[..., :half], rgb_kv[..., half:], None, 0,
-                                n.rgb_spatial_attn._scale_f).view(B, P, -1)
-        att_dep = ops.attention(tq, dep_kv[..., :half], dep_kv[..., half:], None, 0,
-                                n.depth_spatial_attn._scale_f).view(B, P, -1)
+        att_rgb = ops.attention_kv(tq, rgb_kv, half, None, 0,
+                                   n.rgb_spatial_attn._scale_f).view(B, P, -1)
+        att_dep = ops.attention_kv(tq, dep_kv, half, None, 0,
+                                   n.depth_spatial_attn._scale_f).view(B, P, -1)
 
         vis_feats = torch.cat([att_rgb, att_dep, angle_features], dim=2)  # [B,12,d]
         shared = vis_feats.permute(0, 2, 1)  # logical [B, d, 12]
