@@ -516,8 +516,10 @@ int vlnce_rnn_seq_bwd2(int kind, int dirs, const float* const* w_hh, const int* 
  * weight_hh, bias_ih, bias_hh): dw_hh[d] [G*H,H] = dGh^T Hprev, db_hh[d] = colsum dGh (dGh = dgh
  * for a GRU, dgi for an LSTM), dw_ih[d] [G*H,E] = dgi^T X, db_ih[d] = colsum dgi (skipped when
  * db_ih[d] == db_hh[d]: an LSTM's two bias gradients are equal), dx_tm [L*B, E] (may be NULL) =
- * sum_d dgi[d] W_ih[d].  x_tm: the time-major input rows [L*B, E] (row stride ldx). */
-int vlnce_rnn_seq_wgrad(int kind, int dirs, const float* const* dgi, const float* const* dgh,
+ * sum_d dgi[d] W_ih[d].  x_tm: the time-major input rows [L*B, E] (row stride ldx).  first_dir: the
+ * direction element 0 of the arrays is (0 forward, 1 reverse: a call for one direction alone, so that
+ * a host can run the two directions on two streams). */
+int vlnce_rnn_seq_wgrad(int kind, int dirs, int first_dir, const float* const* dgi, const float* const* dgh,
                         const float* const* out_tm, const float* x_tm, int ldx, int E,
                         const float* const* w_ih, float* const* dw_ih, float* const* dw_hh,
                         float* const* db_ih, float* const* db_hh, float* dx_tm, int B, int L, int H,

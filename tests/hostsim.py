@@ -748,7 +748,7 @@ class HostSim:
                          dout, dh_final, dgi, dgh, B, Lm, H)
 
     def rnn_seq_wgrad(self, kind, dirs, dgi, dgh, out_tm, x_tm, ldx, E, w_ih, dw_ih, dw_hh, db_ih,
-                      db_hh, dx_tm, B, Lm, H):
+                      db_hh, dx_tm, B, Lm, H, first_dir=0):
         GH = dgi[0].shape[-1]
         x = x_tm.reshape(Lm * B, -1)[:, :E]
         if dx_tm is not None:
@@ -757,7 +757,7 @@ class HostSim:
             dG = (dgh[d] if kind == 1 else dgi[d]).reshape(Lm, B, GH)
             hprev = torch.zeros(Lm, B, H)
             if Lm > 1:
-                if d == 1:
+                if first_dir + d == 1:
                     hprev[:-1] = out_tm[d][1:]
                 else:
                     hprev[1:] = out_tm[d][:-1]

@@ -121,7 +121,7 @@ _SIGNATURES = {
     "vlnce_linear_rows_bwd": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _P, _P, _P, _I, _I, _I, _P]),
     "vlnce_rnn_seq_fwd2": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _L, _L, _P, _P, _P, _I, _I, _I, _P]),
     "vlnce_rnn_seq_bwd2": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _L, _L, _P, _P, _P, _P, _I, _I, _I, _P]),
-    "vlnce_rnn_seq_wgrad": (_I, [_I, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "vlnce_rnn_seq_wgrad": (_I, [_I, _I, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "vlnce_group_norm_small": (_I, [_P, _I, _I, _I, _I, _P, _P, _F, _P, _I, _P, _P]),
     "vlnce_gru_rollout_supported": (_I, [_I, _I]),
     "vlnce_gru_rollout_workspace_bytes": (C.c_long, [_I, _I]),
@@ -643,10 +643,10 @@ class HipLib:
             pa(dgi, dirs), pa(dgh, dirs), B, Lm, H, _stream()), "vlnce_rnn_seq_bwd2")
 
     def rnn_seq_wgrad(self, kind, dirs, dgi, dgh, out_tm, x_tm, ldx, E, w_ih, dw_ih, dw_hh, db_ih,
-                      db_hh, dx_tm, B, Lm, H):
+                      db_hh, dx_tm, B, Lm, H, first_dir=0):
         pa = self._parr
         self._check(self.dll.vlnce_rnn_seq_wgrad(
-            kind, dirs, pa(dgi, dirs), pa(dgh, dirs), pa(out_tm, dirs), _ptr(x_tm), ldx, E,
+            kind, dirs, first_dir, pa(dgi, dirs), pa(dgh, dirs), pa(out_tm, dirs), _ptr(x_tm), ldx, E,
             pa(w_ih, dirs), pa(dw_ih, dirs), pa(dw_hh, dirs), pa(db_ih, dirs), pa(db_hh, dirs),
             _ptr(dx_tm), B, Lm, H, _stream()), "vlnce_rnn_seq_wgrad")
 

@@ -803,8 +803,10 @@ extern "C" int vlnce_rnn_seq_bwd2(int kind, int dirs, const float* const* w_hh, 
 // left in dgi / dgh:  dW_hh[d] = dGh^T Hprev (Hprev = the time-major outputs shifted by one step in
 // processing order: outputs past a row's length are zeros, so the shift is two views),
 // db_hh[d] = colsum dGh, dW_ih[d] = dgi^T X, db_ih[d] = colsum dgi (LSTM: dGh = dgi, so db_ih ==
-// db_hh and the caller may pass the same pointer), dX = sum_d dgi[d] W_ih[d].
-extern "C" int vlnce_rnn_seq_wgrad(int kind, int dirs, const float* const* dgi,
+// db_hh and the caller may pass the same pointer), dX = sum_d dgi[d] W_ih[d].  `first_dir`: which
+// direction array element 0 is (0 = forward; 1 = a call for the reverse direction alone -- the
+// host runs the two directions' calls on two streams).
+extern "C" int vlnce_rnn_seq_wgrad(int kind, int dirs, int first_dir, const float* const* dgi,
                                    const float* const* dgh, const float* const* out_tm,
                                    const float* x_tm, int ldx, int E, const float* const* w_ih,
                                    float* const* dw_ih, float* const* dw_hh, float* const* db_ih,
@@ -813,6 +815,8 @@ extern "C" int vlnce_rnn_seq_wgrad(int kind, int dirs, const float* const* dgi,
   VLNCE_CHECK_ARG(dgi && out_tm && x_tm && dw_ih && dw_hh && db_ih && db_hh,
                   "rnn_seq_wgrad: null argument");
   VLNCE_CHECK_ARG(dirs == 1 || dirs == 2, "rnn_seq_wgrad: dirs must be 1 or 2");
+  VLNCE_CHECK_ARG((first_dir == 0 || first_dir == 1) && first_dir + dirs <= 2,
+                  "rnn_seq_wgrad: first_dir + dirs must stay within the two directions");
   VLNCE_CHECK_ARG(kind == 0 || dgh, "rnn_seq_wgrad: GRU needs dgh");
   VLNCE_CHECK_ARG(!dx_tm || w_ih, "rnn_seq_wgrad: dx_tm needs w_ih");
   const int GH = (kind == 0 ? 4 : 3) * H;
@@ -823,8 +827,9 @@ extern "C" int vlnce_rnn_seq_wgrad(int kind, int dirs, const float* const* dgi,
     const float* dGh = kind == 1 ? dgh[d] : dgi[d];
     if (L > 1) {
       // forward direction: step t's previous state is the output of t - 1; reverse: of t + 1
-      const float* dG_s = d == 1 ? dGh : dGh + (long)B * GH;
-      const float* h_s = d == 1 ? out_tm[d] + (long)B * H : out_tm[d];
+      const bool reverse = first_dir + d == 1;
+      const float* dG_s = reverse ? dGh : dGh + (long)B * GH;
+      const float* h_s = reverse ? out_tm[d] + (long)B * H : out_tm[d];
       int rc = vlnce_gemm(dG_s, GH, 1, h_s, H, 1, dw_hh[d], H, GH, H, (int)((long)(L - 1) * B), nullptr, stream);
       if (rc != 0) return rc;
     } else {

@@ -1127,9 +1127,35 @@ class RNNLayerFn(Function):
         dw_hh = [new(GH, H) for _ in range(dirs)]
         db_ih = [new(GH) for _ in range(dirs)]
         db_hh = [new(GH) for _ in range(dirs)]
-        dx = new(Lm * B, E) if ctx.needs_input_grad[6] else None
-        lib.rnn_seq_wgrad(kind, dirs, dgi, dgh, list(out_tm), x_tm, ldx, E, list(w_ih), dw_ih, dw_hh,
-                          db_ih, db_hh, dx, B, Lm, H)
+        need_dx = ctx.needs_input_grad[6]
+        dx = new(Lm * B, E) if need_dx else None
+        if dirs == 2 and dev.type == "cuda" and os.environ.get("VLNCE_RNN_WGRAD_STREAMS", "1") != "0":
+            # the two directions' parameter gradients (10 launches each, ~80 us) on two streams: this
+            # is the tail end of a step's backward and nothing else is running
+            from .streams import BranchStreams
+
+            cur = torch.cuda.current_stream(dev)
+            side = BranchStreams()._stream(1, dev)
+            if side is cur:
+                side = BranchStreams()._stream(2, dev)
+            dx1 = new(Lm * B, E) if need_dx else None
+            fork = torch.cuda.Event()
+            fork.record(cur)
+            side.wait_event(fork)
+            with torch.cuda.stream(side):
+                lib.rnn_seq_wgrad(kind, 1, dgi[1:], dgh[1:] if dgh else None, list(out_tm[1:]), x_tm, ldx, E,
+                                  list(w_ih[1:]), dw_ih[1:], dw_hh[1:], db_ih[1:], db_hh[1:], dx1, B, Lm,
+                                  H, first_dir=1)
+                done = torch.cuda.Event()
+                done.record(side)
+            lib.rnn_seq_wgrad(kind, 1, dgi[:1], dgh[:1] if dgh else None, list(out_tm[:1]), x_tm, ldx, E,
+                              list(w_ih[:1]), dw_ih[:1], dw_hh[:1], db_ih[:1], db_hh[:1], dx, B, Lm, H)
+            cur.wait_event(done)
+            if need_dx:
+                dx.add_(dx1)
+        else:
+            lib.rnn_seq_wgrad(kind, dirs, dgi, dgh, list(out_tm), x_tm, ldx, E, list(w_ih), dw_ih, dw_hh,
+                              db_ih, db_hh, dx, B, Lm, H)
         res = [None, None, None, None, None, None, dx]
         for d in range(dirs):
             res += [dw_ih[d], db_ih[d], dw_hh[d], db_hh[d]]
