@@ -346,7 +346,7 @@ class HipResNetTrunk(DropsGraphsOnApply, nn.Sequential):
         habitat's batch_obs casts them -- channels-last, possibly a centre-crop view; or the
         tuple (frames [B,F,H,W,3], extra frame [B,H,W,3], mask [B]) of ops.frames.  Returns
         logical NCHW features."""
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self._plist()):
             # trainable encoder: layer-by-layer forward that records what backward needs
             x = ops.frames_f32(ops.frames(x_nhwc_raw))
             return tb.TrunkFn.apply(self, x, *self.trainable_params()).permute(0, 3, 1, 2)
@@ -360,8 +360,8 @@ class HipResNetTrunk(DropsGraphsOnApply, nn.Sequential):
         modes = tuple(m.training for m in self._norms)
         if any(modes) and not all(modes):
             raise NotImplementedError("mixed train/eval BatchNorm modes inside one trunk")
-        key = (signature, modes[0], tuple(p._version for p in self.parameters()),
-               id(self.input_scale[0]), len(list(self.children())),
+        key = (signature, modes[0], tuple(p._version for p in self._plist()),
+               id(self.input_scale[0]), len(self._modules),
                0 if modes[0] else self._bn_gen)
         return key, modes[0]
 
@@ -617,7 +617,7 @@ class TorchVisionResNet(nn.Module):
         return self.cnn(rgb)
 
     def trunk_parameters(self):
-        return self.cnn.parameters()
+        return self.cnn._plist()
 
     def trunk_ready(self, observations):
         self.cnn.input_scale = self._input_transform(_GraphRunner._parts(observations["rgb"])[0].device)
@@ -766,13 +766,13 @@ class HipResNetEncoder(DropsGraphsOnApply, nn.Module):
 
     def forward(self, observations):
         x = observations["depth"]  # [B,H,W,1] channels-last already; or the ops.frames tuple
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self._plist()):
             x = ops.frames_f32(ops.frames(x))
             return tb.TrunkFn.apply(self, x, *self.trainable_params()).permute(0, 3, 1, 2)
         return self._graphs(x, self._graph_key(ops.frames_signature(x))).permute(0, 3, 1, 2)
 
     def _graph_key(self, signature):
-        return (signature, tuple(p._version for p in self.parameters()))
+        return (signature, tuple(p._version for p in self._plist()))
 
     def graph_ready(self, x):
         return self._graphs.captured(self._graph_key(ops.frames_signature(x)))
@@ -939,7 +939,7 @@ class VlnResnetDepthEncoder(nn.Module):
         return self.visual_encoder(observations)
 
     def trunk_parameters(self):
-        return self.visual_encoder.parameters()
+        return self.visual_encoder._plist()
 
     def trunk_ready(self, observations):
         return self.visual_encoder.graph_ready(observations["depth"])

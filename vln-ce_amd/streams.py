@@ -384,8 +384,21 @@ class DropsGraphsOnApply:
 
     _graph_holders = ("_graphs", "_tail", "_act_graph")
 
+    def _plist(self):
+        """the module's parameters as a list built once: the trunks' graph keys read every
+        parameter's version on every call, and walking the module tree for that
+        (`self.parameters()`: ~0.1 ms for a ResNet-50 trunk, twice per call) was host time at the
+        very start of a step, with the GPU idle (profiles/r05_h_*).  The trunks' module structure
+        is fixed after construction; _apply drops the list with the graphs."""
+        pl = self.__dict__.get("_param_list")
+        if pl is None:
+            pl = list(self.parameters())
+            object.__setattr__(self, "_param_list", pl)
+        return pl
+
     def _apply(self, fn, *args, **kwargs):
         out = super()._apply(fn, *args, **kwargs)
+        self.__dict__.pop("_param_list", None)
         for name in self._graph_holders:
             holder = self.__dict__.get(name)
             if holder is not None:
