@@ -138,3 +138,59 @@ def test_graphed_tail_cache_is_lru():
     while len(t.entries) >= t.MAX_GRAPHS:
         t.entries.popitem(last=False)
     assert list(t.entries) == ["a"]
+
+
+def test_categorical_net_falls_back_past_16_actions(monkeypatch):
+    """ the one-launch action head covers up to 16 classes; a larger discrete action
+    space takes linear + Categorical instead of raising."""
+    import hostsim
+    from vlnce_amd import _lib
+    from vlnce_amd.policy import CategoricalNet
+
+    monkeypatch.setattr(_lib, "_LIB", hostsim.HostSim())
+    net = CategoricalNet(24, 20)
+    x = torch.randn(5, 24)
+    d = net(x)
+    ref = torch.distributions.Categorical(logits=torch.nn.functional.linear(x, net.linear.weight, net.linear.bias))
+    assert torch.allclose(d.logits, ref.logits, atol=1e-5)
+
+
+def test_malformed_tuning_variable_is_ignored_with_a_warning(monkeypatch):
+    """ VLNCE_U3=off must not break loading the library."""
+    import warnings
+
+    from vlnce_amd import _lib
+
+    calls = []
+    fake = type("L", (), {"OPTION_NAMES": _lib.HipLib.OPTION_NAMES,
+                          "set_option": lambda self, n, v: calls.append((n, v))})()
+    monkeypatch.setenv("VLNCE_U3", "off")
+    monkeypatch.setenv("VLNCE_P3", "3")
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        _lib.HipLib._options_from_env(fake)
+    assert ("p3", 3) in calls and not any(n == "u3" for n, _ in calls)
+    assert any("VLNCE_U3" in str(x.message) for x in w)
+
+
+def test_batchnorm_sums_live_on_the_module_and_are_cleared_on_failure(monkeypatch):
+    """ the persistent BatchNorm column sums are an attribute of the layer (not a global
+    keyed by id()), and a failure between the convolution and the finalize leaves them zero."""
+    import hostsim
+    from vlnce_amd import _lib, ops
+
+    monkeypatch.setattr(_lib, "_LIB", hostsim.HostSim())
+    bn = torch.nn.BatchNorm2d(8)
+    acc = ops._bn_state(bn)
+    assert bn.__dict__["_vlnce_acc"] is acc and "_vlnce_acc" not in bn.state_dict()
+    assert ops._bn_state(bn) is acc
+    acc += 1.0
+
+    def boom(*a, **k):
+        raise RuntimeError("boom")
+
+    monkeypatch.setattr(ops, "bn_finalize_sums", boom)
+    monkeypatch.setattr(ops, "conv2d_bn_sums", lambda *a, **k: torch.zeros(1, 2, 2, 8))
+    with pytest.raises(RuntimeError, match="boom"):
+        ops.conv2d_bn_train(torch.zeros(1, 2, 2, 4), torch.zeros(8, 1, 1, 4), 1, 0, bn)
+    assert float(acc.abs().sum()) == 0.0

@@ -230,7 +230,14 @@ class HipLib:
                 v = 0 if v[:1] in ("f", "0") else 1
             elif name in ("igemm_nobuf", "igemm_no_splitk"):
                 v = 0 if v in ("", "0") else 1
-            self.set_option(name, int(v))
+            try:
+                v = int(v)
+            except ValueError:   #  a malformed tuning variable must not break the load
+                import warnings
+                warnings.warn(f"VLNCE_{name.upper()}={v!r} is not an integer: ignored "
+                              f"(the option keeps its default)")
+                continue
+            self.set_option(name, v)
 
     def set_option(self, name, value):
         self._check(self.dll.vlnce_set_option(name.encode(), int(value)), "vlnce_set_option")

@@ -116,18 +116,19 @@ def conv2d_nhwc(x, w_ohwi, stride, pad, *, in_scale=None, in_shift=None, in_cent
 
 
 BN_SHARDS = 16   # VLNCE_BN_SHARDS of include/vlnce_hip.h
-_BN_STATE = {}   # id(BatchNorm module) -> (device, acc [BN_SHARDS,C,2] f64): zero between launches
 
 
 def _bn_state(bn):
     """the persistent column sums (vlnce_bn_sums.acc) of one BatchNorm layer; bn_finalize_sums
-    leaves them zero.  Created on the first (eager) call of a layer, i.e. before any graph capture."""
+    leaves them zero.  Created on the first (eager) call of a layer, i.e. before any graph capture.
+    Lives ON the module (a plain attribute: not a buffer, not in state_dict; freed with the module,
+    never mistaken for another layer's after an id() is re-used -- ADVICE r4)."""
     w = bn.weight
-    hit = _BN_STATE.get(id(bn))
-    if hit is None or hit[0] != w.device or hit[1].size(1) != w.numel():
-        hit = (w.device, torch.zeros((BN_SHARDS, w.numel(), 2), device=w.device, dtype=torch.float64))
-        _BN_STATE[id(bn)] = hit
-    return hit[1]
+    acc = bn.__dict__.get("_vlnce_acc")
+    if acc is None or acc.device != w.device or acc.size(1) != w.numel():
+        acc = torch.zeros((BN_SHARDS, w.numel(), 2), device=w.device, dtype=torch.float64)
+        bn.__dict__["_vlnce_acc"] = acc
+    return acc
 
 
 def conv2d_bn_sums(x, w_ohwi, stride, pad, acc, **pro):
@@ -167,8 +168,16 @@ def conv2d_bn_train(x, w_ohwi, stride, pad, bn, **pro):
     frozen trunk's BatchNorm stays in training mode.)"""
     assert bn.momentum is not None
     acc = _bn_state(bn)
-    y = conv2d_bn_sums(x, w_ohwi, stride, pad, acc, **pro)
-    return y, bn_finalize_sums(acc, y.numel() // y.size(-1), bn)
+    try:
+        y = conv2d_bn_sums(x, w_ohwi, stride, pad, acc, **pro)
+        return y, bn_finalize_sums(acc, y.numel() // y.size(-1), bn)
+    except Exception:
+        # the sums must be zero between launches: a failure between the convolution and the
+        # finalize (an allocation, an argument check) would otherwise leak this pass's sums into
+        # the next forward's statistics
+        if not (acc.is_cuda and torch.cuda.is_current_stream_capturing()):
+            acc.zero_()
+        raise
 
 
 def bn_finalize(stats, M, gamma, beta, eps, momentum, running_mean, running_var):
@@ -472,6 +481,12 @@ def rowzero_mask(x3):
 
 
 # ----------------------------------------------------------------- linear / 1x1 conv
+def _planes_eligible(x, M, K, N):
+    """x[M,K] w[N,K]^T is large enough for the bf16-plane kernels (see _planes_gemm)"""
+    return (x.is_cuda and M >= 1024 and K % 32 == 0 and N % 32 == 0 and 2.0 * M * N * K >= 1e9
+            and os.environ.get("VLNCE_LINEAR_PLANES", "1") != "0")
+
+
 def _planes_gemm(x, ldx, w, y, bias=None, act=ACT_NONE):
     """y[M,N] = act(x[M,K] w[N,K]^T + bias) through the convolution entry point (a 1x1 convolution
     over M pixels: the bf16-plane kernels, fp32-class arithmetic at 1.5-2.5x the fp32-MFMA GEMM's
@@ -480,8 +495,7 @@ def _planes_gemm(x, ldx, w, y, bias=None, act=ACT_NONE):
     small launches per call: a trainable layer's weights change every step).  False: not taken, use lib.gemm."""
     M, K = x.shape
     N = w.size(0)
-    if (not x.is_cuda or M < 1024 or K % 32 or N % 32 or 2.0 * M * N * K < 1e9
-            or os.environ.get("VLNCE_LINEAR_PLANES", "1") == "0"):
+    if not _planes_eligible(x, M, K, N):
         return False
     Wd = next((d for d in range(min(M, 1024), 0, -1) if M % d == 0), 1)   # rows of <= 1024 pixels
     if M // Wd > 32767:
@@ -555,8 +569,9 @@ class LinearFn(Function):
             else:
                 dx = torch.empty((M, K), device=dz.device, dtype=torch.float32)
                 # dx[M,K] = dz[M,N] * W[N,K]   (B stored [K'=N, N'=K]); large: as dz (W^T)^T on the
-                # bf16-plane kernels (one transpose of the weights)
-                if not (M >= 1024 and _planes_gemm(dz, N, w.t().contiguous(), dx)):
+                # bf16-plane kernels (one transpose of the weights, made only when that path
+                # is taken -- ADVICE r4)
+                if not (_planes_eligible(dz, M, N, K) and _planes_gemm(dz, N, w.t().contiguous(), dx)):
                     lib.gemm(dz, N, 0, w, K, 1, dx, K, M, K, N)
         if ctx.needs_input_grad[1]:
             dw = torch.empty((N, K), device=dz.device, dtype=torch.float32)

@@ -28,7 +28,10 @@ class CategoricalNet(nn.Module):
         test of the argument validation in ONE launch (ops.action_head; ~16 host-paced launches as
         torch ops), and the whole backward in one more."""
         capturing = x.is_cuda and torch.cuda.is_current_stream_capturing()
-        if os.environ.get("VLNCE_ACTION_HEAD", "1") == "0":   # A/B: the head as separate torch ops
+        # (the one-launch head holds a row's logits in registers: action spaces of up to 16 classes;
+        # a larger discrete space takes the plain linear layer + Categorical)
+        if (os.environ.get("VLNCE_ACTION_HEAD", "1") == "0"   # A/B: the head as separate torch ops
+                or self.linear.weight.size(0) > 16):
             logits = ops.linear(x, self.linear.weight, self.linear.bias)
             return CustomFixedCategorical(logits=logits, validate_args=False if capturing else None)
         validate = torch.distributions.Distribution._validate_args and not capturing
