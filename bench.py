@@ -187,12 +187,12 @@ def f32_mfma_compare(args):
 
 def pmc_traffic(n_conv):
     """HBM bytes per conv launch from the committed rocprofv3 PMC passes of this same
-    workload (profiles/r04_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate
+    workload (profiles/r05_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate
     passes of `bench.py --pmc-step`, gfx950 corrections applied as MI355X_MICROARCH.md
     prescribes).  None when the file is absent or was taken for a different launch count."""
     prof = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
     rec = None
-    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json"):   # newest collection first
+    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json"):   # newest first
         try:
             rec = json.load(open(os.path.join(prof, name)))
             break

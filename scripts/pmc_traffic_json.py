@@ -33,10 +33,13 @@ def conv_sum(seg):
 
 fetch, write = segments(sys.argv[1]), segments(sys.argv[2])
 copy_kb = 256 * 1024
-f_frac = fetch[1][0][1] / copy_kb
-w_frac = write[1][0][1] / copy_kb
-nf, fkb = conv_sum(fetch[2])
-nw, wkb = conv_sum(write[2])
+# the layout's markers are the LAST three spin kernels of the run (other spin kernels, e.g. the
+# stream-placement probe of streams.pick_concurrent_stream, come before them): count from the end
+last = max(fetch)
+f_frac = fetch[last - 2][0][1] / copy_kb
+w_frac = write[last - 2][0][1] / copy_kb
+nf, fkb = conv_sum(fetch[last - 1])
+nw, wkb = conv_sum(write[last - 1])
 assert nf == nw, (nf, nw)
 fb, wb = fkb * 1024 / f_frac, wkb * 1024 / w_frac
 out = {

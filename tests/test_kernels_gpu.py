@@ -613,7 +613,9 @@ def test_linear_rows_fwd_bwd_match_torch(hip, M, N, K, act, bias, strided):
         yh.backward(gy.to(DEV))
     finally:
         del lib.linear_rows_fwd, lib.linear_rows_bwd
-    assert calls == ["fwd", "bwd"], calls   # this layer did run on the skinny-linear kernels
+    # this layer did run on the skinny-linear kernels (the forward of a reduction past 2048 stays
+    # on the general GEMM, ops.LinearFn.forward)
+    assert calls == (["fwd", "bwd"] if K <= 2048 else ["bwd"]), calls
     close(yh, yr, 2e-5, what="y")
     close(xh.grad, xr.grad, 2e-5, what="dx")
     close(wh.grad, wr.grad, 2e-5, what="dW")

@@ -1144,11 +1144,16 @@ class RNNLayerFn(Function):
         db_hh = [new(GH) for _ in range(dirs)]
         need_dx = ctx.needs_input_grad[6]
         dx = new(Lm * B, E) if need_dx else None
-        if dirs == 2 and dev.type == "cuda" and os.environ.get("VLNCE_RNN_WGRAD_STREAMS", "1") != "0":
-            # the two directions' parameter gradients (10 launches each, ~80 us) on two streams: this
-            # is the tail end of a step's backward and nothing else is running
-            from .streams import BranchStreams
+        from .streams import BranchStreams
 
+        if (dirs == 2 and Lm * B >= 2048 and BranchStreams.enabled(dev)
+                and os.environ.get("VLNCE_RNN_WGRAD_STREAMS", "1") != "0"):
+            # the two directions' parameter gradients (10 launches each, ~80 us at 64 x 80 rows) on
+            # two streams: this is the tail end of a step's backward and nothing else is running
+            # (9.58 -> 9.47 ms/step, profiles/r05_g_*).  Not for the few distinct instructions of a
+            # sequence-mode batch (5 x 200 rows): there the second stream's launches run beside the
+            # state encoders' one-launch rollout backward and the update got 1 ms SLOWER
+            # (7.97 -> 8.9 ms, profiles/r05_i_same_box_round4_vs_round5.txt)
             cur = torch.cuda.current_stream(dev)
             side = BranchStreams()._stream(1, dev)
             if side is cur:
