@@ -44,8 +44,10 @@ class RNNStateEncoder(nn.Module):
             return y, new_states
         outs = []
         for t in range(t_steps):
-            m = m_u8[t * n:(t + 1) * n]
-            g = gi[t * n:(t + 1) * n]
+            # (one step: no slicing.  The autograd of a slice is zeros + copy_, and a dense copy_
+            # is a MEMCPY NODE in the tail's backward graph, not a kernel node.)
+            m = m_u8 if t_steps == 1 else m_u8[t * n:(t + 1) * n]
+            g = gi if t_steps == 1 else gi[t * n:(t + 1) * n]
             h = ops.mask_rows(h, m)
             if self.is_lstm:
                 c = ops.mask_rows(c, m)
