@@ -615,6 +615,19 @@ int vlnce_ppo_returns(const float* rewards, float* value_preds, const float* mas
                       const float* next_value, float* returns, int T, int N, float gamma, float tau,
                       int use_gae, vlnce_stream_t stream);
 
+/* WDDPPO minibatch loss (ddppo_alg.py:78-121: entropy terms, clipped surrogate,
+ * clipped value loss, offset L1 term) and its gradients in ONE launch (ABI 141).  All inputs [B]
+ * (one value per rollout row); radians may be NULL (no "offset" action component).  stats[8] =
+ * {loss, value_loss, action_loss, entropy_loss, mean pano / offset / distance entropy, offset_loss};
+ * grads [5][B] = d loss / d {values, logp, ent_pano, ent_offset, ent_distance} for a unit upstream
+ * gradient (torch's tie rules for max / min / clamp). */
+int vlnce_ppo_loss(const float* values, const float* returns, const float* value_preds,
+                   const float* logp, const float* old_logp, const float* adv,
+                   const float* ent_pano, const float* ent_offset, const float* ent_distance,
+                   const float* radians, int B, float clip, float value_coef, float entropy_coef,
+                   float pano_coef, float offset_coef, float distance_coef, float reg_coef,
+                   int use_clipped, float* stats, float* grads, vlnce_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -277,6 +277,31 @@ class HostSim:
             weights.view(Tmax, B)[: e - o, b] = torch.where(infl, torch.tensor(float(coef)),
                                                            torch.tensor(1.0))
 
+    def ppo_loss(self, values, returns, value_preds, logp, old_logp, adv, ent_pano, ent_offset,
+                 ent_distance, radians, B, clip, value_coef, entropy_coef, pano_coef, offset_coef,
+                 distance_coef, reg_coef, use_clipped, stats, grads):
+        """contract of vlnce_ppo_loss: torch's own formulas and autograd (ddppo_alg.py:78-121)"""
+        with torch.enable_grad():   # (called from inside an autograd.Function's forward)
+            leaves = [t.detach().clone().requires_grad_(True)
+                      for t in (values, logp, ent_pano, ent_offset, ent_distance)]
+            v, lp, ep, eo, ed = leaves
+            entropy_loss = (pano_coef * ep + offset_coef * eo + distance_coef * ed).mean() * entropy_coef
+            ratio = torch.exp(lp - old_logp)
+            action_loss = -torch.min(ratio * adv, torch.clamp(ratio, 1 - clip, 1 + clip) * adv).mean()
+            if use_clipped:
+                vpc = value_preds + (v - value_preds).clamp(-clip, clip)
+                value_loss = 0.5 * torch.max((v - returns).pow(2), (vpc - returns).pow(2)).mean()
+            else:
+                value_loss = 0.5 * (returns - v).pow(2).mean()
+            value_loss = value_loss * value_coef
+            offset_loss = reg_coef * radians.abs().mean() if radians is not None else torch.zeros(())
+            loss = value_loss + action_loss + offset_loss - entropy_loss
+            gs = torch.autograd.grad(loss, leaves, allow_unused=True)
+        stats.copy_(torch.stack([loss, value_loss, action_loss, entropy_loss, ep.mean(), eo.mean(),
+                                 ed.mean(), offset_loss]).detach().float())
+        for k, g in enumerate(gs):
+            grads.view(5, B)[k].copy_(g if g is not None else torch.zeros(B))
+
     def ppo_returns(self, rewards, value_preds, masks, next_value, returns, T, N, gamma, tau,
                     use_gae):
         r, v, m, ret = (t.view(-1, N) for t in (rewards, value_preds, masks, returns))

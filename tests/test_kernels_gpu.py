@@ -570,6 +570,55 @@ def test_instruction_encoder_matches_torch_packed_rnn(hip, rnn_type, bidir, fina
         close(ph.grad, pr.grad, 5e-4, what=f"d {n}")
 
 
+@pytest.mark.parametrize("B,clipped,with_offset", [(6, True, True), (416, True, True), (1000, False, False),
+                                                   (3, True, False)])
+def test_ppo_loss_and_gradients_match_torch(hip, B, clipped, with_offset):
+    """vlnce_ppo_loss (the WDDPPO minibatch loss, ddppo_alg.py:78-121, and all its gradients in one
+    launch) against the reference's formulas evaluated by torch with autograd: rows inside and
+    outside both clipping ranges, exact ties (value_preds == values, ratio == 1), zero advantages."""
+    from vlnce_amd.ppo_harness import PPOConfig, PPOLossFn
+
+    cfg = PPOConfig(pano_entropy_coef=1.5, offset_entropy_coef=1.0, distance_entropy_coef=0.25,
+                    use_clipped_value_loss=clipped)
+    values, vp = rnd(B, 1, seed=1), rnd(B, 1, seed=2) * 0.6
+    vp[::5] = values[::5]                        # ties of the two value losses
+    returns = values + rnd(B, 1, seed=3) * 0.5
+    old = -2.0 + 0.3 * rnd(B, 1, seed=4)
+    logp = old + 0.25 * rnd(B, 1, seed=5)       # ratios on both sides of [0.8, 1.2]
+    logp[1::7] = old[1::7]                       # ratio == 1 exactly
+    adv = rnd(B, 1, seed=6)
+    adv[2::9] = 0.0
+    ents = [rnd(B, seed=7 + k).abs() for k in range(3)]
+    radians = rnd(B, 1, seed=11) * 0.2 if with_offset else None
+
+    leaves = [t.clone().requires_grad_(True) for t in (values, logp, *ents)]
+    v, lp, ep, eo, ed = leaves
+    entropy_loss = (cfg.pano_entropy_coef * ep + cfg.offset_entropy_coef * eo
+                    + cfg.distance_entropy_coef * ed).mean() * cfg.entropy_coef
+    ratio = torch.exp(lp - old)
+    action_loss = -torch.min(ratio * adv, torch.clamp(ratio, 1 - cfg.clip_param, 1 + cfg.clip_param) * adv).mean()
+    if clipped:
+        vpc = vp + (v - vp).clamp(-cfg.clip_param, cfg.clip_param)
+        value_loss = 0.5 * torch.max((v - returns).pow(2), (vpc - returns).pow(2)).mean()
+    else:
+        value_loss = 0.5 * (returns - v).pow(2).mean()
+    value_loss = value_loss * cfg.value_loss_coef
+    offset_loss = cfg.offset_regularize_coef * radians.abs().mean() if with_offset else 0.0
+    loss_r = value_loss + action_loss + offset_loss - entropy_loss
+    (3.0 * loss_r).backward()
+
+    hl = [t.clone().to(DEV).requires_grad_(True) for t in (values, logp, *ents)]
+    loss, stats = PPOLossFn.apply(*hl, vp.to(DEV), returns.to(DEV), old.to(DEV), adv.to(DEV),
+                                  radians.to(DEV) if with_offset else None, cfg)
+    (3.0 * loss).backward()
+    want = torch.stack([loss_r.detach(), value_loss.detach(), action_loss.detach(), entropy_loss.detach(),
+                        ents[0].mean(), ents[1].mean(), ents[2].mean(), torch.as_tensor(float(offset_loss))])
+    close(stats, want, 2e-6, what="stats")
+    close(loss, loss_r, 2e-6, what="loss")
+    for name, h, r in zip(("values", "logp", "ent_pano", "ent_offset", "ent_distance"), hl, leaves):
+        close(h.grad, r.grad, 1e-5, what=f"d {name}")
+
+
 LINEAR_ROWS_CASES = [
     # M,   N,    K,   act, bias, strided x
     (64, 256, 2112, 1, True, False),    # rgb_linear of a 64-environment CMA step

@@ -81,6 +81,8 @@ _SIGNATURES = {
     "vlnce_ragged_pad_rows": (_I, [_P, _I, _P, _I, _I, _L, _F, _P, _P]),
     "vlnce_ragged_pad_rows_i64": (_I, [_P, _P, _I, _I, _L, _L, _P, _P]),
     "vlnce_dagger_targets": (_I, [_P, _P, _I, _I, _F, _P, _P, _P, _P]),
+    "vlnce_ppo_loss": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _F, _F, _F, _F, _F, _F, _I,
+                            _P, _P, _P]),
     "vlnce_ppo_returns": (_I, [_P, _P, _P, _P, _P, _I, _I, _F, _F, _I, _P]),
     "vlnce_space_to_depth2": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
     "vlnce_frames_s2d": (_I, [C.POINTER(Frames), _P, _I, _I, _P, _P, _P]),
@@ -413,6 +415,15 @@ class HipLib:
         self._check(self.dll.vlnce_dagger_targets(
             _ptr(oracle), _ptr(offsets), B, Tmax, float(coef), _ptr(corrected),
             _ptr(weights), _ptr(masks), _stream()), "vlnce_dagger_targets")
+
+    def ppo_loss(self, values, returns, value_preds, logp, old_logp, adv, ent_pano, ent_offset,
+                 ent_distance, radians, B, clip, value_coef, entropy_coef, pano_coef, offset_coef,
+                 distance_coef, reg_coef, use_clipped, stats, grads):
+        self._check(self.dll.vlnce_ppo_loss(
+            _ptr(values), _ptr(returns), _ptr(value_preds), _ptr(logp), _ptr(old_logp), _ptr(adv),
+            _ptr(ent_pano), _ptr(ent_offset), _ptr(ent_distance), _ptr(radians), B, clip, value_coef,
+            entropy_coef, pano_coef, offset_coef, distance_coef, reg_coef, int(use_clipped),
+            _ptr(stats), _ptr(grads), _stream()), "vlnce_ppo_loss")
 
     def ppo_returns(self, rewards, value_preds, masks, next_value, returns, T, N, gamma, tau,
                     use_gae):

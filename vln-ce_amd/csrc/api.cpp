@@ -26,7 +26,7 @@ extern "C" const char* vlnce_last_error(void) { return g_err; }
 // 138: vlnce_action_head_fwd / _bwd.
 // 139: vlnce_attn_fwd_shared / _bwd_shared, vlnce_segment_sum.
 // 140: option "m3" (conv_m3_kernel).
-// 141: vlnce_rnn_seq_fwd2 / _bwd2 / _wgrad, vlnce_linear_rows_fwd / _bwd.
+// 141: vlnce_rnn_seq_fwd2 / _bwd2 / _wgrad, vlnce_linear_rows_fwd / _bwd, vlnce_ppo_loss.
 extern "C" int vlnce_version(void) { return 141; }
 
 // ---- dispatch options: one int per name, process-wide, relaxed atomics (a tuning / test knob,

@@ -189,6 +189,93 @@ __global__ __launch_bounds__(256) void ppo_returns_kernel(const float* __restric
     }
   }
 }
+
+// WDDPPO minibatch loss (ddppo_alg.py:78-121) and ALL its gradients in one launch of one
+// workgroup: clipped surrogate, (clipped) value loss, the three entropy terms, the offset L1
+// regulariser (a constant: the sampled offsets carry no gradient).  stats[8] = {loss, value_loss,
+// action_loss, entropy_loss, mean pano / offset / distance entropy, offset_loss}; grads [5][B] =
+// d loss / d {values, log-probs, pano / offset / distance entropy} for a unit upstream gradient.
+// Ties follow torch: max / min send half the gradient to each side, clamp passes it on [lo, hi].
+struct PpoLossParams {
+  const float *values, *returns, *value_preds, *logp, *old_logp, *adv, *ent[3], *radians;
+  float* stats;
+  float* grads;
+  int B;
+  float clip, value_coef, entropy_coef, ent_coef[3], reg_coef;
+  int use_clipped;
+};
+__global__ __launch_bounds__(256) void ppo_loss_kernel(PpoLossParams p) {
+  __shared__ double red[4][8];
+  const int tid = threadIdx.x, B = p.B;
+  const double inv = 1.0 / (double)B;
+  double acc[7] = {0, 0, 0, 0, 0, 0, 0};   // value, surrogate, weighted entropy, 3 entropies, |radians|
+  for (int i = tid; i < B; i += 256) {
+    const float v = p.values[i], R = p.returns[i];
+    const float a = (v - R) * (v - R);
+    float vl = a, dv = 2.f * (v - R);
+    if (p.use_clipped) {
+      const float vp = p.value_preds[i];
+      const float diff = v - vp;
+      const float cl = fminf(fmaxf(diff, -p.clip), p.clip);
+      const bool pass = diff >= -p.clip && diff <= p.clip;   // clamp backward
+      const float vpc = vp + cl;
+      const float b = (vpc - R) * (vpc - R);
+      const float db = pass ? 2.f * (vpc - R) : 0.f;
+      if (a > b) { vl = a; }
+      else if (a < b) { vl = b; dv = db; }
+      else { vl = a; dv = 0.5f * dv + 0.5f * db; }
+    }
+    acc[0] += (double)vl;
+    p.grads[i] = (float)(0.5 * (double)p.value_coef * inv) * dv;
+    const float A = p.adv[i];
+    const float r = __expf(p.logp[i] - p.old_logp[i]);
+    const float lo = 1.f - p.clip, hi = 1.f + p.clip;
+    const float rc = fminf(fmaxf(r, lo), hi);
+    const float s1 = r * A, s2 = rc * A;
+    const float d2 = (r >= lo && r <= hi) ? A : 0.f;
+    float dr;
+    if (s1 < s2) dr = A;
+    else if (s1 > s2) dr = d2;
+    else dr = 0.5f * A + 0.5f * d2;
+    acc[1] += (double)fminf(s1, s2);
+    p.grads[B + i] = (float)(-inv) * dr * r;
+    double we = 0.0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float e = p.ent[k][i];
+      acc[3 + k] += (double)e;
+      we += (double)p.ent_coef[k] * (double)e;
+      p.grads[(2 + k) * B + i] = (float)(-(double)p.entropy_coef * (double)p.ent_coef[k] * inv);
+    }
+    acc[2] += we;
+    if (p.radians) acc[6] += (double)fabsf(p.radians[i]);
+  }
+#pragma unroll
+  for (int k = 0; k < 7; ++k) {
+    double v = acc[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if ((tid & 63) == 0) red[tid >> 6][k] = v;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double t[7];
+    for (int k = 0; k < 7; ++k) t[k] = (red[0][k] + red[1][k] + red[2][k] + red[3][k]) * inv;
+    const double value_loss = 0.5 * t[0] * (double)p.value_coef;
+    const double action_loss = -t[1];
+    const double entropy_loss = t[2] * (double)p.entropy_coef;
+    const double offset_loss = p.radians ? (double)p.reg_coef * t[6] : 0.0;
+    p.stats[0] = (float)(value_loss + action_loss + offset_loss - entropy_loss);
+    p.stats[1] = (float)value_loss;
+    p.stats[2] = (float)action_loss;
+    p.stats[3] = (float)entropy_loss;
+    p.stats[4] = (float)t[3];
+    p.stats[5] = (float)t[4];
+    p.stats[6] = (float)t[5];
+    p.stats[7] = (float)offset_loss;
+  }
+}
+
 }  // namespace
 
 extern "C" int vlnce_ppo_returns(const float* rewards, float* value_preds, const float* masks,
@@ -200,5 +287,28 @@ extern "C" int vlnce_ppo_returns(const float* rewards, float* value_preds, const
                      reinterpret_cast<hipStream_t>(stream), rewards, value_preds, masks, next_value,
                      returns, T, N, gamma, (float)((double)gamma * (double)tau), use_gae);
   VLNCE_CHECK_LAUNCH("ppo_returns");
+  return 0;
+}
+
+extern "C" int vlnce_ppo_loss(const float* values, const float* returns, const float* value_preds,
+                              const float* logp, const float* old_logp, const float* adv,
+                              const float* ent_pano, const float* ent_offset, const float* ent_distance,
+                              const float* radians, int B, float clip, float value_coef,
+                              float entropy_coef, float pano_coef, float offset_coef,
+                              float distance_coef, float reg_coef, int use_clipped, float* stats,
+                              float* grads, vlnce_stream_t stream) {
+  VLNCE_CHECK_ARG(values && returns && logp && old_logp && adv && ent_pano && ent_offset && ent_distance &&
+                      stats && grads && (value_preds || !use_clipped),
+                  "ppo_loss: null argument");
+  VLNCE_CHECK_ARG(B > 0, "ppo_loss: empty minibatch");
+  PpoLossParams p{};
+  p.values = values; p.returns = returns; p.value_preds = value_preds; p.logp = logp;
+  p.old_logp = old_logp; p.adv = adv; p.ent[0] = ent_pano; p.ent[1] = ent_offset; p.ent[2] = ent_distance;
+  p.radians = radians; p.stats = stats; p.grads = grads; p.B = B; p.clip = clip;
+  p.value_coef = value_coef; p.entropy_coef = entropy_coef; p.ent_coef[0] = pano_coef;
+  p.ent_coef[1] = offset_coef; p.ent_coef[2] = distance_coef; p.reg_coef = reg_coef;
+  p.use_clipped = use_clipped;
+  hipLaunchKernelGGL(ppo_loss_kernel, dim3(1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
+  VLNCE_CHECK_LAUNCH("ppo_loss");
   return 0;
 }

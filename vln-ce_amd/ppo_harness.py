@@ -46,30 +46,51 @@ def compute_returns(rewards, value_preds, masks, next_value, gamma, tau, use_gae
     return returns
 
 
+class PPOLossFn(torch.autograd.Function):
+    """The WDDPPO minibatch loss (ddppo_alg.py:78-121) as ONE launch that also produces every
+    gradient (vlnce_ppo_loss), instead of ~40 elementwise / reduction launches forward and as many
+    backward, all host-paced.  forward(values, logp, ent_pano, ent_offset, ent_distance,
+    value_preds, returns, old_logp, adv, radians | None, cfg) -> (loss [], stats [8] = loss,
+    value_loss, action_loss, entropy_loss, mean pano / offset / distance entropy, offset_loss)."""
+
+    @staticmethod
+    def forward(ctx, values, logp, ent_p, ent_o, ent_d, value_preds, returns, old_logp, adv, radians,
+                cfg):
+        from . import ops
+
+        B = values.numel()
+        flat = [ops._f32c(t.detach()).reshape(-1) if t is not None else None
+                for t in (values, returns, value_preds, logp, old_logp, adv, ent_p, ent_o, ent_d,
+                          radians)]
+        assert all(t is None or t.numel() == B for t in flat), "one value per rollout row"
+        stats = torch.empty(8, device=values.device, dtype=torch.float32)
+        grads = torch.empty((5, B), device=values.device, dtype=torch.float32)
+        ops.L().ppo_loss(*flat, B, cfg.clip_param, cfg.value_loss_coef, cfg.entropy_coef,
+                         cfg.pano_entropy_coef, cfg.offset_entropy_coef, cfg.distance_entropy_coef,
+                         cfg.offset_regularize_coef, cfg.use_clipped_value_loss, stats, grads)
+        ctx.save_for_backward(grads)
+        ctx.shapes = tuple(t.shape for t in (values, logp, ent_p, ent_o, ent_d))
+        loss = stats[0].clone()
+        ctx.mark_non_differentiable(stats)
+        return loss, stats
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_stats):
+        (grads,) = ctx.saved_tensors
+        g = grads * g_loss
+        out = [g[k].view(shape) for k, shape in enumerate(ctx.shapes)]
+        return (*out, None, None, None, None, None, None)
+
+
 def wddppo_minibatch_update(policy, optimizer, sample, cfg=PPOConfig(), *, step_grad=True,
                             clip_grads=True, grad_hook=None):
     (obs, h0, actions, prev_actions, value_preds, returns, masks, old_logp, adv) = sample
     values, logp, entropy, _ = policy.evaluate_actions(obs, h0, prev_actions, masks, actions)
-
-    weighted_entropy = (cfg.pano_entropy_coef * entropy["pano"]
-                        + cfg.offset_entropy_coef * entropy["offset"]
-                        + cfg.distance_entropy_coef * entropy["distance"])
-    entropy_loss = weighted_entropy.mean() * cfg.entropy_coef
-
-    ratio = (logp - old_logp).exp()
-    lo, hi = 1.0 - cfg.clip_param, 1.0 + cfg.clip_param
-    action_loss = -torch.minimum(ratio * adv, ratio.clamp(lo, hi) * adv).mean()
-
-    err = (values - returns).square()
-    if cfg.use_clipped_value_loss:
-        near = value_preds + (values - value_preds).clamp(-cfg.clip_param, cfg.clip_param)
-        err = torch.maximum(err, (near - returns).square())
-    value_loss = 0.5 * err.mean() * cfg.value_loss_coef
-
-    loss = value_loss + action_loss - entropy_loss
-    if "offset" in actions:  # keep predicted headings near the pano centre
-        radians = policy.net.offset_to_continuous(actions["offset"])
-        loss = loss + cfg.offset_regularize_coef * radians.abs().mean()
+    # keep predicted headings near the pano centre (a constant: sampled offsets carry no gradient)
+    radians = policy.net.offset_to_continuous(actions["offset"]) if "offset" in actions else None
+    loss, stats = PPOLossFn.apply(values, logp, entropy["pano"], entropy["offset"],
+                                  entropy["distance"], value_preds, returns, old_logp, adv, radians,
+                                  cfg)
 
     if optimizer is not None:
         optimizer.zero_grad()
@@ -80,6 +101,5 @@ def wddppo_minibatch_update(policy, optimizer, sample, cfg=PPOConfig(), *, step_
         torch.nn.utils.clip_grad_norm_(policy.parameters(), cfg.max_grad_norm)
     if step_grad and optimizer is not None:
         optimizer.step()
-    return tuple(v.detach() for v in (
-        value_loss, action_loss, entropy_loss, entropy["pano"].mean(),
-        entropy["offset"].mean(), entropy["distance"].mean()))
+    # (value_loss, action_loss, entropy_loss, pano / offset / distance entropy) as WDDPPO.update sums
+    return tuple(stats[1:7].unbind(0))
