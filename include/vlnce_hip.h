@@ -31,6 +31,8 @@ typedef void* vlnce_stream_t;
 enum { VLNCE_ACT_NONE = 0, VLNCE_ACT_RELU = 1, VLNCE_ACT_SIGMOID = 2, VLNCE_ACT_TANH = 3 };
 
 int vlnce_version(void); /* major*100 + minor; 141 = this header */
+int vlnce_option_count(void);              /* length of vlnce_prologue.options                        */
+int vlnce_option_index(const char* name);  /* index of a named dispatch option in it, -1 if unknown   */
 const char* vlnce_last_error(void);
 
 /* Dispatch options: which of the library's equivalent kernels a launch is given to.  Explicit
@@ -106,6 +108,11 @@ typedef struct {
    * conv_p3_kernel (A operand transformed once per workgroup into an LDS patch, B fragments
    * straight from L2); NULL = conv_x3_kernel / igemm_kernel as above. */
   const void* w_frag;
+  /* Optional: the dispatch options of THIS launch -- vlnce_option_count() ints indexed by
+   * vlnce_option_index(name), a negative entry = the process value (vlnce_set_option); NULL = the
+   * process values.  Two policies (or a test forcing a kernel) in one process then do not share
+   * mutable dispatch state: the library only reads what the call hands it. */
+  const int* options;
 } vlnce_prologue;
 
 /* Train-mode BatchNorm statistics taken BY the convolution (torch.nn.BatchNorm2d.forward in

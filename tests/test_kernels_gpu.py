@@ -1197,11 +1197,47 @@ def test_options_are_explicit_state(hip):
     unknown name is an error (the library reads no environment variable)."""
     for name in hip.OPTION_NAMES:
         d = hip.option_default(name)
+        before = hip.get_option(name)
         with hip.options(**{name: d + 1}):
-            assert hip.get_option(name) == d + 1
-        assert hip.get_option(name) == hip.option_default(name) or os.environ.get("VLNCE_" + name.upper())
+            if name in hip.PER_LAUNCH:
+                # convolution-kernel options travel with each launch (vlnce_prologue.options): the
+                # library's process state is not touched
+                assert hip.get_option(name) == before and hip._scoped[name] == d + 1
+            else:
+                assert hip.get_option(name) == d + 1
+        assert hip.get_option(name) == before and getattr(hip, "_scoped", None) is None
+        assert before == hip.option_default(name) or os.environ.get("VLNCE_" + name.upper())
     with pytest.raises(RuntimeError, match="unknown option"):
         hip.set_option("no_such_option", 1)
+    with pytest.raises(RuntimeError, match="unknown dispatch option"):
+        hip.options(no_such_option=1)
+
+
+def test_per_launch_options_do_not_leak_between_launches(hip):
+    """vlnce_prologue.options: the same 1x1 convolution dispatched three ways from one process --
+    explicit per-call options, an enclosing lib.options block, nothing -- lands on the kernel each
+    call names (vlnce_conv2d_last_path) and leaves the process values alone."""
+    x, w = rnd(2, 16, 16, 64, seed=1).to(DEV), (rnd(256, 1, 1, 64, seed=2) * 0.1).to(DEV)
+    g = ops.conv_geometry(x, w, 1, 0)
+    y = torch.empty(2, 16, 16, 256, device=DEV)
+    kw = dict(w_split=ops.split_weights(w), w_frag=ops.pack_weights(w))
+    hip.conv2d_fwd(x, w, y, g, **kw)
+    default_path = hip.conv2d_last_path()
+    ref = y.clone()
+    hip.conv2d_fwd(x, w, y, g, options=dict(conv_math=0), **kw)
+    assert hip.conv2d_last_path() == 0                      # the fp32-MFMA kernel, this launch only
+    close(y, ref, 1e-5, what="fp32-MFMA kernel vs default")
+    hip.conv2d_fwd(x, w, y, g, **kw)
+    assert hip.conv2d_last_path() == default_path
+    assert default_path == 3                                # a small launch: conv_m3_kernel
+    with hip.options(m3=0):
+        hip.conv2d_fwd(x, w, y, g, **kw)
+        assert hip.conv2d_last_path() != 3                  # conv_m3 switched off for the block
+        hip.conv2d_fwd(x, w, y, g, options=dict(conv_math=0), **kw)   # explicit options win
+        assert hip.conv2d_last_path() == 0
+    hip.conv2d_fwd(x, w, y, g, **kw)
+    assert hip.conv2d_last_path() == default_path
+    assert hip.get_option("conv_math") == hip.option_default("conv_math") or os.environ.get("VLNCE_CONV_MATH")
 
 
 def test_conv_p3_matches_fp64_better_than_1e_6(hip):

@@ -31,7 +31,7 @@ class ConvDesc(C.Structure):
 class Prologue(C.Structure):
     _fields_ = [("in_scale", _P), ("in_shift", _P), ("in_center", _P), ("in_relu", _I),
                 ("x2", _P), ("in2_scale", _P), ("in2_shift", _P), ("in2_center", _P),
-                ("side_out", _P), ("w_split", _P), ("w_frag", _P)]
+                ("side_out", _P), ("w_split", _P), ("w_frag", _P), ("options", _P)]
 
 
 class Frames(C.Structure):
@@ -118,6 +118,8 @@ _SIGNATURES = {
     "vlnce_rnn_seq_supported": (_I, [_I, _I]),
     "vlnce_rnn_seq_fwd": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "vlnce_rnn_seq_bwd": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "vlnce_option_count": (_I, []),
+    "vlnce_option_index": (_I, [C.c_char_p]),
     "vlnce_linear_rows_supported": (_I, [_I, _I, _I]),
     "vlnce_linear_rows_fwd": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P]),
     "vlnce_linear_rows_bwd": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _P, _P, _P, _I, _I, _I, _P]),
@@ -254,18 +256,45 @@ class HipLib:
         self._check(self.dll.vlnce_option_default(name.encode(), C.byref(v)), "vlnce_option_default")
         return v.value
 
+    # options that choose among the CONVOLUTION kernels travel with each launch
+    # (vlnce_prologue.options); the diagnostic switches of the GEMM / rollout entry points, which
+    # take no prologue, stay process values
+    PER_LAUNCH = ("conv_math", "p3", "p3_tile", "s3", "u3", "u3_waves", "x3_tile", "m3")
+
+    def _launch_options(self, overrides):
+        """ctypes int array for vlnce_prologue.options from {name: value} (None = no overrides)"""
+        if not overrides:
+            return None
+        arr = (C.c_int * int(self.dll.vlnce_option_count()))(*([-1] * int(self.dll.vlnce_option_count())))
+        for name, v in overrides.items():
+            i = int(self.dll.vlnce_option_index(name.encode()))
+            if i < 0:
+                raise RuntimeError(f"unknown dispatch option {name!r}")
+            arr[i] = int(v)
+        return arr
+
     def options(self, **kw):
-        """`with lib.options(u3=2, s3=0): ...` -- sets, then restores what was there before."""
+        """`with lib.options(u3=2, s3=0): ...` -- convolution-kernel options (PER_LAUNCH) are handed
+        to every conv2d_fwd of the block through its prologue: the library's process state is not
+        touched; the GEMM / rollout diagnostics are set, then restored."""
         lib = self
+        unknown = [k for k in kw if k not in self.OPTION_NAMES]
+        if unknown:
+            raise RuntimeError(f"unknown dispatch option(s) {unknown}")
 
         class _Scope:
             def __enter__(self_inner):
-                self_inner.old = {k: lib.get_option(k) for k in kw}
-                for k, v in kw.items():
-                    lib.set_option(k, v)
+                self_inner.prev = getattr(lib, "_scoped", None)
+                scoped = dict(self_inner.prev or {})
+                scoped.update({k: v for k, v in kw.items() if k in lib.PER_LAUNCH})
+                lib._scoped = scoped or None
+                self_inner.old = {k: lib.get_option(k) for k in kw if k not in lib.PER_LAUNCH}
+                for k in self_inner.old:
+                    lib.set_option(k, kw[k])
                 return lib
 
             def __exit__(self_inner, *exc):
+                lib._scoped = self_inner.prev
                 for k, v in self_inner.old.items():
                     lib.set_option(k, v)
                 return False
@@ -289,13 +318,17 @@ class HipLib:
     def conv2d_fwd(self, x, w, y, g, in_scale=None, in_shift=None, in_relu=0, scale=None,
                    shift=None, residual=None, ldr=0, act=0, accumulate=0, stat_partial=None,
                    in_center=None, x2=None, in2_scale=None, in2_shift=None, in2_center=None,
-                   side_out=None, w_split=None, w_frag=None, bn=None):
+                   side_out=None, w_split=None, w_frag=None, bn=None, options=None):
         """bn: train-mode BatchNorm statistics added by the launch (vlnce_bn_sums): (acc
-        [16, C, 2] f64, workspace uint8) -- finish them with bn_finalize_sums()."""
+        [16, C, 2] f64, workspace uint8) -- finish them with bn_finalize_sums().
+        options: {name: value} dispatch options of this launch (default: those of the enclosing
+        `with lib.options(...)` block, else the process values)."""
         d = self._desc(g)
+        opts = self._launch_options(options if options is not None else getattr(self, "_scoped", None))
         pro = Prologue(_ptr(in_scale), _ptr(in_shift), _ptr(in_center), int(in_relu), _ptr(x2),
                        _ptr(in2_scale), _ptr(in2_shift), _ptr(in2_center), _ptr(side_out),
-                       _ptr(w_split), _ptr(w_frag))
+                       _ptr(w_split), _ptr(w_frag),
+                       C.cast(opts, C.c_void_p) if opts is not None else None)
         bnp = None
         if bn is not None:
             acc, ws = bn

@@ -26,7 +26,7 @@ extern "C" const char* vlnce_last_error(void) { return g_err; }
 // 138: vlnce_action_head_fwd / _bwd.
 // 139: vlnce_attn_fwd_shared / _bwd_shared, vlnce_segment_sum.
 // 140: option "m3" (conv_m3_kernel).
-// 141: vlnce_rnn_seq_fwd2 / _bwd2 / _wgrad, vlnce_linear_rows_fwd / _bwd, vlnce_ppo_loss.
+// 141: vlnce_rnn_seq_fwd2 / _bwd2 / _wgrad, vlnce_linear_rows_fwd / _bwd, vlnce_ppo_loss, vlnce_prologue.options (per-launch dispatch options).
 extern "C" int vlnce_version(void) { return 141; }
 
 // ---- dispatch options: one int per name, process-wide, relaxed atomics (a tuning / test knob,
@@ -53,7 +53,20 @@ int opt_index(const char* name) {
 }
 }  // namespace
 
-int vlnce_opt(int id) { return g_opt[id].load(std::memory_order_relaxed); }
+namespace {
+thread_local const int* t_call_opts = nullptr;   // vlnce_prologue.options of the launch being dispatched
+}
+VlnceOptScope::VlnceOptScope(const int* per_call) : prev(t_call_opts) { t_call_opts = per_call; }
+VlnceOptScope::~VlnceOptScope() { t_call_opts = prev; }
+
+int vlnce_opt(int id) {
+  if (t_call_opts && t_call_opts[id] >= 0) return t_call_opts[id];
+  return g_opt[id].load(std::memory_order_relaxed);
+}
+
+extern "C" int vlnce_option_count(void) { return VLNCE_OPT_COUNT; }
+
+extern "C" int vlnce_option_index(const char* name) { return opt_index(name); }
 
 extern "C" int vlnce_set_option(const char* name, int value) {
   const int i = opt_index(name);

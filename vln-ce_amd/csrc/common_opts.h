@@ -23,3 +23,11 @@ enum {
   VLNCE_OPT_COUNT
 };
 int vlnce_opt(int id);
+
+// Options of ONE launch (vlnce_prologue.options: VLNCE_OPT_COUNT ints, negative = the process value):
+// an entry point that takes them installs them for the calling thread while it dispatches.
+struct VlnceOptScope {
+  explicit VlnceOptScope(const int* per_call);
+  ~VlnceOptScope();
+  const int* prev;
+};

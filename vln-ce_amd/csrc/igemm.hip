@@ -1540,6 +1540,7 @@ extern "C" int vlnce_conv2d_fwd(const float* x, const float* w, float* y, const 
   VLNCE_CHECK_ARG(x && w && y && d, "conv2d_fwd: null argument");
   VLNCE_CHECK_ARG(d->N > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0,
                   "conv2d_fwd: bad shape");
+  const VlnceOptScope opt_scope(pro ? pro->options : nullptr);   // this launch's dispatch options
   VLNCE_CHECK_ARG(d->H < 32768 && d->W < 32768, "conv2d_fwd: H/W must be < 32768");
   const int ho = (d->H + 2 * d->pad - d->KH) / d->stride + 1;
   const int wo = (d->W + 2 * d->pad - d->KW) / d->stride + 1;
