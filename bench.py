@@ -192,7 +192,7 @@ def pmc_traffic(n_conv):
     prescribes).  None when the file is absent or was taken for a different launch count."""
     prof = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
     rec = None
-    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json"):   # newest first
+    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json"):   # newest first
         try:
             rec = json.load(open(os.path.join(prof, name)))
             break
@@ -931,7 +931,7 @@ def main():
                                        "the nine are kept (dropped <= 2^-26 relative), accumulation "
                                        "is fp32; measured relative rms error vs an fp64 convolution "
                                        "1.6-2.8x torch's own fp32 convolution on the same operands "
-                                       "(profiles/r03_e_conv_accuracy_*.txt; the truncation split of "
+                                       "(profiles/archive/r03_e_conv_accuracy_*.txt; the truncation split of "
                                        "round 2 was 2-5x); VLNCE_CONV_MATH=f32 selects the fp32-MFMA "
                                        "kernel everywhere",
                          "per_launch_floor": {

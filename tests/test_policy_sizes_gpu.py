@@ -188,7 +188,7 @@ def test_bench_geometry_planes_vs_fp32_mfma_kernels(tmp_path):
     Yardstick: a randomly initialised 53-layer trunk with batch-statistics BatchNorm amplifies
     rounding noise; the third run is the SAME fp32-MFMA kernel on frames moved by one fp32 rounding
     (x * (1 + 2^-23)).  The bf16-plane kernels may differ from the fp32-MFMA kernels by at most 4x
-    what that single input rounding does (measured: 0.3-0.5x, profiles/r03_c_cross_kernel_floor.txt)
+    what that single input rounding does (measured: 0.3-0.5x, profiles/archive/r03_c_cross_kernel_floor.txt)
     and in any case by less than the north-star 1e-4 on the trunk features; the H1 loss within
     1e-5, BatchNorm running statistics within 2e-5, tail gradients within 1e-4."""
     a, b, c = _cross_kernel("cma", tmp_path)

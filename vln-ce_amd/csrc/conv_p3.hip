@@ -732,7 +732,7 @@ __global__ __launch_bounds__((WM * WN + P3_PRODUCERS) * 64) void conv_p3_kernel(
 // LINEAR: stride 1 (input pixel = output pixel).  A compile-time flag: as a runtime one the
 // strided path's division constants stayed live through the chunk loop, were spilled, and were
 // reloaded from scratch behind every chunk's MFMAs -- each reload followed by an
-// s_waitcnt vmcnt(0) that drained the wave's whole prefetch queue (profiles/r03_n_*).
+// s_waitcnt vmcnt(0) that drained the wave's whole prefetch queue (profiles/archive/r03_n_*).
 // DUAL: 0 = one input; 1 = block end with an identity skip (second input added as is); 2 = block
 // end whose skip path has its own BatchNorm.  Compile-time: the identity form carries half the
 // prologue vectors and its chunk body has no branch.
@@ -1107,7 +1107,7 @@ __global__ __launch_bounds__(WAVES * 64) void conv_u3_kernel(IgemmParams p) {
           wave_stats<MT, NT>(acc, p.stat_partial, m0 / BM, p.M - m0, BM, col0, p.N, half, l31);
       }
       // -------------------------------------------------------------- epilogue from registers
-      // (Measured alternatives, round 3, profiles/r03_h_*: turning each 32x32 block around in a
+      // (Measured alternatives, round 3, profiles/archive/r03_h_*: turning each 32x32 block around in a
       // per-wave LDS square and storing 128-byte rows with 16-byte stores -- a quarter of the
       // store instructions -- changes nothing (126 vs 122 us on the 64->256 layer): the burst
       // drains at ~5.6 TB/s either way, and what is lost is that a wave's next loads queue
@@ -1206,7 +1206,7 @@ int launch_u3_(const IgemmParams& p, hipStream_t stream) {
 // 2.2-2.7 TB/s: a tile there is 2-4 K-chunks of MFMAs and a 128 KB store burst, and the loads of
 // the next tile (B fragments of its second k-slab, raw A two chunks ahead) queue behind the burst
 // in the wave's one in-order vmcnt, so a wave alternates between draining and computing
-// (profiles/r03_h_u3_phase_timers_short_k.txt).  Here nothing a tile needs is loaded less than
+// (profiles/archive/r03_h_u3_phase_timers_short_k.txt).  Here nothing a tile needs is loaded less than
 // a tile before its use, and a tile's stores are issued UNDER the next tile's MFMAs:
 //   * the B fragments of the wave's 32 columns for ALL of K stay in registers for the whole
 //     launch (K = 64: 48 VGPRs, K = 128: 96) -- a workgroup keeps its column tile;
@@ -1578,7 +1578,7 @@ int dispatch_p3(const IgemmParams& p, int tile, int rows, hipStream_t s) {
 
 int p3_try_launch(const IgemmParams& p, hipStream_t stream) {
   // option "p3": 0 = off, 1 = every layer it covers, 2 = the KxK (patch) layers only, 3 = the 1x1
-  // layers only.  Default 2: measured per layer at num_envs 64 (profiles/r03_*_convbench_ab.txt),
+  // layers only.  Default 2: measured per layer at num_envs 64 (profiles/archive/r03_*_convbench_ab.txt),
   // the patch form is 1.26-1.51x conv_x3_kernel on every stride-1 3x3 layer of the trunks, the
   // 1x1 form (4 producer waves) is within +-10 % of it and slower on most.
   const int mode_env = vlnce_opt(VLNCE_OPT_P3);
@@ -1598,7 +1598,7 @@ int p3_try_launch(const IgemmParams& p, hipStream_t stream) {
   // 1x1 layers wide enough for 256-column tiles: conv_u3_kernel (no producer waves), where its
   // 128-row tiles fill the CUs.  option "u3": 0 = off, 1 = default, 2 / 3 = force 64- / 128-row tiles
   // for every N >= 256 1x1 layer (tests).  Measured
-  // per layer at num_envs 64 (profiles/r03_b_convbench_ab_u3.txt): 1.07-1.23x conv_x3_kernel on
+  // per layer at num_envs 64 (profiles/archive/r03_b_convbench_ab_u3.txt): 1.07-1.23x conv_x3_kernel on
   // every N >= 256 layer of the RGB trunk with M >= 16384.
   // short-K wide 1x1 (the bottleneck expansions): conv_s3_kernel.  option "s3": 0 = off, 1 = default
   // (where the 64-row tiles give every CU at least four), 2 = every eligible shape (tests)

@@ -17,7 +17,7 @@
 //     and flag travel together, so a step costs one store -> load latency across the chip and
 //     needs no fence, no counter and no second round trip (a first version with an arrival
 //     counter + thread fences, the cooperative-groups grid-sync pattern, measured 6.2 us per
-//     step; profiles/r03_f_*);
+//     step; profiles/archive/r03_f_*);
 //   * the [N, K] operand of the step (N <= 16 episodes) is staged in LDS, each thread multiplies
 //     its register slice with all N rows (fp32 FMA: this is the literal fp32 arithmetic of the
 //     step kernels in rnn.hip, only the summation order differs), slice partials meet in LDS and

@@ -460,7 +460,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
       // take one float per lane and MFMA from consecutive m = consecutive banks (the pitch puts
       // the other half-wave's k + 4 on the other 32 banks).  Writing it transposed into the
       // [m][k] image of the row-major modes was four 4-byte writes, 4-way bank-conflicted, and
-      // bound the weight-gradient GEMMs (profiles/r03_i_*).
+      // bound the weight-gradient GEMMs (profiles/archive/r03_i_*).
       constexpr int TPR = BM / 4;
       constexpr int KPP = 256 / TPR;
       const int km = tid / TPR;
@@ -700,12 +700,12 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
 // each exact in the fp32 accumulator; the dropped terms are <= 2^-26 relative.  Round 2 split by
 // TRUNCATION (dropped terms 2^-24): measured against fp64 that was rms 3.4-5.0e-7 on the 3x3
 // layers = 1.1-1.2x the fp32-MFMA kernel above and 2-3x torch's own fp32 convolution (1.6-1.7e-7;
-// profiles/r02_o_conv_accuracy_*.txt) -- fp32-class, NOT equal to it as round 2's text claimed.
-// With the round-to-nearest split: profiles/r03_*_conv_accuracy*.txt.  Six
+// profiles/archive/r02_o_conv_accuracy_*.txt) -- fp32-class, NOT equal to it as round 2's text claimed.
+// With the round-to-nearest split: profiles/archive/r03_*_conv_accuracy*.txt.  Six
 // bf16 MFMAs of 32 cycles replace eight fp32 MFMAs of 64 cycles per 32x32x16 block: 2.7x less
 // matrix-pipe time.
 //
-// What the fp32-MFMA kernel taught (profiles/r02_c_*): with every wave doing "load, transform,
+// What the fp32-MFMA kernel taught (profiles/archive/r02_c_*): with every wave doing "load, transform,
 // write LDS, barrier, read fragments, MFMA", the matrix pipe idles while the wave does anything
 // else, and the co-resident workgroup runs in lock-step, so nothing covers it.  Here the roles
 // are split.  A workgroup is 16 waves, four per SIMD, one workgroup per CU:
@@ -1814,7 +1814,7 @@ extern "C" int vlnce_conv2d_wgrad(const float* x, const float* dy, float* dw_ohw
                   "conv2d_wgrad: operands must be 16-byte aligned");
   fill_epilogue(p, nullptr);
   // option "wgrad_tile" = 128: 128x128 tiles where both output dimensions allow.  Measured slower on
-  // the trainable-encoder step (46.7 vs 45.0 ms, profiles/r03_g_*): fewer workgroups per
+  // the trainable-encoder step (46.7 vs 45.0 ms, profiles/archive/r03_g_*): fewer workgroups per
   // split-K slice, and the transposed-operand LDS writes do not get cheaper.  Default 64.
   const int tile_pref = vlnce_opt(VLNCE_OPT_WGRAD_TILE);
   const bool big = tile_pref >= 128 && p.M >= 128 && p.N >= 128;

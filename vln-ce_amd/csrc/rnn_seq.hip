@@ -84,7 +84,7 @@ __device__ __forceinline__ void zero_tails(float* __restrict__ base, long st, lo
 // Gate non-linearities on the hardware exp2 / rcp (v_exp_f32, v_rcp_f32; absolute error < 3e-7,
 // tests at 1e-5): libm's expf / tanhf are ~25 / ~50 VALU instructions each and a step evaluates
 // five per (row, unit) -- 2/3 of the forward step's instruction stream, which the two waves of a
-// SIMD execute one after the other (measured: 5.0 -> see profiles/r03_f_seqbench.txt us per step).
+// SIMD execute one after the other (measured: 5.0 -> see profiles/archive/r03_f_seqbench.txt us per step).
 __device__ __forceinline__ float sigm(float x) {
   return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
 }
@@ -142,7 +142,7 @@ constexpr int X3_PB[6] = {0, 2, 1, 0, 1, 0};
 // 64-byte segments.  (Tried: the transposed product W_slice x h^T, which gives a lane four
 // consecutive units of ONE row and 16-byte accesses -- a quarter of the memory instructions, but
 // 64 separate 16-byte requests per instruction: 4.4 vs 3.4 us per forward step at 64 rows, better
-// only for nearly empty tiles; profiles/r03_g_seqbench_transposed_assignment.txt.)
+// only for nearly empty tiles; profiles/archive/r03_g_seqbench_transposed_assignment.txt.)
 template <int KIND, int H, int NW>
 __global__ __launch_bounds__(NW * 64) void rnn_seq_fwd_kernel(RnnSeqParams p) {
   constexpr int G = KIND == 0 ? 4 : 3;

@@ -57,7 +57,7 @@ def encode_three_branches(net, observations, device, distinct_instructions=False
     if not torch.is_grad_enabled():
         # act() at a handful of environments: every branch is a chain of latency-bound launches
         # and the longest is the depth trunk (~250 of them, GroupNorm = 3-4 launches per layer;
-        # profiles/r03_f_act_one_call.txt), which used to start only after the instruction
+        # profiles/archive/r03_f_act_one_call.txt), which used to start only after the instruction
         # encoder's host sync because both shared side stream 0.  It is issued first and on its
         # own stream (the one a run-ahead depth trunk would use), then RGB, then the instruction.
         dep, join_dep = branches.run(fork, 2, device, lambda: net.depth_encoder(observations))

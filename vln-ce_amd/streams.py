@@ -302,7 +302,7 @@ class ActGraph:
     empty-instruction check of the eager path (one host sync) is not made; the action
     distribution is built without argument validation (another sync).
     Used under no_grad, in eval mode, for at most MAX_ENVS rows, and only when VLNCE_ACT_GRAPH=1:
-    measured on MI355X (profiles/r03_l_*) the call is bound by the GPU, not the host -- the bare
+    measured on MI355X (profiles/archive/r03_l_*) the call is bound by the GPU, not the host -- the bare
     replay of the captured graph is 1.37 ms at 1 environment against 1.52 ms for the eager call
     (three smaller graphs + an eager instruction encoder), and with the input / output copies
     the graphed call is 1.61 / 1.84 / 2.40 ms at 1 / 4 / 8 environments against 1.52 / 1.90 /
