@@ -9,7 +9,6 @@ sys.path.insert(0, REPO)
 sys.path.insert(0, os.path.join(REPO, "tests"))
 sys.path.insert(0, os.path.join(REPO, "tests", "golden"))
 import numpy as np  # noqa: E402
-import torch  # noqa: E402
 
 import cases  # noqa: E402
 import vlnce_amd  # noqa: E402

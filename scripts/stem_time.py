@@ -1,6 +1,6 @@
 import sys, os, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import bench, vlnce_amd
+import vlnce_amd  # noqa: F401  (registers the package alias)
 from vlnce_amd import ops
 dev = torch.device("cuda:0")
 for n, dt in ((64, torch.float32), (64, torch.uint8), (416, torch.float32)):
