@@ -99,6 +99,23 @@ def host_cpu_facts():
             "usable_logical_cpus": usable}
 
 
+_UNBOUND_AFFINITY = None  # the process's CPU mask before the rank was bound to its GPU's socket
+
+
+class whole_host:
+    """The CPU baseline is the host's best, not one socket's: its child process starts from the
+    mask this process had before bind_host_threads_to_gpu_socket()."""
+
+    def __enter__(self):
+        self.bound = os.sched_getaffinity(0) if _UNBOUND_AFFINITY else None
+        if self.bound:
+            os.sched_setaffinity(0, _UNBOUND_AFFINITY)
+
+    def __exit__(self, *exc):
+        if self.bound:
+            os.sched_setaffinity(0, self.bound)
+
+
 def cpu_baseline_worker(num_envs, hw, L, threads):
     """Runs in a child process: CPU oracle (port of the reference policy) timed on the host
     cores on a bounded sample of the bench workload.  `threads` is a comma list: each count
@@ -115,7 +132,10 @@ def cpu_baseline_worker(num_envs, hw, L, threads):
     sweep = {}
     t_start = time.time()
     for th in [int(t) for t in str(threads).split(",")]:
-        if sweep and time.time() - t_start > 60:  # bounded: the default bench run finishes within minutes
+        # bounded (the default bench run finishes within minutes): counts come in ascending
+        # order and the sweep ends once a larger count is slower than the best so far -- on the
+        # 2 x 64-core hosts 32 threads win and 128 threads cost 12-17 s per iteration
+        if sweep and (time.time() - t_start > 60 or sweep[max(sweep)] > 1.1 * min(sweep.values())):
             break
         torch.set_num_threads(th)
         times = []
@@ -146,10 +166,15 @@ def cpu_baseline(num_envs, hw, L, timeout_s=150):
     `host_cpu` (north_star: "core count stated")."""
     import subprocess
 
+    with whole_host():
+        return _cpu_baseline(num_envs, hw, L, timeout_s, subprocess)
+
+
+def _cpu_baseline(num_envs, hw, L, timeout_s, subprocess):
     facts = host_cpu_facts()
     usable = facts["usable_logical_cpus"]
     phys = min(facts["physical_cores"] or usable, usable)
-    counts = sorted({min(c, usable) for c in (32, 64, phys)}, reverse=True)
+    counts = sorted({min(c, usable) for c in (32, 64, phys)})
     threads = max(counts)
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--num-envs",
            str(num_envs), "--hw", str(hw), "--tokens", str(L), "--threads",
@@ -635,6 +660,17 @@ def main():
                              f"{torch.cuda.device_count()} GPU(s)")
         torch.cuda.set_device(local)
         dev = torch.device("cuda", local)
+        # one process per GPU, on the CPU socket that GPU hangs off (what a production launcher
+        # does with numactl); VLNCE_BIND_SOCKET=0 leaves the placement to the scheduler
+        from vlnce_amd.distributed import bind_host_threads_to_gpu_socket
+
+        global _UNBOUND_AFFINITY
+        before = os.sched_getaffinity(0)
+        node = bind_host_threads_to_gpu_socket(local)
+        if node is not None:
+            _UNBOUND_AFFINITY = before
+            log(f"rank {rank}: host threads bound to NUMA node {node} (cuda:{local}'s socket), "
+                f"{len(os.sched_getaffinity(0))} of {len(before)} CPUs")
     use_dist = world > 1 or args.force_dist
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -858,6 +894,10 @@ def main():
                                    f"{args.hw}x{args.hw} RGB-D, {args.tokens}-token instruction, "
                                    f"{NB} distinct batches in rotation",
                        "global_batch": args.num_envs * world, "parallelism": f"dp{world}",
+                       "host_threads": (
+                           f"rank bound to its GPU's CPU socket ({len(os.sched_getaffinity(0))} of "
+                           f"{len(_UNBOUND_AFFINITY)} CPUs; VLNCE_BIND_SOCKET=0 to leave it to the "
+                           f"scheduler)" if _UNBOUND_AFFINITY else "placed by the scheduler"),
                        "host_readbacks_per_step": "loss.item(), action_loss.item() [, aux_loss.item()] "
                                                   "as base_il_trainer.py:176-180",
                        "loss_first_last_timed_step": [round(timed_losses[0], 5),

@@ -453,3 +453,53 @@ def test_reducer_issues_buckets_in_order_when_ranks_disagree_on_unused_parameter
     # last step (2): rank 0 took the branch, rank 1 did not -- and on step 1 the other way round;
     # either way the parameter ends up with the averaged gradient on BOTH ranks
     assert g["sometimes.weight"] is not None and g["sometimes.weight"].abs().max() > 0
+
+
+def _fake_sysfs(tmp_path, bdf, node, cpulist):
+    d = tmp_path / "bus/pci/devices" / bdf
+    d.mkdir(parents=True)
+    (d / "numa_node").write_text(f"{node}\n")
+    if node >= 0:
+        n = tmp_path / f"devices/system/node/node{node}"
+        n.mkdir(parents=True)
+        (n / "cpulist").write_text(cpulist + "\n")
+    return str(tmp_path)
+
+
+def test_cpulist_parser():
+    from vlnce_amd.distributed import _parse_cpulist
+
+    assert _parse_cpulist("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11}
+    assert _parse_cpulist("5") == {5}
+    assert _parse_cpulist("") == set()
+
+
+def test_bind_host_threads_to_gpu_socket(tmp_path, monkeypatch):
+    """One process per GPU on the socket its GPU hangs off: the node comes from the GPU's PCI
+    address, every thread of the process gets the node's CPUs (intersected with the mask the
+    process already had), and unknown topologies change nothing."""
+    import os
+    import types
+
+    from vlnce_amd import distributed as D
+
+    before = os.sched_getaffinity(0)
+    props = types.SimpleNamespace(pci_domain_id=0, pci_bus_id=0xD9, pci_device_id=0)
+    monkeypatch.setattr(torch.cuda, "get_device_properties", lambda i: props)
+    keep = sorted(before)[: max(1, len(before) // 2)]
+    sysfs = _fake_sysfs(tmp_path / "a", "0000:d9:00.0", 1, ",".join(str(c) for c in keep) + ",100000")
+    try:
+        assert D.gpu_numa_node(0, sysfs) == 1
+        assert D.bind_host_threads_to_gpu_socket(0, sysfs=sysfs) == 1
+        assert os.sched_getaffinity(0) == set(keep)
+        for tid in os.listdir("/proc/self/task"):
+            assert os.sched_getaffinity(int(tid)) == set(keep)
+    finally:
+        for tid in os.listdir("/proc/self/task"):
+            os.sched_setaffinity(int(tid), before)
+    # single-socket hosts report -1; a node whose CPUs are all outside the mask; the switch
+    assert D.bind_host_threads_to_gpu_socket(0, sysfs=_fake_sysfs(tmp_path / "b", "0000:d9:00.0", -1, "")) is None
+    assert D.bind_host_threads_to_gpu_socket(0, sysfs=_fake_sysfs(tmp_path / "c", "0000:d9:00.0", 0, "100000-100003")) is None
+    monkeypatch.setenv("VLNCE_BIND_SOCKET", "0")
+    assert D.bind_host_threads_to_gpu_socket(0, sysfs=sysfs) is None
+    assert os.sched_getaffinity(0) == before

@@ -256,3 +256,67 @@ def shard_rows(n_total, rank, world):
     assert n_total % world == 0, "num_envs must be divisible by the number of ranks"
     per = n_total // world
     return slice(rank * per, (rank + 1) * per)
+
+
+def _parse_cpulist(text):
+    cpus = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def gpu_numa_node(device_index=0, sysfs="/sys"):
+    """NUMA node of the host socket GPU `device_index` hangs off (PCI sysfs), or None when the
+    platform does not say (single-socket hosts report -1)."""
+    import os
+
+    p = torch.cuda.get_device_properties(device_index)
+    try:
+        bdf = "%04x:%02x:%02x.0" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+    except AttributeError:
+        return None
+    try:
+        with open(os.path.join(sysfs, "bus/pci/devices", bdf, "numa_node")) as f:
+            node = int(f.read())
+    except (OSError, ValueError):
+        return None
+    return node if node >= 0 else None
+
+
+def bind_host_threads_to_gpu_socket(device_index=0, node=None, sysfs="/sys"):
+    """One process per GPU: keep this rank's threads (the issuing thread, autograd's, the HIP
+    runtime's) on the CPU socket its GPU is attached to.  Half of a step's phases are paced by
+    the issuing thread, and on the two-socket hosts of the MI355X nodes the
+    scheduler otherwise places it on either socket -- measured as two speeds of the same loop
+    (profiles/r05_zz_step_jitter*.txt).  Returns the node bound to, or None when nothing was
+    changed (unknown topology, an affinity mask that already excludes the node, or
+    VLNCE_BIND_SOCKET=0)."""
+    import os
+
+    if os.environ.get("VLNCE_BIND_SOCKET", "1") == "0":
+        return None
+    if node is None:
+        node = gpu_numa_node(device_index, sysfs)
+    if node is None:
+        return None
+    try:
+        with open(os.path.join(sysfs, "devices/system/node/node%d/cpulist" % node)) as f:
+            cpus = _parse_cpulist(f.read())
+    except (OSError, ValueError):
+        return None
+    cpus &= os.sched_getaffinity(0)
+    if not cpus:
+        return None
+    try:
+        tids = [int(t) for t in os.listdir("/proc/self/task")]
+    except OSError:
+        tids = [0]
+    for tid in tids:
+        try:
+            os.sched_setaffinity(tid, cpus)
+        except OSError:
+            pass  # a thread that exited between the listing and the call
+    return node
