@@ -660,8 +660,8 @@ def main():
                              f"{torch.cuda.device_count()} GPU(s)")
         torch.cuda.set_device(local)
         dev = torch.device("cuda", local)
-        # one process per GPU, on the CPU socket that GPU hangs off (what a production launcher
-        # does with numactl); VLNCE_BIND_SOCKET=0 leaves the placement to the scheduler
+        # one process per GPU, on one L3 domain of the CPU socket that GPU hangs off (what a
+        # production launcher does with numactl); VLNCE_BIND_SOCKET=0 leaves it to the scheduler
         from vlnce_amd.distributed import bind_host_threads_to_gpu_socket
 
         global _UNBOUND_AFFINITY
@@ -669,8 +669,10 @@ def main():
         node = bind_host_threads_to_gpu_socket(local)
         if node is not None:
             _UNBOUND_AFFINITY = before
+            now = os.sched_getaffinity(0)
             log(f"rank {rank}: host threads bound to NUMA node {node} (cuda:{local}'s socket), "
-                f"{len(os.sched_getaffinity(0))} of {len(before)} CPUs")
+                f"{len(now)} of {len(before)} CPUs"
+                + (f" {sorted(now)}" if len(now) <= 32 else f" ({min(now)}..{max(now)})"))
     use_dist = world > 1 or args.force_dist
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -895,8 +897,9 @@ def main():
                                    f"{NB} distinct batches in rotation",
                        "global_batch": args.num_envs * world, "parallelism": f"dp{world}",
                        "host_threads": (
-                           f"rank bound to its GPU's CPU socket ({len(os.sched_getaffinity(0))} of "
-                           f"{len(_UNBOUND_AFFINITY)} CPUs; VLNCE_BIND_SOCKET=0 to leave it to the "
+                           f"rank bound to one L3 domain of its GPU's CPU socket "
+                           f"({len(os.sched_getaffinity(0))} of {len(_UNBOUND_AFFINITY)} CPUs; "
+                           f"VLNCE_BIND_SOCKET=socket for the whole socket, 0 to leave it to the "
                            f"scheduler)" if _UNBOUND_AFFINITY else "placed by the scheduler"),
                        "host_readbacks_per_step": "loss.item(), action_loss.item() [, aux_loss.item()] "
                                                   "as base_il_trainer.py:176-180",

@@ -20,8 +20,18 @@ from vlnce_amd.distributed import bind_host_threads_to_gpu_socket, gpu_numa_node
 mode = os.environ.get("BIND", "none")  # none | local | remote
 local = gpu_numa_node(0)
 bound = None
-if mode != "none" and local is not None:
+if mode in ("local", "remote") and local is not None:
     bound = bind_host_threads_to_gpu_socket(0, node=local if mode == "local" else 1 - local)
+if mode == "l3" and local is not None:  # the socket first, then one L3 domain (CCD) of it
+    from vlnce_amd.distributed import _parse_cpulist
+
+    bound = bind_host_threads_to_gpu_socket(0, node=local)
+    first = min(os.sched_getaffinity(0))
+    with open(f"/sys/devices/system/cpu/cpu{first}/cache/index3/shared_cpu_list") as f:
+        ccd = _parse_cpulist(f.read()) & os.sched_getaffinity(0)
+    for tid in os.listdir("/proc/self/task"):
+        os.sched_setaffinity(int(tid), ccd)
+    print(f"one L3 domain: {sorted(ccd)}")
 print(f"GPU on NUMA node {local}; BIND={mode}: threads bound to node {bound}")
 torch.manual_seed(0)
 policy = vlnce_amd.build_model(vlnce_amd.make_config("CMAPolicy"), *vlnce_amd.make_spaces(256, 256)).to(dev)

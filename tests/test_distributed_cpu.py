@@ -4,6 +4,8 @@ the global batch, including a parameter that never receives a gradient."""
 import os
 import socket
 
+import pytest
+
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -455,14 +457,27 @@ def test_reducer_issues_buckets_in_order_when_ranks_disagree_on_unused_parameter
     assert g["sometimes.weight"] is not None and g["sometimes.weight"].abs().max() > 0
 
 
-def _fake_sysfs(tmp_path, bdf, node, cpulist):
-    d = tmp_path / "bus/pci/devices" / bdf
-    d.mkdir(parents=True)
-    (d / "numa_node").write_text(f"{node}\n")
+def _fake_sysfs(tmp_path, bdf, node, cpulist, l3=None, other_gpus=()):
+    """l3: {cpu: "shared_cpu_list"}; other_gpus: (bdf, node) of further AMD GPUs of the host."""
+    for name, nn in ((bdf, node),) + tuple(other_gpus):
+        d = tmp_path / "bus/pci/devices" / name
+        d.mkdir(parents=True)
+        (d / "numa_node").write_text(f"{nn}\n")
+        (d / "vendor").write_text("0x1002\n")
+        (d / "class").write_text("0x120000\n")
+    nic = tmp_path / "bus/pci/devices/0000:01:00.0"   # not a GPU: never counted
+    nic.mkdir(parents=True)
+    (nic / "numa_node").write_text(f"{max(node, 0)}\n")
+    (nic / "vendor").write_text("0x15b3\n")
+    (nic / "class").write_text("0x020000\n")
     if node >= 0:
         n = tmp_path / f"devices/system/node/node{node}"
         n.mkdir(parents=True)
         (n / "cpulist").write_text(cpulist + "\n")
+    for cpu, shared in (l3 or {}).items():
+        c = tmp_path / f"devices/system/cpu/cpu{cpu}/cache/index3"
+        c.mkdir(parents=True)
+        (c / "shared_cpu_list").write_text(shared + "\n")
     return str(tmp_path)
 
 
@@ -483,6 +498,7 @@ def test_bind_host_threads_to_gpu_socket(tmp_path, monkeypatch):
 
     from vlnce_amd import distributed as D
 
+    monkeypatch.delenv("VLNCE_BIND_SOCKET", raising=False)
     before = os.sched_getaffinity(0)
     props = types.SimpleNamespace(pci_domain_id=0, pci_bus_id=0xD9, pci_device_id=0)
     monkeypatch.setattr(torch.cuda, "get_device_properties", lambda i: props)
@@ -490,6 +506,7 @@ def test_bind_host_threads_to_gpu_socket(tmp_path, monkeypatch):
     sysfs = _fake_sysfs(tmp_path / "a", "0000:d9:00.0", 1, ",".join(str(c) for c in keep) + ",100000")
     try:
         assert D.gpu_numa_node(0, sysfs) == 1
+        # no cache topology in this tree: the default scope falls back to the whole socket
         assert D.bind_host_threads_to_gpu_socket(0, sysfs=sysfs) == 1
         assert os.sched_getaffinity(0) == set(keep)
         for tid in os.listdir("/proc/self/task"):
@@ -503,3 +520,41 @@ def test_bind_host_threads_to_gpu_socket(tmp_path, monkeypatch):
     monkeypatch.setenv("VLNCE_BIND_SOCKET", "0")
     assert D.bind_host_threads_to_gpu_socket(0, sysfs=sysfs) is None
     assert os.sched_getaffinity(0) == before
+
+
+def test_bind_scope_l3_spreads_the_gpus_of_a_socket_over_its_l3_domains(tmp_path, monkeypatch):
+    """Default scope: ONE L3 domain of the GPU's socket; the GPUs of a socket (PCI order, other
+    jobs' GPUs included -- sysfs shows the whole host) get different domains."""
+    import os
+    import types
+
+    from vlnce_amd import distributed as D
+
+    monkeypatch.delenv("VLNCE_BIND_SOCKET", raising=False)
+    before = os.sched_getaffinity(0)
+    cpus = sorted(before)
+    if len(cpus) < 4:
+        pytest.skip("needs four usable CPUs")
+    a, b = cpus[:2], cpus[2:4]                       # two fake L3 domains of two CPUs each
+    as_list = lambda xs: ",".join(str(c) for c in xs)
+    l3 = {a[0]: as_list(a), a[1]: as_list(a), b[0]: as_list(b), b[1]: as_list(b)}
+    gpus = (("0000:c9:00.0", 1), ("0000:05:00.0", 0))  # one more GPU on node 1 (before ours), one on node 0
+    sysfs = _fake_sysfs(tmp_path, "0000:d9:00.0", 1, as_list(a + b), l3=l3, other_gpus=gpus)
+    assert D._l3_domains(set(a + b), sysfs) == [set(a), set(b)]
+    assert D._gpu_slot_on_node("0000:d9:00.0", 1, sysfs) == (1, 2)
+    assert D._gpu_slot_on_node("0000:c9:00.0", 1, sysfs) == (0, 2)
+    try:
+        for bus, want in ((0xD9, b), (0xC9, a)):
+            props = types.SimpleNamespace(pci_domain_id=0, pci_bus_id=bus, pci_device_id=0)
+            monkeypatch.setattr(torch.cuda, "get_device_properties", lambda i, p=props: p)
+            for tid in os.listdir("/proc/self/task"):
+                os.sched_setaffinity(int(tid), before)
+            assert D.bind_host_threads_to_gpu_socket(0, sysfs=sysfs) == 1
+            assert os.sched_getaffinity(0) == set(want)
+        for tid in os.listdir("/proc/self/task"):
+            os.sched_setaffinity(int(tid), before)
+        assert D.bind_host_threads_to_gpu_socket(0, sysfs=sysfs, scope="socket") == 1
+        assert os.sched_getaffinity(0) == set(a + b)
+    finally:
+        for tid in os.listdir("/proc/self/task"):
+            os.sched_setaffinity(int(tid), before)

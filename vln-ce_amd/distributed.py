@@ -268,48 +268,111 @@ def _parse_cpulist(text):
     return cpus
 
 
+def _gpu_bdf(device_index):
+    p = torch.cuda.get_device_properties(device_index)
+    try:
+        return "%04x:%02x:%02x.0" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+    except AttributeError:
+        return None
+
+
+def _read(path):
+    with open(path) as f:
+        return f.read().strip()
+
+
 def gpu_numa_node(device_index=0, sysfs="/sys"):
     """NUMA node of the host socket GPU `device_index` hangs off (PCI sysfs), or None when the
     platform does not say (single-socket hosts report -1)."""
     import os
 
-    p = torch.cuda.get_device_properties(device_index)
-    try:
-        bdf = "%04x:%02x:%02x.0" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
-    except AttributeError:
+    bdf = _gpu_bdf(device_index)
+    if bdf is None:
         return None
     try:
-        with open(os.path.join(sysfs, "bus/pci/devices", bdf, "numa_node")) as f:
-            node = int(f.read())
+        node = int(_read(os.path.join(sysfs, "bus/pci/devices", bdf, "numa_node")))
     except (OSError, ValueError):
         return None
     return node if node >= 0 else None
 
 
-def bind_host_threads_to_gpu_socket(device_index=0, node=None, sysfs="/sys"):
-    """One process per GPU: keep this rank's threads (the issuing thread, autograd's, the HIP
-    runtime's) on the CPU socket its GPU is attached to.  Half of a step's phases are paced by
-    the issuing thread, and on the two-socket hosts of the MI355X nodes the
-    scheduler otherwise places it on either socket -- measured as two speeds of the same loop
-    (profiles/r05_zz_step_jitter*.txt).  Returns the node bound to, or None when nothing was
-    changed (unknown topology, an affinity mask that already excludes the node, or
-    VLNCE_BIND_SOCKET=0)."""
+def _l3_domains(cpus, sysfs):
+    """The L3 domains (CCDs on EPYC) the CPU set `cpus` spans, each cut down to `cpus`, ordered by
+    their lowest CPU; [] when the cache topology is not readable."""
     import os
 
-    if os.environ.get("VLNCE_BIND_SOCKET", "1") == "0":
+    doms = {}
+    for c in sorted(cpus):
+        if any(c in d for d in doms.values()):
+            continue
+        try:
+            d = _parse_cpulist(_read(os.path.join(
+                sysfs, "devices/system/cpu/cpu%d/cache/index3/shared_cpu_list" % c))) & cpus
+        except (OSError, ValueError):
+            return []
+        if d:
+            doms[min(d)] = d
+    return [doms[k] for k in sorted(doms)]
+
+
+def _gpu_slot_on_node(bdf, node, sysfs):
+    """(k, n): this GPU is the k-th (PCI order) of the n AMD GPUs on NUMA node `node`.  sysfs
+    shows the host's PCI devices to every container, so ranks of DIFFERENT jobs on one host get
+    different slots too."""
+    import os
+
+    root = os.path.join(sysfs, "bus/pci/devices")
+    gpus = []
+    try:
+        names = sorted(os.listdir(root))
+    except OSError:
+        names = []
+    for name in names:
+        try:
+            if (_read(os.path.join(root, name, "vendor")) == "0x1002"
+                    and _read(os.path.join(root, name, "class"))[:4] in ("0x03", "0x12")
+                    and int(_read(os.path.join(root, name, "numa_node"))) == node):
+                gpus.append(name)
+        except (OSError, ValueError):
+            continue
+    return (gpus.index(bdf), len(gpus)) if bdf in gpus else (0, 1)
+
+
+def bind_host_threads_to_gpu_socket(device_index=0, node=None, sysfs="/sys", scope=None):
+    """One process per GPU: keep this rank's threads (the issuing thread, autograd's, the HIP
+    runtime's) on the CPU socket its GPU is attached to -- by default on ONE L3 domain of it.
+    Half of a step's phases are paced by the issuing thread and its hand-overs to autograd's
+    thread; on the two-socket hosts of the MI355X nodes the scheduler
+    otherwise places those threads on either socket, measured as two speeds of the same loop
+    (profiles/r05_zz_step_jitter*.txt: 9.4-9.7 ms unbound in the slow mode, 9.0-9.2 on one socket,
+    8.94-8.98 on one L3 domain).
+
+    scope (default: VLNCE_BIND_SOCKET, else "l3"): "l3" = one L3 domain (a CCD: 8 cores + their
+    SMT siblings) of the GPU's socket, the GPUs of a socket spread evenly over its domains by PCI
+    order; "socket" / "1" = every CPU of the socket; "0" = do nothing.  Returns the NUMA node
+    bound to, or None when nothing was changed (unknown topology, or an affinity mask that
+    already excludes the node)."""
+    import os
+
+    scope = (scope or os.environ.get("VLNCE_BIND_SOCKET") or "l3").lower()
+    if scope == "0":
         return None
     if node is None:
         node = gpu_numa_node(device_index, sysfs)
     if node is None:
         return None
     try:
-        with open(os.path.join(sysfs, "devices/system/node/node%d/cpulist" % node)) as f:
-            cpus = _parse_cpulist(f.read())
+        cpus = _parse_cpulist(_read(os.path.join(sysfs, "devices/system/node/node%d/cpulist" % node)))
     except (OSError, ValueError):
         return None
     cpus &= os.sched_getaffinity(0)
     if not cpus:
         return None
+    if scope == "l3":
+        doms = _l3_domains(cpus, sysfs)
+        if doms:
+            k, n = _gpu_slot_on_node(_gpu_bdf(device_index), node, sysfs)
+            cpus = doms[(k * len(doms)) // max(n, 1) % len(doms)]
     try:
         tids = [int(t) for t in os.listdir("/proc/self/task")]
     except OSError:
