@@ -21,8 +21,9 @@ backward and Adam, over 4 distinct resident batches in rotation.  Beside it
 trunks of batch k+1 issued on side HIP streams before batch k's update is enqueued.
 
 The JSON line also carries `roofline` (dominant kernel = the implicit-GEMM convolution:
-conv_p3 / conv_u3 / conv_s3 / conv_x3 / conv_m3 / stem7 kernels, fp32 operands split exactly into three bf16
-planes and multiplied as six plane products on the bf16 matrix pipe, plus the fp32-MFMA igemm_kernel
+conv_p3 / conv_u3 / conv_s3 / conv_x3 / conv_m3 / stem7 kernels, fp32 operands split into 16-bit planes
+(round 6 default: two fp16 planes per activation, three plane products per multiply; VLNCE_CONV_MATH=bf16:
+three bf16 planes, six products) on the 16-bit matrix pipe, plus the fp32-MFMA igemm_kernel
 for the depth stem and the small layers; every launch timed with HIP events on the launch stream and
 attributed to the kernel the library dispatched it to; `frac` prices the ALGORITHMIC fp32 FLOPs
 against the fp32 MFMA peak, `bf16_pipe.frac` the hardware FLOPs of the bf16-plane launches
@@ -42,7 +43,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32
-BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16 / _f16, dense
 HBM_PEAK_TBS = 8.0           # MI355X_MICROARCH.md: HBM3E spec
 HBM_ACHIEVABLE_TBS = 6.3     # MI355X_MICROARCH.md: measured float4 copy (79 % of spec)
 # algorithmic FLOPs per policy-step (one env), CMA 256x256 L=80
@@ -50,6 +51,13 @@ CMA_FWD_GFLOP = 11.461
 CMA_FWD_BWD_FROZEN_GFLOP = 11.630
 CONV_GFLOP_PER_ENV = 10.677 + 0.699  # RGB ResNet-50 + depth ResNet-50 trunks (conv MACs x2)
 STEM_GFLOP_PER_ENV = 0.308 + 0.051   # 7x7/s2 stems at 256x256 (3->64 and 1->32 channels)
+
+
+def plane_products():
+    """16-bit MFMA products the plane kernels issue per fp32 multiply: 3 in plane format 2 (fp16
+    planes, the default), 6 in format 1 (three bf16 planes; VLNCE_CONV_MATH=bf16)"""
+    from vlnce_amd import ops
+    return 3 if ops.plane_format() == 2 else 6
 
 
 def log(msg):
@@ -360,7 +368,7 @@ def conv_kernel_time(policy, obs, dev, repeats=3):
         d["flop"] += fl
         t_hbm = nb / (HBM_ACHIEVABLE_TBS * 1e12) * 1e3
         t_pipe = (fl / (FP32_MFMA_PEAK_TFLOPS * 1e12) if path == 0
-                  else 6.0 * fl / (BF16_MFMA_PEAK_TFLOPS * 1e12)) * 1e3
+                  else plane_products() * fl / (BF16_MFMA_PEAK_TFLOPS * 1e12)) * 1e3
         floor_ms += max(t_hbm, t_pipe)
         if t_hbm >= t_pipe:
             hbm_bound_n += 1
@@ -666,7 +674,10 @@ def main():
 
         global _UNBOUND_AFFINITY
         before = os.sched_getaffinity(0)
-        node = bind_host_threads_to_gpu_socket(local)
+        # (scope "l3": this process forks no simulator / loader workers; the library default is
+        # the whole socket)
+        node = bind_host_threads_to_gpu_socket(
+            local, scope=os.environ.get("VLNCE_BIND_SOCKET") or "l3")
         if node is not None:
             _UNBOUND_AFFINITY = before
             now = os.sched_getaffinity(0)
@@ -916,7 +927,15 @@ def main():
                                           "equals_plain_loop); NOT what `value` measures",
                        "act_fwd_only_eval_steps_per_sec_per_gpu": round(args.num_envs / act_s, 1),
                        "act_latency_ms_by_num_envs": act_small},
-            "roofline": {"bound": "mfma",
+            "roofline": {"schema": 3,
+                         "schema_is": "3 (round 6): the plane kernels issue `bf16_pipe."
+                                      "hw_flops_per_algorithmic_flop` 16-bit MFMA FLOPs per fp32 FLOP "
+                                      "(3 with fp16 planes, 6 with bf16 planes) and the per-launch "
+                                      "floor prices that count; 2 (round 5): `frac` / `peak` = the "
+                                      "per-launch max(HBM, MFMA) floor, the fp32-MFMA-peak figure "
+                                      "under `fp32_mfma_peak`; 1 (rounds 1-4): frac = achieved / fp32 "
+                                      "MFMA peak",
+                         "bound": "mfma",
                          "kernel": "conv2d fwd of the two visual trunks: conv_p3_kernel (stride-1 "
                                    "KxK: A transformed once per workgroup into an LDS patch, B "
                                    "fragments from L2), conv_u3_kernel (wide 1x1: no producer "
@@ -929,8 +948,13 @@ def main():
                                    "memory, reduction split over a workgroup's waves) and "
                                    "stem7_kernel (the 7x7/s2 RGB stem straight from the frames); "
                                    "all six: fp32 operands "
-                                   "split exactly into 3 bf16 planes, 6 x "
-                                   "v_mfma_f32_32x32x16_bf16 per 32x32x16 block, fp32 accumulate, "
+                                   + ("split into fp16 planes (activations a1 + a2, weights b1 + b2, "
+                                      "11 + 11 mantissa bits each), 3 x v_mfma_f32_32x32x16_f16 "
+                                      "(a1 b1 + a1 b2 + a2 b1) per 32x32x16 block"
+                                      if plane_products() == 3 else
+                                      "split exactly into 3 bf16 planes, 6 x "
+                                      "v_mfma_f32_32x32x16_bf16 per 32x32x16 block")
+                                   + ", fp32 accumulate, "
                                    "train-mode BatchNorm column sums taken in the epilogue; "
                                    "igemm_kernel (v_mfma_f32_32x32x2_f32) for the depth stem and "
                                    "the handful-of-tiles layers",
@@ -948,14 +972,15 @@ def main():
                          "fp32_mfma_peak": {"peak": FP32_MFMA_PEAK_TFLOPS,
                                             "frac": (round(achieved / FP32_MFMA_PEAK_TFLOPS, 4)
                                                      if ok else None)},
-                         "bf16_pipe": {"instruction": "v_mfma_f32_32x32x16_bf16",
-                                       "hw_flops_per_algorithmic_flop": 6,
+                         "bf16_pipe": {"instruction": ("v_mfma_f32_32x32x16_f16" if plane_products() == 3
+                                                       else "v_mfma_f32_32x32x16_bf16"),
+                                       "hw_flops_per_algorithmic_flop": plane_products(),
                                        "peak": BF16_MFMA_PEAK_TFLOPS,
                                        "launches": sum(v["launches"] for v in bf),
                                        "kernel_ms_per_step": round(bf_ms, 3),
                                        "achieved_algorithmic_tflops": (
                                            round(bf_flop / (bf_ms * 1e-3) / 1e12, 2) if bf_ms else None),
-                                       "frac": (round(6 * bf_flop / (bf_ms * 1e-3) / 1e12
+                                       "frac": (round(plane_products() * bf_flop / (bf_ms * 1e-3) / 1e12
                                                       / BF16_MFMA_PEAK_TFLOPS, 4) if bf_ms and ok
                                                 else None),
                                        "by_kernel": {k: {"launches": v["launches"],
@@ -969,14 +994,23 @@ def main():
                                                 if f32["ms"] and ok else None)},
                          "flop_check": {"per_launch_geometry_gflop": round(conv["flop"] / 1e9, 2),
                                         "survey_a3_gflop": round(conv_flop / 1e9, 2)},
-                         "arithmetic": "fp32-class: operands are represented exactly by three bf16 "
-                                       "planes (round-to-nearest split), products are exact, six of "
-                                       "the nine are kept (dropped <= 2^-26 relative), accumulation "
-                                       "is fp32; measured relative rms error vs an fp64 convolution "
-                                       "1.6-2.8x torch's own fp32 convolution on the same operands "
-                                       "(profiles/archive/r03_e_conv_accuracy_*.txt; the truncation split of "
-                                       "round 2 was 2-5x); VLNCE_CONV_MATH=f32 selects the fp32-MFMA "
-                                       "kernel everywhere",
+                         "arithmetic": (
+                             "fp32-class: a = a1 + a2 with a1 = fp16(a), a2 = fp16((a - a1) 2^11) / 2^11 "
+                             "(11 + 11 mantissa bits and the sign of a2, residual <= 2^-22 |a|), the "
+                             "same for the weights; a1 b1 + a1 b2 + a2 b1 accumulated in fp32 at the "
+                             "common scale 2^11 (dropped a2 b2 <= 2^-22); against an fp64 convolution "
+                             "as close as the six-product bf16 form (half as many fp32 accumulator "
+                             "updates; tests/test_kernels_gpu.py::test_conv_p3_matches_fp64_better_"
+                             "than_1e_6 holds both to 1e-6 rms); |x| < 65504, |w| < 32; "
+                             "VLNCE_CONV_MATH=bf16 selects three bf16 planes / six products, =f32 the "
+                             "fp32-MFMA kernel everywhere" if plane_products() == 3 else
+                             "fp32-class: operands are represented exactly by three bf16 "
+                             "planes (round-to-nearest split), products are exact, six of "
+                             "the nine are kept (dropped <= 2^-26 relative), accumulation "
+                             "is fp32; measured relative rms error vs an fp64 convolution "
+                             "1.6-2.8x torch's own fp32 convolution on the same operands "
+                             "(profiles/archive/r03_e_conv_accuracy_*.txt); VLNCE_CONV_MATH=f32 "
+                             "selects the fp32-MFMA kernel everywhere"),
                          "per_launch_floor": {
                              "what": "sum over the conv launches of max(algorithmic bytes / "
                                      "achievable HBM rate, instruction FLOPs / the peak of the pipe "

@@ -30,7 +30,7 @@ typedef void* vlnce_stream_t;
 
 enum { VLNCE_ACT_NONE = 0, VLNCE_ACT_RELU = 1, VLNCE_ACT_SIGMOID = 2, VLNCE_ACT_TANH = 3 };
 
-int vlnce_version(void); /* major*100 + minor; 141 = this header */
+int vlnce_version(void); /* major*100 + minor; 142 = this header */
 int vlnce_option_count(void);              /* length of vlnce_prologue.options                        */
 int vlnce_option_index(const char* name);  /* index of a named dispatch option in it, -1 if unknown   */
 const char* vlnce_last_error(void);
@@ -40,8 +40,13 @@ const char* vlnce_last_error(void);
  * shape in-process and restore the default afterwards.  No reference counterpart (torch picks its
  * cuDNN / MIOpen algorithm through torch.backends.cudnn.benchmark, never set by the reference).
  *   name               default  meaning
- *   "conv_math"        1        1: fp32 operands as three bf16 planes on the bf16 matrix pipe
- *                               (conv_p3 / conv_u3 / conv_s3 / conv_x3); 0: v_mfma_f32_32x32x2_f32 only
+ *   "conv_math"        2        0: v_mfma_f32_32x32x2_f32 only; non-zero: the plane kernels (conv_p3 /
+ *                               conv_u3 / conv_s3 / conv_m3 / conv_x3 / stem7) on the 16-bit matrix pipe.
+ *                               The library tests zero / non-zero only; the HOST reads the value as the
+ *                               plane format in which it packs the weights (vlnce_prologue.w_format):
+ *                               1 = three bf16 planes, six products per multiply (fp32's exponent range);
+ *                               2 = fp16 planes, THREE products per multiply (ABI 142; |x| < 65504,
+ *                               |w| < 32, forward operands -- see vlnce_conv2d_pack_weights)
  *   "p3"               2        conv_p3_kernel: 0 off, 1 every layer it covers, 2 KxK only, 3 1x1 only
  *   "p3_tile"          0        0: by CU fill; 1..6: forced tile shape
  *   "s3"               1        conv_s3_kernel (short-K wide 1x1): 0 off, 1 default rule, 2 every eligible shape
@@ -113,6 +118,10 @@ typedef struct {
    * process values.  Two policies (or a test forcing a kernel) in one process then do not share
    * mutable dispatch state: the library only reads what the call hands it. */
   const int* options;
+  /* Plane format of w_split / w_frag (ABI 142) = the arithmetic of the plane kernels for this
+   * launch: 0 or 1 = three bf16 planes (six plane products per multiply), 2 = fp16 planes (three
+   * products); must be the `format` the two buffers were made with. */
+  int w_format;
 } vlnce_prologue;
 
 /* Train-mode BatchNorm statistics taken BY the convolution (torch.nn.BatchNorm2d.forward in
@@ -161,10 +170,22 @@ int vlnce_bn_finalize_sums(double* acc, int M, int C, const float* gamma, const 
 int vlnce_conv2d_tiles_m(const vlnce_conv_desc* d);   /* rows of stat_partial  */
 int vlnce_conv2d_tile_rows(const vlnce_conv_desc* d); /* BM chosen for `d`      */
 
-/* planes[q][i], q = 0..2: bf16 words with w[i] == planes[0][i] + planes[1][i] + planes[2][i]
- * exactly (round-to-nearest three-way split, 8 + 8 + 8 mantissa bits).  `planes` holds 3 * count
- * 16-bit words. */
-int vlnce_conv2d_split_weights(const float* w, void* planes, long count, vlnce_stream_t stream);
+/* planes[q][i], q = 0..2; `planes` holds 3 * count 16-bit words.
+ * format 1: bf16 words with w[i] == planes[0][i] + planes[1][i] + planes[2][i] exactly
+ *   (round-to-nearest three-way split, 8 + 8 + 8 mantissa bits); a product of two operands split
+ *   this way is six plane products (dropped terms <= 2^-26 relative).
+ * format 2 (ABI 142): fp16 words {h * 2^11, (w - h) * 2^11 rounded, h} with h = fp16(w) -- 11 + 11
+ *   mantissa bits (+ the sign of the second term: |w - h - l| <= 2^-22 |w|); the activations are
+ *   split the same way in the operand loader ({a1, a2 * 2^11}) and a product is the THREE plane
+ *   products a1 b1 + a1 b2 + a2 b1, all at the scale 2^11 (the low planes stay clear of fp16's
+ *   subnormals; the accumulator is multiplied by 2^-11 where it leaves the registers).  Measured
+ *   against fp64 the result is as close as format 1's (fp32 accumulation dominates both, and
+ *   format 2 does half as many accumulator updates) at half the matrix-pipe time.  Range:
+ *   |w| < 32 and |activation| < 65504, beyond that the output is inf / NaN (never a wrong finite
+ *   value); operands far below 6e-5 (gradients) lose relative precision: backward launches use
+ *   format 1. */
+int vlnce_conv2d_split_weights(const float* w, void* planes, long count, int format,
+                               vlnce_stream_t stream);
 
 /* frag = the weights of `d` as bf16-plane MFMA B fragments, layout
  * [Cout/32][K/16][3 planes][64 lanes][8 bf16] with the k-slabs ordered (32-channel chunk, filter
@@ -174,7 +195,7 @@ int vlnce_conv2d_split_weights(const float* w, void* planes, long count, vlnce_s
  * re-layout of nn.Conv2d.weight (resnet_encoders.py:136-139). */
 long vlnce_conv2d_pack_bytes(const vlnce_conv_desc* d);
 int vlnce_conv2d_pack_weights(const float* w_ohwi, void* frag, const vlnce_conv_desc* d,
-                              vlnce_stream_t stream);
+                              int format /* as vlnce_conv2d_split_weights */, vlnce_stream_t stream);
 
 /* Which kernel the calling thread's last vlnce_conv2d_fwd was dispatched to: the measurement
  * harness prices bf16-pipe launches (6 plane products per multiply) and fp32-MFMA launches
@@ -325,14 +346,15 @@ int vlnce_frames_s2d(const vlnce_frames* frames, float* y, int pad_lo, int pad_h
 /* RGB stem in one launch, from the frames: y[img, ho, wo, :] = conv 7x7 / stride 2 / pad 3 of
  * (frame * in_scale[c] + in_shift[c]) (zero outside the frame) with `Cout` = 32 | 64 filters --
  * torchvision ResNet.conv1 behind the encoder's /255 (+ ImageNet mean/std),
- * resnet_encoders.py:131-139,171-199 -- on the bf16 matrix pipe (three exact bf16 planes per
- * operand, six plane products, fp32 accumulation).  w_frag: the filters as B fragments
- * [Cout/32][11 k-slabs][3 planes][64 lanes][8 bf16], k' = kh * 24 + kw * 3 + c (21 of every 24 used,
- * the rest and k' >= 168 zero), lane (l, h) = output channel 32 nb + l, k' = 16 ks + 8 h + [0, 8).
+ * resnet_encoders.py:131-139,171-199 -- on the 16-bit matrix pipe (w_format 1: three exact bf16
+ * planes per operand, six plane products; 2: fp16 planes, three products -- the formats of
+ * vlnce_conv2d_split_weights; fp32 accumulation).  w_frag: the filters as B fragments
+ * [Cout/32][11 k-slabs][3 planes][64 lanes][8 x 16 bit], k' = kh * 24 + kw * 3 + c (21 of every 24
+ * used, the rest and k' >= 168 zero), lane (l, h) = output channel 32 nb + l, k' = 16 ks + 8 h + [0, 8).
  * epi: NULL, {scale, shift, act} (eval: folded BatchNorm + ReLU) or {bn} (train: raw output, the
  * launch adds its column sums to bn->acc; workspace unused). */
 int vlnce_stem7_fwd(const vlnce_frames* frames, const float* in_scale, const float* in_shift,
-                    const void* w_frag, float* y, int Cout, const vlnce_epilogue* epi,
+                    const void* w_frag, int w_format, float* y, int Cout, const vlnce_epilogue* epi,
                     vlnce_stream_t stream);
 /* depth stem input: F.avg_pool2d(x, 2) of every frame, y [N*(F+..), H/2, W/2, C] fp32 */
 int vlnce_frames_avgpool2(const vlnce_frames* frames, float* y, vlnce_stream_t stream);

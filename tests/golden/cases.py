@@ -111,6 +111,22 @@ CASES = {
         policy="CMAPolicy", hw=256, N=64, T=1, lengths=[80 - (i % 6) for i in range(64)],
         mode="train", call="update", outputs_only=True, capture_logits=True,
     ),
+    # BASELINE.json configs[1] at full size: Seq2Seq `_update_agent`, num_envs = 32, 256x256 RGB-D,
+    # <= 80 tokens (outputs only, as above)
+    "seq2seq_update_n32_256": dict(
+        policy="Seq2SeqPolicy", hw=256, N=32, T=1, lengths=[80 - (i % 6) for i in range(32)],
+        mode="train", call="update", outputs_only=True, capture_logits=True,
+    ),
+    # BASELINE.json configs[4] at full size: one WDDPPO minibatch update (ddppo_alg.py:38-149) of
+    # the WaypointPolicy at num_envs = 32 -- 12 panorama frames + the history frame = 416 frames of
+    # 256x256 RGB-D through ResNet-18 / the GroupNorm ResNet-50, RxR-length instructions of up to 200
+    # tokens, encoders in eval mode (ddppo_waypoint_trainer.py:526-530).  Outputs only + the action
+    # components the reference's own act() chose (a few hundred bytes); the 440 MB of frames
+    # regenerate from the seed.  The batch at which the library picks the 416-frame tile plans.
+    "waypoint_update_n32_256": dict(
+        policy="WaypointPolicy", hw=256, N=32, T=1, lengths=[200 - 7 * (i % 9) for i in range(32)],
+        mode="ppo", call="ppo_update", outputs_only=True,
+    ),
 }
 
 VOCAB = 2504
@@ -364,6 +380,10 @@ def save_case(path, case_name, obs, prev, masks, extra, outputs):
     blob = {}
     if CASES.get(case_name, {}).get("outputs_only"):
         blob.update(to_numpy_tree(outputs, "out/"))
+        # (a PPO case: the action components the reference's act() chose are inputs that do not
+        # regenerate from the seed)
+        blob.update(to_numpy_tree({k: v for k, v in extra.items() if k.startswith("act_")},
+                                  "in/extra/"))
         np.savez_compressed(path, **blob)
         return
     ins = dict(obs=dict(obs), masks=masks, extra=extra)
@@ -386,6 +406,9 @@ def load_case(path, device="cpu"):
         outs = {k[4:]: (z[k] if z[k].dtype.kind in "US" else torch.from_numpy(z[k]))
                 for k in z.files if k.startswith("out/")}
         obs, prev, masks, extra = build_inputs(CASES[name])
+        for k in z.files:
+            if k.startswith("in/extra/"):
+                extra[k[9:]] = torch.from_numpy(z[k])
         mv = lambda t: t.to(device) if isinstance(t, torch.Tensor) else t  # noqa: E731
         return ({k: mv(v) for k, v in obs.items()}, mv(prev), mv(masks),
                 {k: mv(v) for k, v in extra.items()}, outs)

@@ -105,7 +105,9 @@ def main(names):
                 extra["act_" + k] = v.clone()
             # spread the pano choices (the synthetic weights pick STOP everywhere); keep one
             # STOP row (= num_panos) so the distance/offset mask is exercised
-            extra["act_pano"] = torch.tensor([[3], [12], [0], [7], [11], [5]])
+            B = extra["act_pano"].size(0)
+            extra["act_pano"] = (torch.tensor([[3], [12], [0], [7], [11], [5]]) if B == 6
+                                 else (torch.arange(B) * 5 % 13).view(B, 1))
         outs = cases.run_case(policy, case, obs, prev, masks, extra, update_fn, ref.AuxLosses,
                               ppo_fn=reference_ppo_fn)
         path = os.path.join(HERE, name + ".npz")

@@ -32,6 +32,9 @@ class HostSim:
     TILE_ROWS = 128
 
     # ---- conv / gemm
+    def plane_format(self, options=None):
+        return 2   # the product default (option "conv_math"); the simulator's arithmetic is fp32
+
     def conv2d_tiles(self, g):
         M = g["N"] * g["Ho"] * g["Wo"]
         return (M + self.TILE_ROWS - 1) // self.TILE_ROWS, self.TILE_ROWS
@@ -63,7 +66,7 @@ class HostSim:
     def conv2d_fwd(self, x, w, y, g, in_scale=None, in_shift=None, in_relu=0, scale=None,
                    shift=None, residual=None, ldr=0, act=0, accumulate=0, stat_partial=None,
                    in_center=None, x2=None, in2_scale=None, in2_shift=None, in2_center=None,
-                   side_out=None, w_split=None, w_frag=None, bn=None, options=None):
+                   side_out=None, w_split=None, w_frag=None, bn=None, options=None, w_format=1):
         N, H, W, Cin, Cout = g["N"], g["H"], g["W"], g["Cin"], g["Cout"]
         xi = x.as_strided((N, H, W, Cin), (H * W * g["ldx"], W * g["ldx"], g["ldx"], 1))
         if in_scale is not None:
@@ -382,14 +385,19 @@ class HostSim:
         v = self._frames_f32(fr)
         self.space_to_depth2(v, y, v.size(0), fr["H"], fr["W"], fr["C"], pad_lo, pad_hi, scale, shift)
 
-    def stem7_fwd(self, fr, in_scale, in_shift, w_frag, y, scale=None, shift=None, act=0, bn=None):
+    def stem7_fwd(self, fr, in_scale, in_shift, w_frag, y, scale=None, shift=None, act=0, bn=None,
+                  w_format=None):
         """vlnce_stem7_fwd: conv 7x7 / stride 2 / pad 3 of (frame * in_scale + in_shift), the
         filters given as B fragments [Cout/32][11][3][64 lanes][8 bf16] (k' = kh*24 + kw*3 + c)."""
         v = self._frames_f32(fr)
         if in_scale is not None:
             v = v * in_scale + in_shift
         Cout = y.size(-1)
-        pl = w_frag.view(torch.bfloat16).view(Cout // 32, 11, 3, 2, 32, 8).float().sum(2)  # nb ks half l31 e
+        if (w_format or getattr(w_frag, "_vlnce_fmt", 1)) == 2:   # fp16 planes {h * 2^11, (w - h) * 2^11, h}
+            pf = w_frag.view(torch.float16).view(Cout // 32, 11, 3, 2, 32, 8).float()
+            pl = pf[:, :, 2] + pf[:, :, 1] / 2048.0
+        else:
+            pl = w_frag.view(torch.bfloat16).view(Cout // 32, 11, 3, 2, 32, 8).float().sum(2)  # nb ks half l31 e
         w = pl.permute(0, 3, 1, 2, 4).reshape(Cout, 176)[:, :168].reshape(Cout, 7, 24)[:, :, :21]
         w = w.reshape(Cout, 7, 7, 3).permute(0, 3, 1, 2)
         raw = F.conv2d(v.permute(0, 3, 1, 2), w, stride=2, padding=3).permute(0, 2, 3, 1)

@@ -194,3 +194,58 @@ def test_batchnorm_sums_live_on_the_module_and_are_cleared_on_failure(monkeypatc
     with pytest.raises(RuntimeError, match="boom"):
         ops.conv2d_bn_train(torch.zeros(1, 2, 2, 4), torch.zeros(8, 1, 1, 4), 1, 0, bn)
     assert float(acc.abs().sum()) == 0.0
+
+
+def test_cached_parameter_list_notices_rebound_parameters():
+    """ DropsGraphsOnApply._plist() is what the trunks' graph keys read the parameter
+    versions from; a Parameter rebound behind the module's back (assignment, load_state_dict(
+    assign=True)) must not leave it -- and the captured graphs -- on the old tensors."""
+    import torch.nn as nn
+
+    from vlnce_amd.streams import DropsGraphsOnApply
+
+    class Trunk(DropsGraphsOnApply, nn.Sequential):
+        pass
+
+    class Holder:
+        def __init__(self):
+            self.entries = {"k": "graph"}
+
+    t = Trunk(nn.Conv2d(3, 4, 1), nn.BatchNorm2d(4))
+    object.__setattr__(t, "_graphs", Holder())
+    pl = t._plist()
+    assert [id(p) for p in pl] == [id(p) for p in t.parameters()] and t._plist() is pl
+    t[0].weight = nn.Parameter(torch.zeros(4, 3, 1, 1))
+    pl2 = t._plist()
+    assert pl2 is not pl and pl2[0] is t[0].weight and not t._graphs.entries
+    t._graphs.entries["k"] = "graph"
+    t.load_state_dict({k: v.clone() for k, v in t.state_dict().items()}, assign=True)
+    pl3 = t._plist()
+    assert [id(p) for p in pl3] == [id(p) for p in t.parameters()] and not t._graphs.entries
+    t._graphs.entries["k"] = "graph"
+    assert t._plist() is pl3 and t._graphs.entries      # nothing changed: nothing dropped
+
+
+def test_option_scope_is_per_thread():
+    """ `with lib.options(...)` must not change the dispatch of launches made from other
+    threads (autograd workers, side-stream helpers): the scope lives in a threading.local."""
+    import threading
+
+    import hostsim
+    from vlnce_amd import _lib
+
+    lib = _lib.HipLib.__new__(_lib.HipLib)     # the scope logic only: no shared library needed
+    lib._tls = threading.local()
+    lib._conv_math = 2
+    lib.get_option = lambda name: 0
+    lib.set_option = lambda name, v: None
+    seen = {}
+    with _lib.HipLib.options(lib, conv_math=1, u3=2):
+        assert lib._tls.scoped == {"conv_math": 1, "u3": 2} and lib.plane_format() == 1
+        th = threading.Thread(target=lambda: seen.update(scoped=getattr(lib._tls, "scoped", None),
+                                                         fmt=lib.plane_format()))
+        th.start()
+        th.join()
+    assert seen == {"scoped": None, "fmt": 2}
+    assert getattr(lib._tls, "scoped", None) is None and lib.plane_format() == 2
+    del hostsim

@@ -506,11 +506,15 @@ def test_bind_host_threads_to_gpu_socket(tmp_path, monkeypatch):
     sysfs = _fake_sysfs(tmp_path / "a", "0000:d9:00.0", 1, ",".join(str(c) for c in keep) + ",100000")
     try:
         assert D.gpu_numa_node(0, sysfs) == 1
-        # no cache topology in this tree: the default scope falls back to the whole socket
+        # the default scope is the whole socket (worker processes inherit the mask)
+        monkeypatch.setattr(D, "_AFFINITY_BEFORE_BIND", None)
         assert D.bind_host_threads_to_gpu_socket(0, sysfs=sysfs) == 1
         assert os.sched_getaffinity(0) == set(keep)
         for tid in os.listdir("/proc/self/task"):
             assert os.sched_getaffinity(int(tid)) == set(keep)
+        # ... and a worker's init function gets the trainer's original mask back
+        assert D.restore_worker_affinity() == before
+        assert os.sched_getaffinity(0) == before
     finally:
         for tid in os.listdir("/proc/self/task"):
             os.sched_setaffinity(int(tid), before)
@@ -523,8 +527,8 @@ def test_bind_host_threads_to_gpu_socket(tmp_path, monkeypatch):
 
 
 def test_bind_scope_l3_spreads_the_gpus_of_a_socket_over_its_l3_domains(tmp_path, monkeypatch):
-    """Default scope: ONE L3 domain of the GPU's socket; the GPUs of a socket (PCI order, other
-    jobs' GPUs included -- sysfs shows the whole host) get different domains."""
+    """scope "l3" (what bench.py asks for): ONE L3 domain of the GPU's socket; the GPUs of a socket
+    (PCI order, other jobs' GPUs included -- sysfs shows the whole host) get different domains."""
     import os
     import types
 
@@ -549,7 +553,7 @@ def test_bind_scope_l3_spreads_the_gpus_of_a_socket_over_its_l3_domains(tmp_path
             monkeypatch.setattr(torch.cuda, "get_device_properties", lambda i, p=props: p)
             for tid in os.listdir("/proc/self/task"):
                 os.sched_setaffinity(int(tid), before)
-            assert D.bind_host_threads_to_gpu_socket(0, sysfs=sysfs) == 1
+            assert D.bind_host_threads_to_gpu_socket(0, sysfs=sysfs, scope="l3") == 1
             assert os.sched_getaffinity(0) == set(want)
         for tid in os.listdir("/proc/self/task"):
             os.sched_setaffinity(int(tid), before)

@@ -128,14 +128,20 @@ def test_conv2d_fwd(hip, case):
 
 def test_conv_identity_weight_is_not_transposed(hip):
     """A = I style check with an asymmetric operand: a 1x1 conv whose weight is a
-    permutation matrix must permute channels exactly (bit-exact)."""
+    permutation matrix must permute channels exactly: bit-exact in plane format 1 (three bf16
+    planes hold all 24 mantissa bits) and on the fp32-MFMA kernel, to 2^-22 relative in format 2
+    (two fp16 planes: 11 + 11 bits and a sign)."""
     Cc = 64
     perm = torch.randperm(Cc, generator=torch.Generator().manual_seed(3))
     w = torch.zeros(Cc, 1, 1, Cc)
     w[torch.arange(Cc), 0, 0, perm] = 1.0
     x = rnd(2, 9, 5, Cc, seed=11).to(DEV)
-    y = ops.conv2d_nhwc(x, w.to(DEV), 1, 0)
-    assert torch.equal(y, x[..., perm.to(DEV)])
+    want = x[..., perm.to(DEV)]
+    assert torch.equal(ops.conv2d_nhwc(x, w.to(DEV), 1, 0, w_format=1), want)
+    with hip.options(conv_math=0):
+        assert torch.equal(ops.conv2d_nhwc(x, w.to(DEV), 1, 0), want)
+    y = ops.conv2d_nhwc(x, w.to(DEV), 1, 0, w_format=2)
+    assert bool(((y - want).abs() <= want.abs() * 2.0 ** -22).all())
 
 
 # ------------------------------------------------------------------ gemm
@@ -566,6 +572,32 @@ def test_instruction_encoder_matches_torch_packed_rnn(hip, rnn_type, bidir, fina
     wgt = rnd(*yr.shape, seed=9)
     (yr * wgt).sum().backward()
     (yh * wgt.to(DEV)).sum().backward()
+    for (n, pr), (_, ph) in zip(ref.named_parameters(), hipm.named_parameters()):
+        close(ph.grad, pr.grad, 5e-4, what=f"d {n}")
+
+
+def test_instruction_encoder_backward_takes_an_expanded_gradient(hip):
+    """ An upstream gradient that is an EXPANDED tensor -- seq.mean over the time axis, a
+    broadcast add: unit inner stride, zero time stride -- must reach vlnce_rnn_seq_bwd2 as real rows
+    (the entry point rejects non-positive strides)."""
+    from oracle import policy_cpu as oc
+    from oracle import thirdparty as tp
+    from vlnce_amd.encoders.instruction_encoder import InstructionEncoder
+
+    cfg = tp.default_model_config().INSTRUCTION_ENCODER
+    cfg.rnn_type, cfg.bidirectional, cfg.final_state_only = "LSTM", True, False
+    ref = oc.InstructionEncoder(cfg)
+    hipm = InstructionEncoder(cfg)
+    hipm.load_state_dict(ref.state_dict())
+    hipm.to(DEV)
+    tok = torch.zeros(5, 200, dtype=torch.long)
+    gen = torch.Generator().manual_seed(4)
+    for i in range(5):
+        tok[i, :7 + 3 * i] = torch.randint(1, 2504, (7 + 3 * i,), generator=gen)
+    yr = ref({"instruction": tok})        # [B, C, L]
+    yh = hipm({"instruction": tok.to(DEV)})
+    yr.mean(dim=2).sum().backward()       # d/dseq = 1 / L expanded along the time axis
+    yh.mean(dim=2).sum().backward()
     for (n, pr), (_, ph) in zip(ref.named_parameters(), hipm.named_parameters()):
         close(ph.grad, pr.grad, 5e-4, what=f"d {n}")
 
@@ -1056,17 +1088,44 @@ def test_split_weights_is_exact(hip):
     w = torch.randn(64, 3, 3, 32) * torch.exp(8 * torch.randn(64, 1, 1, 1))
     w.view(-1)[:6] = torch.tensor([0.0, -0.0, 1e-30, -3e38, 1.0, -1.0 + 2.0 ** -23])
     wg = w.to(DEV)
-    planes = ops.split_weights(wg)
-    assert planes is not None and planes.shape == (3, w.numel())
-    assert ops.split_weights(wg) is planes  # cached on the tensor
+    planes = ops.split_weights(wg, ops.PLANES_BF16X6)
+    assert planes is not None and planes.shape == (3, w.numel()) and planes._vlnce_fmt == 1
+    assert ops.split_weights(wg, ops.PLANES_BF16X6) is planes  # cached on the tensor, per format
+    assert ops.split_weights(wg, ops.PLANES_F16X3) is not planes
     p = (planes.cpu().to(torch.int32) & 0xFFFF) << 16
     f = p.view(torch.float32).double()
     assert torch.equal((f[0] + f[1] + f[2]).float(), w.view(-1))
     wg.mul_(2.0)  # written in place: split again
-    assert ops.split_weights(wg) is not planes
+    assert ops.split_weights(wg, ops.PLANES_BF16X6) is not planes
     tiny = torch.full((1, 1, 1, 32), 1e-38, device=DEV)
-    q = (ops.split_weights(tiny).cpu().to(torch.int32) & 0xFFFF) << 16
+    q = (ops.split_weights(tiny, ops.PLANES_BF16X6).cpu().to(torch.int32) & 0xFFFF) << 16
     assert (q.view(torch.float32).double().sum(0) - 1e-38).abs().max().item() < 2.0 ** -126
+
+
+def _f16_planes_check(planes_i16, w_flat):
+    """format 2 (include/vlnce_hip.h): planes {h * 2^11, (w - h) * 2^11 rounded, h}, h = fp16(w) --
+    bit-exact against torch's own fp16 rounding, and h + l within 2^-22 |w| of w"""
+    pl = planes_i16.cpu().view(torch.float16).float()
+    h = w_flat.to(torch.float16).float()
+    assert torch.equal(pl[2], h)
+    assert torch.equal(pl[0], h * 2048.0)
+    lo = ((w_flat - h) * 2048.0).to(torch.float16).float()
+    assert torch.equal(pl[1], lo)
+    err = (h.double() + lo.double() / 2048.0 - w_flat.double()).abs()
+    assert bool((err <= w_flat.double().abs() * 2.0 ** -22 + 2.0 ** -36).all())
+
+
+def test_split_weights_fp16_planes(hip):
+    """vlnce_conv2d_split_weights, format 2: weights of ordinary size (|w| < 32), tiny ones (the low
+    plane is scaled by 2^11: no subnormals down to 2^-25) and signed zeros."""
+    torch.manual_seed(4)
+    w = torch.randn(64, 3, 3, 32) * torch.exp(2 * torch.randn(64, 1, 1, 1)) * 0.05
+    w.clamp_(-31.0, 31.0)
+    w.view(-1)[:6] = torch.tensor([0.0, -0.0, 1e-6, -31.99, 1.0, -1.0 + 2.0 ** -23])
+    wg = w.to(DEV)
+    planes = ops.split_weights(wg, ops.PLANES_F16X3)
+    assert planes.shape == (3, w.numel()) and planes._vlnce_fmt == 2
+    _f16_planes_check(planes, w.view(-1))
 
 
 def _conv_cases_under(hip, cases, want_path=None, **opts):
@@ -1103,9 +1162,9 @@ def test_pack_weights_layout_and_exactness(hip):
     w = torch.randn(Cout, KH, KW, Cin) * torch.exp(6 * torch.randn(Cout, 1, 1, 1))
     w.view(-1)[:6] = torch.tensor([0.0, -0.0, 1e-30, -3e38, 1.0, -1.0 + 2.0 ** -23])
     wg = w.to(DEV)
-    frag = ops.pack_weights(wg)
-    assert frag is not None and frag.numel() == w.numel() * 3
-    assert ops.pack_weights(wg) is frag  # cached on the tensor
+    frag = ops.pack_weights(wg, ops.PLANES_BF16X6)
+    assert frag is not None and frag.numel() == w.numel() * 3 and frag._vlnce_fmt == 1
+    assert ops.pack_weights(wg, ops.PLANES_BF16X6) is frag  # cached on the tensor, per format
     T, KS = KH * KW, KH * KW * Cin // 16
     f = ((frag.cpu().to(torch.int32) & 0xFFFF) << 16).view(torch.float32).double()
     f = f.view(Cout // 32, KS, 3, 64, 8).sum(2)  # the three planes added up: [nb, ks, lane, e]
@@ -1119,8 +1178,23 @@ def test_pack_weights_layout_and_exactness(hip):
             want = torch.stack([w.view(Cout, T, Cin)[n, t, ci + e] for e in range(8)], 1)
             assert torch.equal(f[nb, ks].float(), want), (nb, ks)
     assert ops.pack_weights(torch.randn(48, 1, 1, 32, device=DEV)) is None  # Cout % 32 != 0
+    # format 2: the same fragment order, planes {h * 2^11, (w - h) * 2^11, h}
+    w2 = (torch.randn(Cout, KH, KW, Cin) * 0.05)
+    f2 = ops.pack_weights(w2.to(DEV), ops.PLANES_F16X3)
+    assert f2._vlnce_fmt == 2
+    f2 = f2.cpu().view(Cout // 32, KS, 3, 64, 8)
+    flat = torch.empty(3, Cout, T, Cin, dtype=torch.int16)
+    for nb in range(Cout // 32):
+        for ks in range(KS):
+            s, ct = ks & 1, ks >> 1
+            t, c = ct % T, ct // T
+            n = nb * 32 + (lane & 31)
+            ci = c * 32 + s * 16 + (lane >> 5) * 8
+            for e in range(8):
+                flat[:, n, t, ci + e] = f2[nb, ks, :, :, e]
+    _f16_planes_check(flat.view(3, -1), w2.view(-1))
     wg.mul_(2.0)
-    assert ops.pack_weights(wg) is not frag
+    assert ops.pack_weights(wg, ops.PLANES_BF16X6) is not frag
 
 
 P3_CASES = [
@@ -1192,6 +1266,40 @@ def test_conv_s3_forced(hip):
     _conv_cases_under(hip, CONV_CASES + P3_CASES, want_path=2, s3=2)
 
 
+FORCED = [dict(), dict(m3=2), dict(u3=2), dict(u3=3), dict(s3=2), dict(p3_tile=1), dict(p3_tile=2),
+          dict(p3_tile=3), dict(p3_tile=4), dict(p3_tile=5), dict(p3_tile=6), dict(x3_tile=1),
+          dict(x3_tile=2), dict(x3_tile=3), dict(x3_tile=4)]
+
+
+@pytest.mark.parametrize("forced", FORCED, ids=["-".join(f"{k}{v}" for k, v in f.items()) or "default"
+                                                for f in FORCED])
+def test_conv_kernels_three_bf16_planes(hip, forced):
+    """The tests above run in the default plane format (fp16 planes, three products per multiply);
+    the same cases, kernel families and forced tile shapes in format 1 (three bf16 planes, six
+    products: option "conv_math" = 1 -- what the data-gradient launches of the trainable encoders
+    use)."""
+    _conv_cases_under(hip, CONV_CASES + P3_CASES, conv_math=1, **forced)
+
+
+def test_fp16_planes_range_and_gradient_sized_operands(hip):
+    """What format 2 promises (include/vlnce_hip.h): activations up to fp16's range are fine,
+    an activation beyond it gives inf / NaN (never a wrong finite value), and operands of gradient
+    size (1e-7) need format 1 -- the reason trunk_backward passes PLANES_BF16X6."""
+    x = rnd(2, 16, 16, 64, seed=71).to(DEV)
+    w = (rnd(64, 3, 3, 64, seed=72) * 0.04).to(DEV)
+    ref = F.conv2d(x.double().permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2), padding=1)
+    ref = ref.permute(0, 2, 3, 1)
+    big = ops.conv2d_nhwc(x * 3.0e4, w, 1, 1, w_format=2)          # |x| up to ~1.2e5 > 65504
+    assert not bool(torch.isfinite(big).all())
+    ok = ops.conv2d_nhwc(x * 1.0e4, w, 1, 1, w_format=2)           # |x| up to ~4e4
+    close(ok, ref.float().to(DEV) * 1.0e4, 1e-5, what="large activations")
+    tiny2 = ops.conv2d_nhwc(x * 1.0e-7, w, 1, 1, w_format=2)
+    tiny1 = ops.conv2d_nhwc(x * 1.0e-7, w, 1, 1, w_format=1)
+    e2 = ((tiny2.double().cpu() - ref * 1e-7).abs().max() / (ref.abs().max() * 1e-7)).item()
+    e1 = ((tiny1.double().cpu() - ref * 1e-7).abs().max() / (ref.abs().max() * 1e-7)).item()
+    assert e1 < 1e-5 and e2 > 10 * e1, (e1, e2)
+
+
 def test_options_are_explicit_state(hip):
     """vlnce_set_option / vlnce_get_option / vlnce_option_default: set, read back, restore; an
     unknown name is an error (the library reads no environment variable)."""
@@ -1202,10 +1310,10 @@ def test_options_are_explicit_state(hip):
             if name in hip.PER_LAUNCH:
                 # convolution-kernel options travel with each launch (vlnce_prologue.options): the
                 # library's process state is not touched
-                assert hip.get_option(name) == before and hip._scoped[name] == d + 1
+                assert hip.get_option(name) == before and hip._tls.scoped[name] == d + 1
             else:
                 assert hip.get_option(name) == d + 1
-        assert hip.get_option(name) == before and getattr(hip, "_scoped", None) is None
+        assert hip.get_option(name) == before and getattr(hip._tls, "scoped", None) is None
         assert before == hip.option_default(name) or os.environ.get("VLNCE_" + name.upper())
     with pytest.raises(RuntimeError, match="unknown option"):
         hip.set_option("no_such_option", 1)
@@ -1240,16 +1348,20 @@ def test_per_launch_options_do_not_leak_between_launches(hip):
     assert hip.get_option("conv_math") == hip.option_default("conv_math") or os.environ.get("VLNCE_CONV_MATH")
 
 
-def test_conv_p3_matches_fp64_better_than_1e_6(hip):
-    """The round-to-nearest bf16x3 split keeps the convolution fp32-class: relative rms error
-    against an fp64 convolution of the same operands below 1e-6 (torch's own fp32 conv: ~2e-7)."""
-    x = rnd(4, 16, 16, 256, seed=21).to(DEV)
-    w = (rnd(256, 3, 3, 256, seed=22) * (256 * 9) ** -0.5).to(DEV)
-    y = ops.conv2d_nhwc(x, w, 1, 1)
-    ref = F.conv2d(x.double().permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2), padding=1)
-    ref = ref.permute(0, 2, 3, 1)
-    rms = ((y.double() - ref).pow(2).mean() / ref.pow(2).mean()).sqrt().item()
-    assert rms < 1e-6, rms
+@pytest.mark.parametrize("fmt", [2, 1], ids=["f16x3", "bf16x6"])
+def test_conv_p3_matches_fp64_better_than_1e_6(hip, fmt):
+    """Both plane formats keep the convolution fp32-class: relative rms error against an fp64
+    convolution of the same operands below 1e-6 (torch's own fp32 conv: ~2e-7), post-ReLU-like
+    (non-negative) and signed activations."""
+    for sign in (False, True):
+        x = rnd(4, 16, 16, 256, seed=21)
+        x = (x if sign else x.abs()).to(DEV)
+        w = (rnd(256, 3, 3, 256, seed=22) * (256 * 9) ** -0.5).to(DEV)
+        y = ops.conv2d_nhwc(x, w, 1, 1, w_format=fmt)
+        ref = F.conv2d(x.double().permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2), padding=1)
+        ref = ref.permute(0, 2, 3, 1)
+        rms = ((y.double() - ref).pow(2).mean() / ref.pow(2).mean()).sqrt().item()
+        assert rms < 1e-6, (fmt, sign, rms)
 
 
 def test_embedding_backward_matches_torch(hip):
@@ -1365,12 +1477,13 @@ STEM7_CASES = [
 ]
 
 
+@pytest.mark.parametrize("fmt", [2, 1], ids=["f16x3", "bf16x6"])
 @pytest.mark.parametrize("case", STEM7_CASES, ids=[c[0] for c in STEM7_CASES])
-def test_stem7_from_frames(hip, case):
-    """vlnce_stem7_fwd (7x7 / stride 2 / pad 3 on the bf16 pipe, straight from uint8 / fp32
-    frames, crop window, frame stack + masked extra frame, input transform) against the CPU
-    contract (tests/hostsim.py: F.conv2d on the transformed frames): raw output + BatchNorm
-    column sums, or the folded-BatchNorm + ReLU epilogue."""
+def test_stem7_from_frames(hip, case, fmt):
+    """vlnce_stem7_fwd (7x7 / stride 2 / pad 3 on the 16-bit matrix pipe, both plane formats,
+    straight from uint8 / fp32 frames, crop window, frame stack + masked extra frame, input
+    transform) against the CPU contract (tests/hostsim.py: F.conv2d on the transformed frames): raw
+    output + BatchNorm column sums, or the folded-BatchNorm + ReLU epilogue."""
     name, N, F_, Hs, Ws, crop, Cout, dtype, extra, mode = case
     g = torch.Generator().manual_seed(61)
     shape = (N, F_, Hs, Ws, 3) if F_ > 1 or extra else (N, Hs, Ws, 3)
@@ -1392,7 +1505,7 @@ def test_stem7_from_frames(hip, case):
         to = (lambda t: t.to(dev)) if dev != "cpu" else (lambda t: t)
         xs = (to(x), to(x2), to(mask)) if extra else to(x)
         fr = ops.frames(xs)
-        wf = ops.stem7_pack_weights(to(w))
+        wf = ops.stem7_pack_weights(to(w), fmt)
         yv = torch.empty((fr["images"], (fr["H"] - 1) // 2 + 1, (fr["W"] - 1) // 2 + 1, Cout), device=dev)
         acc = torch.zeros((ops.BN_SHARDS, Cout, 2), device=dev, dtype=torch.float64)
         if mode == "bn":

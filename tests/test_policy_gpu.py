@@ -55,6 +55,28 @@ def test_hip_policy_matches_reference_golden(name):
     compare(outs, gold, atol=1e-4, rtol=1e-4)
 
 
+FULL_SIZE = ["seq2seq_update_n32_256", "waypoint_update_n32_256"]
+
+
+@pytest.mark.parametrize("name", FULL_SIZE)
+def test_full_size_updates_match_reference_goldens(name):
+    """BASELINE.json configs[1] and configs[4] at FULL size against fixtures written by the real
+    reference classes (tests/golden/make_goldens.py; outputs only, the frames regenerate from the
+    seed): Seq2Seq `_update_agent` at num_envs 32 / 256x256 / 80 tokens, and one WDDPPO minibatch
+    update of the WaypointPolicy at num_envs 32 = 416 frames of 256x256 RGB-D / 200 tokens -- the
+    batches at which the library picks the tile plans `bench.py --policy seq2seq|waypoint` times
+    (conv_p3<128,256,1,8> / <256,64,4,2> for the 416-frame ResNet-18, ...).  1e-4 (north_star) on
+    the loss / PPO statistics, the logits, every parameter-gradient norm and the stored gradients."""
+    case = cases.CASES[name]
+    obs, prev, masks, extra, gold = cases.load_case(os.path.join(GOLD, name + ".npz"))
+    policy, _ = cases.build_policy(vlnce_amd, case, vlnce_amd.make_config, vlnce_amd.make_spaces,
+                                   tp.synth_state_dict)
+    policy.to(DEV)
+    outs = cases.run_case(policy, case, to_dev(obs), to_dev(prev), to_dev(masks), to_dev(extra),
+                          hip_update, vlnce_amd.AuxLosses, ppo_fn=hip_ppo)
+    compare(outs, gold, atol=1e-4, rtol=1e-4)
+
+
 class _PinnedReLU(torch.nn.Module):
     """relu(z) whose BACKWARD uses a given 0/1 pattern instead of (z > 0): the sub-gradient side of
     the units whose pre-activation is within rounding noise of zero is taken from the other

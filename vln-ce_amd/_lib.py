@@ -23,6 +23,18 @@ _F = C.c_float
 _L = C.c_long
 
 
+def _buffer_format(explicit, *bufs):
+    """plane format of a launch's weight buffers: the tag ops.split_weights / pack_weights /
+    stem7_pack_weights leave on them (`_vlnce_fmt`); an explicit value that contradicts a tag -- the
+    kernel would read fp16 planes as bf16 or the reverse, silently -- raises."""
+    tags = {getattr(b, "_vlnce_fmt", None) for b in bufs if b is not None} - {None}
+    if explicit:
+        tags.add(int(explicit))
+    if len(tags) > 1:
+        raise RuntimeError(f"weight buffers / w_format disagree on the plane format: {sorted(tags)}")
+    return tags.pop() if tags else 1
+
+
 class ConvDesc(C.Structure):
     _fields_ = [(n, _I) for n in
                 ("N", "H", "W", "Cin", "Cout", "KH", "KW", "stride", "pad", "Ho", "Wo", "ldx", "ldy")]
@@ -31,7 +43,7 @@ class ConvDesc(C.Structure):
 class Prologue(C.Structure):
     _fields_ = [("in_scale", _P), ("in_shift", _P), ("in_center", _P), ("in_relu", _I),
                 ("x2", _P), ("in2_scale", _P), ("in2_shift", _P), ("in2_center", _P),
-                ("side_out", _P), ("w_split", _P), ("w_frag", _P), ("options", _P)]
+                ("side_out", _P), ("w_split", _P), ("w_frag", _P), ("options", _P), ("w_format", _I)]
 
 
 class Frames(C.Structure):
@@ -54,11 +66,11 @@ _SIGNATURES = {
     "vlnce_set_option": (_I, [C.c_char_p, _I]),
     "vlnce_get_option": (_I, [C.c_char_p, C.POINTER(_I)]),
     "vlnce_option_default": (_I, [C.c_char_p, C.POINTER(_I)]),
-    "vlnce_conv2d_split_weights": (_I, [_P, _P, C.c_long, _P]),
+    "vlnce_conv2d_split_weights": (_I, [_P, _P, C.c_long, _I, _P]),
     "vlnce_conv2d_last_path": (_I, []),
     "vlnce_embedding_bwd": (_I, [_P, _P, _P, _L, _I, _L, _L, _P]),
     "vlnce_conv2d_pack_bytes": (C.c_long, [C.POINTER(ConvDesc)]),
-    "vlnce_conv2d_pack_weights": (_I, [_P, _P, C.POINTER(ConvDesc), _P]),
+    "vlnce_conv2d_pack_weights": (_I, [_P, _P, C.POINTER(ConvDesc), _I, _P]),
     "vlnce_conv2d_tiles_m": (_I, [C.POINTER(ConvDesc)]),
     "vlnce_conv2d_tile_rows": (_I, [C.POINTER(ConvDesc)]),
     "vlnce_conv2d_bn_workspace_bytes": (C.c_long, [C.POINTER(ConvDesc)]),
@@ -87,7 +99,7 @@ _SIGNATURES = {
     "vlnce_space_to_depth2": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
     "vlnce_frames_s2d": (_I, [C.POINTER(Frames), _P, _I, _I, _P, _P, _P]),
     "vlnce_frames_avgpool2": (_I, [C.POINTER(Frames), _P, _P]),
-    "vlnce_stem7_fwd": (_I, [C.POINTER(Frames), _P, _P, _P, _P, _I, C.POINTER(Epilogue), _P]),
+    "vlnce_stem7_fwd": (_I, [C.POINTER(Frames), _P, _P, _P, _I, _P, _I, C.POINTER(Epilogue), _P]),
     "vlnce_frames_f32": (_I, [C.POINTER(Frames), _P, _P, _P, _P]),
     "vlnce_frames_gather": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "vlnce_frames_resize_area": (_I, [_P] + [_I] * 11 + [_P, _P]),
@@ -209,7 +221,7 @@ class HipLib:
 
     name = "hip"
 
-    ABI = 141  # include/vlnce_hip.h
+    ABI = 142  # include/vlnce_hip.h
 
     def __init__(self, path=LIB_PATH):
         self.dll = load_cdll(path)
@@ -218,6 +230,11 @@ class HipLib:
             raise RuntimeError(f"{path} has ABI {have}, this package binds ABI {self.ABI}: "
                                "rebuild it (python __graft_entry__.py)")
 
+        self._conv_math = None
+        #  the `with lib.options(...)` scope is per THREAD, like the library's own
+        # thread-local per-launch options: autograd worker threads and side-stream helpers must not
+        # see, or restore, another thread's overrides
+        self._tls = threading.local()
         self._options_from_env()
 
     # ---- dispatch options (vlnce_set_option): the library itself never reads the environment;
@@ -230,8 +247,8 @@ class HipLib:
             v = os.environ.get("VLNCE_" + name.upper())
             if v is None:
                 continue
-            if name == "conv_math":
-                v = 0 if v[:1] in ("f", "0") else 1
+            if name == "conv_math":   # f32 | 0: fp32 MFMA; bf16 | 1: three bf16 planes; f16 | 2: fp16 planes
+                v = {"f32": 0, "0": 0, "bf16": 1, "1": 1, "f16": 2, "2": 2}.get(v.strip().lower(), v)
             elif name in ("igemm_nobuf", "igemm_no_splitk"):
                 v = 0 if v in ("", "0") else 1
             try:
@@ -245,6 +262,26 @@ class HipLib:
 
     def set_option(self, name, value):
         self._check(self.dll.vlnce_set_option(name.encode(), int(value)), "vlnce_set_option")
+        if name == "conv_math":
+            self._conv_math = int(value)
+
+    def plane_format(self, options=None):
+        """the plane format (1 = three bf16 planes, 2 = fp16 planes; include/vlnce_hip.h) in which the
+        weights of a launch are packed = the effective "conv_math" of that launch: its own options,
+        else the enclosing `with lib.options(...)`, else the process value (0 = fp32 MFMA: the planes
+        are not read; packed as 1)."""
+        v = None
+        if options:
+            v = options.get("conv_math")
+        if v is None:
+            sc = getattr(self._tls, "scoped", None)
+            if sc:
+                v = sc.get("conv_math")
+        if v is None or v < 0:
+            v = self._conv_math
+            if v is None:
+                v = self._conv_math = self.get_option("conv_math")
+        return 2 if v == 2 else 1
 
     def get_option(self, name):
         v = _I(0)
@@ -284,17 +321,17 @@ class HipLib:
 
         class _Scope:
             def __enter__(self_inner):
-                self_inner.prev = getattr(lib, "_scoped", None)
+                self_inner.prev = getattr(lib._tls, "scoped", None)
                 scoped = dict(self_inner.prev or {})
                 scoped.update({k: v for k, v in kw.items() if k in lib.PER_LAUNCH})
-                lib._scoped = scoped or None
+                lib._tls.scoped = scoped or None
                 self_inner.old = {k: lib.get_option(k) for k in kw if k not in lib.PER_LAUNCH}
                 for k in self_inner.old:
                     lib.set_option(k, kw[k])
                 return lib
 
             def __exit__(self_inner, *exc):
-                lib._scoped = self_inner.prev
+                lib._tls.scoped = self_inner.prev
                 for k, v in self_inner.old.items():
                     lib.set_option(k, v)
                 return False
@@ -318,17 +355,21 @@ class HipLib:
     def conv2d_fwd(self, x, w, y, g, in_scale=None, in_shift=None, in_relu=0, scale=None,
                    shift=None, residual=None, ldr=0, act=0, accumulate=0, stat_partial=None,
                    in_center=None, x2=None, in2_scale=None, in2_shift=None, in2_center=None,
-                   side_out=None, w_split=None, w_frag=None, bn=None, options=None):
+                   side_out=None, w_split=None, w_frag=None, bn=None, options=None, w_format=None):
         """bn: train-mode BatchNorm statistics added by the launch (vlnce_bn_sums): (acc
         [16, C, 2] f64, workspace uint8) -- finish them with bn_finalize_sums().
         options: {name: value} dispatch options of this launch (default: those of the enclosing
-        `with lib.options(...)` block, else the process values)."""
+        `with lib.options(...)` block, else the process values).
+        w_format: plane format of w_split / w_frag; default: the format the buffers were made with
+        (ops.split_weights / pack_weights tag them), which any explicit value must agree with."""
         d = self._desc(g)
-        opts = self._launch_options(options if options is not None else getattr(self, "_scoped", None))
+        w_format = _buffer_format(w_format, w_split, w_frag)
+        opts = self._launch_options(options if options is not None
+                                    else getattr(self._tls, "scoped", None))
         pro = Prologue(_ptr(in_scale), _ptr(in_shift), _ptr(in_center), int(in_relu), _ptr(x2),
                        _ptr(in2_scale), _ptr(in2_shift), _ptr(in2_center), _ptr(side_out),
                        _ptr(w_split), _ptr(w_frag),
-                       C.cast(opts, C.c_void_p) if opts is not None else None)
+                       C.cast(opts, C.c_void_p) if opts is not None else None, int(w_format))
         bnp = None
         if bn is not None:
             acc, ws = bn
@@ -350,8 +391,8 @@ class HipLib:
         d = self._desc(g)
         return int(self.dll.vlnce_conv2d_bn_workspace_bytes(C.byref(d)))
 
-    def conv2d_split_weights(self, w, planes):
-        self._check(self.dll.vlnce_conv2d_split_weights(_ptr(w), _ptr(planes), w.numel(),
+    def conv2d_split_weights(self, w, planes, fmt=1):
+        self._check(self.dll.vlnce_conv2d_split_weights(_ptr(w), _ptr(planes), w.numel(), int(fmt),
                                                         _stream()), "vlnce_conv2d_split_weights")
 
     def conv2d_last_path(self):
@@ -361,10 +402,10 @@ class HipLib:
         d = self._desc(g)
         return int(self.dll.vlnce_conv2d_pack_bytes(C.byref(d)))
 
-    def conv2d_pack_weights(self, w, frag, g):
+    def conv2d_pack_weights(self, w, frag, g, fmt=1):
         d = self._desc(g)
-        self._check(self.dll.vlnce_conv2d_pack_weights(_ptr(w), _ptr(frag), C.byref(d), _stream()),
-                    "vlnce_conv2d_pack_weights")
+        self._check(self.dll.vlnce_conv2d_pack_weights(_ptr(w), _ptr(frag), C.byref(d), int(fmt),
+                                                       _stream()), "vlnce_conv2d_pack_weights")
 
     def gemm(self, A, lda, transA, B, ldb, transB, Cm, ldc, M, N, K, scale=None, shift=None,
              residual=None, ldr=0, act=0, accumulate=0):
@@ -486,17 +527,19 @@ class HipLib:
         self._check(self.dll.vlnce_frames_s2d(C.byref(d), _ptr(y), pad_lo, pad_hi, _ptr(scale),
                                               _ptr(shift), _stream()), "vlnce_frames_s2d")
 
-    def stem7_fwd(self, fr, in_scale, in_shift, w_frag, y, scale=None, shift=None, act=0, bn=None):
+    def stem7_fwd(self, fr, in_scale, in_shift, w_frag, y, scale=None, shift=None, act=0, bn=None,
+                  w_format=None):
         """RGB stem (7x7 / stride 2 / pad 3) straight from the frame descriptor; epilogue =
         scale / shift / act, or bn = the column-sum accumulator of vlnce_bn_sums."""
         d = self._frames(fr)
+        w_format = _buffer_format(w_format, w_frag)
         bnp = None
         if bn is not None:
             bnp = C.pointer(BnSums(_ptr(bn), None, 0))
         epi = Epilogue(_ptr(scale), _ptr(shift), None, 0, int(act), 0, None, bnp)
         self._check(self.dll.vlnce_stem7_fwd(C.byref(d), _ptr(in_scale), _ptr(in_shift),
-                                             _ptr(w_frag), _ptr(y), y.size(-1), C.byref(epi),
-                                             _stream()), "vlnce_stem7_fwd")
+                                             _ptr(w_frag), int(w_format), _ptr(y), y.size(-1),
+                                             C.byref(epi), _stream()), "vlnce_stem7_fwd")
 
     def frames_avgpool2(self, fr, y):
         d = self._frames(fr)

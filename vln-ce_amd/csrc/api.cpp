@@ -27,7 +27,10 @@ extern "C" const char* vlnce_last_error(void) { return g_err; }
 // 139: vlnce_attn_fwd_shared / _bwd_shared, vlnce_segment_sum.
 // 140: option "m3" (conv_m3_kernel).
 // 141: vlnce_rnn_seq_fwd2 / _bwd2 / _wgrad, vlnce_linear_rows_fwd / _bwd, vlnce_ppo_loss, vlnce_prologue.options (per-launch dispatch options).
-extern "C" int vlnce_version(void) { return 141; }
+// 142: plane format 2 (fp16 planes, three plane products per multiply): vlnce_prologue.w_format, a
+// `format` argument of vlnce_conv2d_split_weights / _pack_weights, `w_format` of vlnce_stem7_fwd;
+// option "conv_math" defaults to 2.
+extern "C" int vlnce_version(void) { return 142; }
 
 // ---- dispatch options: one int per name, process-wide, relaxed atomics (a tuning / test knob,
 // not a synchronisation point: set them before the launches they are meant for)
@@ -37,13 +40,13 @@ struct OptDef {
   int def;
 };
 const OptDef kOpts[VLNCE_OPT_COUNT] = {
-    {"conv_math", 1},   {"p3", 2},          {"p3_tile", 0},         {"s3", 1},
+    {"conv_math", 2},   {"p3", 2},          {"p3_tile", 0},         {"s3", 1},
     {"u3", 1},          {"u3_waves", 8},    {"x3_tile", 0},         {"igemm_tile", 0},
     {"igemm_nobuf", 0}, {"igemm_no_splitk", 0}, {"wgrad_tile", 64}, {"rollout_one_xcd", 0},
     {"m3", 1},
 };
 std::atomic<int> g_opt[VLNCE_OPT_COUNT] = {
-    {1}, {2}, {0}, {1}, {1}, {8}, {0}, {0}, {0}, {0}, {64}, {0}, {1},
+    {2}, {2}, {0}, {1}, {1}, {8}, {0}, {0}, {0}, {0}, {64}, {0}, {1},
 };
 int opt_index(const char* name) {
   if (name)

@@ -7,7 +7,8 @@ void vlnce_set_error(const char* fmt, ...);
 // Dispatch options (vlnce_set_option / vlnce_get_option in include/vlnce_hip.h; table in api.cpp).
 // The library never reads the environment: the host sets what it wants, tests set and restore.
 enum {
-  VLNCE_OPT_CONV_MATH,        // 1 = bf16 planes on the bf16 pipe (default), 0 = fp32 MFMA everywhere
+  VLNCE_OPT_CONV_MATH,        // 0 = fp32 MFMA everywhere; non-zero = the plane kernels (the host packs the weights as
+                              // 1 = three bf16 planes / six products, 2 = fp16 planes / three products: default)
   VLNCE_OPT_P3,               // conv_p3_kernel: 0 off, 1 every layer it covers, 2 KxK only (default), 3 1x1 only
   VLNCE_OPT_P3_TILE,          // 0 = by CU fill, 1..6 = forced tile
   VLNCE_OPT_S3,               // conv_s3_kernel: 0 off, 1 default rule, 2 every eligible shape

@@ -35,33 +35,30 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-// 8 consecutive k of one row -> the A fragments of the three planes (round-to-nearest split)
-__device__ __forceinline__ void m3_split(f32x4 lo, f32x4 hi, bf16x8 (&f)[3]) {
+// 8 consecutive k of one row -> the A fragments of the planes (round-to-nearest split)
+template <int MATH>
+__device__ __forceinline__ void m3_split(f32x4 lo, f32x4 hi, bf16x8 (&f)[Planes<MATH>::NA]) {
+  constexpr int NA = Planes<MATH>::NA;
   float x[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-  u32x4 w[3];
+  u32x4 w[NA];
 #pragma unroll
   for (int pr = 0; pr < 4; ++pr) {
-    f32x2 v = {x[2 * pr], x[2 * pr + 1]};
+    unsigned wp[NA];
+    split_pair<MATH>(x[2 * pr], x[2 * pr + 1], wp);
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
-      const unsigned hb = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
-      w[q][pr] = hb;
-      if (q < 2) {
-        v[0] -= __builtin_bit_cast(float, hb << 16);
-        v[1] -= __builtin_bit_cast(float, hb & 0xffff0000u);
-      }
-    }
+    for (int q = 0; q < NA; ++q) w[q][pr] = wp[q];
   }
 #pragma unroll
-  for (int q = 0; q < 3; ++q) f[q] = __builtin_bit_cast(bf16x8, w[q]);
+  for (int q = 0; q < NA; ++q) f[q] = __builtin_bit_cast(bf16x8, w[q]);
 }
 
 // NT: 32-column blocks per wave; KSPLIT: waves sharing one output block, each taking every
 // KSPLIT-th k-slab; RB: 32-row blocks per workgroup (waves of different row blocks fetch the same B
 // fragments at the same time: one L2 request, the others hit in L1).  RB * KSPLIT waves.
-template <int NT, int KSPLIT, int RB, int DEPTH>
+template <int NT, int KSPLIT, int RB, int DEPTH, int MATH>
 __global__ __launch_bounds__(RB * KSPLIT * 64) void conv_m3_kernel(IgemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
+  typedef Planes<MATH> PL;
   static_assert(KSPLIT == 1 || KSPLIT == 4 || KSPLIT == 8, "k split");
   static_assert(KSPLIT == 1 || KSPLIT >= NT, "wave j of a row block finishes column block j");
   constexpr int BM = RB * 32;
@@ -165,8 +162,6 @@ __global__ __launch_bounds__(RB * KSPLIT * 64) void conv_m3_kernel(IgemmParams p
   for (int j = 0; j < NT; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.f;
-  constexpr int PA[6] = {2, 1, 0, 1, 0, 0};  // smallest products first
-  constexpr int PB[6] = {0, 1, 2, 0, 1, 0};
 
   auto consume = [&](const Slab& s) {
     f32x4 v0 = s.a0, v1 = s.a1;
@@ -184,13 +179,13 @@ __global__ __launch_bounds__(RB * KSPLIT * 64) void conv_m3_kernel(IgemmParams p
         v1 = v0;
       }
     }
-    bf16x8 fa[3];
-    m3_split(v0, v1, fa);
+    bf16x8 fa[PL::NA];
+    m3_split<MATH>(v0, v1, fa);
 #pragma unroll
-    for (int q = 0; q < 6; ++q)
+    for (int q = 0; q < PL::NP; ++q)
 #pragma unroll
       for (int j = 0; j < NT; ++j)
-        acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[q]], s.b[j][PB[q]], acc[0][j], 0, 0, 0);
+        acc[0][j] = plane_mfma<MATH>(fa[PL::PA[q]], s.b[j][PL::PB[q]], acc[0][j]);
   };
 
   // this wave's slabs kpart, kpart + KSPLIT, ...: a ring of DEPTH register sets, DEPTH - 1 slabs
@@ -231,15 +226,15 @@ __global__ __launch_bounds__(RB * KSPLIT * 64) void conv_m3_kernel(IgemmParams p
     if (p.bn.acc != nullptr) {
       WaveBn<1> wbn;
       wave_bn_reset(wbn);
-      wave_bn_tile<1, 1>(sum, wbn, p.bn.acc, col0, p.N, p.M - m0, half, l31);
+      wave_bn_tile<1, 1>(sum, wbn, p.bn.acc, col0, p.N, p.M - m0, half, l31, PL::POST);
       wave_bn_flush(wbn, p.bn.acc, p.N, half, l31);
     } else if (p.stat_partial != nullptr) {
       if (p.stat_rows == 32)
-        wave_stats_block<1>(sum[0], p.stat_partial, m0 / 32, p.M - m0, col0, p.N, half, l31);
+        wave_stats_block<1>(sum[0], p.stat_partial, m0 / 32, p.M - m0, col0, p.N, half, l31, PL::POST);
       else
-        wave_stats_fine<1, 1>(sum, p.stat_partial, p.stat_rows, m0, p.M, col0, p.N, half, l31);
+        wave_stats_fine<1, 1>(sum, p.stat_partial, p.stat_rows, m0, p.M, col0, p.N, half, l31, PL::POST);
     }
-    const float e_sc[1] = {p.scale ? p.scale[col] : 1.f};
+    const float e_sc[1] = {(p.scale ? p.scale[col] : 1.f) * PL::POST};
     const float e_sh[1] = {p.shift ? p.shift[col] : 0.f};
     const int e_voff[1] = {(int)((((long)(m0 + 4 * half)) * p.ldc + col) * 4)};
     wave_epilogue<1, 1>(sum, e_sc, e_sh, e_voff, p.M - (m0 + 4 * half), p.ldc, p.act,
@@ -250,20 +245,20 @@ __global__ __launch_bounds__(RB * KSPLIT * 64) void conv_m3_kernel(IgemmParams p
     if (p.bn.acc != nullptr) {
       WaveBn<NT> wbn;
       wave_bn_reset(wbn);
-      wave_bn_tile<1, NT>(acc, wbn, p.bn.acc, col0, p.N, p.M - m0, half, l31);
+      wave_bn_tile<1, NT>(acc, wbn, p.bn.acc, col0, p.N, p.M - m0, half, l31, PL::POST);
       wave_bn_flush(wbn, p.bn.acc, p.N, half, l31);
     } else if (p.stat_partial != nullptr) {
       if (p.stat_rows == 32)
-        wave_stats_block<NT>(acc[0], p.stat_partial, m0 / 32, p.M - m0, col0, p.N, half, l31);
+        wave_stats_block<NT>(acc[0], p.stat_partial, m0 / 32, p.M - m0, col0, p.N, half, l31, PL::POST);
       else
-        wave_stats_fine<1, NT>(acc, p.stat_partial, p.stat_rows, m0, p.M, col0, p.N, half, l31);
+        wave_stats_fine<1, NT>(acc, p.stat_partial, p.stat_rows, m0, p.M, col0, p.N, half, l31, PL::POST);
     }
     float e_sc[NT], e_sh[NT];
     int e_voff[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       const int col = col0 + j * 32 + l31;
-      e_sc[j] = p.scale ? p.scale[col] : 1.f;
+      e_sc[j] = (p.scale ? p.scale[col] : 1.f) * PL::POST;
       e_sh[j] = p.shift ? p.shift[col] : 0.f;
       e_voff[j] = (int)((((long)(m0 + 4 * half)) * p.ldc + col) * 4);
     }
@@ -273,8 +268,8 @@ __global__ __launch_bounds__(RB * KSPLIT * 64) void conv_m3_kernel(IgemmParams p
 #endif
 }
 
-template <int NT, int KSPLIT, int RB, int DEPTH = 3>
-int launch_m3(const IgemmParams& p, hipStream_t stream) {
+template <int NT, int KSPLIT, int RB, int MATH, int DEPTH = 3>
+int launch_m3_(const IgemmParams& p, hipStream_t stream) {
   IgemmParams q = p;
   q.tiles_m = ceil_div(p.M, RB * 32);
   q.tiles_n = p.N / (NT * 32);
@@ -282,7 +277,7 @@ int launch_m3(const IgemmParams& p, hipStream_t stream) {
   const long grid = (long)ceil_div(q.tiles_m, 8) * 8 * q.tiles_n;
   const int smem =
       ((KSPLIT > 1 ? RB * KSPLIT * NT * 16 * 64 : 0) + (p.in_scale ? 3 * p.Cin : 0)) * 4;
-  auto kern = conv_m3_kernel<NT, KSPLIT, RB, DEPTH>;
+  auto kern = conv_m3_kernel<NT, KSPLIT, RB, DEPTH, MATH>;
   if (smem > 64 * 1024) {
     static bool attr_set = false;   // (per instantiation)
     if (!attr_set) {
@@ -298,6 +293,11 @@ int launch_m3(const IgemmParams& p, hipStream_t stream) {
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(RB * KSPLIT * 64), smem, stream, q);
   VLNCE_CHECK_LAUNCH("conv_m3");
   return 0;
+}
+template <int NT, int KSPLIT, int RB>
+int launch_m3(const IgemmParams& p, hipStream_t stream) {
+  return p.math == MATH_F16X3 ? launch_m3_<NT, KSPLIT, RB, MATH_F16X3>(p, stream)
+                              : launch_m3_<NT, KSPLIT, RB, MATH_BF16X6>(p, stream);
 }
 
 }  // namespace

@@ -37,8 +37,10 @@ using namespace vlnce_detail;
 namespace vlnce_detail {
 namespace {
 
-constexpr int P3_ROW = 208;      // bytes per patch row (13 x 16 B: consecutive rows are conflict-free)
+// bytes per patch row: Planes<MATH>::ROW (208 = 13 x 16 B / 144 = 9 x 16 B: consecutive rows are
+// conflict-free for ds_read_b128)
 constexpr int P3_PRODUCERS = 4;  // producer waves
+constexpr int P3_MAX_ROWS = 512;  // patch rows the KxK producers address: 16 row groups of 32 (4 items of 128)
 #ifndef P3_MPRIO
 #define P3_MPRIO 1   // s_setprio of the matrix waves
 #endif
@@ -66,29 +68,22 @@ __device__ __forceinline__ void p3_wait(const int* flag, int need) {
   asm volatile("" ::: "memory");
 }
 
-// x (4 consecutive k of one patch row) -> the three planes' 8-byte words, round-to-nearest split
+// x (4 consecutive k of one patch row) -> the A planes' 8-byte words, round-to-nearest split
+template <int MATH>
 __device__ __forceinline__ void p3_split_store(f32x4 x, char* row_ptr) {
-  u32x2 w[3];
+  constexpr int NA = Planes<MATH>::NA;
+  unsigned w0[NA], w1[NA];
+  split_pair<MATH>(x[0], x[1], w0);
+  split_pair<MATH>(x[2], x[3], w1);
 #pragma unroll
-  for (int pr = 0; pr < 2; ++pr) {
-    f32x2 v = {x[2 * pr], x[2 * pr + 1]};
-#pragma unroll
-    for (int q = 0; q < 3; ++q) {
-      const unsigned hb = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
-      w[q][pr] = hb;
-      if (q < 2) {
-        v[0] -= __builtin_bit_cast(float, hb << 16);
-        v[1] -= __builtin_bit_cast(float, hb & 0xffff0000u);
-      }
-    }
-  }
-#pragma unroll
-  for (int q = 0; q < 3; ++q) *reinterpret_cast<u32x2*>(row_ptr + q * 64) = w[q];
+  for (int q = 0; q < NA; ++q) *reinterpret_cast<u32x2*>(row_ptr + q * 64) = u32x2{w0[q], w1[q]};
 }
 
-template <int BM, int BN, int WM, int WN, int DUAL, int MODE>
+template <int BM, int BN, int WM, int WN, int DUAL, int MODE, int MATH>
 __global__ __launch_bounds__((WM * WN + P3_PRODUCERS) * 64) void conv_p3_kernel(IgemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
+  typedef Planes<MATH> PL;
+  constexpr int P3_ROW = PL::ROW, NA = PL::NA;
   constexpr int MATRIX = WM * WN;
   constexpr int WTM = BM / WM, WTN = BN / WN, MT = WTM / 32, NT = WTN / 32;
   static_assert(MT >= 1 && NT >= 1 && WTM % 32 == 0 && WTN % 32 == 0, "tile");
@@ -217,7 +212,7 @@ __global__ __launch_bounds__((WM * WN + P3_PRODUCERS) * 64) void conv_p3_kernel(
           if (side_dst != nullptr && ok) *reinterpret_cast<f32x4*>(side_dst) = v;
         }
       }
-      p3_split_store(v, dst);
+      p3_split_store<MATH>(v, dst);
     };
 #ifdef P3_DBG_TIME
     long long d_wait = 0, d_vmw = 0, d_tr = 0, d_ld = 0;
@@ -364,7 +359,8 @@ __global__ __launch_bounds__((WM * WN + P3_PRODUCERS) * 64) void conv_p3_kernel(
       // (scalars and wave-uniform branches: a runtime-indexed array would live in scratch memory)
       int l_round = 0, l_c = 0, l_part = 0, l_nparts = 0;
       int r0 = 0, r1 = 0, r2 = 0, r3 = 0, r4 = 0, r5 = 0, r6 = 0, r7 = 0, r8 = 0, r9 = 0, r10 = 0,
-          r11 = 0;   // byte offsets of this thread's rows in row groups 0..11 (p3_rows <= 384)
+          r11 = 0, r12 = 0, r13 = 0, r14 = 0,
+          r15 = 0;   // byte offsets of this thread's rows in row groups 0..15 (p3_rows <= P3_MAX_ROWS = 512)
       unsigned l_ok = 0;
       auto l_setup = [&](int round) {
         int m0, n0;
@@ -395,6 +391,7 @@ __global__ __launch_bounds__((WM * WN + P3_PRODUCERS) * 64) void conv_p3_kernel(
         next_row(0, r0); next_row(1, r1); next_row(2, r2); next_row(3, r3);
         next_row(4, r4); next_row(5, r5); next_row(6, r6); next_row(7, r7);
         next_row(8, r8); next_row(9, r9); next_row(10, r10); next_row(11, r11);
+        next_row(12, r12); next_row(13, r13); next_row(14, r14); next_row(15, r15);
       };
       auto load = [&](Staged& s) {
         const bool live = l_round < my_tiles;
@@ -406,8 +403,10 @@ __global__ __launch_bounds__((WM * WN + P3_PRODUCERS) * 64) void conv_p3_kernel(
           s.a[0] = P3_LD(r0); s.a[1] = P3_LD(r1); s.a[2] = P3_LD(r2); s.a[3] = P3_LD(r3);
         } else if (l_part == 1) {
           s.a[0] = P3_LD(r4); s.a[1] = P3_LD(r5); s.a[2] = P3_LD(r6); s.a[3] = P3_LD(r7);
-        } else {
+        } else if (l_part == 2) {
           s.a[0] = P3_LD(r8); s.a[1] = P3_LD(r9); s.a[2] = P3_LD(r10); s.a[3] = P3_LD(r11);
+        } else {
+          s.a[0] = P3_LD(r12); s.a[1] = P3_LD(r13); s.a[2] = P3_LD(r14); s.a[3] = P3_LD(r15);
         }
 #undef P3_LD
         if (!live) return;
@@ -510,7 +509,7 @@ __global__ __launch_bounds__((WM * WN + P3_PRODUCERS) * 64) void conv_p3_kernel(
     // 69 with neither -- against 58 us of pure MFMA issue at the 1.9 GHz the launch runs at
     // (profiles/r04_u_*): what the loop loses is the issue cost of its 9 memory instructions per
     // 12 MFMAs (768 B of operands per MFMA at these per-wave tiles), not their latency.)
-    bf16x8 fa[MT][3];
+    bf16x8 fa[MT][NA];
     bf16x8 b0[NT][3], b1[NT][3];
     f32x16 acc[MT][NT];
     auto loadB = [&](bf16x8 (&b)[NT][3], const int (&vb)[NT], int soff) {
@@ -536,16 +535,13 @@ __global__ __launch_bounds__((WM * WN + P3_PRODUCERS) * 64) void conv_p3_kernel(
       }
     };
     auto mma = [&](const bf16x8 (&b)[NT][3]) {
-      constexpr int PA[6] = {2, 1, 0, 1, 0, 0};  // smallest products first
-      constexpr int PB[6] = {0, 1, 2, 0, 1, 0};
 #pragma unroll
-      for (int q = 0; q < 6; ++q)
+      for (int q = 0; q < PL::NP; ++q)
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
           for (int j = 0; j < NT; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][PA[q]], b[j][PB[q]],
-                                                                acc[i][j], 0, 0, 0);
+            acc[i][j] = plane_mfma<MATH>(fa[i][PL::PA[q]], b[j][PL::PB[q]], acc[i][j]);
     };
     auto vb_of = [&](int n0, int (&vb)[NT]) {
 #pragma unroll
@@ -601,7 +597,7 @@ __global__ __launch_bounds__((WM * WN + P3_PRODUCERS) * 64) void conv_p3_kernel(
       for (int j = 0; j < NT; ++j) {
         const int col = n0 + wn * WTN + j * 32 + l31;
         const bool ok = col < p.N;
-        e_sc[j] = (ok && p.scale) ? p.scale[col] : 1.f;
+        e_sc[j] = ((ok && p.scale) ? p.scale[col] : 1.f) * PL::POST;
         e_sh[j] = (ok && p.shift) ? p.shift[col] : 0.f;
         e_voff[j] = ok ? (int)((((long)(m0 + wm * WTM + 4 * half)) * p.ldc + col) * 4) : BUF_OOB;
       }
@@ -633,7 +629,7 @@ __global__ __launch_bounds__((WM * WN + P3_PRODUCERS) * 64) void conv_p3_kernel(
 #pragma unroll
           for (int i = 0; i < MT; ++i)
 #pragma unroll
-            for (int q = 0; q < 3; ++q)
+            for (int q = 0; q < NA; ++q)
               fa[i][q] = *reinterpret_cast<const bf16x8*>(abase + a_row[i] + q * 64);
           __builtin_amdgcn_sched_barrier(0);
 #ifdef P3_DBG_TIME
@@ -656,7 +652,7 @@ __global__ __launch_bounds__((WM * WN + P3_PRODUCERS) * 64) void conv_p3_kernel(
 #pragma unroll
           for (int i = 0; i < MT; ++i)
 #pragma unroll
-            for (int q = 0; q < 3; ++q)
+            for (int q = 0; q < NA; ++q)
               fa[i][q] = *reinterpret_cast<const bf16x8*>(abase + a_row[i] + q * 64 + 32);
           if (last_of_chunk) {
             // this wave's reads of the patch buffer are complete once they have all returned
@@ -676,7 +672,8 @@ __global__ __launch_bounds__((WM * WN + P3_PRODUCERS) * 64) void conv_p3_kernel(
 
       // -------------------------------------------------------------- statistics
       if (p.bn.acc != nullptr) {
-        wave_bn_tile<MT, NT>(acc, wbn, p.bn.acc, n0 + wn * WTN, p.N, p.M - (m0 + wm * WTM), half, l31);
+        wave_bn_tile<MT, NT>(acc, wbn, p.bn.acc, n0 + wn * WTN, p.N, p.M - (m0 + wm * WTM), half, l31,
+                             PL::POST);
         if (round == my_tiles - 1) wave_bn_flush(wbn, p.bn.acc, p.N, half, l31);  // in front of the stores
       } else if (p.stat_partial != nullptr) {
         const int tile_m = m0 / BM;
@@ -684,13 +681,14 @@ __global__ __launch_bounds__((WM * WN + P3_PRODUCERS) * 64) void conv_p3_kernel(
 #pragma unroll
           for (int i = 0; i < MT; ++i)
             wave_stats_block<NT>(acc[i], p.stat_partial, (m0 + wm * WTM) / 32 + i,
-                                 p.M - (m0 + wm * WTM + i * 32), n0 + wn * WTN, p.N, half, l31);
+                                 p.M - (m0 + wm * WTM + i * 32), n0 + wn * WTN, p.N, half, l31,
+                                 PL::POST);
         } else if (p.stat_rows > 0 && p.stat_rows < WTM)
           wave_stats_fine<MT, NT>(acc, p.stat_partial, p.stat_rows, m0 + wm * WTM, p.M,
-                                  n0 + wn * WTN, p.N, half, l31);
+                                  n0 + wn * WTN, p.N, half, l31, PL::POST);
         else
           wave_stats<MT, NT>(acc, p.stat_partial, tile_m * WM + wm, p.M - (m0 + wm * WTM), WTM,
-                             n0 + wn * WTN, p.N, half, l31);
+                             n0 + wn * WTN, p.N, half, l31, PL::POST);
       }
       // -------------------------------------------------------------- epilogue from registers
       // one store = 2 rows x 32 columns = two full 128-byte lines; rows past M get an
@@ -736,9 +734,11 @@ __global__ __launch_bounds__((WM * WN + P3_PRODUCERS) * 64) void conv_p3_kernel(
 // DUAL: 0 = one input; 1 = block end with an identity skip (second input added as is); 2 = block
 // end whose skip path has its own BatchNorm.  Compile-time: the identity form carries half the
 // prologue vectors and its chunk body has no branch.
-template <int BM, int DUAL, int WAVES, int LINEAR>
+template <int BM, int DUAL, int WAVES, int LINEAR, int MATH>
 __global__ __launch_bounds__(WAVES * 64) void conv_u3_kernel(IgemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
+  typedef Planes<MATH> PL;
+  constexpr int P3_ROW = PL::ROW, NA = PL::NA;
   constexpr int BN = 256, MT = BM / 32, NT = 8 / WAVES;
   constexpr int RG = WAVES * 8;                  // rows per group of the transform's thread map
   constexpr int NPT = BM / RG;                   // float4 of a K-chunk's A rows per thread
@@ -900,14 +900,14 @@ __global__ __launch_bounds__(WAVES * 64) void conv_u3_kernel(IgemmParams p) {
           v[e] = ok ? v[e] : 0.f;
         }
       }
-      p3_split_store(v, buf + (i * RG + trow) * P3_ROW + lk4 * 2);
+      p3_split_store<MATH>(v, buf + (i * RG + trow) * P3_ROW + lk4 * 2);
     }
   };
 
   // ---------------------------------------------------------------- the matrix side (per wave)
   constexpr int HM = MT / 2;  // row blocks per half (two-wave form)
   static_assert(ADB || HM >= 1, "tile");
-  bf16x8 fa[ADB ? MT : 1][3], fa1[ADB ? MT : 1][3], fh0[ADB ? 1 : HM][3], fh1[ADB ? 1 : HM][3];
+  bf16x8 fa[ADB ? MT : 1][NA], fa1[ADB ? MT : 1][NA], fh0[ADB ? 1 : HM][NA], fh1[ADB ? 1 : HM][NA];
   bf16x8 b0[NT][3], b1[NT][3];
   f32x16 acc[MT][NT];
   const int a_off = l31 * P3_ROW + half * 16;   // + i * 32 * P3_ROW + q * 64 + s * 32
@@ -920,42 +920,39 @@ __global__ __launch_bounds__(WAVES * 64) void conv_u3_kernel(IgemmParams p) {
             bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
                         rsrc_b, vb[j] == BUF_OOB ? BUF_OOB : vb[j] + q * 1024, soff, 0));
   };
-  auto readA = [&](bf16x8 (&f)[ADB ? MT : 1][3], const char* buf, int s) {
+  auto readA = [&](bf16x8 (&f)[ADB ? MT : 1][NA], const char* buf, int s) {
 #pragma unroll
     for (int i = 0; i < (ADB ? MT : 1); ++i)
 #pragma unroll
-      for (int q = 0; q < 3; ++q)
+      for (int q = 0; q < NA; ++q)
         f[i][q] = *reinterpret_cast<const bf16x8*>(buf + a_off + i * 32 * P3_ROW + q * 64 + s * 32);
   };
-  auto readH = [&](bf16x8 (&f)[ADB ? 1 : HM][3], const char* buf, int s, int h) {
+  auto readH = [&](bf16x8 (&f)[ADB ? 1 : HM][NA], const char* buf, int s, int h) {
 #pragma unroll
     for (int i = 0; i < (ADB ? 1 : HM); ++i)
 #pragma unroll
-      for (int q = 0; q < 3; ++q)
+      for (int q = 0; q < NA; ++q)
         f[i][q] = *reinterpret_cast<const bf16x8*>(buf + a_off + (h * HM + i) * 32 * P3_ROW + q * 64 +
                                                    s * 32);
   };
-  constexpr int PA[6] = {2, 1, 0, 1, 0, 0};  // smallest products first
-  constexpr int PB[6] = {0, 1, 2, 0, 1, 0};
-  auto mma = [&](const bf16x8 (&f)[ADB ? MT : 1][3], const bf16x8 (&b)[NT][3]) {
+  constexpr int NP = PL::NP;
+  auto mma = [&](const bf16x8 (&f)[ADB ? MT : 1][NA], const bf16x8 (&b)[NT][3]) {
 #pragma unroll
-    for (int q = 0; q < 6; ++q)
+    for (int q = 0; q < NP; ++q)
 #pragma unroll
       for (int i = 0; i < (ADB ? MT : 1); ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[i][PA[q]], b[j][PB[q]], acc[i][j],
-                                                              0, 0, 0);
+          acc[i][j] = plane_mfma<MATH>(f[i][PL::PA[q]], b[j][PL::PB[q]], acc[i][j]);
   };
-  auto mmaH = [&](const bf16x8 (&f)[ADB ? 1 : HM][3], const bf16x8 (&b)[NT][3], int h) {
+  auto mmaH = [&](const bf16x8 (&f)[ADB ? 1 : HM][NA], const bf16x8 (&b)[NT][3], int h) {
 #pragma unroll
-    for (int q = 0; q < 6; ++q)
+    for (int q = 0; q < NP; ++q)
 #pragma unroll
       for (int i = 0; i < (ADB ? 1 : HM); ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j)
-          acc[h * HM + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-              f[i][PA[q]], b[j][PB[q]], acc[h * HM + i][j], 0, 0, 0);
+          acc[h * HM + i][j] = plane_mfma<MATH>(f[i][PL::PA[q]], b[j][PL::PB[q]], acc[h * HM + i][j]);
   };
   auto vb_of = [&](int n0, int (&vb)[NT]) {
 #pragma unroll
@@ -1053,7 +1050,7 @@ __global__ __launch_bounds__(WAVES * 64) void conv_u3_kernel(IgemmParams p) {
 #endif
     if constexpr (ADB) {
 #pragma unroll
-      for (int k = 0; k < 12 * MT * NT; ++k) {
+      for (int k = 0; k < 2 * NP * MT * NT; ++k) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x002, U3_VPM, 0);
       }
@@ -1065,14 +1062,14 @@ __global__ __launch_bounds__(WAVES * 64) void conv_u3_kernel(IgemmParams p) {
       // (Measured and dropped, profiles/r04_a_convbench_u3_loads_first.txt: pinning the chunk's raw-row
       // and slab-1 B loads in front of the first MFMA with a VMEM-read group changes no layer by
       // more than 2 %.)
-      __builtin_amdgcn_sched_group_barrier(0x100, 3 * HM, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, NA * HM, 0);
 #pragma unroll
       for (int ph = 0; ph < 4; ++ph) {
 #pragma unroll
-        for (int k = 0; k < 6 * HM * NT; ++k) {
+        for (int k = 0; k < NP * HM * NT; ++k) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x002, U3_VPM, 0);
-          if (ph < 3 && k < 3 * HM) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, MATH == MATH_F16X3 ? 2 * U3_VPM : U3_VPM, 0);
+          if (ph < 3 && k < NA * HM) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
       }
     }
@@ -1092,7 +1089,7 @@ __global__ __launch_bounds__(WAVES * 64) void conv_u3_kernel(IgemmParams p) {
     if (last_of_tile) {
       // -------------------------------------------------------------- statistics
       if (p.bn.acc != nullptr) {
-        wave_bn_tile<MT, NT>(acc, wbn, p.bn.acc, n0 + wave * NT * 32, p.N, p.M - m0, half, l31);
+        wave_bn_tile<MT, NT>(acc, wbn, p.bn.acc, n0 + wave * NT * 32, p.N, p.M - m0, half, l31, PL::POST);
         if (round == my_tiles - 1) wave_bn_flush(wbn, p.bn.acc, p.N, half, l31);  // in front of the stores
       } else if (p.stat_partial != nullptr) {
         const int col0 = n0 + wave * NT * 32;
@@ -1100,11 +1097,12 @@ __global__ __launch_bounds__(WAVES * 64) void conv_u3_kernel(IgemmParams p) {
 #pragma unroll
           for (int i = 0; i < MT; ++i)
             wave_stats_block<NT>(acc[i], p.stat_partial, m0 / 32 + i, p.M - (m0 + i * 32), col0, p.N,
-                                 half, l31);
+                                 half, l31, PL::POST);
         } else if (p.stat_rows > 0 && p.stat_rows < BM)
-          wave_stats_fine<MT, NT>(acc, p.stat_partial, p.stat_rows, m0, p.M, col0, p.N, half, l31);
+          wave_stats_fine<MT, NT>(acc, p.stat_partial, p.stat_rows, m0, p.M, col0, p.N, half, l31,
+                                  PL::POST);
         else
-          wave_stats<MT, NT>(acc, p.stat_partial, m0 / BM, p.M - m0, BM, col0, p.N, half, l31);
+          wave_stats<MT, NT>(acc, p.stat_partial, m0 / BM, p.M - m0, BM, col0, p.N, half, l31, PL::POST);
       }
       // -------------------------------------------------------------- epilogue from registers
       // (Measured alternatives, round 3, profiles/archive/r03_h_*: turning each 32x32 block around in a
@@ -1120,7 +1118,7 @@ __global__ __launch_bounds__(WAVES * 64) void conv_u3_kernel(IgemmParams p) {
       for (int j = 0; j < NT; ++j) {
         const int col = n0 + (wave * NT + j) * 32 + l31;
         const bool okc = col < p.N;
-        e_sc[j] = (okc && p.scale) ? p.scale[col] : 1.f;
+        e_sc[j] = ((okc && p.scale) ? p.scale[col] : 1.f) * PL::POST;
         e_sh[j] = (okc && p.shift) ? p.shift[col] : 0.f;
         e_voff[j] = okc ? (int)((((long)(m0 + 4 * half)) * p.ldc + col) * 4) : BUF_OOB;
       }
@@ -1170,10 +1168,10 @@ __global__ __launch_bounds__(WAVES * 64) void conv_u3_kernel(IgemmParams p) {
 #endif
 }
 
-template <int BM, int DUAL, int WAVES, int LINEAR>
+template <int BM, int DUAL, int WAVES, int LINEAR, int MATH>
 int launch_u3_(const IgemmParams& p, hipStream_t stream) {
-  constexpr int smem_bytes = 2 * BM * P3_ROW;
-  auto kern = conv_u3_kernel<BM, DUAL, WAVES, LINEAR>;
+  constexpr int smem_bytes = 2 * BM * Planes<MATH>::ROW;
+  auto kern = conv_u3_kernel<BM, DUAL, WAVES, LINEAR, MATH>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -1225,9 +1223,11 @@ int launch_u3_(const IgemmParams& p, hipStream_t stream) {
 //     drain the previous tile's stores on every trip.
 // 8 waves (two per SIMD), wave w owns columns [32w, 32w + 32) of a 64 x 256 tile; one barrier
 // per tile.  Arithmetic, patch rows, fragment layout and statistics are conv_u3_kernel's.
-template <int NCC>
+template <int NCC, int MATH>
 __global__ __launch_bounds__(512) void conv_s3_kernel(IgemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
+  typedef Planes<MATH> PL;
+  constexpr int P3_ROW = PL::ROW, NA = PL::NA, NP = PL::NP;
   constexpr int BM = 64, MT = 2, KS = NCC * 2;
   constexpr int CBUF = BM * P3_ROW;            // one chunk of a tile's patch
   constexpr int PBUF = NCC * CBUF;             // one tile's patch
@@ -1285,7 +1285,7 @@ __global__ __launch_bounds__(512) void conv_s3_kernel(IgemmParams p) {
   }
   __syncthreads();
   const int col = n0 + wave * 32 + l31;
-  const float e_sc = p.scale ? p.scale[col] : 1.f;
+  const float e_sc = (p.scale ? p.scale[col] : 1.f) * PL::POST;
   const float e_sh = p.shift ? p.shift[col] : 0.f;
 
   // raw A ring: two tiles ahead for K = 64; ONE for K = 128, where the second
@@ -1309,8 +1309,6 @@ __global__ __launch_bounds__(512) void conv_s3_kernel(IgemmParams p) {
     for (int i = 0; i < MT; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[b][i][r] = 0.f;
-  constexpr int PA[6] = {2, 1, 0, 1, 0, 0};  // smallest products first
-  constexpr int PB[6] = {0, 1, 2, 0, 1, 0};
   const int a_off = l31 * P3_ROW + half * 16;
 
   WaveBn<1> wbn;   // BatchNorm finished in this launch (p.bn): the wave's running column sums
@@ -1319,12 +1317,12 @@ __global__ __launch_bounds__(512) void conv_s3_kernel(IgemmParams p) {
   auto stats = [&](const f32x16 (&a)[MT], int m0) {
     if (p.bn.acc != nullptr) {
       wave_bn_tile<MT, 1>(reinterpret_cast<const f32x16(&)[MT][1]>(a), wbn, p.bn.acc, n0 + wave * 32,
-                          p.N, p.M - m0, half, l31);
+                          p.N, p.M - m0, half, l31, PL::POST);
     } else if (p.stat_partial != nullptr) {
 #pragma unroll
       for (int i = 0; i < MT; ++i)
         wave_stats_block<1>(reinterpret_cast<const f32x16(&)[1]>(a[i]), p.stat_partial,
-                            m0 / 32 + i, p.M - (m0 + i * 32), n0 + wave * 32, p.N, half, l31);
+                            m0 / 32 + i, p.M - (m0 + i * 32), n0 + wave * 32, p.N, half, l31, PL::POST);
     }
   };
   // stores [first, first + count) of the 32 of a finished tile; the registers are cleared behind
@@ -1362,7 +1360,7 @@ __global__ __launch_bounds__(512) void conv_s3_kernel(IgemmParams p) {
         v[e] = fmaxf(fmaf(v[e] - c_[e], s_[e], t_[e]), relu_floor);
         v[e] = row_ok ? v[e] : 0.f;
       }
-      p3_split_store(v, pb + c * CBUF + trow * P3_ROW + lk4 * 2);
+      p3_split_store<MATH>(v, pb + c * CBUF + trow * P3_ROW + lk4 * 2);
     }
     load_raw(r, round + RING);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1372,34 +1370,52 @@ __global__ __launch_bounds__(512) void conv_s3_kernel(IgemmParams p) {
     for (int c = 0; c < NCC; ++c)
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
-        bf16x8 f[MT][3];
+        bf16x8 f[MT][NA];
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
-          for (int q = 0; q < 3; ++q)
+          for (int q = 0; q < NA; ++q)
             f[i][q] = *reinterpret_cast<const bf16x8*>(pb + c * CBUF + a_off + i * 32 * P3_ROW +
                                                        q * 64 + s2 * 32);
 #pragma unroll
-        for (int q = 0; q < 6; ++q)
+        for (int q = 0; q < NP; ++q)
 #pragma unroll
           for (int i = 0; i < MT; ++i)
-            cur[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[i][PA[q]], bres[c * 2 + s2][PB[q]],
-                                                             cur[i], 0, 0, 0);
+            cur[i] = plane_mfma<MATH>(f[i][PL::PA[q]], bres[c * 2 + s2][PL::PB[q]], cur[i]);
         // the previous tile's next SPS stores ride behind this slab's 12 MFMAs (a tile whose
         // predecessor does not exist stores to the out-of-range offset: no branch in the body)
         stores(prv, has_prev ? m0_prev : p.M, (c * 2 + s2) * SPS, SPS);
         // schedule of the slab: its 12 MFMAs with the SPS stores spread evenly between them
         // (K = 64: 2 MFMAs, store, 1 MFMA, store, four times; K = 128: 3 MFMAs, store, four times)
+        if constexpr (MATH == MATH_F16X3) {
+          // 6 MFMAs per slab: K = 64: MFMA, store, store, MFMA, store (x2, then 2 MFMAs + 2 stores);
+          // K = 128: 3 MFMAs, 2 stores, twice
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          if constexpr (SPS == 8) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);  // MFMA
-            __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);  // VMEM write
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);
-          } else {
-            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
-            __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);
+          for (int g = 0; g < 2; ++g) {
+            if constexpr (SPS == 8) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+              __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+              __builtin_amdgcn_sched_group_barrier(0x040, 2, 0);
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+              __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);
+            } else {
+              __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+              __builtin_amdgcn_sched_group_barrier(0x040, 2, 0);
+            }
+          }
+        } else {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            if constexpr (SPS == 8) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);  // MFMA
+              __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);  // VMEM write
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+              __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);
+            } else {
+              __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+              __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);
+            }
           }
         }
       }
@@ -1432,10 +1448,10 @@ __global__ __launch_bounds__(512) void conv_s3_kernel(IgemmParams p) {
 #endif
 }
 
-template <int NCC>
+template <int NCC, int MATH>
 int launch_s3(const IgemmParams& p, hipStream_t stream) {
-  constexpr int smem_bytes = 2 * NCC * 64 * P3_ROW + 3 * NCC * 32 * 4;  // two tile patches + the prologue vectors
-  auto kern = conv_s3_kernel<NCC>;
+  constexpr int smem_bytes = 2 * NCC * 64 * Planes<MATH>::ROW + 3 * NCC * 32 * 4;  // two tile patches + the prologue vectors
+  auto kern = conv_s3_kernel<NCC, MATH>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -1458,15 +1474,17 @@ int launch_s3(const IgemmParams& p, hipStream_t stream) {
   return 0;
 }
 
-template <int BM, int DUAL, int WAVES>
+template <int BM, int DUAL, int WAVES, int MATH>
 int launch_u3(const IgemmParams& p, hipStream_t stream) {
-  return p.stride == 1 ? launch_u3_<BM, DUAL, WAVES, 1>(p, stream) : launch_u3_<BM, DUAL, WAVES, 0>(p, stream);
+  return p.stride == 1 ? launch_u3_<BM, DUAL, WAVES, 1, MATH>(p, stream)
+                       : launch_u3_<BM, DUAL, WAVES, 0, MATH>(p, stream);
 }
 
 // w_ohwi [N][KH][KW][Cin] fp32 -> B fragments [N/32][K/16][3][64 lanes][8 bf16]: k-slab
 // ks = ((chunk * T + tap) * 2 + s) holds input channels chunk*32 + s*16 + [0, 16) of that tap;
 // lane (l31, half) holds output channel nb*32 + l31, channels half*8 + [0, 8) of the slab;
 // plane q is the q-th term of the exact round-to-nearest three-way bf16 split.
+template <int MATH>
 __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restrict__ w,
                                                            unsigned short* __restrict__ frag,
                                                            int N, int T, int Cin) {
@@ -1485,13 +1503,10 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
     unsigned short out[3][8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      float v = src[e];
+      unsigned short o3[3];
+      split_weight<MATH>(src[e], o3);
 #pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        const __bf16 hb = (__bf16)v;  // round to nearest even
-        out[q][e] = __builtin_bit_cast(unsigned short, hb);
-        v -= (float)hb;
-      }
+      for (int q = 0; q < 3; ++q) out[q][e] = o3[q];
     }
     unsigned short* dst = frag + ((rest * 3) * 64 + lane) * 8;
 #pragma unroll
@@ -1501,12 +1516,12 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
   }
 }
 
-template <int BM, int BN, int WM, int WN, int DUAL, int MODE>
+template <int BM, int BN, int WM, int WN, int DUAL, int MODE, int MATH>
 int launch_p3(const IgemmParams& p, int rows_alloc, hipStream_t stream) {
   // two patch buffers (+ two B stages for the 1x1 form) + 4 counters
-  const int smem_bytes = 2 * rows_alloc * P3_ROW + (MODE == P3_GATHER ? 2 * BN * 192 : 0) + 16;
+  const int smem_bytes = 2 * rows_alloc * Planes<MATH>::ROW + (MODE == P3_GATHER ? 2 * BN * 192 : 0) + 16;
   constexpr int threads = (WM * WN + P3_PRODUCERS) * 64;
-  auto kern = conv_p3_kernel<BM, BN, WM, WN, DUAL, MODE>;
+  auto kern = conv_p3_kernel<BM, BN, WM, WN, DUAL, MODE, MATH>;
   static int attr_bytes = 0;  // per instantiation: the largest dynamic LDS size enabled so far
   if (smem_bytes > attr_bytes) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -1562,21 +1577,21 @@ int p3_rows_for(const IgemmParams& p, int bm, bool dense) {
 // Tiles: 8 matrix waves, each a (BM / WM) x 32 sub-tile.  B fragments come straight from L2 (one
 // 1 KB load per plane and k-slab, used for BM / WM / 32 MFMAs), so the sub-tile is TALL: with
 // 128 rows the texture path carries 16 B/clk per CU, with 32 rows it would saturate (64 B/clk).
-template <int DUAL, int MODE>
+template <int DUAL, int MODE, int MATH>
 int dispatch_p3(const IgemmParams& p, int tile, int rows, hipStream_t s) {
   switch (tile) {
-    case 0: return launch_p3<128, 256, 1, 8, DUAL, MODE>(p, rows, s);
-    case 1: return launch_p3<64, 256, 1, 8, DUAL, MODE>(p, rows, s);
-    case 2: return launch_p3<256, 128, 2, 4, DUAL, MODE>(p, rows, s);
-    case 3: return launch_p3<128, 128, 2, 4, DUAL, MODE>(p, rows, s);
-    case 4: return launch_p3<256, 64, 4, 2, DUAL, MODE>(p, rows, s);
-    default: return launch_p3<128, 64, 4, 2, DUAL, MODE>(p, rows, s);
+    case 0: return launch_p3<128, 256, 1, 8, DUAL, MODE, MATH>(p, rows, s);
+    case 1: return launch_p3<64, 256, 1, 8, DUAL, MODE, MATH>(p, rows, s);
+    case 2: return launch_p3<256, 128, 2, 4, DUAL, MODE, MATH>(p, rows, s);
+    case 3: return launch_p3<128, 128, 2, 4, DUAL, MODE, MATH>(p, rows, s);
+    case 4: return launch_p3<256, 64, 4, 2, DUAL, MODE, MATH>(p, rows, s);
+    default: return launch_p3<128, 64, 4, 2, DUAL, MODE, MATH>(p, rows, s);
   }
 }
 
-}  // namespace
-
-int p3_try_launch(const IgemmParams& p, hipStream_t stream) {
+template <int MATH>
+int p3_try_launch_(const IgemmParams& p, hipStream_t stream) {
+  constexpr int P3_ROW = Planes<MATH>::ROW;
   // option "p3": 0 = off, 1 = every layer it covers, 2 = the KxK (patch) layers only, 3 = the 1x1
   // layers only.  Default 2: measured per layer at num_envs 64 (profiles/archive/r03_*_convbench_ab.txt),
   // the patch form is 1.26-1.51x conv_x3_kernel on every stride-1 3x3 layer of the trunks, the
@@ -1608,7 +1623,7 @@ int p3_try_launch(const IgemmParams& p, hipStream_t stream) {
       (p.act == VLNCE_ACT_NONE || p.act == VLNCE_ACT_RELU) &&
       (s3_env == 2 || (long)ceil_div(p.M, 64) * (p.N / 256) >= 4L * x3_cus()))
   {
-    return p.Cin == 64 ? launch_s3<2>(p, stream) : launch_s3<4>(p, stream);
+    return p.Cin == 64 ? launch_s3<2, MATH>(p, stream) : launch_s3<4, MATH>(p, stream);
   }
   const int u3_env = vlnce_opt(VLNCE_OPT_U3);
   const int u3_waves = vlnce_opt(VLNCE_OPT_U3_WAVES);
@@ -1627,13 +1642,13 @@ int p3_try_launch(const IgemmParams& p, hipStream_t stream) {
     if (eff(bm) >= 0.8 || u3_env >= 2) {
       const int kind = !dual ? 0 : (p.in2_scale != nullptr ? 2 : 1);
       if (u3_waves == 4)   // one wave per SIMD, 64 x 256 tiles (a wave owns 64 x 64): experiment
-        return kind == 2 ? launch_u3<64, 2, 4>(p, stream)
-                         : kind ? launch_u3<64, 1, 4>(p, stream) : launch_u3<64, 0, 4>(p, stream);
+        return kind == 2 ? launch_u3<64, 2, 4, MATH>(p, stream)
+                         : kind ? launch_u3<64, 1, 4, MATH>(p, stream) : launch_u3<64, 0, 4, MATH>(p, stream);
       if (bm == 128)
-        return kind == 2 ? launch_u3<128, 2, 8>(p, stream)
-                         : kind ? launch_u3<128, 1, 8>(p, stream) : launch_u3<128, 0, 8>(p, stream);
-      return kind == 2 ? launch_u3<64, 2, 8>(p, stream)
-                       : kind ? launch_u3<64, 1, 8>(p, stream) : launch_u3<64, 0, 8>(p, stream);
+        return kind == 2 ? launch_u3<128, 2, 8, MATH>(p, stream)
+                         : kind ? launch_u3<128, 1, 8, MATH>(p, stream) : launch_u3<128, 0, 8, MATH>(p, stream);
+      return kind == 2 ? launch_u3<64, 2, 8, MATH>(p, stream)
+                       : kind ? launch_u3<64, 1, 8, MATH>(p, stream) : launch_u3<64, 0, 8, MATH>(p, stream);
     }
   }
   if (mode_env == 2 && !dense) return -1;  // VLNCE_P3=2: only the patch (KxK) layers
@@ -1653,6 +1668,9 @@ int p3_try_launch(const IgemmParams& p, hipStream_t stream) {
     if (forced ? ci != force - 1 : c.bn > bn) continue;  // (narrower tiles only to fill the CUs)
     const int rows = p3_rows_for(p, c.bm, dense);
     if (2L * rows * P3_ROW + (dense ? 0 : 2L * c.bn * 192) + 16 > x3_lds_max()) continue;
+    // (with the 144-byte rows of MATH_F16X3 the LDS would hold 568 rows: the producers' 16 row
+    // groups are the bound there)
+    if (dense && rows > P3_MAX_ROWS) continue;
     const long tiles = (long)ceil_div(p.M, c.bm) * ceil_div(p.N, c.bn);
     const long rounds = (tiles + cus - 1) / cus;
     const double eff = (double)tiles / (double)(rounds * cus);
@@ -1664,9 +1682,16 @@ int p3_try_launch(const IgemmParams& p, hipStream_t stream) {
     if (eff >= 0.8) break;
   }
   if (pick < 0 || (best < 0.4 && !forced)) return -1;
-  if (dual) return dispatch_p3<1, P3_GATHER>(p, pick, pick_rows, stream);
-  if (dense) return dispatch_p3<0, P3_DENSE>(p, pick, pick_rows, stream);
-  return dispatch_p3<0, P3_GATHER>(p, pick, pick_rows, stream);
+  if (dual) return dispatch_p3<1, P3_GATHER, MATH>(p, pick, pick_rows, stream);
+  if (dense) return dispatch_p3<0, P3_DENSE, MATH>(p, pick, pick_rows, stream);
+  return dispatch_p3<0, P3_GATHER, MATH>(p, pick, pick_rows, stream);
+}
+
+}  // namespace
+
+int p3_try_launch(const IgemmParams& p, hipStream_t stream) {
+  return p.math == MATH_F16X3 ? p3_try_launch_<MATH_F16X3>(p, stream)
+                              : p3_try_launch_<MATH_BF16X6>(p, stream);
 }
 
 }  // namespace vlnce_detail
@@ -1677,15 +1702,19 @@ extern "C" long vlnce_conv2d_pack_bytes(const vlnce_conv_desc* d) {
 }
 
 extern "C" int vlnce_conv2d_pack_weights(const float* w_ohwi, void* frag, const vlnce_conv_desc* d,
-                                         vlnce_stream_t stream) {
+                                         int format, vlnce_stream_t stream) {
   VLNCE_CHECK_ARG(w_ohwi && frag && d, "conv2d_pack_weights: null argument");
+  VLNCE_CHECK_ARG(format == MATH_BF16X6 || format == MATH_F16X3,
+                  "conv2d_pack_weights: format must be 1 (three bf16 planes) or 2 (fp16 planes)");
   VLNCE_CHECK_ARG(vlnce_conv2d_pack_bytes(d) > 0,
                   "conv2d_pack_weights: needs Cin %% 32 == 0 and Cout %% 32 == 0");
   const int T = d->KH * d->KW;
   const long total = (long)(d->Cout / 32) * (T * d->Cin / 16) * 64;
   const long blocks = (total + 255) / 256;
-  hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)(blocks > 8192 ? 8192 : blocks)), dim3(256),
-                     0, reinterpret_cast<hipStream_t>(stream), w_ohwi,
+  hipLaunchKernelGGL(format == MATH_F16X3 ? pack_weights_kernel<MATH_F16X3>
+                                          : pack_weights_kernel<MATH_BF16X6>,
+                     dim3((unsigned)(blocks > 8192 ? 8192 : blocks)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), w_ohwi,
                      reinterpret_cast<unsigned short*>(frag), d->Cout, T, d->Cin);
   VLNCE_CHECK_LAUNCH("conv2d_pack_weights");
   return 0;

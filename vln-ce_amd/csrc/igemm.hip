@@ -742,39 +742,27 @@ struct X3Staged {
 // x (4 consecutive k of one row) -> the three planes' 8-byte LDS words.  Round-to-nearest split
 // (v_cvt_pk_bf16_f32): x = x1 + x2 + x3 exactly, |x2| <= 2^-9 |x|, |x3| <= 2^-18 |x|, so the three
 // dropped cross terms are <= 2^-26 relative (truncation, rounds 2: 2^-24); same instruction count.
+// (MATH_F16X3: two fp16 A planes, see Planes<> in igemm_shared.h)
+template <int MATH>
 __device__ __forceinline__ void x3_split_store(f32x4 x, char* row_ptr, int plane_bytes) {
   typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-  typedef float f32x2 __attribute__((ext_vector_type(2)));
-  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-  u32x2 w[3];
+  constexpr int NA = Planes<MATH>::NA;
+  unsigned w0[NA], w1[NA];
+  split_pair<MATH>(x[0], x[1], w0);
+  split_pair<MATH>(x[2], x[3], w1);
 #pragma unroll
-  for (int pr = 0; pr < 2; ++pr) {
-    f32x2 v = {x[2 * pr], x[2 * pr + 1]};
-#pragma unroll
-    for (int q = 0; q < 3; ++q) {
-#ifdef X3_DBG_NOSPLIT  // ceiling probe: what the kernel does when the split costs nothing
-      const unsigned hb = __builtin_bit_cast(unsigned, v[0]);
-#else
-      const unsigned hb = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
-#endif
-      w[q][pr] = hb;
-      if (q < 2) {
-        v[0] -= __builtin_bit_cast(float, hb << 16);
-        v[1] -= __builtin_bit_cast(float, hb & 0xffff0000u);
-      }
-    }
-  }
-#pragma unroll
-  for (int q = 0; q < 3; ++q) *reinterpret_cast<u32x2*>(row_ptr + q * plane_bytes) = w[q];
+  for (int q = 0; q < NA; ++q) *reinterpret_cast<u32x2*>(row_ptr + q * plane_bytes) = u32x2{w0[q], w1[q]};
 }
 
-template <int BM, int BN, int WM, int WN, int DUAL>
+template <int BM, int BN, int WM, int WN, int DUAL, int MATH>
 __global__ __launch_bounds__((WM * WN + X3_PRODUCERS) * 64) void conv_x3_kernel(IgemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
+  typedef Planes<MATH> PL;
+  constexpr int NA = PL::NA;
   constexpr int X3_MATRIX = WM * WN;  // matrix waves (8: two per SIMD take turns on the pipe)
   constexpr int WTM = BM / WM, WTN = BN / WN, MT = WTM / 32, NT = WTN / 32;
   constexpr int A_PLANE = BM * X3_PITCH, B_PLANE = BN * X3_PITCH;
-  constexpr int A_BYTES = 3 * A_PLANE, B_BYTES = 3 * B_PLANE;
+  constexpr int A_BYTES = NA * A_PLANE, B_BYTES = 3 * B_PLANE;
   constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
   constexpr int PR = X3_PRODUCERS * 64 / 8;          // rows per producer pass (8 float4 each)
   constexpr int A_ROWS = BM / PR;                    // producer passes over the A tile
@@ -967,7 +955,7 @@ __global__ __launch_bounds__((WM * WN + X3_PRODUCERS) * 64) void conv_x3_kernel(
                                         lk4) = v;
           }
         }
-        x3_split_store(v, arow + i * PR * X3_PITCH, A_PLANE);
+        x3_split_store<MATH>(v, arow + i * PR * X3_PITCH, A_PLANE);
       }
       if (brow < BN) {
         char* bdst = stage + A_BYTES + brow * X3_PITCH + bchunk * 16;
@@ -1027,7 +1015,7 @@ __global__ __launch_bounds__((WM * WN + X3_PRODUCERS) * 64) void conv_x3_kernel(
     // ================================================================ matrix waves
     const int wm = wave / WN, wn = wave % WN;
     struct Frag {
-      bf16x8 a[MT][3];
+      bf16x8 a[MT][NA];
       bf16x8 b[NT][3];
     };
     const char* abase = xsm + (wm * WTM + l31) * X3_PITCH + half * 16;
@@ -1037,7 +1025,7 @@ __global__ __launch_bounds__((WM * WN + X3_PRODUCERS) * 64) void conv_x3_kernel(
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int q = 0; q < 3; ++q)
+        for (int q = 0; q < NA; ++q)
           f.a[i][q] = *reinterpret_cast<const bf16x8*>(abase + off + q * A_PLANE + i * 32 * X3_PITCH);
 #pragma unroll
       for (int j = 0; j < NT; ++j)
@@ -1047,16 +1035,13 @@ __global__ __launch_bounds__((WM * WN + X3_PRODUCERS) * 64) void conv_x3_kernel(
     };
     f32x16 acc[MT][NT];
     auto mma = [&](const Frag& f) {
-      constexpr int PA[6] = {2, 0, 1, 1, 0, 0};  // smallest products first
-      constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
-      for (int q = 0; q < 6; ++q)
+      for (int q = 0; q < PL::NP; ++q)
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
           for (int j = 0; j < NT; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][PA[q]], f.b[j][PB[q]],
-                                                                acc[i][j], 0, 0, 0);
+            acc[i][j] = plane_mfma<MATH>(f.a[i][PL::PA[q]], f.b[j][PL::PB[q]], acc[i][j]);
     };
     const __amdgpu_buffer_rsrc_t rsrc_c = __builtin_amdgcn_make_buffer_rsrc(
         reinterpret_cast<char*>(p.C), 0, (int)p.c_bytes, 0x00020000);
@@ -1090,7 +1075,7 @@ __global__ __launch_bounds__((WM * WN + X3_PRODUCERS) * 64) void conv_x3_kernel(
       for (int j = 0; j < NT; ++j) {
         const int col = n0 + wn * WTN + j * 32 + l31;
         const bool ok = col < p.N;
-        e_sc[j] = (ok && p.scale) ? p.scale[col] : 1.f;
+        e_sc[j] = ((ok && p.scale) ? p.scale[col] : 1.f) * PL::POST;
         e_sh[j] = (ok && p.shift) ? p.shift[col] : 0.f;
         e_voff[j] = ok ? (int)((((long)(m0 + wm * WTM + 4 * half)) * p.ldc + col) * 4) : BUF_OOB;
       }
@@ -1121,7 +1106,7 @@ __global__ __launch_bounds__((WM * WN + X3_PRODUCERS) * 64) void conv_x3_kernel(
         }
         __builtin_amdgcn_sched_barrier(0);
         // this wave's reads of K-tile g are complete once fb has arrived (LDS returns in order)
-        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(3 * (MT + NT)) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NA * MT + 3 * NT) : "memory");
         if (lane == 0) x3_signal(empty + (g & 1));
         __builtin_amdgcn_sched_barrier(0);
         mma(fb);
@@ -1130,7 +1115,8 @@ __global__ __launch_bounds__((WM * WN + X3_PRODUCERS) * 64) void conv_x3_kernel(
 
       // -------------------------------------------------------------- statistics
       if (p.bn.acc != nullptr) {
-        wave_bn_tile<MT, NT>(acc, wbn, p.bn.acc, n0 + wn * WTN, p.N, p.M - (m0 + wm * WTM), half, l31);
+        wave_bn_tile<MT, NT>(acc, wbn, p.bn.acc, n0 + wn * WTN, p.N, p.M - (m0 + wm * WTM), half, l31,
+                             PL::POST);
         if (round == my_tiles - 1) wave_bn_flush(wbn, p.bn.acc, p.N, half, l31);  // in front of the stores
       } else if (p.stat_partial != nullptr) {
         const int tile_m = m0 / BM;
@@ -1139,13 +1125,14 @@ __global__ __launch_bounds__((WM * WN + X3_PRODUCERS) * 64) void conv_x3_kernel(
 #pragma unroll
           for (int i = 0; i < MT; ++i)
             wave_stats_block<NT>(acc[i], p.stat_partial, (m0 + wm * WTM) / 32 + i,
-                                 p.M - (m0 + wm * WTM + i * 32), n0 + wn * WTN, p.N, half, l31);
+                                 p.M - (m0 + wm * WTM + i * 32), n0 + wn * WTN, p.N, half, l31,
+                                 PL::POST);
         } else if (p.stat_rows > 0 && p.stat_rows < WTM)
           wave_stats_fine<MT, NT>(acc, p.stat_partial, p.stat_rows, m0 + wm * WTM, p.M,
-                                  n0 + wn * WTN, p.N, half, l31);
+                                  n0 + wn * WTN, p.N, half, l31, PL::POST);
         else
           wave_stats<MT, NT>(acc, p.stat_partial, tile_m * WM + wm, p.M - (m0 + wm * WTM), WTM,
-                             n0 + wn * WTN, p.N, half, l31);
+                             n0 + wn * WTN, p.N, half, l31, PL::POST);
       }
       // -------------------------------------------------------------- epilogue from registers
       // one store = 2 rows x 32 columns = two full 128-byte lines; rows past M fall outside
@@ -1331,11 +1318,11 @@ void fill_epilogue(IgemmParams& p, const vlnce_epilogue* e) {
 bool aligned16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
 // conv_x3_kernel launch: one workgroup (16 or 12 waves) per CU, walking tiles
-template <int BM, int BN, int WM, int WN, int DUAL>
+template <int BM, int BN, int WM, int WN, int DUAL, int MATH>
 int launch_x3(const IgemmParams& p, hipStream_t stream) {
-  constexpr int smem_bytes = 2 * 3 * (BM + BN) * X3_PITCH + 16;  // two stages + 4 counters
+  constexpr int smem_bytes = 2 * (Planes<MATH>::NA * BM + 3 * BN) * X3_PITCH + 16;  // two stages + 4 counters
   constexpr int threads = (WM * WN + X3_PRODUCERS) * 64;
-  auto kern = conv_x3_kernel<BM, BN, WM, WN, DUAL>;
+  auto kern = conv_x3_kernel<BM, BN, WM, WN, DUAL, MATH>;
   static bool attr_set = false;  // per instantiation
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -1398,12 +1385,17 @@ bool x3_plan(const IgemmParams& p, X3Plan* out) {
   }
   return best >= 0.4;  // below that the problem is a handful of tiles: split-K / small-tile path
 }
+template <int DUAL, int MATH>
+int dispatch_x3_(const IgemmParams& p, const X3Plan& t, hipStream_t s) {
+  if (t.bm == 128 && t.bn == 128) return launch_x3<128, 128, 2, 4, DUAL, MATH>(p, s);
+  if (t.bm == 64 && t.bn == 128) return launch_x3<64, 128, 2, 4, DUAL, MATH>(p, s);
+  if (t.bm == 128 && t.bn == 64) return launch_x3<128, 64, 4, 2, DUAL, MATH>(p, s);
+  return launch_x3<64, 64, 2, 2, DUAL, MATH>(p, s);
+}
 template <int DUAL>
 int dispatch_x3(const IgemmParams& p, const X3Plan& t, hipStream_t s) {
-  if (t.bm == 128 && t.bn == 128) return launch_x3<128, 128, 2, 4, DUAL>(p, s);
-  if (t.bm == 64 && t.bn == 128) return launch_x3<64, 128, 2, 4, DUAL>(p, s);
-  if (t.bm == 128 && t.bn == 64) return launch_x3<128, 64, 4, 2, DUAL>(p, s);
-  return launch_x3<64, 64, 2, 2, DUAL>(p, s);
+  return p.math == MATH_F16X3 ? dispatch_x3_<DUAL, MATH_F16X3>(p, t, s)
+                              : dispatch_x3_<DUAL, MATH_BF16X6>(p, t, s);
 }
 
 }  // namespace
@@ -1427,25 +1419,27 @@ extern "C" int vlnce_conv2d_tiles_m(const vlnce_conv_desc* d) {
 
 // w[i] -> planes[q][i], q = 0..2: the exact three-way (round-to-nearest) bf16 split of
 // conv_x3_kernel's B operand
+template <int MATH>
 __global__ __launch_bounds__(256) void split_weights_kernel(const float* __restrict__ w,
                                                             unsigned short* __restrict__ planes,
                                                             long count) {
   for (long i = blockIdx.x * 256L + threadIdx.x; i < count; i += gridDim.x * 256L) {
-    float v = w[i];   // round-to-nearest three-way split, exact: w == plane0 + plane1 + plane2
+    unsigned short o[3];   // MATH_BF16X6: w == plane0 + plane1 + plane2 exactly
+    split_weight<MATH>(w[i], o);
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
-      const __bf16 hb = (__bf16)v;
-      planes[q * count + i] = __builtin_bit_cast(unsigned short, hb);
-      v -= (float)hb;
-    }
+    for (int q = 0; q < 3; ++q) planes[q * count + i] = o[q];
   }
 }
 
-extern "C" int vlnce_conv2d_split_weights(const float* w, void* planes, long count,
+extern "C" int vlnce_conv2d_split_weights(const float* w, void* planes, long count, int format,
                                           vlnce_stream_t stream) {
   VLNCE_CHECK_ARG(w && planes && count > 0, "conv2d_split_weights: bad argument");
+  VLNCE_CHECK_ARG(format == MATH_BF16X6 || format == MATH_F16X3,
+                  "conv2d_split_weights: format must be 1 (three bf16 planes) or 2 (fp16 planes)");
   const long blocks = (count + 255) / 256;
-  hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)),
+  hipLaunchKernelGGL(format == MATH_F16X3 ? split_weights_kernel<MATH_F16X3>
+                                          : split_weights_kernel<MATH_BF16X6>,
+                     dim3((unsigned)(blocks > 4096 ? 4096 : blocks)),
                      dim3(256), 0, reinterpret_cast<hipStream_t>(stream), w,
                      reinterpret_cast<unsigned short*>(planes), count);
   VLNCE_CHECK_LAUNCH("conv2d_split_weights");
@@ -1579,6 +1573,9 @@ extern "C" int vlnce_conv2d_fwd(const float* x, const float* w, float* y, const 
   p.side_out = pro ? pro->side_out : nullptr;
   p.Bsplit = pro ? pro->w_split : nullptr;
   p.Bfrag = pro ? pro->w_frag : nullptr;
+  p.math = (pro && pro->w_format) ? pro->w_format : MATH_BF16X6;
+  VLNCE_CHECK_ARG(p.math == MATH_BF16X6 || p.math == MATH_F16X3,
+                  "conv2d_fwd: w_format must be 0 / 1 (three bf16 planes) or 2 (fp16 planes)");
   VLNCE_CHECK_ARG((p.in_scale == nullptr) == (p.in_shift == nullptr),
                   "conv2d_fwd: in_scale and in_shift must come together");
   fill_epilogue(p, epi);

@@ -36,6 +36,7 @@ struct IgemmParams {
   float* side_out;
   const void* Bsplit;  // conv_x3_kernel: the weights as three bf16 planes [3][N*K]
   const void* Bfrag;   // conv_p3_kernel: the weights as MFMA B fragments (vlnce_conv2d_pack_weights)
+  int math;            // plane format of Bsplit / Bfrag and arithmetic of the plane kernels (MATH_*)
   int p3_rows;         // conv_p3_kernel: patch rows allocated per LDS buffer (multiple of 32)
   const float* scale;
   const float* shift;
@@ -60,7 +61,7 @@ __device__ __forceinline__ f32x4 ldg4(const float* p) { return *reinterpret_cast
 template <int MT, int NT>
 __device__ __forceinline__ void wave_stats(const f32x16 (&acc)[MT][NT], float* stat_partial,
                                            int part_row, int rows_left, int rows_full, int col0,
-                                           int N, int half, int l31) {
+                                           int N, int half, int l31, float post = 1.f) {
   const int rows_valid = min(rows_full, rows_left);
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
@@ -87,8 +88,8 @@ __device__ __forceinline__ void wave_stats(const f32x16 (&acc)[MT][NT], float* s
     const int col = col0 + j * 32 + l31;
     if (half == 0 && col < N && rows_left > 0) {
       float* dst = stat_partial + ((long)part_row * N + col) * 2;
-      dst[0] = s;
-      dst[1] = m2;
+      dst[0] = s * post;
+      dst[1] = m2 * post * post;
     }
   }
 }
@@ -99,7 +100,7 @@ __device__ __forceinline__ void wave_stats(const f32x16 (&acc)[MT][NT], float* s
 template <int MT, int NT>
 __device__ __forceinline__ void wave_stats_fine(const f32x16 (&acc)[MT][NT], float* stat_partial,
                                                 int rows, int row0, int M, int col0, int N,
-                                                int half, int l31) {
+                                                int half, int l31, float post = 1.f) {
   const int nblk = MT * 32 / rows;
   for (int b = 0; b < nblk; ++b) {
     const int r_first = b * rows;                  // first row of the block inside the wave tile
@@ -130,8 +131,8 @@ __device__ __forceinline__ void wave_stats_fine(const f32x16 (&acc)[MT][NT], flo
       const int col = col0 + j * 32 + l31;
       if (half == 0 && col < N && left > 0) {
         float* dst = stat_partial + ((long)((row0 + r_first) / rows) * N + col) * 2;
-        dst[0] = s;
-        dst[1] = m2;
+        dst[0] = s * post;
+        dst[1] = m2 * post * post;
       }
     }
   }
@@ -141,7 +142,7 @@ __device__ __forceinline__ void wave_stats_fine(const f32x16 (&acc)[MT][NT], flo
 template <int NT>
 __device__ __forceinline__ void wave_stats_block(const f32x16 (&acc)[NT], float* stat_partial,
                                                  int part_row, int rows_left, int col0, int N,
-                                                 int half, int l31) {
+                                                 int half, int l31, float post = 1.f) {
   const int rows_valid = min(32, rows_left);
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
@@ -161,8 +162,8 @@ __device__ __forceinline__ void wave_stats_block(const f32x16 (&acc)[NT], float*
     const int col = col0 + j * 32 + l31;
     if (half == 0 && col < N && rows_left > 0) {
       float* dst = stat_partial + ((long)part_row * N + col) * 2;
-      dst[0] = s;
-      dst[1] = m2;
+      dst[0] = s * post;
+      dst[1] = m2 * post * post;
     }
   }
 }
@@ -205,7 +206,7 @@ __device__ __forceinline__ void wave_bn_flush(WaveBn<NT>& w, double* acc, int N,
 // that exist (<= 0: none)
 template <int NT>
 __device__ __forceinline__ void wave_bn_block(const f32x16 (&acc)[NT], WaveBn<NT>& w, int rows_left,
-                                              int half) {
+                                              int half, float post = 1.f) {
   const int rows_valid = min(32, rows_left);
   if (rows_valid <= 0) return;   // (wave-uniform)
   const double inv_n = 1.0 / (double)rows_valid;
@@ -224,21 +225,23 @@ __device__ __forceinline__ void wave_bn_block(const f32x16 (&acc)[NT], WaveBn<NT
       if ((r & 3) + 8 * (r >> 2) + 4 * half < rows_valid) m2 += d * d;
     }
     m2 += __shfl_xor(m2, 32, 64);
-    w.s[j] += (double)s;
-    w.q[j] += (double)m2 + (double)s * (double)s * inv_n;
+    // (post: the power-of-two scale the accumulators carry -- MATH_F16X3 -- exact in fp64)
+    w.s[j] += (double)s * (double)post;
+    w.q[j] += ((double)m2 + (double)s * (double)s * inv_n) * ((double)post * (double)post);
   }
 }
 // a wave's MT x NT blocks of one finished tile: col0 = its first column, rows_left = rows of the
 // wave's sub-tile that exist
 template <int MT, int NT>
 __device__ __forceinline__ void wave_bn_tile(const f32x16 (&acc)[MT][NT], WaveBn<NT>& w, double* gacc,
-                                             int col0, int N, int rows_left, int half, int l31) {
+                                             int col0, int N, int rows_left, int half, int l31,
+                                             float post = 1.f) {
   if (w.col0 != col0) {
     wave_bn_flush(w, gacc, N, half, l31);
     w.col0 = col0;
   }
 #pragma unroll
-  for (int i = 0; i < MT; ++i) wave_bn_block<NT>(acc[i], w, rows_left - i * 32, half);
+  for (int i = 0; i < MT; ++i) wave_bn_block<NT>(acc[i], w, rows_left - i * 32, half, post);
 }
 // (Measured and dropped, round 4: finishing the statistics INSIDE the convolution -- ticket per
 // workgroup, the last one reads the sums back with atomic exchanges and writes the vectors -- costs
@@ -303,6 +306,91 @@ __device__ __forceinline__ void wave_epilogue(f32x16 (&acc)[MT][NT], const float
 }
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+// ---- arithmetic of the plane kernels (option "conv_math", vlnce_prologue.w_format) -------------
+// MATH_BF16X6: every fp32 operand = three bf16 planes x1 + x2 + x3 (exact, 8 + 8 + 8 mantissa bits,
+//   fp32's exponent range); a product = six plane products on v_mfma_f32_32x32x16_bf16.
+// MATH_F16X3 (round 6): a = a1 + a2, a1 = fp16(a), a2 = fp16((a - a1) * 2^11) / 2^11 (11 + 11
+//   mantissa bits + the sign of a2: |a - a1 - a2| <= 2^-22 |a|); a product = THREE plane products
+//   a1 b1 + a1 b2 + a2 b1 on v_mfma_f32_32x32x16_f16 (the dropped a2 b2 <= 2^-22 |a b|), all three
+//   accumulated at the common scale 2^11 -- A planes {a1, a2 * 2^11}, B planes {b1 * 2^11,
+//   b2 * 2^11, b1} -- so that the low planes stay out of fp16's subnormal range, and the
+//   accumulator is multiplied by 2^-11 (exact) where it leaves the registers.  Against an fp64
+//   convolution this is as close as the six-product form (the fp32 accumulation dominates both:
+//   half the accumulator updates), at half the matrix-pipe time and two thirds of the operand
+//   bytes.  Range: |a| < 65504, |b| < 32 (outside: inf / NaN in the output, never a wrong finite
+//   value); operands far below fp16's normal range (gradients) lose relative precision -- the
+//   data-gradient launches of the trainable encoders stay on MATH_BF16X6.
+enum { MATH_F32 = 0, MATH_BF16X6 = 1, MATH_F16X3 = 2 };
+template <int MATH>
+struct Planes;
+template <>
+struct Planes<MATH_BF16X6> {
+  static constexpr int NA = 3, NB = 3, NP = 6;
+  static constexpr int ROW = 208;   // bytes of a patch row: NA planes x 32 x 2 B + 16 pad (13 x 16 B)
+  static constexpr float POST = 1.f;
+  static constexpr int PA[6] = {2, 1, 0, 1, 0, 0};   // smallest products first
+  static constexpr int PB[6] = {0, 1, 2, 0, 1, 0};
+};
+template <>
+struct Planes<MATH_F16X3> {
+  static constexpr int NA = 2, NB = 3, NP = 3;
+  static constexpr int ROW = 144;   // 9 x 16 B: consecutive rows are conflict-free as well
+  static constexpr float POST = 1.f / 2048.f;
+  static constexpr int PA[6] = {1, 0, 0, 0, 0, 0};   // a2 b1, a1 b2, a1 b1 (at scale 2^11)
+  static constexpr int PB[6] = {2, 1, 0, 0, 0, 0};
+};
+template <int MATH>
+__device__ __forceinline__ f32x16 plane_mfma(bf16x8 a, bf16x8 b, f32x16 c) {
+  if constexpr (MATH == MATH_F16X3)
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a),
+                                                  __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+// two consecutive fp32 values -> one 32-bit word (two 16-bit plane values) per A plane
+template <int MATH>
+__device__ __forceinline__ void split_pair(float v0, float v1, unsigned (&w)[Planes<MATH>::NA]) {
+  typedef float f32x2_ __attribute__((ext_vector_type(2)));
+  if constexpr (MATH == MATH_F16X3) {
+    typedef _Float16 f16x2_ __attribute__((ext_vector_type(2)));
+    const f32x2_ v = {v0, v1};
+    const f16x2_ h = __builtin_convertvector(v, f16x2_);   // round to nearest even
+    w[0] = __builtin_bit_cast(unsigned, h);
+    const f32x2_ r = {(v0 - (float)h[0]) * 2048.f, (v1 - (float)h[1]) * 2048.f};   // exact
+    w[1] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2_));
+  } else {
+    typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+    f32x2_ v = {v0, v1};
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const unsigned hb = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_));
+      w[q] = hb;
+      if (q < 2) {
+        v[0] -= __builtin_bit_cast(float, hb << 16);
+        v[1] -= __builtin_bit_cast(float, hb & 0xffff0000u);
+      }
+    }
+  }
+}
+// one weight -> its three B-plane values (16-bit words)
+template <int MATH>
+__device__ __forceinline__ void split_weight(float v, unsigned short (&o)[3]) {
+  if constexpr (MATH == MATH_F16X3) {
+    const _Float16 h = (_Float16)v;
+    o[0] = __builtin_bit_cast(unsigned short, (_Float16)((float)h * 2048.f));   // exact unless |v| >= 32
+    o[1] = __builtin_bit_cast(unsigned short, (_Float16)((v - (float)h) * 2048.f));
+    o[2] = __builtin_bit_cast(unsigned short, h);
+  } else {
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const __bf16 hb = (__bf16)v;   // round to nearest even
+      o[q] = __builtin_bit_cast(unsigned short, hb);
+      v -= (float)hb;
+    }
+  }
+}
 
 __device__ __forceinline__ int x3_peek(const int* flag) {
   return __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -346,9 +434,9 @@ static inline int x3_lds_max() {
   return v;
 }
 
-// convolution arithmetic: 1 = fp32 operands split into three bf16 planes, six products on the
-// bf16 matrix pipe (conv_p3_kernel / conv_x3_kernel; fp32-class result, see the kernels'
-// headers); 0 = v_mfma_f32_32x32x2_f32 everywhere (igemm_kernel).  Option "conv_math".
+// convolution arithmetic, option "conv_math": 0 = v_mfma_f32_32x32x2_f32 everywhere (igemm_kernel);
+// non-zero = the plane kernels (conv_p3 / u3 / s3 / m3 / x3) in the arithmetic of the planes the
+// launch hands over (vlnce_prologue.w_format -> IgemmParams::math: MATH_BF16X6 or MATH_F16X3).
 static inline int conv_math() { return vlnce_opt(VLNCE_OPT_CONV_MATH) != 0; }
 
 // conv_p3.hip: the patch-resident bf16-plane convolution.  Returns -1 when the problem is not

@@ -238,13 +238,15 @@ struct Stem7Params {
 // waves either way; as TWO workgroups of 4 waves their phases (patch build / matrix
 // instructions / output stores, which a workgroup runs one after the other: 79 + 100 + 77 us of
 // the 258 us launch at num_envs 64, profiles/r04_zh_*) drift apart and overlap.
-template <int NB, int WAVES>   // NB = Cout / 32 (1 or 2)
+template <int NB, int WAVES, int MATH>   // NB = Cout / 32 (1 or 2); MATH: Planes<> of igemm_shared.h
 __global__ __launch_bounds__(WAVES * 64, 8 / WAVES) void stem7_kernel(Stem7Params p) {
 #if defined(__HIP_DEVICE_COMPILE__)
+  typedef Planes<MATH> PL;
+  constexpr int NA = PL::NA, NP = PL::NP;
   constexpr int NTHR = WAVES * 64;
   constexpr int TH = 2 * WAVES / NB;              // output rows of a tile
   constexpr int PH = 2 * TH + 5, PW = 2 * S7_TW + 5;
-  constexpr int PLANE = PH * S7_ROWB, PBUF = 3 * PLANE;
+  constexpr int PLANE = PH * S7_ROWB, PBUF = NA * PLANE;
   extern __shared__ __attribute__((aligned(16))) char xsm[];   // [2][PBUF]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -275,7 +277,7 @@ __global__ __launch_bounds__(WAVES * 64, 8 / WAVES) void stem7_kernel(Stem7Param
     }
   }
   const int col = wn * 32 + l31;
-  const float e_sc = p.scale ? p.scale[col] : 1.f, e_sh = p.shift ? p.shift[col] : 0.f;
+  const float e_sc = (p.scale ? p.scale[col] : 1.f) * PL::POST, e_sh = p.shift ? p.shift[col] : 0.f;
   double bn_s = 0.0, bn_q = 0.0;
   const bool relu_out = p.act == VLNCE_ACT_RELU;   // (the launcher admits none / ReLU)
   const __amdgpu_buffer_rsrc_t rsrc_y = __builtin_amdgcn_make_buffer_rsrc(
@@ -319,11 +321,18 @@ __global__ __launch_bounds__(WAVES * 64, 8 / WAVES) void stem7_kernel(Stem7Param
         for (int c = 0; c < 3; ++c) {
           float v = pv[k][c];
           char* dst = buf + row * S7_ROWB + (px * 3 + c) * 2;
+          if constexpr (MATH == MATH_F16X3) {
+            const _Float16 h = (_Float16)v;   // round to nearest even
+            *reinterpret_cast<unsigned short*>(dst) = __builtin_bit_cast(unsigned short, h);
+            *reinterpret_cast<unsigned short*>(dst + PLANE) =
+                __builtin_bit_cast(unsigned short, (_Float16)((v - (float)h) * 2048.f));
+          } else {
 #pragma unroll
-          for (int q = 0; q < 3; ++q) {
-            const __bf16 hb = (__bf16)v;   // round to nearest even
-            *reinterpret_cast<unsigned short*>(dst + q * PLANE) = __builtin_bit_cast(unsigned short, hb);
-            v -= (float)hb;
+            for (int q = 0; q < 3; ++q) {
+              const __bf16 hb = (__bf16)v;   // round to nearest even
+              *reinterpret_cast<unsigned short*>(dst + q * PLANE) = __builtin_bit_cast(unsigned short, hb);
+              v -= (float)hb;
+            }
           }
         }
       }
@@ -338,8 +347,6 @@ __global__ __launch_bounds__(WAVES * 64, 8 / WAVES) void stem7_kernel(Stem7Param
   __syncthreads();
   if (tile + gridDim.x < ntiles) fetch(tile + gridDim.x);
   int par = 0;
-  constexpr int PA[6] = {2, 1, 0, 1, 0, 0};  // smallest products first
-  constexpr int PB[6] = {0, 1, 2, 0, 1, 0};
   // The 16 stores of a finished tile are issued UNDER the next tile's matrix instructions
   // (conv_s3_kernel's recipe: a second accumulator set, one or two stores behind each k-slab's six
   // MFMAs, fire-and-forget): a tile used to be [patch build | 66 MFMAs | 16 stores] back to back,
@@ -383,7 +390,7 @@ __global__ __launch_bounds__(WAVES * 64, 8 / WAVES) void stem7_kernel(Stem7Param
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     // A fragments one k-slab ahead (two register sets, the loop is fully unrolled): left to the
     // compiler every slab was [6 LDS reads, s_waitcnt lgkmcnt(0), 6 MFMAs]
-    auto readA = [&](u32x4 (&fa)[3], int ks) {
+    auto readA = [&](u32x4 (&fa)[NA], int ks) {
       // k' = 16 ks + 8 half + [0, 8): filter row kh = k' / 24 (clamped for the all-zero tail
       // slab), offset k' % 24 inside the row's 24
       const int k0 = 16 * ks;
@@ -392,7 +399,7 @@ __global__ __launch_bounds__(WAVES * 64, 8 / WAVES) void stem7_kernel(Stem7Param
       const int o0 = (kh0 > 6 ? 6 : kh0) * S7_ROWB + off0 * 2, o1 = (kh1 > 6 ? 6 : kh1) * S7_ROWB + off1 * 2;
       const char* a = abase + (half ? o1 : o0);
 #pragma unroll
-      for (int q = 0; q < 3; ++q) {
+      for (int q = 0; q < NA; ++q) {
 #ifdef S7_DBG_NOA   // bisection build (results are garbage)
         fa[q] = u32x4{(unsigned)ks, (unsigned)q, 1u, 2u};
         (void)a;
@@ -402,7 +409,7 @@ __global__ __launch_bounds__(WAVES * 64, 8 / WAVES) void stem7_kernel(Stem7Param
 #endif
       }
     };
-    u32x4 f0[3], f1[3];
+    u32x4 f0[NA], f1[NA];
     readA(f0, 0);
 #pragma unroll
     for (int ks = 0; ks < S7_KS; ++ks) {
@@ -412,24 +419,22 @@ __global__ __launch_bounds__(WAVES * 64, 8 / WAVES) void stem7_kernel(Stem7Param
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int q = 0; q < 6; ++q) {
+      for (int q = 0; q < NP; ++q) {
         if (ks & 1)
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f1[PA[q]]),
-                                                        bres[ks][PB[q]], acc, 0, 0, 0);
+          acc = plane_mfma<MATH>(__builtin_bit_cast(bf16x8, f1[PL::PA[q]]), bres[ks][PL::PB[q]], acc);
         else
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f0[PA[q]]),
-                                                        bres[ks][PB[q]], acc, 0, 0, 0);
+          acc = plane_mfma<MATH>(__builtin_bit_cast(bf16x8, f0[PL::PA[q]]), bres[ks][PL::PB[q]], acc);
       }
       // the previous tile's stores: two behind each of the first five slabs, one behind the rest
       if (ks < 5) {
         store_prev(2 * ks, 2);
-        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);  // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x008, NP / 2, 0);  // MFMA
         __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);  // VMEM write
-        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, NP - NP / 2, 0);
         __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);
       } else {
         store_prev(10 + (ks - 5), 1);
-        __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, NP, 0);
         __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -461,8 +466,8 @@ __global__ __launch_bounds__(WAVES * 64, 8 / WAVES) void stem7_kernel(Stem7Param
           m2 += ok ? d * d : 0.f;
         }
         m2 += __shfl_xor(m2, 32, 64);
-        bn_s += (double)s;
-        bn_q += (double)m2 + (double)s * (double)s / (double)nvalid;
+        bn_s += (double)s * (double)PL::POST;
+        bn_q += ((double)m2 + (double)s * (double)s / (double)nvalid) * ((double)PL::POST * (double)PL::POST);
       }
     }
     // stores: pixel pi -> output row pi >> 4 = r >> 3 (wave-uniform per register), column
@@ -534,10 +539,12 @@ extern "C" int vlnce_frames_s2d(const vlnce_frames* frames, float* y, int pad_lo
 }
 
 extern "C" int vlnce_stem7_fwd(const vlnce_frames* frames, const float* in_scale,
-                               const float* in_shift, const void* w_frag, float* y, int Cout,
-                               const vlnce_epilogue* epi, vlnce_stream_t stream) {
+                               const float* in_shift, const void* w_frag, int w_format, float* y,
+                               int Cout, const vlnce_epilogue* epi, vlnce_stream_t stream) {
   Stem7Params p{};
   if (int rc = fill(frames, &p.f, "stem7_fwd")) return rc;
+  VLNCE_CHECK_ARG(w_format == MATH_BF16X6 || w_format == MATH_F16X3,
+                  "stem7_fwd: w_format must be 1 (three bf16 planes) or 2 (fp16 planes)");
   VLNCE_CHECK_ARG(w_frag && y && p.f.C == 3 && (Cout == 32 || Cout == 64) && (!in_scale == !in_shift),
                   "stem7_fwd: 3-channel frames, 32 or 64 output channels");
   VLNCE_CHECK_ARG(!epi || (!epi->residual && !epi->accumulate && !epi->stat_partial),
@@ -563,10 +570,16 @@ extern "C" int vlnce_stem7_fwd(const vlnce_frames* frames, const float* in_scale
   const long ntiles = (long)p.f.N * p.f.Ft * ceil_div(p.Ho, TH) * ceil_div(p.Wo, S7_TW);
   const long resident = (long)x3_cus() * (8 / WAVES);   // 8 waves of 231 registers per CU
   const unsigned grid = (unsigned)(ntiles < resident ? ntiles : resident);
-  const int smem = 2 * 3 * (2 * TH + 5) * S7_ROWB;
+  const int NA = w_format == MATH_F16X3 ? 2 : 3;
+  const int smem = 2 * NA * (2 * TH + 5) * S7_ROWB;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (Cout == 64) hipLaunchKernelGGL((stem7_kernel<2, WAVES>), dim3(grid), dim3(WAVES * 64), smem, s, p);
-  else hipLaunchKernelGGL((stem7_kernel<1, WAVES>), dim3(grid), dim3(WAVES * 64), smem, s, p);
+  if (w_format == MATH_F16X3) {
+    if (Cout == 64) hipLaunchKernelGGL((stem7_kernel<2, WAVES, MATH_F16X3>), dim3(grid), dim3(WAVES * 64), smem, s, p);
+    else hipLaunchKernelGGL((stem7_kernel<1, WAVES, MATH_F16X3>), dim3(grid), dim3(WAVES * 64), smem, s, p);
+  } else {
+    if (Cout == 64) hipLaunchKernelGGL((stem7_kernel<2, WAVES, MATH_BF16X6>), dim3(grid), dim3(WAVES * 64), smem, s, p);
+    else hipLaunchKernelGGL((stem7_kernel<1, WAVES, MATH_BF16X6>), dim3(grid), dim3(WAVES * 64), smem, s, p);
+  }
   VLNCE_CHECK_LAUNCH("stem7_fwd");
   return 0;
 }

@@ -338,23 +338,48 @@ def _gpu_slot_on_node(bdf, node, sysfs):
     return (gpus.index(bdf), len(gpus)) if bdf in gpus else (0, 1)
 
 
+_AFFINITY_BEFORE_BIND = None   # the mask this process had before the first bind (inherited by forks)
+
+
+def restore_worker_affinity():
+    """For the init function of worker processes started after bind_host_threads_to_gpu_socket()
+    (`DataLoader(worker_init_fn=...)`, habitat VectorEnv workers): give the calling process the
+    CPU mask the trainer had BEFORE it bound its own threads.  Returns the mask, or None when the
+    parent never bound (or under spawn, where the module state is not inherited: nothing to undo
+    there either -- a spawned child starts from the parent's mask at exec time, so bind after
+    creating the workers in that case)."""
+    import os
+
+    if _AFFINITY_BEFORE_BIND is None:
+        return None
+    try:
+        os.sched_setaffinity(0, _AFFINITY_BEFORE_BIND)
+    except OSError:
+        return None
+    return set(_AFFINITY_BEFORE_BIND)
+
+
 def bind_host_threads_to_gpu_socket(device_index=0, node=None, sysfs="/sys", scope=None):
     """One process per GPU: keep this rank's threads (the issuing thread, autograd's, the HIP
-    runtime's) on the CPU socket its GPU is attached to -- by default on ONE L3 domain of it.
+    runtime's) on the CPU socket its GPU is attached to -- with scope "l3" on ONE L3 domain of it.
     Half of a step's phases are paced by the issuing thread and its hand-overs to autograd's
     thread; on the two-socket hosts of the MI355X nodes the scheduler
     otherwise places those threads on either socket, measured as two speeds of the same loop
     (profiles/r05_zz_step_jitter*.txt: 9.4-9.7 ms unbound in the slow mode, 9.0-9.2 on one socket,
     8.94-8.98 on one L3 domain).
 
-    scope (default: VLNCE_BIND_SOCKET, else "l3"): "l3" = one L3 domain (a CCD: 8 cores + their
-    SMT siblings) of the GPU's socket, the GPUs of a socket spread evenly over its domains by PCI
-    order; "socket" / "1" = every CPU of the socket; "0" = do nothing.  Returns the NUMA node
-    bound to, or None when nothing was changed (unknown topology, or an affinity mask that
-    already excludes the node)."""
+    scope (default: VLNCE_BIND_SOCKET, else "socket"): "socket" / "1" = every CPU of the socket;
+    "l3" = one L3 domain (a CCD: 8 cores + their SMT siblings) of the GPU's socket, the GPUs of a
+    socket spread evenly over its domains by PCI order; "0" = do nothing.  The library default is
+    the whole socket: processes forked or spawned AFTERWARDS -- habitat's VectorEnv
+    workers, DataLoader workers -- inherit the mask, and a trainer that builds 32-64 simulator
+    workers must not pin them to eight cores; `bench.py` (no workers) asks for "l3" itself, and
+    `restore_worker_affinity()` in a worker's init function undoes the inheritance.  Returns the
+    NUMA node bound to, or None when nothing was changed (unknown topology, or an affinity mask
+    that already excludes the node)."""
     import os
 
-    scope = (scope or os.environ.get("VLNCE_BIND_SOCKET") or "l3").lower()
+    scope = (scope or os.environ.get("VLNCE_BIND_SOCKET") or "socket").lower()
     if scope == "0":
         return None
     if node is None:
@@ -373,6 +398,9 @@ def bind_host_threads_to_gpu_socket(device_index=0, node=None, sysfs="/sys", sco
         if doms:
             k, n = _gpu_slot_on_node(_gpu_bdf(device_index), node, sysfs)
             cpus = doms[(k * len(doms)) // max(n, 1) % len(doms)]
+    global _AFFINITY_BEFORE_BIND
+    if _AFFINITY_BEFORE_BIND is None:
+        _AFFINITY_BEFORE_BIND = os.sched_getaffinity(0)
     try:
         tids = [int(t) for t in os.listdir("/proc/self/task")]
     except OSError:

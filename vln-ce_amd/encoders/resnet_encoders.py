@@ -62,13 +62,15 @@ class _WeightCache:
         return hit[1]
 
     def stem7(self, conv):
-        """the 7x7 stem filters as the B fragments of vlnce_stem7_fwd (ops.stem7_pack_weights)"""
-        k = self._key(conv.weight)
+        """the 7x7 stem filters as the B fragments of vlnce_stem7_fwd (ops.stem7_pack_weights) in
+        the launch's plane format; returns (fragments, format)"""
+        fmt = ops.plane_format()
+        k = self._key(conv.weight) + (fmt,)
         hit = self._packed.get(("stem7", id(conv)))
         if hit is None or hit[0] != k:
-            hit = (k, ops.stem7_pack_weights(self.conv(conv)))
+            hit = (k, ops.stem7_pack_weights(self.conv(conv), fmt))
             self._packed[("stem7", id(conv))] = hit
-        return hit[1]
+        return hit[1], fmt
 
     def bn_eval(self, bn, gen=0):
         # `gen` counts train-mode forwards: the HIP kernels update the running statistics
@@ -360,9 +362,9 @@ class HipResNetTrunk(DropsGraphsOnApply, nn.Sequential):
         modes = tuple(m.training for m in self._norms)
         if any(modes) and not all(modes):
             raise NotImplementedError("mixed train/eval BatchNorm modes inside one trunk")
-        key = (signature, modes[0], tuple(p._version for p in self._plist()),
+        key = (signature, modes[0], tuple(p._version for p in self._plist(checked=False)),
                id(self.input_scale[0]), len(self._modules),
-               0 if modes[0] else self._bn_gen)
+               0 if modes[0] else self._bn_gen, ops.plane_format())
         return key, modes[0]
 
     def graph_ready(self, x):
@@ -382,18 +384,19 @@ class HipResNetTrunk(DropsGraphsOnApply, nn.Sequential):
             if stem7:
                 # the 7x7 / stride-2 stem straight from the frames on the bf16 matrix pipe
                 # (vlnce_stem7_fwd): no regrouped copy of the frames, no fp32-MFMA convolution
-                wf = self._cache.stem7(kids[0])
+                wf, wfmt = self._cache.stem7(kids[0])
                 if train:
                     bn = kids[1]
                     acc = ops._bn_state(bn)
-                    raw = ops.stem7(fr, wf, kids[0].out_channels, pro[0], pro[1], bn_acc=acc)
+                    raw = ops.stem7(fr, wf, kids[0].out_channels, pro[0], pro[1], bn_acc=acc,
+                                    w_format=wfmt)
                     pend = ops.bn_finalize_sums(acc, raw.numel() // raw.size(-1), bn)
                     touched.append(bn.num_batches_tracked)
                     x = ops.maxpool3x3s2(raw, pend[0], pend[1], in_relu=True, in_center=pend[2])
                 else:
                     sc, sh = self._cache.bn_eval(kids[1], self._bn_gen)
                     x = ops.stem7(fr, wf, kids[0].out_channels, pro[0], pro[1], scale=sc, shift=sh,
-                                  act=ops.ACT_RELU)
+                                  act=ops.ACT_RELU, w_format=wfmt)
                     x = ops.maxpool3x3s2(x)
             else:
                 if s2d:  # /255 (+mean/std) applied while regrouping, before the zero border
@@ -772,7 +775,7 @@ class HipResNetEncoder(DropsGraphsOnApply, nn.Module):
         return self._graphs(x, self._graph_key(ops.frames_signature(x))).permute(0, 3, 1, 2)
 
     def _graph_key(self, signature):
-        return (signature, tuple(p._version for p in self._plist()))
+        return (signature, tuple(p._version for p in self._plist(checked=False)), ops.plane_format())
 
     def graph_ready(self, x):
         return self._graphs.captured(self._graph_key(ops.frames_signature(x)))

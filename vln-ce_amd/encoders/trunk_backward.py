@@ -38,13 +38,14 @@ def conv_backward(x, w_ohwi, dy, stride, pad, need_dx):
     if not need_dx:
         return None, dw_oihw
     N, H, W, _ = x.shape
-    # flipped taps, in/out channels swapped: [Cin, KH, KW, Cout]
+    # flipped taps, in/out channels swapped: [Cin, KH, KW, Cout].  Gradient operands: three bf16
+    # planes (fp32's exponent range); the fp16 planes of the forward would flush them
     wt = w_ohwi.flip(1, 2).permute(3, 1, 2, 0).contiguous()
     if stride == 1:
-        dx = ops.conv2d_nhwc(dy, wt, 1, KH - 1 - pad)
+        dx = ops.conv2d_nhwc(dy, wt, 1, KH - 1 - pad, w_format=ops.PLANES_BF16X6)
     elif KH == 1:
         # 1x1 / stride s: only the sampled pixels receive gradient
-        small = ops.conv2d_nhwc(dy, wt, 1, 0)
+        small = ops.conv2d_nhwc(dy, wt, 1, 0, w_format=ops.PLANES_BF16X6)
         dx = torch.zeros((N, H, W, Cin), device=x.device, dtype=torch.float32)
         dx[:, ::stride, ::stride] = small
     else:
@@ -53,7 +54,7 @@ def conv_backward(x, w_ohwi, dy, stride, pad, need_dx):
         Hu, Wu = H + 2 * pad - KH + 1, W + 2 * pad - KW + 1
         up = torch.zeros((N, Hu, Wu, Cout), device=x.device, dtype=torch.float32)
         up[:, ::stride, ::stride] = dy
-        dx = ops.conv2d_nhwc(up, wt, 1, KH - 1 - pad)
+        dx = ops.conv2d_nhwc(up, wt, 1, KH - 1 - pad, w_format=ops.PLANES_BF16X6)
     return dx, dw_oihw
 
 

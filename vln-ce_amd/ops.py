@@ -36,30 +36,46 @@ def _rows2d(t):
 
 
 # ----------------------------------------------------------------- conv (forward only)
-def split_weights(w_ohwi):
-    """The weights as three bf16 planes (vlnce_conv2d_split_weights) for the bf16-matrix-pipe
-    convolution kernel, or None where that kernel does not apply (Cin % 32 != 0).  Cached on
-    the weight tensor itself and redone when the tensor is written in place; the encoders pass
-    their packed OHWI tensors (one object per parameter version), so a frozen trunk splits once."""
+PLANES_BF16X6, PLANES_F16X3 = 1, 2   # plane formats of include/vlnce_hip.h (vlnce_prologue.w_format)
+
+
+def plane_format(w_format=None):
+    """the plane format of a launch: the caller's (backward launches pass PLANES_BF16X6: gradients
+    live below fp16's normal range) or the effective "conv_math" option (default 2 = fp16 planes,
+    three plane products per multiply)."""
+    return int(w_format) if w_format else L().plane_format()
+
+
+def split_weights(w_ohwi, fmt=None):
+    """The weights as three 16-bit planes (vlnce_conv2d_split_weights, format `fmt`) for
+    conv_x3_kernel, or None where that kernel does not apply (Cin % 32 != 0).  Cached on
+    the weight tensor itself, per format, and redone when the tensor is written in place; the
+    encoders pass their packed OHWI tensors (one object per parameter version), so a frozen trunk
+    splits once."""
     if not w_ohwi.is_cuda or w_ohwi.shape[-1] % 32 != 0 or w_ohwi.dtype != torch.float32:
         return None
-    hit = getattr(w_ohwi, "_vlnce_split", None)
+    fmt = plane_format(fmt)
+    cache = w_ohwi.__dict__.setdefault("_vlnce_split", {})
+    hit = cache.get(fmt)
     if hit is None or hit[0] != w_ohwi._version:
         planes = torch.empty((3, w_ohwi.numel()), device=w_ohwi.device, dtype=torch.int16)
-        L().conv2d_split_weights(w_ohwi, planes)
+        L().conv2d_split_weights(w_ohwi, planes, fmt)
+        planes._vlnce_fmt = fmt
         hit = (w_ohwi._version, planes)
-        w_ohwi._vlnce_split = hit
+        cache[fmt] = hit
     return hit[1]
 
 
-def pack_weights(w_ohwi):
-    """The weights as bf16-plane MFMA B fragments (vlnce_conv2d_pack_weights) for the
-    patch-resident convolution kernel, or None where it does not apply (Cin or Cout not a
-    multiple of 32).  Cached on the weight tensor like split_weights()."""
+def pack_weights(w_ohwi, fmt=None):
+    """The weights as 16-bit-plane MFMA B fragments (vlnce_conv2d_pack_weights, format `fmt`) for
+    the fragment kernels (conv_p3 / u3 / s3 / m3), or None where they do not apply (Cin or Cout not
+    a multiple of 32).  Cached on the weight tensor like split_weights()."""
     if (not w_ohwi.is_cuda or w_ohwi.dtype != torch.float32 or w_ohwi.shape[-1] % 32 != 0
             or w_ohwi.shape[0] % 32 != 0):
         return None
-    hit = getattr(w_ohwi, "_vlnce_frag", None)
+    fmt = plane_format(fmt)
+    cache = w_ohwi.__dict__.setdefault("_vlnce_frag", {})
+    hit = cache.get(fmt)
     if hit is None or hit[0] != w_ohwi._version:
         Cout, KH, KW, Cin = w_ohwi.shape
         g = dict(N=1, H=KH, W=KW, Cin=Cin, Cout=Cout, KH=KH, KW=KW, stride=1, pad=0, Ho=1, Wo=1,
@@ -68,9 +84,10 @@ def pack_weights(w_ohwi):
         if nbytes <= 0:
             return None
         frag = torch.empty((nbytes // 2,), device=w_ohwi.device, dtype=torch.int16)
-        L().conv2d_pack_weights(w_ohwi, frag, g)
+        L().conv2d_pack_weights(w_ohwi, frag, g, fmt)
+        frag._vlnce_fmt = fmt
         hit = (w_ohwi._version, frag)
-        w_ohwi._vlnce_frag = hit
+        cache[fmt] = hit
     return hit[1]
 
 
@@ -87,11 +104,12 @@ def conv_geometry(x, w, stride, pad, ldx=None):
 def conv2d_nhwc(x, w_ohwi, stride, pad, *, in_scale=None, in_shift=None, in_center=None,
                 in_relu=False, scale=None, shift=None, residual=None, act=ACT_NONE,
                 want_stats=False, x2=None, in2_scale=None, in2_shift=None, in2_center=None,
-                side_out=None):
+                side_out=None, w_format=None):
     """y[N,Ho,Wo,Cout] = act((conv(prologue(x), w)) * scale + shift + residual), with
     prologue(x) = act((x - in_center) * in_scale + in_shift).
     want_stats=True additionally returns the BatchNorm partials of the RAW
-    accumulator: (partial[tiles_m, Cout, 2], tiles_m, tile_rows)."""
+    accumulator: (partial[tiles_m, Cout, 2], tiles_m, tile_rows).
+    w_format: plane format of the launch (plane_format()); backward launches pass PLANES_BF16X6."""
     assert x.is_contiguous() and w_ohwi.is_contiguous()
     g = conv_geometry(x, w_ohwi, stride, pad)
     y = torch.empty((g["N"], g["Ho"], g["Wo"], g["Cout"]), device=x.device, dtype=torch.float32)
@@ -109,9 +127,11 @@ def conv2d_nhwc(x, w_ohwi, stride, pad, *, in_scale=None, in_shift=None, in_cent
         assert side_out is None or (side_out.is_contiguous() and side_out.shape == x.shape)
         dual = dict(x2=x2, in2_scale=in2_scale, in2_shift=in2_shift, in2_center=in2_center,
                     side_out=side_out)
+    fmt = plane_format(w_format)
     L().conv2d_fwd(x, w_ohwi, y, g, in_scale=in_scale, in_shift=in_shift, in_center=in_center,
                    in_relu=int(in_relu), **dual, scale=scale, shift=shift, residual=residual, ldr=g["Cout"], act=act,
-                   stat_partial=partial, w_split=split_weights(w_ohwi), w_frag=pack_weights(w_ohwi))
+                   stat_partial=partial, w_split=split_weights(w_ohwi, fmt),
+                   w_frag=pack_weights(w_ohwi, fmt), w_format=fmt)
     return (y, stats) if want_stats else y
 
 
@@ -143,8 +163,9 @@ def conv2d_bn_sums(x, w_ohwi, stride, pad, acc, **pro):
         assert pro["x2"].is_contiguous() and pro["x2"].shape == x.shape
     if "in_relu" in pro:
         pro = dict(pro, in_relu=int(pro["in_relu"]))
-    lib.conv2d_fwd(x, w_ohwi, y, g, **pro, ldr=g["Cout"], w_split=split_weights(w_ohwi),
-                   w_frag=pack_weights(w_ohwi), bn=(acc, ws))
+    fmt = plane_format()
+    lib.conv2d_fwd(x, w_ohwi, y, g, **pro, ldr=g["Cout"], w_split=split_weights(w_ohwi, fmt),
+                   w_frag=pack_weights(w_ohwi, fmt), bn=(acc, ws), w_format=fmt)
     return y
 
 
@@ -385,32 +406,42 @@ def frames_s2d(fr, pad_lo, pad_hi, scale=None, shift=None):
     return y
 
 
-def stem7_pack_weights(w_ohwi):
-    """[Cout, 7, 7, 3] -> the B fragments vlnce_stem7_fwd reads: three exact bf16 planes (round to
-    nearest) of the filters laid out [Cout/32][11 k-slabs][3][64 lanes][8], k' = kh * 24 + kw * 3 + c."""
+def stem7_pack_weights(w_ohwi, fmt=None):
+    """[Cout, 7, 7, 3] -> the B fragments vlnce_stem7_fwd reads: the three 16-bit planes of format
+    `fmt` (include/vlnce_hip.h: 1 = exact bf16 split, 2 = fp16 {h * 2^11, (w - h) * 2^11, h}) of the
+    filters laid out [Cout/32][11 k-slabs][3][64 lanes][8], k' = kh * 24 + kw * 3 + c."""
+    fmt = plane_format(fmt)
     Cout = w_ohwi.size(0)
     assert tuple(w_ohwi.shape[1:]) == (7, 7, 3) and Cout % 32 == 0
     wk = torch.zeros((Cout, 7, 24), device=w_ohwi.device, dtype=torch.float32)
     wk[:, :, :21] = w_ohwi.detach().float().reshape(Cout, 7, 21)
     wk = F.pad(wk.reshape(Cout, 168), (0, 8))                      # [Cout, 176]
-    planes, r = [], wk
-    for _ in range(3):
-        hb = r.to(torch.bfloat16)
-        planes.append(hb)
-        r = r - hb.float()
+    if fmt == PLANES_F16X3:
+        h = wk.to(torch.float16)
+        lo = ((wk - h.float()) * 2048.0).to(torch.float16)
+        planes = [(h.float() * 2048.0).to(torch.float16).view(torch.int16), lo.view(torch.int16),
+                  h.view(torch.int16)]
+    else:
+        planes, r = [], wk
+        for _ in range(3):
+            hb = r.to(torch.bfloat16)
+            planes.append(hb.view(torch.int16))
+            r = r - hb.float()
     pl = torch.stack(planes, 0)                                    # [3, Cout, 176]
     # [3, nb, l31, ks, half, e] -> [nb, ks, 3, half, l31, e]  (lane = half * 32 + l31)
     frag = pl.view(3, Cout // 32, 32, 11, 2, 8).permute(1, 3, 0, 4, 2, 5).contiguous()
-    return frag.view(torch.int16)
+    frag._vlnce_fmt = fmt
+    return frag
 
 
 def stem7(fr, w_frag, Cout, in_scale=None, in_shift=None, *, scale=None, shift=None, act=ACT_NONE,
-          bn_acc=None):
+          bn_acc=None, w_format=None):
     """The 7x7 / stride-2 / pad-3 RGB stem in one launch from the frame descriptor
     (vlnce_stem7_fwd); raw output + BatchNorm column sums when bn_acc is given."""
     Ho, Wo = (fr["H"] - 1) // 2 + 1, (fr["W"] - 1) // 2 + 1
     y = torch.empty((fr["images"], Ho, Wo, Cout), device=fr["x"].device, dtype=torch.float32)
-    L().stem7_fwd(fr, in_scale, in_shift, w_frag, y, scale=scale, shift=shift, act=act, bn=bn_acc)
+    L().stem7_fwd(fr, in_scale, in_shift, w_frag, y, scale=scale, shift=shift, act=act, bn=bn_acc,
+                  w_format=w_format)
     return y
 
 
@@ -487,7 +518,7 @@ def _planes_eligible(x, M, K, N):
             and os.environ.get("VLNCE_LINEAR_PLANES", "1") != "0")
 
 
-def _planes_gemm(x, ldx, w, y, bias=None, act=ACT_NONE):
+def _planes_gemm(x, ldx, w, y, bias=None, act=ACT_NONE, w_format=None):
     """y[M,N] = act(x[M,K] w[N,K]^T + bias) through the convolution entry point (a 1x1 convolution
     over M pixels: the bf16-plane kernels, fp32-class arithmetic at 1.5-2.5x the fp32-MFMA GEMM's
     rate) when the product is large enough (>= 1024 rows and >= 1 GFLOP: rgb_kv of a 64-environment
@@ -503,8 +534,9 @@ def _planes_gemm(x, ldx, w, y, bias=None, act=ACT_NONE):
     g = dict(N=1, H=M // Wd, W=Wd, Cin=K, Cout=N, KH=1, KW=1, stride=1, pad=0, Ho=M // Wd, Wo=Wd,
              ldx=ldx, ldy=N)
     w4 = w.view(N, 1, 1, K)
-    L().conv2d_fwd(x, w4, y, g, shift=bias, ldr=N, act=act, w_split=split_weights(w4),
-                   w_frag=pack_weights(w4))
+    fmt = plane_format(w_format)
+    L().conv2d_fwd(x, w4, y, g, shift=bias, ldr=N, act=act, w_split=split_weights(w4, fmt),
+                   w_frag=pack_weights(w4, fmt), w_format=fmt)
     return True
 
 
@@ -571,7 +603,9 @@ class LinearFn(Function):
                 # dx[M,K] = dz[M,N] * W[N,K]   (B stored [K'=N, N'=K]); large: as dz (W^T)^T on the
                 # bf16-plane kernels (one transpose of the weights, made only when that path
                 # is taken -- ADVICE r4)
-                if not (_planes_eligible(dz, M, N, K) and _planes_gemm(dz, N, w.t().contiguous(), dx)):
+                # (a gradient operand: three bf16 planes, fp32's exponent range)
+                if not (_planes_eligible(dz, M, N, K)
+                        and _planes_gemm(dz, N, w.t().contiguous(), dx, w_format=PLANES_BF16X6)):
                     lib.gemm(dz, N, 0, w, K, 1, dx, K, M, K, N)
         if ctx.needs_input_grad[1]:
             dw = torch.empty((N, K), device=dz.device, dtype=torch.float32)
@@ -1124,7 +1158,10 @@ class RNNLayerFn(Function):
         dev = x_tm.device
         st = sb = 0
         if dseq is not None:
-            if dseq.dtype != torch.float32 or dseq.stride(2) != 1:
+            #  an EXPANDED upstream gradient -- seq.mean(dim=1), a broadcast add -- has a
+            # unit inner stride and a zero batch / time stride, which vlnce_rnn_seq_bwd2 rejects
+            if (dseq.dtype != torch.float32 or dseq.stride(2) != 1 or dseq.stride(0) <= 0
+                    or dseq.stride(1) <= 0):
                 dseq = _f32c(dseq)
             sb, st = dseq.stride(0), dseq.stride(1)
         dhf = [(_f32c(g) if g is not None else None) for g in dhf[:dirs]]

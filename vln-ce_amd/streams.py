@@ -316,8 +316,22 @@ class ActGraph:
         self.entries = OrderedDict()
         self._tracked = None  # (parameters + buffers, modules with a _graph_key): walked once
 
+    def _hooked(self):
+        """forward hooks on any module of the policy (DAgger's feature capture registers them on
+        `.net.rgb_encoder.cnn` / `.net.depth_encoder.visual_encoder`, dagger_trainer.py:300-314, and
+        reads `o.cpu()` inside): a hook runs when Python calls the module, i.e. once, at capture --
+        and a device-to-host copy inside a capture is an error.  With hooks the call stays eager."""
+        import torch.nn.modules.module as _m
+        if _m._global_forward_hooks or _m._global_forward_pre_hooks:
+            return True
+        mods = self.__dict__.get("_modules_list")
+        if mods is None:
+            mods = self._modules_list = list(self.policy.modules())
+        return any(m._forward_hooks or m._forward_pre_hooks for m in mods)
+
     def usable(self, observations, rnn_states):
         return (rnn_states.is_cuda and rnn_states.size(0) <= self.MAX_ENVS
+                and not self._hooked()
                 and not torch.is_grad_enabled() and not self.policy.training
                 and os.environ.get("VLNCE_ACT_GRAPH", "0") == "1"
                 and os.environ.get("VLNCE_HIP_GRAPHS", "1") != "0"
@@ -384,21 +398,40 @@ class DropsGraphsOnApply:
 
     _graph_holders = ("_graphs", "_tail", "_act_graph")
 
-    def _plist(self):
+    def _plist(self, checked=True):
         """the module's parameters as a list built once: the trunks' graph keys read every
         parameter's version on every call, and walking the module tree for that
         (`self.parameters()`: ~0.1 ms for a ResNet-50 trunk, twice per call) was host time at the
         very start of a step, with the GPU idle (profiles/r05_h_*).  The trunks' module structure
         is fixed after construction; _apply drops the list with the graphs."""
         pl = self.__dict__.get("_param_list")
+        if pl is not None and checked:   # (checked=False: the caller validated it in this call already)
+            # (ADVICE r5) a Parameter REBOUND behind the module's back -- load_state_dict(assign=True),
+            # `conv.weight = nn.Parameter(...)`, a child-only .to() under
+            # torch.__future__.set_overwrite_module_params_on_conversion -- leaves the list pointing at
+            # the old tensors: the graph keys would keep reading their versions and the graphs keep
+            # replaying on their storage.  One dict lookup per parameter (~10 us per trunk) instead of
+            # the module-tree walk.  (An in-place storage swap of a CHILD module, `trunk[4].to(...)`,
+            # keeps identity and version: move the policy as a whole, or call .to() on the trunk.)
+            for owner, name, par in self.__dict__["_param_slots"]:
+                if owner._parameters.get(name) is not par:
+                    pl = None
+                    self._drop_graphs()
+                    break
         if pl is None:
-            pl = list(self.parameters())
+            slots = [(m, n, p) for m in self.modules() for n, p in m._parameters.items() if p is not None]
+            seen, pl = set(), []
+            for _, _, p in slots:   # (order and de-duplication of nn.Module.parameters())
+                if id(p) not in seen:
+                    seen.add(id(p))
+                    pl.append(p)
+            object.__setattr__(self, "_param_slots", slots)
             object.__setattr__(self, "_param_list", pl)
         return pl
 
-    def _apply(self, fn, *args, **kwargs):
-        out = super()._apply(fn, *args, **kwargs)
+    def _drop_graphs(self):
         self.__dict__.pop("_param_list", None)
+        self.__dict__.pop("_param_slots", None)
         for name in self._graph_holders:
             holder = self.__dict__.get(name)
             if holder is not None:
@@ -407,6 +440,10 @@ class DropsGraphsOnApply:
                     holder.sightings.clear()
                 if hasattr(holder, "_tracked"):
                     holder._tracked = None
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        self._drop_graphs()
         return out
 
 
