@@ -124,19 +124,52 @@ class whole_host:
             os.sched_setaffinity(0, self.bound)
 
 
-def cpu_baseline_worker(num_envs, hw, L, threads):
+def cpu_baseline_worker(num_envs, hw, L, threads, which="cma"):
     """Runs in a child process: CPU oracle (port of the reference policy) timed on the host
     cores on a bounded sample of the bench workload.  `threads` is a comma list: each count
     gets 1 warm-up + 2 timed iterations and the best count is reported (oneDNN/OpenMP on a
-    many-core shared host is not monotone in the thread count)."""
+    many-core shared host is not monotone in the thread count).  which: cma | seq2seq (one
+    `_update_agent`) | waypoint (one WDDPPO minibatch update, encoders in eval mode)."""
     from oracle import policy_cpu as oc
     from oracle import thirdparty as tp
 
-    pol = oc.CMAPolicy.from_config(tp.make_config("CMAPolicy"), *tp.make_spaces(hw, hw))
-    opt = torch.optim.Adam(pol.parameters(), lr=2.5e-4)
     n = num_envs   # the bench workload itself (num_envs = 64): ~3-6 s per iteration on this host
-    obs, prev, masks, tgt, w = synth_batch(n, hw, L, "cpu")
     oc.AuxLosses.activate()
+    if which == "waypoint":
+        pol = oc.WaypointPolicy.from_config(tp.make_config("WaypointPolicy"),
+                                            *tp.make_spaces(hw, hw, pano=True))
+        pol.train()
+        pol.net.rgb_encoder.eval()
+        pol.net.depth_encoder.eval()
+        opt = torch.optim.Adam([q for q in pol.parameters() if q.requires_grad], lr=2.5e-4)
+        obs, prev, ex = synth_pano_batch(n, hw, L, "cpu")
+        masks = torch.ones(n, 1, dtype=torch.uint8)
+        h0 = torch.zeros(n, pol.net.num_recurrent_layers,
+                         pol.net.model_config.STATE_ENCODER.hidden_size)
+        torch.set_num_threads(int(str(threads).split(",")[0]))
+        with torch.no_grad():   # action components inside the truncated-normal supports
+            out = pol.act(obs, h0, {k: v.clone() for k, v in prev.items()}, masks, deterministic=True)
+        actions = {k: v.clone() for k, v in out[2].items()}
+        actions["pano"] = ex["pano_action"]
+        sample = (obs, h0, actions, prev, ex["value_preds"], ex["value_preds"] + 0.3, masks,
+                  torch.full((n, 1), -2.0), ex["adv"])
+
+        def one_update():
+            smp = list(sample)
+            smp[3] = {k: v.clone() for k, v in prev.items()}
+            oc.ppo_update(pol, opt, tuple(smp))
+        what = (f"WaypointPolicy WDDPPO minibatch update (oracle/policy_cpu.py), {n} envs x 13 "
+                f"frames {hw}x{hw} RGB-D, L={L}")
+    else:
+        name = "CMAPolicy" if which == "cma" else "Seq2SeqPolicy"
+        pol = getattr(oc, name).from_config(tp.make_config(name), *tp.make_spaces(hw, hw))
+        opt = torch.optim.Adam(pol.parameters(), lr=2.5e-4)
+        obs, prev, masks, tgt, w = synth_batch(n, hw, L, "cpu")
+
+        def one_update():
+            oc.il_update(pol, opt, obs, prev, masks, tgt, w, 512)
+        what = (f"{'CMA' if which == 'cma' else 'Seq2Seq'} fwd+bwd+Adam (oracle/policy_cpu.py), "
+                f"{n} envs x {hw}x{hw} RGB-D, L={L}")
     sweep = {}
     t_start = time.time()
     for th in [int(t) for t in str(threads).split(",")]:
@@ -149,7 +182,7 @@ def cpu_baseline_worker(num_envs, hw, L, threads):
         times = []
         for i in range(3):
             t0 = time.time()
-            oc.il_update(pol, opt, obs, prev, masks, tgt, w, 512)
+            one_update()
             dt = time.time() - t0
             log(f"cpu_baseline {th} threads iter {i}: {dt:.2f}s")
             if i > 0:
@@ -160,14 +193,14 @@ def cpu_baseline_worker(num_envs, hw, L, threads):
     print(json.dumps({
         "value": round(n / sweep[best_th], 2), "unit": "policy-steps/sec", "cores": best_th,
         "physical_cores": facts["physical_cores"], "kind": "port",
-        "sample": f"CMA fwd+bwd+Adam (oracle/policy_cpu.py), {n} envs x {hw}x{hw} RGB-D, L={L}, "
+        "sample": f"{what}, "
                   f"min of 2 iters after 1 warm-up, torch CPU fp32, best of thread counts "
                   f"{sorted(sweep)} = {best_th} threads",
         "host_cpu": facts,
         "steps_per_sec_by_threads": {str(k): round(n / v, 2) for k, v in sorted(sweep.items())}}))
 
 
-def cpu_baseline(num_envs, hw, L, timeout_s=150):
+def cpu_baseline(num_envs, hw, L, timeout_s=150, which="cma"):
     """Bounded: the child is killed after `timeout_s` (the default bench run must finish within
     minutes).  The child sweeps a few thread counts up to the host's physical cores and reports
     the best one as `cores`; the host's CPU model / socket / core counts ride along in
@@ -175,17 +208,17 @@ def cpu_baseline(num_envs, hw, L, timeout_s=150):
     import subprocess
 
     with whole_host():
-        return _cpu_baseline(num_envs, hw, L, timeout_s, subprocess)
+        return _cpu_baseline(num_envs, hw, L, timeout_s, subprocess, which)
 
 
-def _cpu_baseline(num_envs, hw, L, timeout_s, subprocess):
+def _cpu_baseline(num_envs, hw, L, timeout_s, subprocess, which="cma"):
     facts = host_cpu_facts()
     usable = facts["usable_logical_cpus"]
     phys = min(facts["physical_cores"] or usable, usable)
     counts = sorted({min(c, usable) for c in (32, 64, phys)})
     threads = max(counts)
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--num-envs",
-           str(num_envs), "--hw", str(hw), "--tokens", str(L), "--threads",
+           str(num_envs), "--hw", str(hw), "--tokens", str(L), "--policy", which, "--threads",
            ",".join(str(c) for c in counts)]
     env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads))
     try:
@@ -238,7 +271,7 @@ def pmc_traffic(n_conv):
     return rec.get("hbm_bytes_per_launch")
 
 
-def conv_kernel_time(policy, obs, dev, repeats=3):
+def conv_kernel_time(policy, obs, dev, repeats=3, trunk_pass=None):
     """GPU-paced duration of every convolution launch of the two visual trunks' forward
     (the 107 convolution launches of a step).
 
@@ -300,6 +333,9 @@ def conv_kernel_time(policy, obs, dev, repeats=3):
 
     def trunks():
         with torch.no_grad():
+            if trunk_pass is not None:   # (a policy whose encoders take something else than `obs`)
+                trunk_pass()
+                return
             policy.net.rgb_encoder.trunk_features(obs)
             policy.net.depth_encoder.trunk_features(obs)
 
@@ -558,16 +594,44 @@ def secondary_policy_bench(args, dev, rank, world, sim, use_dist, dev_sync):
         elapsed = tmax.item()
     log(f"timed region: {args.steps} steps in {elapsed:.3f}s; last step's read-backs {last}")
     roof = None
-    if rank == 0 and not sim and not way:
-        c = conv_kernel_time(policy, batches[0][0], dev)
+    if rank == 0 and not sim:
+        if way:   # the 12 panorama frames + the masked history frame, as _encode_frames hands them over
+            wobs, wmask = samples[0][0], samples[0][6].reshape(-1)
+
+            def way_trunks():
+                policy.net.rgb_encoder.trunk_features(
+                    {"rgb": (wobs["rgb"], wobs["rgb_history"], wmask)})
+                policy.net.depth_encoder.trunk_features(
+                    {"depth": (wobs["depth"], wobs["depth_history"], wmask)})
+            c = conv_kernel_time(policy, None, dev, trunk_pass=way_trunks)
+        else:
+            c = conv_kernel_time(policy, batches[0][0], dev)
         if c["reason"] is None:
-            roof = {"bound": "mfma", "kernel": "conv2d fwd launches of the visual trunks",
+            roof = {"schema": 3, "bound": "mfma",
+                    "kernel": "conv2d fwd launches of the visual trunks (the plane kernels: "
+                              f"{plane_products()} 16-bit MFMA products per fp32 multiply)",
                     "achieved": round(c["flop"] / (c["conv_ms"] * 1e-3) / 1e12, 2),
                     "peak": round(c["flop"] / (c["floor_ms"] * 1e-3) / 1e12, 2), "unit": "TFLOP/s",
                     "frac": round(c["floor_ms"] / c["conv_ms"], 4),
-                    "peak_is": "per-launch max(HBM, MFMA) floor, as in the headline line",
+                    "peak_is": "per-launch max(algorithmic bytes / 6.3 TB/s, instruction FLOPs / the "
+                               "pipe's peak) floor, as in the headline line; frac = floor_ms / "
+                               "kernel_ms_per_step",
+                    "floor_ms": round(c["floor_ms"], 3),
+                    "algorithmic_GFLOP": round(c["flop"] / 1e9, 1),
+                    "algorithmic_GB": round(c["bytes"] / 1e9, 3),
+                    "hbm_bound": {"launches": c["hbm_bound_n"], "ms": round(c["hbm_bound_ms"], 3),
+                                  "floor_ms": round(c["hbm_floor_ms"], 3)},
+                    "by_kernel": {{0: "fp32_mfma", 1: "planes_x3", 2: "planes_p3", 3: "planes_m3"}.get(k, str(k)):
+                                  {"launches": v["launches"], "ms": round(v["ms"], 3),
+                                   "tflops": round(v["flop"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] else None}
+                                  for k, v in c["by_path"].items()},
                     "launches_per_step": c["n"], "kernel_ms_per_step": round(c["conv_ms"], 3),
+                    "eager_single_stream_trunks_ms": round(c["eager_trunks_ms"], 3),
+                    "timing": "HIP events per launch behind a device-side backlog (GPU-paced), "
+                              "empty-pair cost subtracted, min of 3 passes",
                     "traffic": None}
+        else:
+            roof = {"schema": 3, "invalid_reason": c["reason"]}
     if rank == 0:
         ms = 1e3 * elapsed / args.steps
         line = {
@@ -589,6 +653,9 @@ def secondary_policy_bench(args, dev, rank, world, sim, use_dist, dev_sync):
             **exchange_fields(exchange)}
         if roof:
             line["roofline"] = roof
+        if world == 1 and not sim and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(n, hw, L, timeout_s=240 if way else 150,
+                                                which=args.policy)
         final = json.dumps(line)
     if use_dist:
         dist.destroy_process_group()
@@ -644,7 +711,7 @@ def main():
     if args.tokens is None:
         args.tokens = 200 if args.policy == "waypoint" else 80
     if args.cpu_baseline_only:
-        cpu_baseline_worker(args.num_envs, args.hw, args.tokens, args.threads)
+        cpu_baseline_worker(args.num_envs, args.hw, args.tokens, args.threads, args.policy)
         return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args.gpus))

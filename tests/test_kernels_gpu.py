@@ -1288,11 +1288,11 @@ def test_fp16_planes_range_and_gradient_sized_operands(hip):
     x = rnd(2, 16, 16, 64, seed=71).to(DEV)
     w = (rnd(64, 3, 3, 64, seed=72) * 0.04).to(DEV)
     ref = F.conv2d(x.double().permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2), padding=1)
-    ref = ref.permute(0, 2, 3, 1)
+    ref = ref.permute(0, 2, 3, 1).cpu()
     big = ops.conv2d_nhwc(x * 3.0e4, w, 1, 1, w_format=2)          # |x| up to ~1.2e5 > 65504
     assert not bool(torch.isfinite(big).all())
     ok = ops.conv2d_nhwc(x * 1.0e4, w, 1, 1, w_format=2)           # |x| up to ~4e4
-    close(ok, ref.float().to(DEV) * 1.0e4, 1e-5, what="large activations")
+    close(ok, ref.float() * 1.0e4, 1e-5, what="large activations")
     tiny2 = ops.conv2d_nhwc(x * 1.0e-7, w, 1, 1, w_format=2)
     tiny1 = ops.conv2d_nhwc(x * 1.0e-7, w, 1, 1, w_format=1)
     e2 = ((tiny2.double().cpu() - ref * 1e-7).abs().max() / (ref.abs().max() * 1e-7)).item()

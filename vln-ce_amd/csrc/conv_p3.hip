@@ -40,7 +40,20 @@ namespace {
 // bytes per patch row: Planes<MATH>::ROW (208 = 13 x 16 B / 144 = 9 x 16 B: consecutive rows are
 // conflict-free for ds_read_b128)
 constexpr int P3_PRODUCERS = 4;  // producer waves
-constexpr int P3_MAX_ROWS = 512;  // patch rows the KxK producers address: 16 row groups of 32 (4 items of 128)
+constexpr int U3_MAX_CIN = 4096;   // conv_u3_kernel: input channels whose prologue vectors fit its LDS
+// patch rows the KxK producers address: 12 row groups of 32 (3 items of 128), their byte offsets in
+// twelve registers.  (Round 6, measured and dropped: with the 144-byte rows of the fp16 planes the LDS
+// would hold 568 rows, i.e. 256-row tiles on 64x64 maps -- but 16 offsets in registers pushed the
+// workgroup's register allocation (the maximum over both roles) over the edge, the MATRIX waves'
+// k-loop reloaded two spilled values per 24 MFMAs behind an s_waitcnt vmcnt(0), and every 3x3
+// layer ran 1.5-2.7x slower: profiles/r6_06; the offsets in LDS instead, read back with one
+// ds_read_b128 per item, left 120 spilled registers: profiles/r6_07.)
+constexpr int P3_MAX_ROWS = 384;
+#ifndef P3_DENSE_VEC_GLOBAL   // (A/B switch: the KxK producers' prologue vectors as per-chunk global loads)
+#define P3_DENSE_VEC_LDS 1
+#else
+#define P3_DENSE_VEC_LDS 0
+#endif
 #ifndef P3_MPRIO
 #define P3_MPRIO 1   // s_setprio of the matrix waves
 #endif
@@ -101,6 +114,8 @@ __global__ __launch_bounds__((WM * WN + P3_PRODUCERS) * 64) void conv_p3_kernel(
   char* const bstage = xsm + 2 * pbuf;                         // [2][BST]
   int* const pfull = reinterpret_cast<int*>(bstage + 2 * BST);  // [2] producer waves done writing
   int* const pempty = pfull + 2;                               // [2] matrix waves done reading
+  // KxK form: the prologue vectors [3][Cin] behind the counters (conv_u3_kernel's arrangement)
+  float* const vlds = reinterpret_cast<float*>(pfull + 4);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -139,6 +154,14 @@ __global__ __launch_bounds__((WM * WN + P3_PRODUCERS) * 64) void conv_p3_kernel(
   };
 
   if (tid < 4) pfull[tid] = 0;
+  if constexpr (MODE == P3_DENSE && P3_DENSE_VEC_LDS) {
+    const bool pro = p.in_scale != nullptr;
+    for (int ch = tid; ch < p.Cin; ch += (MATRIX + P3_PRODUCERS) * 64) {
+      vlds[ch] = pro ? p.in_scale[ch] : 1.f;
+      vlds[p.Cin + ch] = pro ? p.in_shift[ch] : 0.f;
+      vlds[2 * p.Cin + ch] = (pro && p.in_center) ? p.in_center[ch] : 0.f;
+    }
+  }
   __syncthreads();
 
   if (wave >= MATRIX) {
@@ -359,8 +382,7 @@ __global__ __launch_bounds__((WM * WN + P3_PRODUCERS) * 64) void conv_p3_kernel(
       // (scalars and wave-uniform branches: a runtime-indexed array would live in scratch memory)
       int l_round = 0, l_c = 0, l_part = 0, l_nparts = 0;
       int r0 = 0, r1 = 0, r2 = 0, r3 = 0, r4 = 0, r5 = 0, r6 = 0, r7 = 0, r8 = 0, r9 = 0, r10 = 0,
-          r11 = 0, r12 = 0, r13 = 0, r14 = 0,
-          r15 = 0;   // byte offsets of this thread's rows in row groups 0..15 (p3_rows <= P3_MAX_ROWS = 512)
+          r11 = 0;   // byte offsets of this thread's rows in row groups 0..11 (p3_rows <= P3_MAX_ROWS)
       unsigned l_ok = 0;
       auto l_setup = [&](int round) {
         int m0, n0;
@@ -391,7 +413,6 @@ __global__ __launch_bounds__((WM * WN + P3_PRODUCERS) * 64) void conv_p3_kernel(
         next_row(0, r0); next_row(1, r1); next_row(2, r2); next_row(3, r3);
         next_row(4, r4); next_row(5, r5); next_row(6, r6); next_row(7, r7);
         next_row(8, r8); next_row(9, r9); next_row(10, r10); next_row(11, r11);
-        next_row(12, r12); next_row(13, r13); next_row(14, r14); next_row(15, r15);
       };
       auto load = [&](Staged& s) {
         const bool live = l_round < my_tiles;
@@ -403,10 +424,8 @@ __global__ __launch_bounds__((WM * WN + P3_PRODUCERS) * 64) void conv_p3_kernel(
           s.a[0] = P3_LD(r0); s.a[1] = P3_LD(r1); s.a[2] = P3_LD(r2); s.a[3] = P3_LD(r3);
         } else if (l_part == 1) {
           s.a[0] = P3_LD(r4); s.a[1] = P3_LD(r5); s.a[2] = P3_LD(r6); s.a[3] = P3_LD(r7);
-        } else if (l_part == 2) {
-          s.a[0] = P3_LD(r8); s.a[1] = P3_LD(r9); s.a[2] = P3_LD(r10); s.a[3] = P3_LD(r11);
         } else {
-          s.a[0] = P3_LD(r12); s.a[1] = P3_LD(r13); s.a[2] = P3_LD(r14); s.a[3] = P3_LD(r15);
+          s.a[0] = P3_LD(r8); s.a[1] = P3_LD(r9); s.a[2] = P3_LD(r10); s.a[3] = P3_LD(r11);
         }
 #undef P3_LD
         if (!live) return;
@@ -428,7 +447,14 @@ __global__ __launch_bounds__((WM * WN + P3_PRODUCERS) * 64) void conv_p3_kernel(
       auto stash = [&](const Staged& s) {
         char* const buf = xsm + (s_h & 1) * pbuf + lk4 * 2;
         if (s_part == 0) {
+#if P3_DENSE_VEC_LDS
+          const float* const vp = vlds + s_c * 32 + lk4;   // this chunk's vectors (LDS, staged once)
+          cur.s = *reinterpret_cast<const f32x4*>(vp);
+          cur.t = *reinterpret_cast<const f32x4*>(vp + p.Cin);
+          cur.c = *reinterpret_cast<const f32x4*>(vp + 2 * p.Cin);
+#else
           next_vec(s_c + 1);
+#endif
 #ifdef P3_DBG_TIME
           const long long d_a = clock64();
 #endif
@@ -465,7 +491,9 @@ __global__ __launch_bounds__((WM * WN + P3_PRODUCERS) * 64) void conv_p3_kernel(
       };
       l_setup(0);
       s_setup(0);
+#if !P3_DENSE_VEC_LDS
       load_vec(nxt, 0);
+#endif
       load(st[0]);
       while (s_round < my_tiles) {
 #ifdef P3_DBG_TIME
@@ -745,7 +773,13 @@ __global__ __launch_bounds__(WAVES * 64) void conv_u3_kernel(IgemmParams p) {
   constexpr bool ADB = WAVES == 4;               // A fragments double-buffered across the k-slabs
   static_assert(NPT >= 1 && MT >= 1 && (WAVES == 8 || WAVES == 4), "tile");
   constexpr int PBUF = BM * P3_ROW;
-  extern __shared__ __attribute__((aligned(16))) char xsm[];  // [2][PBUF]
+  extern __shared__ __attribute__((aligned(16))) char xsm[];  // [2][PBUF] + prologue vectors [NV][Cin]
+  // The prologue vectors (scale / shift / centre per input channel, twice for a skip path with its
+  // own BatchNorm) live in LDS for the whole launch (round 6).  As per-chunk global loads into a
+  // `cur` / `nxt` register pair they cost 24-48 VGPRs (the 128-row instances spilled) and sat in
+  // the wave's one in-order vmcnt queue between the raw-row and B-fragment prefetches.
+  constexpr int NV = DUAL == 2 ? 6 : 3;
+  float* const vlds = reinterpret_cast<float*>(xsm + 2 * PBUF);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -789,25 +823,19 @@ __global__ __launch_bounds__(WAVES * 64) void conv_u3_kernel(IgemmParams p) {
   constexpr bool linear = LINEAR != 0;
 
   // ---------------------------------------------------------------- the A side (every thread)
-  struct Vec {
-    f32x4 s, t, c, s2, t2, c2;
-  };
-  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f}, one4 = {1.f, 1.f, 1.f, 1.f};
-  Vec cur = {one4, zero4, zero4, one4, zero4, zero4}, nxt = cur;
-  auto load_vec = [&](Vec& v, int ci) {
-    if (has_pro) {
-      v.s = ldg4(p.in_scale + ci + lk4);
-      v.t = ldg4(p.in_shift + ci + lk4);
-      if (p.in_center) v.c = ldg4(p.in_center + ci + lk4);
-      if constexpr (DUAL) {
-        if constexpr (DUAL == 2) {
-          v.s2 = ldg4(p.in2_scale + ci + lk4);
-          v.t2 = ldg4(p.in2_shift + ci + lk4);
-          if (p.in2_center) v.c2 = ldg4(p.in2_center + ci + lk4);
-        }
-      }
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  for (int ch = tid; ch < p.Cin; ch += WAVES * 64) {   // neutral vectors where there is no prologue
+    vlds[ch] = has_pro ? p.in_scale[ch] : 1.f;
+    const float t1 = has_pro ? p.in_shift[ch] : 0.f;
+    vlds[p.Cin + ch] = t1;
+    vlds[2 * p.Cin + ch] = (has_pro && p.in_center) ? p.in_center[ch] : 0.f;
+    if constexpr (DUAL == 2) {
+      vlds[3 * p.Cin + ch] = p.in2_scale[ch];
+      vlds[4 * p.Cin + ch] = t1 + p.in2_shift[ch];   // both shifts in one add
+      vlds[5 * p.Cin + ch] = p.in2_center ? p.in2_center[ch] : 0.f;
     }
-  };
+  }
+  __syncthreads();
   struct Raw {
     f32x4 a[NPT];
     f32x4 a2[DUAL ? NPT : 1];
@@ -865,16 +893,19 @@ __global__ __launch_bounds__(WAVES * 64) void conv_u3_kernel(IgemmParams p) {
   // in the single-input form (neutral vectors where the convolution has no prologue: x*1+0 and
   // max(x, -inf) are exact), so that it shares ONE basic block with the MFMAs of the chunk and
   // the scheduler can interleave the two.
-  // `cur` = the vectors of the chunk being transformed; step_vec() after it: cur <- nxt, and nxt <-
-  // the vectors of the chunk after that (their loads have a whole chunk to land)
-  auto step_vec = [&](int ci_after_next) {
-    cur = nxt;
-    if constexpr (DUAL) {
-      if constexpr (DUAL == 2) cur.t2 = cur.t + cur.t2;
-    }
-    load_vec(nxt, ci_after_next);
-  };
   auto transform = [&](const Raw& r, char* buf) {
+    struct {
+      f32x4 s, t, c, s2, t2, c2;
+    } cur;
+    const float* const vp = vlds + r.ci + lk4;
+    cur.s = *reinterpret_cast<const f32x4*>(vp);
+    cur.t = *reinterpret_cast<const f32x4*>(vp + p.Cin);
+    cur.c = *reinterpret_cast<const f32x4*>(vp + 2 * p.Cin);
+    if constexpr (DUAL == 2) {
+      cur.s2 = *reinterpret_cast<const f32x4*>(vp + 3 * p.Cin);
+      cur.t2 = *reinterpret_cast<const f32x4*>(vp + 4 * p.Cin);
+      cur.c2 = *reinterpret_cast<const f32x4*>(vp + 5 * p.Cin);
+    }
 #pragma unroll
     for (int i = 0; i < NPT; ++i) {
       f32x4 v = r.a[i];
@@ -967,7 +998,6 @@ __global__ __launch_bounds__(WAVES * 64) void conv_u3_kernel(IgemmParams p) {
   // when chunk k is transformed
   Raw rx, ry;
   setup_tile(0);
-  load_vec(nxt, 0);
   load_raw(rx);   // chunk 0
   advance_raw();
   load_raw(ry);   // chunk 1
@@ -984,9 +1014,7 @@ __global__ __launch_bounds__(WAVES * 64) void conv_u3_kernel(IgemmParams p) {
     vb_of(n1, vbn);
   }
   loadB(b0, vb, 0);
-  step_vec(NC > 1 ? 32 : 0);      // cur = chunk 0's vectors, nxt <- chunk 1's
   transform(rx, xsm);
-  step_vec(NC > 2 ? 64 : (2 % NC) * 32);   // cur = chunk 1's, nxt <- chunk 2's
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 #pragma unroll
@@ -1080,7 +1108,6 @@ __global__ __launch_bounds__(WAVES * 64) void conv_u3_kernel(IgemmParams p) {
     d_blk += d_1 - d_0;
 #endif
     advance_raw();
-    step_vec(((g + 3) % NC) * 32);   // cur <- chunk g+2's vectors, nxt <- chunk g+3's
     ks3 += 6144;
 #ifdef P3_DBG_TIME
     const long long d_2 = clock64();
@@ -1170,12 +1197,14 @@ __global__ __launch_bounds__(WAVES * 64) void conv_u3_kernel(IgemmParams p) {
 
 template <int BM, int DUAL, int WAVES, int LINEAR, int MATH>
 int launch_u3_(const IgemmParams& p, hipStream_t stream) {
-  constexpr int smem_bytes = 2 * BM * Planes<MATH>::ROW;
+  constexpr int NV = DUAL == 2 ? 6 : 3;   // prologue vectors kept in LDS
+  const int smem_bytes = 2 * BM * Planes<MATH>::ROW + NV * p.Cin * 4;
+  constexpr int smem_max = 2 * BM * Planes<MATH>::ROW + NV * U3_MAX_CIN * 4;
   auto kern = conv_u3_kernel<BM, DUAL, WAVES, LINEAR, MATH>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, smem_max);
     if (e != hipSuccess) {
       vlnce_set_error("conv_u3: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
       return 2;
@@ -1519,7 +1548,8 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
 template <int BM, int BN, int WM, int WN, int DUAL, int MODE, int MATH>
 int launch_p3(const IgemmParams& p, int rows_alloc, hipStream_t stream) {
   // two patch buffers (+ two B stages for the 1x1 form) + 4 counters
-  const int smem_bytes = 2 * rows_alloc * Planes<MATH>::ROW + (MODE == P3_GATHER ? 2 * BN * 192 : 0) + 16;
+  const int smem_bytes = 2 * rows_alloc * Planes<MATH>::ROW +
+                         (MODE == P3_GATHER ? 2 * BN * 192 : 3 * p.Cin * 4) + 16;
   constexpr int threads = (WM * WN + P3_PRODUCERS) * 64;
   auto kern = conv_p3_kernel<BM, BN, WM, WN, DUAL, MODE, MATH>;
   static int attr_bytes = 0;  // per instantiation: the largest dynamic LDS size enabled so far
@@ -1627,7 +1657,7 @@ int p3_try_launch_(const IgemmParams& p, hipStream_t stream) {
   }
   const int u3_env = vlnce_opt(VLNCE_OPT_U3);
   const int u3_waves = vlnce_opt(VLNCE_OPT_U3_WAVES);
-  if (!dense && u3_env && p.N >= 256) {
+  if (!dense && u3_env && p.N >= 256 && p.Cin <= U3_MAX_CIN) {
     const int cus = x3_cus();
     auto eff = [&](int bm) {
       const long tiles = (long)ceil_div(p.M, bm) * ceil_div(p.N, 256);
@@ -1667,10 +1697,9 @@ int p3_try_launch_(const IgemmParams& p, hipStream_t stream) {
     const P3Tile& c = cand[ci];
     if (forced ? ci != force - 1 : c.bn > bn) continue;  // (narrower tiles only to fill the CUs)
     const int rows = p3_rows_for(p, c.bm, dense);
-    if (2L * rows * P3_ROW + (dense ? 0 : 2L * c.bn * 192) + 16 > x3_lds_max()) continue;
-    // (with the 144-byte rows of MATH_F16X3 the LDS would hold 568 rows: the producers' 16 row
-    // groups are the bound there)
-    if (dense && rows > P3_MAX_ROWS) continue;
+    if (2L * rows * P3_ROW + (dense ? 3L * p.Cin * 4 : 2L * c.bn * 192) + 16 > x3_lds_max())
+      continue;
+    if (dense && rows > P3_MAX_ROWS) continue;   // (the producers' twelve row groups)
     const long tiles = (long)ceil_div(p.M, c.bm) * ceil_div(p.N, c.bn);
     const long rounds = (tiles + cus - 1) / cus;
     const double eff = (double)tiles / (double)(rounds * cus);
