@@ -53,6 +53,14 @@ CONV_GFLOP_PER_ENV = 10.677 + 0.699  # RGB ResNet-50 + depth ResNet-50 trunks (c
 STEM_GFLOP_PER_ENV = 0.308 + 0.051   # 7x7/s2 stems at 256x256 (3->64 and 1->32 channels)
 
 
+# Set by a TEST driver only (tests/bench_on_cpu_simulator.py): the library binding it has put behind
+# the package, named in the JSON line's `data` field.  With it the ranks run on the CPU over gloo:
+# the launcher, the rank set-up, the sharded update through GradientAllReducer and the
+# max-over-ranks timing are this file's real code, nothing is measured (value = None, no roofline).
+# The product harness itself imports nothing from tests/.
+SIMULATED_BACKEND = None
+
+
 def plane_products():
     """16-bit MFMA products the plane kernels issue per fp32 multiply: 3 in plane format 2 (fp16
     planes, the default), 6 in format 1 (three bf16 planes; VLNCE_CONV_MATH=bf16)"""
@@ -253,12 +261,12 @@ def f32_mfma_compare(args):
 
 def pmc_traffic(n_conv):
     """HBM bytes per conv launch from the committed rocprofv3 PMC passes of this same
-    workload (profiles/r05_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate
+    workload (profiles/r06_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate
     passes of `bench.py --pmc-step`, gfx950 corrections applied as MI355X_MICROARCH.md
     prescribes).  None when the file is absent or was taken for a different launch count."""
     prof = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
     rec = None
-    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json"):   # newest first
+    for name in ("r06_pmc_traffic.json", "r05_pmc_traffic.json"):   # newest first
         try:
             rec = json.load(open(os.path.join(prof, name)))
             break
@@ -459,7 +467,7 @@ def self_launch(n):
         port = sock.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
            "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.abspath(__file__)] + sys.argv[1:]
+           os.path.abspath(sys.argv[0])] + sys.argv[1:]   # (this file, or the test driver around it)
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this driver (RCCL)
     env.setdefault("OMP_NUM_THREADS", "8")
@@ -640,7 +648,7 @@ def secondary_policy_bench(args, dev, rank, world, sim, use_dist, dev_sync):
             "unit": "policy-steps/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32",
-            "data": ("hostsim: CPU simulator of the C ABI (tests/hostsim.py) over gloo -- a test of "
+            "data": (f"{SIMULATED_BACKEND} over gloo -- a test of "
                      "the launcher and the rank logic, NOT a measurement") if sim else "synthetic",
             "config": {"workload": (
                 f"WaypointPolicy WDDPPO minibatch update (evaluate_actions + losses + backward + "
@@ -700,11 +708,6 @@ def main():
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise RCCL and run the gradient all-reducer even with one rank "
                          "(exercises the N>1 code path on a 1-GPU box)")
-    # tests only (tests/test_bench_launcher.py): the bench's HOST logic -- self-launch, rank
-    # set-up, sharded update with the gradient all-reducer, max-over-ranks timing, the one JSON
-    # line -- on CPU through tests/hostsim.py over gloo; the line it prints says so and carries
-    # no roofline.  Never a measurement.
-    ap.add_argument("--hostsim", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.num_envs is None:
         args.num_envs = 64 if args.policy == "cma" else 32
@@ -721,13 +724,8 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", 0))
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE={world}")
-    sim = args.hostsim
+    sim = SIMULATED_BACKEND is not None
     if sim:
-        sys.path.insert(0, os.path.join(REPO, "tests"))
-        import hostsim
-        from vlnce_amd import _lib as _l
-
-        _l._LIB = hostsim.HostSim()
         dev = torch.device("cpu")
     else:
         if torch.cuda.device_count() <= local:
@@ -897,7 +895,7 @@ def main():
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
                 "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-                "data": "hostsim: CPU simulator of the C ABI (tests/hostsim.py) over gloo -- a test "
+                "data": f"{SIMULATED_BACKEND} over gloo -- a test "
                         "of the launcher and the rank logic, NOT a measurement",
                 "config": {"workload": "launcher self-test", "global_batch": args.num_envs * world,
                            "parallelism": f"dp{world}"}, **exchange_fields(exchange)}), flush=True)

@@ -17,8 +17,8 @@ for c in FETCH_SIZE WRITE_SIZE; do
   python scripts/rocpd_pmc.py "$(find $O/pmc_$c -name '*.db' | head -1)" > $O/pmc_$c.txt 2>&1
   rm -rf $O/pmc_$c
 done
-python scripts/pmc_traffic_json.py $O/pmc_FETCH_SIZE.txt $O/pmc_WRITE_SIZE.txt profiles/r04_pmc_traffic.json "profiles/r04_zz_pmc_fetch_size.txt, r04_zz_pmc_write_size.txt" | cut -c1-200
-cp profiles/r04_pmc_traffic.json $O/r04_pmc_traffic.json
+python scripts/pmc_traffic_json.py $O/pmc_FETCH_SIZE.txt $O/pmc_WRITE_SIZE.txt profiles/archive/r04_pmc_traffic.json "profiles/archive/r04_zz_pmc_fetch_size.txt, r04_zz_pmc_write_size.txt" | cut -c1-200
+cp profiles/archive/r04_pmc_traffic.json $O/r04_pmc_traffic.json
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace -d $O/kt -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-f32-compare > $O/kt.log 2>&1
 cd $GRAFT_REPO_ROOT

@@ -5,7 +5,7 @@ CUs: GPU event stamps, graph replay, num_envs 64.
 
 Needs a library build with the (since removed) dispatch option "cus" -- the persistent kernels'
 grid size for a masked stream; kept for the record of the experiment
-(profiles/r04_zr_cu_masked_streams_trunks_on_disjoint_cus.txt: the RGB trunk alone takes 8.0 ms on
+(profiles/archive/r04_zr_cu_masked_streams_trunks_on_disjoint_cus.txt: the RGB trunk alone takes 8.0 ms on
 224 CUs and 11.0 ms on 240 against 6.0 ms on all 256 -- a masked queue does not place one
 workgroup per CU --, so partitioning the CUs between the trunks loses to sharing them, 6.7 ms).
 """

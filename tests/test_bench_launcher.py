@@ -1,9 +1,10 @@
 """`python bench.py --gpus N` must start its N ranks itself when no launcher set WORLD_SIZE
 (the driver's multi-GPU command is the N=1 command with the number changed), keep working under
 torch.distributed.run, and print exactly ONE JSON line on stdout from rank 0 with n_gpus = N.
-Run here on CPU: bench.py's hidden --hostsim mode puts tests/hostsim.py behind the package and
-gloo behind torch.distributed, so the launcher, the rank set-up, the sharded update through
-GradientAllReducer and the max-over-ranks timing are the real code; nothing is measured."""
+Run here on CPU through tests/bench_on_cpu_simulator.py, which puts tests/hostsim.py behind the
+package and gloo behind torch.distributed and then calls bench.main(): the launcher, the rank
+set-up, the sharded update through GradientAllReducer and the max-over-ranks timing are bench.py's
+real code; nothing is measured.  (bench.py itself imports nothing from tests/.)"""
 import json
 import os
 import socket
@@ -12,7 +13,8 @@ import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ARGS = ["--steps", "2", "--warmup", "1", "--num-envs", "2", "--hw", "64", "--tokens", "7",
-        "--hostsim", "--no-cpu-baseline", "--no-f32-compare"]
+        "--no-cpu-baseline", "--no-f32-compare"]
+DRIVER = os.path.join(REPO, "tests", "bench_on_cpu_simulator.py")
 
 
 def _clean_env():
@@ -39,7 +41,7 @@ def _one_json_line(stdout, n):
 
 
 def test_bench_gpus_2_launches_its_own_ranks():
-    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2"] + ARGS,
+    r = subprocess.run([sys.executable, DRIVER, "--gpus", "2"] + ARGS,
                        env=_clean_env(), capture_output=True, text=True, timeout=600, cwd=REPO)
     assert r.returncode == 0, r.stderr[-3000:]
     _one_json_line(r.stdout, 2)
@@ -52,7 +54,7 @@ def test_bench_gpus_2_under_torch_distributed_run():
         port = s.getsockname()[1]
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
                         "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
-                        str(port), os.path.join(REPO, "bench.py"), "--gpus", "2"] + ARGS,
+                        str(port), DRIVER, "--gpus", "2"] + ARGS,
                        env=_clean_env(), capture_output=True, text=True, timeout=600, cwd=REPO)
     assert r.returncode == 0, r.stderr[-3000:]
     _one_json_line(r.stdout, 2)
@@ -61,7 +63,7 @@ def test_bench_gpus_2_under_torch_distributed_run():
 
 def test_bench_rejects_a_world_size_that_disagrees_with_gpus():
     env = dict(_clean_env(), WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
-    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "4"] + ARGS,
+    r = subprocess.run([sys.executable, DRIVER, "--gpus", "4"] + ARGS,
                        env=env, capture_output=True, text=True, timeout=120, cwd=REPO)
     assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stderr + r.stdout)
 
@@ -73,7 +75,7 @@ def test_bench_policy_waypoint_and_seq2seq_run_data_parallel():
     `--gpus 2` like the headline and print the same one line."""
     for pol, workload in (("waypoint", "WaypointPolicy WDDPPO minibatch update"),
                           ("seq2seq", "Seq2Seq policy DAgger update")):
-        r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--policy", pol]
+        r = subprocess.run([sys.executable, DRIVER, "--gpus", "2", "--policy", pol]
                            + ARGS, env=_clean_env(), capture_output=True, text=True, timeout=900, cwd=REPO)
         assert r.returncode == 0, r.stderr[-3000:]
         d = _one_json_line(r.stdout, 2)

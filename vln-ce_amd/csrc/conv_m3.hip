@@ -6,7 +6,7 @@
 // through a software pipeline (LDS patch, producer / matrix hand-over): right when a launch is tens
 // of tiles per CU, 10-30 us of fixed latency when it is one tile or less -- the whole reduction of
 // a tile is then ONE serial K loop (a 3x3 over 128 channels at 8 x 8: 36 chunks back to back on
-// 128 of the 256 CUs, 29 us for 1.2 GFLOP; profiles/r04_zn_depth_trunk_convbench_*).  Here:
+// 128 of the 256 CUs, 29 us for 1.2 GFLOP; profiles/archive/r04_zn_depth_trunk_convbench_*).  Here:
 //   * no LDS staging and no hand-over: lane (row l31, k-half) of a wave fetches the 8 consecutive
 //     channels of its A fragment row straight from global memory (32 B), applies the pending
 //     normalisation, splits them into the three bf16 planes in registers -- that IS the
@@ -320,7 +320,7 @@ int m3_try_launch(const IgemmParams& p, hipStream_t stream) {
   // at most ~4 M outputs and 2.5 GFLOP (every layer of the depth trunk at num_envs 64, every layer
   // of a step at a few environments); not the longest reductions (K > 4608: every 32-row tile
   // re-reads its columns' whole weight set from L2, 1.8 MB per tile at K = 9216).  Measured per
-  // layer in profiles/r04_zp_*.
+  // layer in profiles/archive/r04_zp_*.
   if (mode == 1) {
     const double flop = 2.0 * p.M * (double)p.N * p.K;
     if ((long)p.M * p.N > 4L * 1024 * 1024 + 1 || flop > 2.6e9 || p.K > 4608) return -1;

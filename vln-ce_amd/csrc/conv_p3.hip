@@ -47,7 +47,12 @@ constexpr int U3_MAX_CIN = 4096;   // conv_u3_kernel: input channels whose prolo
 // workgroup's register allocation (the maximum over both roles) over the edge, the MATRIX waves'
 // k-loop reloaded two spilled values per 24 MFMAs behind an s_waitcnt vmcnt(0), and every 3x3
 // layer ran 1.5-2.7x slower: profiles/r6_06; the offsets in LDS instead, read back with one
-// ds_read_b128 per item, left 120 spilled registers: profiles/r6_07.)
+// ds_read_b128 per item, left 120 spilled registers: profiles/r6_07; sixteen offsets only in the
+// instantiations whose matrix waves hold <= 2 accumulator blocks made exactly those instantiations
+// 1.9-2.1x slower -- l1 3x3 100 -> 207 us, ResNet-18's 64-channel 3x3 at 416 frames 683 -> 1335 us --
+// and left the others alone: profiles/r06_f_*.  The 64-channel 3x3 layers on 64x64 maps therefore
+// stay on 128x64 tiles (one accumulator block per wave), 185-195 TF/s against 300-330 TF/s for the
+// 128- to 512-channel layers.)
 constexpr int P3_MAX_ROWS = 384;
 #ifndef P3_DENSE_VEC_GLOBAL   // (A/B switch: the KxK producers' prologue vectors as per-chunk global loads)
 #define P3_DENSE_VEC_LDS 1

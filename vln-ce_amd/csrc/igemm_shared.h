@@ -249,7 +249,7 @@ __device__ __forceinline__ void wave_bn_tile(const f32x16 (&acc)[MT][NT], WaveBn
 // exchanges returned: +12 us per launch, as much as the separate finalize launch it removed;
 // with a __threadfence() in front of the ticket +40 us: buffer_wbl2 / buffer_inv by every wave
 // behind a kernel that has just written up to 268 MB).  The convolution only ADDS; a one-workgroup
-// kernel behind it turns the sums into the vectors: profiles/r04_y_*.)
+// kernel behind it turns the sums into the vectors: profiles/archive/r04_y_*.)
 
 // Register epilogue of the bf16-plane kernels for a wave's MT x NT blocks of 32 x 32 outputs:
 // y = act(acc * scale[col] + shift[col] [+ residual[row, col]]), one store = 2 rows x 32 columns.

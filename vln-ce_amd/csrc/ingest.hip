@@ -237,7 +237,7 @@ struct Stem7Params {
 // WAVES: waves of a workgroup = 32-pixel groups x channel blocks.  With 231 registers a CU holds 8
 // waves either way; as TWO workgroups of 4 waves their phases (patch build / matrix
 // instructions / output stores, which a workgroup runs one after the other: 79 + 100 + 77 us of
-// the 258 us launch at num_envs 64, profiles/r04_zh_*) drift apart and overlap.
+// the 258 us launch at num_envs 64, profiles/archive/r04_zh_*) drift apart and overlap.
 template <int NB, int WAVES, int MATH>   // NB = Cout / 32 (1 or 2); MATH: Planes<> of igemm_shared.h
 __global__ __launch_bounds__(WAVES * 64, 8 / WAVES) void stem7_kernel(Stem7Params p) {
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -72,7 +72,7 @@ def encode_three_branches(net, observations, device, distinct_instructions=False
         # 0.2 ms AFTER the RGB trunk (profiles/r05_d_*; 9.71 -> 9.57 ms/step with its own stream,
         # r05_g_depth_trunk_stream_and_order.txt; issuing it before the RGB trunk delays that
         # one by as much as it gains).  GPU event stamps, not the tracer, are the evidence for
-        # overlap on this runtime (profiles/r04_d_overlap_probe2_event_stamps.txt).
+        # overlap on this runtime (profiles/archive/r04_d_overlap_probe2_event_stamps.txt).
         rgb = net.rgb_encoder(observations)
         ins, join_ins = branches.run(fork, 0, device, instruction)
         dep, join_dep = branches.run(fork, 2, device, lambda: net.depth_encoder(observations))

@@ -38,7 +38,7 @@ class CategoricalNet(nn.Module):
         # (argument validation is a host sync: not inside a graph capture, streams.ActGraph)
         logits, nans = ops.action_head(x, self.linear.weight, self.linear.bias, count_nans=validate)
         # The validation's host read-back stays where the reference has it.  Measured
-        # (profiles/r04_i_sync_probe.txt, r04_j_*): WITHOUT it a training step is 1.3-1.7 ms SLOWER
+        # (profiles/archive/r04_i_sync_probe.txt, r04_j_*): WITHOUT it a training step is 1.3-1.7 ms SLOWER
         # -- the host then enqueues loss / backward / Adam while the trunks are still running, and
         # the forward phase takes 9.7 instead of 8.1 ms on the GPU's own clock (launches arriving
         # on the queue of a running graph slow its kernel-to-kernel dispatch).
