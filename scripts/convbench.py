@@ -97,6 +97,10 @@ def main():
                     help="issue each timed round behind a spin kernel: GPU-paced times for launches "
                          "shorter than the host's issue cost")
     ap.add_argument("--opt", default="", help="dispatch options, e.g. u3=2,s3=0 (vlnce_set_option)")
+    ap.add_argument("--rotate", type=int, default=1,
+                    help="R copies of the layer's input (and second input / block output) used in "
+                         "rotation: with R x the input bytes beyond the 256 MB Infinity Cache every "
+                         "launch reads its operands from HBM, as inside a trunk (the weights stay hot)")
     args = ap.parse_args()
     for kv in filter(None, args.opt.split(",")):
         k_, v_ = kv.split("=")
@@ -129,6 +133,9 @@ def main():
         if cin == 3:
             kw.update(in_scale=torch.full((3,), 1 / 255.0, device=dev),
                       in_shift=torch.zeros(3, device=dev))
+        xs = [x] + [x.clone() for _ in range(args.rotate - 1)]
+        kws = [kw] + [dict(kw, **{k_: v_.clone() for k_, v_ in kw.items() if k_ in ("x2", "side_out")})
+                      for _ in range(args.rotate - 1)]
         for _ in range(3):
             ops.conv2d_nhwc(x, w, s, pad, **kw)
         us = 1e30
@@ -137,8 +144,8 @@ def main():
             if args.backlog:
                 torch.cuda._sleep(int(4e7))
             e0.record()
-            for _ in range(args.iters):
-                ops.conv2d_nhwc(x, w, s, pad, **kw)
+            for it_ in range(args.iters):
+                ops.conv2d_nhwc(xs[it_ % args.rotate], w, s, pad, **kws[it_ % args.rotate])
             e1.record()
             torch.cuda.synchronize()
             us = min(us, e0.elapsed_time(e1) * 1e3 / args.iters)

@@ -1300,6 +1300,32 @@ def test_fp16_planes_range_and_gradient_sized_operands(hip):
     assert e1 < 1e-5 and e2 > 10 * e1, (e1, e2)
 
 
+def test_frozen_weights_outside_the_fp16_range_fall_back_to_bf16_planes(hip):
+    """A frozen filter bank with |w| >= 16 (format 2 holds |w| < 32) is pinned to format 1 by the
+    encoder's weight cache (ops.check_weight_range: one read-back per parameter version) instead of
+    overflowing: the convolution stays finite and right."""
+    import torch.nn as nn
+    from vlnce_amd.encoders.resnet_encoders import _WeightCache
+
+    conv = nn.Conv2d(64, 64, 3, padding=1, bias=False).to(DEV)
+    conv.weight.requires_grad_(False)
+    conv.weight.data.mul_(0.3)
+    conv.weight.data[5, 7, 1, 1] = 40.0
+    cache = _WeightCache()
+    w = cache.conv(conv)
+    assert w._vlnce_force_fmt == ops.PLANES_BF16X6 and ops.plane_format(None, w) == 1
+    x = rnd(2, 12, 12, 64, seed=81).to(DEV)
+    y = ops.conv2d_nhwc(x, w, 1, 1)
+    ref = F.conv2d(x.permute(0, 3, 1, 2), conv.weight, padding=1).permute(0, 2, 3, 1)
+    assert bool(torch.isfinite(y).all())
+    close(y, ref, 1e-5, what="large frozen weight")
+    assert not bool(torch.isfinite(ops.conv2d_nhwc(x, w, 1, 1, w_format=2)).all())   # what it avoids
+    with torch.no_grad():
+        conv.weight[5, 7, 1, 1] = 0.4   # (in place on the parameter: version bump, the cache repacks)
+    w2 = cache.conv(conv)
+    assert w2 is not w and w2._vlnce_force_fmt is None and ops.plane_format(None, w2) == 2
+
+
 def test_options_are_explicit_state(hip):
     """vlnce_set_option / vlnce_get_option / vlnce_option_default: set, read back, restore; an
     unknown name is an error (the library reads no environment variable)."""

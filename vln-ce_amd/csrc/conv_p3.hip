@@ -757,6 +757,10 @@ __global__ __launch_bounds__((WM * WN + P3_PRODUCERS) * 64) void conv_p3_kernel(
 // of the rows of K-chunk g + 1 (BatchNorm + ReLU prologue, block end, three-way bf16 split) into
 // the other patch buffer.  One raw s_barrier per K-chunk (48 MFMAs per wave) swaps the buffers;
 // raw A rows are fetched two chunks ahead into registers, B fragments one k-slab ahead.
+// (Round 6, measured and dropped: a ring of three / four raw-row sets -- inside a trunk the rows come
+// from HBM, not from the Infinity Cache scripts/convbench.py keeps them in (--rotate: 1024 -> 256 block
+// end 48 us cache-hot, 69 us from HBM) -- is 5-19 % SLOWER on the 128-row single-input form, cache-hot
+// and from HBM alike, and changes nothing on the 64-row forms: profiles/r06_i_*.)
 // WAVES = 8: two waves per SIMD, 256 registers each, a wave owns BM x 32 outputs;
 // WAVES = 4: ONE wave per SIMD with the whole 512-register file, a wave owns BM x 64 outputs and
 // double-buffers its A fragments (no partner wave to hide LDS latency behind).

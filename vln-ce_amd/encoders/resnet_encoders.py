@@ -48,6 +48,8 @@ class _WeightCache:
         hit = self._packed.get(id(conv))
         if hit is None or hit[0] != k:
             w = conv.weight.detach().permute(0, 2, 3, 1).contiguous()
+            if not conv.weight.requires_grad:   # a frozen bank outside the fp16 planes' range -> bf16 planes
+                ops.check_weight_range(w)
             hit = (k, w)
             self._packed[id(conv)] = hit
         return hit[1]
@@ -64,7 +66,7 @@ class _WeightCache:
     def stem7(self, conv):
         """the 7x7 stem filters as the B fragments of vlnce_stem7_fwd (ops.stem7_pack_weights) in
         the launch's plane format; returns (fragments, format)"""
-        fmt = ops.plane_format()
+        fmt = ops.plane_format(None, self.conv(conv))
         k = self._key(conv.weight) + (fmt,)
         hit = self._packed.get(("stem7", id(conv)))
         if hit is None or hit[0] != k:

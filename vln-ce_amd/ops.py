@@ -39,11 +39,29 @@ def _rows2d(t):
 PLANES_BF16X6, PLANES_F16X3 = 1, 2   # plane formats of include/vlnce_hip.h (vlnce_prologue.w_format)
 
 
-def plane_format(w_format=None):
+def plane_format(w_format=None, w=None):
     """the plane format of a launch: the caller's (backward launches pass PLANES_BF16X6: gradients
-    live below fp16's normal range) or the effective "conv_math" option (default 2 = fp16 planes,
-    three plane products per multiply)."""
-    return int(w_format) if w_format else L().plane_format()
+    live below fp16's normal range), else the one the weight tensor itself demands (`check_weight_range`
+    found a value outside format 2's range), else the effective "conv_math" option (default 2 = fp16
+    planes, three plane products per multiply)."""
+    if w_format:
+        return int(w_format)
+    forced = getattr(w, "_vlnce_force_fmt", None) if w is not None else None
+    return forced or L().plane_format()
+
+
+F16_PLANES_MAX_WEIGHT = 16.0   # format 2 holds |w| < 32 (b1 * 2^11 in fp16); a factor of two in hand
+
+
+def check_weight_range(w_ohwi):
+    """For FROZEN weights (one host read-back per parameter version, in the eager first pass, never
+    inside a capture): a filter bank with a value beyond format 2's range is pinned to format 1
+    (three bf16 planes: fp32's exponent range) instead of producing inf / NaN.  Trainable weights
+    change every step and are not checked (their overflow shows as NaN in the loss)."""
+    if w_ohwi.is_cuda and not torch.cuda.is_current_stream_capturing():
+        w_ohwi._vlnce_force_fmt = (PLANES_BF16X6 if float(w_ohwi.abs().max()) >= F16_PLANES_MAX_WEIGHT
+                                   else None)
+    return w_ohwi
 
 
 def split_weights(w_ohwi, fmt=None):
@@ -127,7 +145,7 @@ def conv2d_nhwc(x, w_ohwi, stride, pad, *, in_scale=None, in_shift=None, in_cent
         assert side_out is None or (side_out.is_contiguous() and side_out.shape == x.shape)
         dual = dict(x2=x2, in2_scale=in2_scale, in2_shift=in2_shift, in2_center=in2_center,
                     side_out=side_out)
-    fmt = plane_format(w_format)
+    fmt = plane_format(w_format, w_ohwi)
     L().conv2d_fwd(x, w_ohwi, y, g, in_scale=in_scale, in_shift=in_shift, in_center=in_center,
                    in_relu=int(in_relu), **dual, scale=scale, shift=shift, residual=residual, ldr=g["Cout"], act=act,
                    stat_partial=partial, w_split=split_weights(w_ohwi, fmt),
@@ -163,7 +181,7 @@ def conv2d_bn_sums(x, w_ohwi, stride, pad, acc, **pro):
         assert pro["x2"].is_contiguous() and pro["x2"].shape == x.shape
     if "in_relu" in pro:
         pro = dict(pro, in_relu=int(pro["in_relu"]))
-    fmt = plane_format()
+    fmt = plane_format(None, w_ohwi)
     lib.conv2d_fwd(x, w_ohwi, y, g, **pro, ldr=g["Cout"], w_split=split_weights(w_ohwi, fmt),
                    w_frag=pack_weights(w_ohwi, fmt), bn=(acc, ws), w_format=fmt)
     return y
