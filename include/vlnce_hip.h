@@ -56,7 +56,9 @@ const char* vlnce_last_error(void);
  *   "igemm_tile"       0        igemm_kernel: 0 rule, 1 128x128, 2 128x64, 3 64x64
  *   "igemm_nobuf"      0        1: no buffer-descriptor operand loads
  *   "igemm_no_splitk"  0        1: no split-K
- *   "wgrad_tile"       64       64 or 128 (vlnce_conv2d_wgrad)
+ *   "wgrad_tile"       64       vlnce_conv2d_wgrad: 1 = the fp32-MFMA kernel everywhere (64x64 tiles; A/B against the
+ *                               bf16-plane kernel that takes Cin % 32 == 0, Cout % 32 == 0 layers otherwise), 64 / 128 =
+ *                               tile of the fp32-MFMA kernel where that one runs
  *   "rollout_one_xcd"  0        1: all workgroups of vlnce_gru_rollout_* on one XCD
  *   "m3"               1        conv_m3_kernel (small launches): 0 off, 1 default rule, 2 / 3 every layer it covers
  * Set options between launches, not concurrently with them (relaxed atomics).  Unknown names
@@ -387,7 +389,10 @@ int vlnce_adaptive_avgpool(const float* x, float* y, int N, int H, int W, int C,
  * (only reached with MODEL.RGB_ENCODER / DEPTH_ENCODER .trainable = True; the reference
  * default keeps both encoders frozen).  Data gradients of stride-1 convolutions reuse
  * vlnce_conv2d_fwd with the flipped / transposed weights. */
-/* dW[Cout,KH,KW,Cin] = sum_m dY[m,co] * im2col(X)[m,(r,q,ci)]   (split-K over output pixels) */
+/* dW[Cout,KH,KW,Cin] = sum_m dY[m,co] * im2col(X)[m,(r,q,ci)]   (split over output pixels, fp32 atomics
+ * into dW, which the call zeroes itself).  Cin % 32 == 0 and Cout % 32 == 0: six bf16-plane products
+ * per multiply on the 16-bit matrix pipe (plane format 1: the operands are gradients); else, and with
+ * option "wgrad_tile" = 1, v_mfma_f32_32x32x2_f32. */
 int vlnce_conv2d_wgrad(const float* x, const float* dy, float* dw_ohwi, const vlnce_conv_desc* d,
                        vlnce_stream_t stream);
 /* BatchNorm2d backward through y = act(x*gamma*rstd + (beta - mean*gamma*rstd) (+ residual)):

@@ -796,6 +796,13 @@ WGRAD_CASES = [
     ("ragged",     3,  7,  9,  36,  48, 3, 1, 1),
     ("deep",       4,  8,  8, 512, 512, 3, 1, 1),
     ("many_rows", 16, 32, 32,  64,  64, 3, 1, 1),     # split-K over 16384 pixels
+    # round 6: wgrad_x6_kernel (three bf16 planes; Cin % 32 == 0, Cout % 32 == 0, >= 256 pixels)
+    ("depth_32",   3, 16, 16,  32,  32, 3, 1, 1),     # a 64-row tile half empty
+    ("wide_k",     2, 16, 16, 256,  64, 3, 1, 1),     # K = 2304: 18 column tiles
+    ("cout_160",   2, 16, 16,  64, 160, 1, 1, 0),     # 128-row tiles, the second one partial
+    ("ragged_m",   3, 13, 11,  64,  96, 3, 2, 1),     # 126 pixels... below the kernel's 256: fp32 kernel
+    ("ragged_m2",  5, 13, 11,  64,  96, 3, 1, 1),     # 715 pixels: last chunk partial
+    ("k_32",       2, 16, 16,  32, 128, 1, 1, 0),     # K = 32: a quarter of a column tile
 ]
 
 
@@ -807,6 +814,14 @@ def test_conv2d_wgrad(hip, case):
     t = dict(x=x, dy=rnd(N, g["Ho"], g["Wo"], Cout, seed=2), dw=torch.zeros(Cout, k, k, Cin))
     cpu, gpu = both("conv2d_wgrad", t, dict(g=g))
     close(gpu["dw"], cpu["dw"], what="wgrad/" + name)
+    # gradient-sized operands (1e-7: far below fp16's range -- the planes are bf16) and the fp32-MFMA
+    # kernel behind option "wgrad_tile" = 1 agree with the same reference
+    t2 = dict(t, dy=t["dy"] * 1e-7, dw=torch.zeros_like(t["dw"]))
+    cpu2, gpu2 = both("conv2d_wgrad", t2, dict(g=g))
+    close(gpu2["dw"], cpu2["dw"], what="wgrad/" + name + "/1e-7")
+    with hip.options(wgrad_tile=1):
+        cpu3, gpu3 = both("conv2d_wgrad", dict(t, dw=torch.zeros_like(t["dw"])), dict(g=g))
+    close(gpu3["dw"], cpu3["dw"], what="wgrad/" + name + "/fp32-MFMA")
 
 
 @pytest.mark.parametrize("stride,k,pad", [(1, 3, 1), (2, 3, 1), (2, 1, 0), (1, 1, 0), (2, 7, 3)])

@@ -1810,6 +1810,11 @@ extern "C" int vlnce_conv2d_wgrad(const float* x, const float* dy, float* dw_ohw
   VLNCE_CHECK_ARG(aligned16(dy) && aligned16(x) && aligned16(dw_ohwi),
                   "conv2d_wgrad: operands must be 16-byte aligned");
   fill_epilogue(p, nullptr);
+  // round 6: three bf16 planes on the 16-bit pipe (wgrad_x6_kernel) where it covers the layer;
+  // option "wgrad_tile" = 1 keeps every layer on the fp32-MFMA kernel below (A/B)
+  if (vlnce_opt(VLNCE_OPT_WGRAD_TILE) != 1)
+    if (const int rc = wgrad_x6_try_launch(x, dy, dw_ohwi, d, reinterpret_cast<hipStream_t>(stream)); rc >= 0)
+      return rc;
   // option "wgrad_tile" = 128: 128x128 tiles where both output dimensions allow.  Measured slower on
   // the trainable-encoder step (46.7 vs 45.0 ms, profiles/archive/r03_g_*): fewer workgroups per
   // split-K slice, and the transposed-operand LDS writes do not get cheaper.  Default 64.

@@ -443,5 +443,8 @@ static inline int conv_math() { return vlnce_opt(VLNCE_OPT_CONV_MATH) != 0; }
 // one it covers (the caller falls through to conv_x3_kernel / igemm_kernel), else a C-ABI status.
 int p3_try_launch(const IgemmParams& p, hipStream_t stream);
 int m3_try_launch(const IgemmParams& p, hipStream_t stream);   // conv_m3.hip
+// wgrad_x6.hip: the weight gradient on the 16-bit pipe (three bf16 planes); -1 = not covered
+int wgrad_x6_try_launch(const float* x, const float* dy, float* dw, const vlnce_conv_desc* d,
+                        hipStream_t stream);
 
 }  // namespace vlnce_detail
