@@ -30,7 +30,7 @@ typedef void* vlnce_stream_t;
 
 enum { VLNCE_ACT_NONE = 0, VLNCE_ACT_RELU = 1, VLNCE_ACT_SIGMOID = 2, VLNCE_ACT_TANH = 3 };
 
-int vlnce_version(void); /* major*100 + minor; 142 = this header */
+int vlnce_version(void); /* major*100 + minor; 143 = this header */
 int vlnce_option_count(void);              /* length of vlnce_prologue.options                        */
 int vlnce_option_index(const char* name);  /* index of a named dispatch option in it, -1 if unknown   */
 const char* vlnce_last_error(void);
@@ -398,11 +398,14 @@ int vlnce_conv2d_wgrad(const float* x, const float* dy, float* dw_ohwi, const vl
 /* BatchNorm2d backward through y = act(x*gamma*rstd + (beta - mean*gamma*rstd) (+ residual)):
  * g = dy*[y>0] when relu; dbeta = sum g; dgamma = sum g*xhat;
  * dx = gamma*rstd*(g - dbeta/M - xhat*dgamma/M) with batch statistics, gamma*rstd*g with
- * running statistics (use_batch_stats = 0).  dres (may be NULL) receives g. */
+ * running statistics (use_batch_stats = 0).  dres (may be NULL) receives g.  workspace (ABI 143):
+ * vlnce_bn_bwd_workspace_floats(M, C) floats -- the per-block partial sums of the two reductions
+ * (no same-address atomics); 0 floats / may be NULL when C % 4 != 0. */
+size_t vlnce_bn_bwd_workspace_floats(long M, int C);
 int vlnce_bn_bwd(const float* dy, const float* y, const float* x, const float* mean,
                  const float* rstd, const float* gamma, long M, int C, int relu,
                  int use_batch_stats, float* dx, float* dres, float* dgamma, float* dbeta,
-                 vlnce_stream_t stream);
+                 float* workspace, vlnce_stream_t stream);
 /* GroupNorm backward (same conventions; mean/rstd are [N,groups]); workspace from
  * vlnce_gn_bwd_workspace_floats() floats. */
 size_t vlnce_gn_bwd_workspace_floats(int Nimg, int HW, int C, int groups);

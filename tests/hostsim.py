@@ -564,8 +564,11 @@ class HostSim:
                                          stride=g["stride"], padding=g["pad"])
         dw.view(Cout, g["KH"], g["KW"], Cin).copy_(gw.permute(0, 2, 3, 1))
 
+    def bn_bwd_workspace_floats(self, M, Cc):
+        return 1
+
     def bn_bwd(self, dy, y, x, mean, rstd, gamma, M, Cc, relu, use_batch_stats, dx, dres, dgamma,
-               dbeta):
+               dbeta, workspace=None):
         g = dy.reshape(M, Cc)
         if relu:
             g = g * (y.reshape(M, Cc) > 0)

@@ -843,7 +843,8 @@ def test_conv_backward_matches_autograd(hip, stride, k, pad):
     close(dw, wr.grad, what="wgrad")
 
 
-@pytest.mark.parametrize("M,Cc", [(512, 64), (1031, 48), (70000, 256), (9, 512), (300, 5)])
+@pytest.mark.parametrize("M,Cc", [(512, 64), (1031, 48), (70000, 256), (9, 512), (300, 5), (4099, 2048),
+                                  (100003, 64), (37, 4), (2000, 1028)])
 @pytest.mark.parametrize("relu,batch,res", [(1, 1, 1), (1, 1, 0), (0, 0, 1), (0, 1, 0)])
 def test_bn_bwd(hip, M, Cc, relu, batch, res):
     x = rnd(M, Cc, seed=1) * 2 + 0.5
@@ -855,7 +856,8 @@ def test_bn_bwd(hip, M, Cc, relu, batch, res):
         y = torch.relu(y)
     t = dict(dy=rnd(M, Cc, seed=4), y=y, x=x, mean=mean, rstd=rstd, gamma=gamma,
              dx=torch.zeros(M, Cc), dres=torch.zeros(M, Cc) if res else None,
-             dgamma=torch.zeros(Cc), dbeta=torch.zeros(Cc))
+             dgamma=torch.zeros(Cc), dbeta=torch.zeros(Cc),
+             workspace=torch.zeros(max(_lib.get_lib().bn_bwd_workspace_floats(M, Cc), 1)))
     cpu, gpu = both("bn_bwd", t, dict(M=M, Cc=Cc, relu=relu, use_batch_stats=batch))
     for k in ("dx", "dgamma", "dbeta") + (("dres",) if res else ()):
         close(gpu[k], cpu[k], 2e-4, what=f"bn_bwd/{k}")
@@ -872,14 +874,16 @@ def test_bn_bwd_matches_autograd(hip):
     mean, rstd = x.mean(0), torch.rsqrt(x.var(0, unbiased=False) + 1e-5)
     dx, dg, db = torch.zeros(M, Cc, device=DEV), torch.zeros(Cc, device=DEV), torch.zeros(Cc, device=DEV)
     hip.bn_bwd(dy.to(DEV), y.detach().to(DEV), x.to(DEV), mean.to(DEV), rstd.to(DEV),
-               gamma.to(DEV), M, Cc, 1, 1, dx, None, dg, db)
+               gamma.to(DEV), M, Cc, 1, 1, dx, None, dg, db,
+               torch.empty(hip.bn_bwd_workspace_floats(M, Cc), device=DEV))
     close(dx, xr.grad, 2e-4, what="bn dx")
     close(dg, gr.grad, 2e-4, what="bn dgamma")
     close(db, br.grad, 2e-4, what="bn dbeta")
 
 
 @pytest.mark.parametrize("N,HW,Cc,groups", [(3, 64, 32, 16), (2, 1024, 64, 32), (5, 16, 256, 128),
-                                            (2, 49, 128, 1), (1, 4096, 32, 16)])
+                                            (2, 49, 128, 1), (1, 4096, 32, 16), (3, 1061, 512, 16),
+                                            (2, 300, 1024, 512), (2, 130, 6, 3)])
 @pytest.mark.parametrize("relu,res", [(1, 1), (0, 0)])
 def test_gn_bwd(hip, N, HW, Cc, groups, relu, res):
     x = rnd(N, HW, Cc, seed=1) * 2 + 0.3

@@ -121,7 +121,8 @@ _SIGNATURES = {
     "vlnce_mean_rows": (_I, [_P, _P, _I, _I, _I, _P]),
     "vlnce_mask_rows": (_I, [_P, _P, _P, _I, _I, _P]),
     "vlnce_conv2d_wgrad": (_I, [_P, _P, _P, C.POINTER(ConvDesc), _P]),
-    "vlnce_bn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P, _P, _P, _P, _P]),
+    "vlnce_bn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
+    "vlnce_bn_bwd_workspace_floats": (C.c_size_t, [_L, _I]),
     "vlnce_gn_bwd_workspace_floats": (C.c_size_t, [_I, _I, _I, _I]),
     "vlnce_gn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "vlnce_maxpool3x3s2_argmax": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
@@ -221,7 +222,7 @@ class HipLib:
 
     name = "hip"
 
-    ABI = 142  # include/vlnce_hip.h
+    ABI = 143  # include/vlnce_hip.h
 
     def __init__(self, path=LIB_PATH):
         self.dll = load_cdll(path)
@@ -649,12 +650,15 @@ class HipLib:
         self._check(self.dll.vlnce_conv2d_wgrad(_ptr(x), _ptr(dy), _ptr(dw), C.byref(d), _stream()),
                     "vlnce_conv2d_wgrad")
 
+    def bn_bwd_workspace_floats(self, M, Cc):
+        return int(self.dll.vlnce_bn_bwd_workspace_floats(M, Cc))
+
     def bn_bwd(self, dy, y, x, mean, rstd, gamma, M, Cc, relu, use_batch_stats, dx, dres, dgamma,
-               dbeta):
+               dbeta, workspace=None):
         self._check(self.dll.vlnce_bn_bwd(_ptr(dy), _ptr(y), _ptr(x), _ptr(mean), _ptr(rstd),
                                           _ptr(gamma), M, Cc, int(relu), int(use_batch_stats),
                                           _ptr(dx), _ptr(dres), _ptr(dgamma), _ptr(dbeta),
-                                          _stream()), "vlnce_bn_bwd")
+                                          _ptr(workspace), _stream()), "vlnce_bn_bwd")
 
     def gn_bwd_workspace_floats(self, Nimg, HW, Cc, groups):
         return int(self.dll.vlnce_gn_bwd_workspace_floats(Nimg, HW, Cc, groups))

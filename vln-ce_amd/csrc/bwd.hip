@@ -1,7 +1,12 @@
 // Backward kernels of the normalisation / pooling layers of the visual trunks (needed only
-// when MODEL.*_ENCODER.trainable=True).  All HBM-bound: float4 channel vectors, per-block
-// partial reductions combined with one atomic per (block, channel).
+// when MODEL.*_ENCODER.trainable=True).  All HBM-bound.  Channel counts that are a multiple of
+// four take the *4 kernels: a thread owns FOUR consecutive channels (one 16-byte request per
+// tensor and row) of a column strip of up to 64 quads and walks rows, so the per-channel vectors
+// are loaded once per thread; the 256/strip row lanes of a block are combined through LDS and
+// one atomic per (block, channel).  Other channel counts keep the scalar kernels.
 #include "common.h"
+#include <cstdint>
+#include <initializer_list>
 
 namespace {
 
@@ -66,6 +71,166 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     float v = g;
     if (use_batch_stats) v = g - dbeta[c] * invM - (x[i] - mean[c]) * rs * dgamma[c] * invM;
     dx[i] = k * v;
+  }
+}
+
+// ---- strip indexing shared by the *4 kernels: quads per strip = 2^qwl (<= 64), lanes = 256 >> qwl
+inline bool aligned16(std::initializer_list<const void*> ps) {
+  uintptr_t bits = 0;
+  for (const void* q : ps) bits |= reinterpret_cast<uintptr_t>(q);
+  return (bits & 15) == 0;
+}
+inline int strip_log2(int cq) {
+  int l = 0;
+  while ((1 << l) < cq && l < 6) ++l;
+  return l;
+}
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float4 relu_mask(float4 g, float4 y) {
+  return make_float4(y.x > 0.f ? g.x : 0.f, y.y > 0.f ? g.y : 0.f, y.z > 0.f ? g.z : 0.f,
+                     y.w > 0.f ? g.w : 0.f);
+}
+
+__global__ __launch_bounds__(256) void zero2_kernel(float* __restrict__ a, float* __restrict__ b,
+                                                    int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) a[i] = 0.f, b[i] = 0.f;
+}
+
+// combine the row lanes of a block: acc[8] = {sum g (4 channels), sum g*xhat (4 channels)}
+__device__ __forceinline__ void strip_reduce(float (&acc)[8], float (*red)[9], int qwl, int ql,
+                                             int lane_row) {
+  const int lanes = 256 >> qwl;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[threadIdx.x][j] = acc[j];
+  __syncthreads();
+  if (lane_row == 0) {
+    for (int l = 1; l < lanes; ++l)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += red[(l << qwl) + ql][j];
+  }
+}
+
+template <int RELU>
+__global__ __launch_bounds__(256) void bn_bwd_reduce4_kernel(
+    const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ x,
+    const float* __restrict__ mean, const float* __restrict__ rstd, long M, int C, int qwl,
+    int rows_per_block, float* __restrict__ partial /* [slices][2][C] */) {
+  __shared__ float red[256][9];
+  const int ql = threadIdx.x & ((1 << qwl) - 1), rl = threadIdx.x >> qwl, lanes = 256 >> qwl;
+  const int c = ((blockIdx.x << qwl) + ql) * 4;
+  const long m0 = (long)blockIdx.y * rows_per_block;
+  const long m1 = m0 + rows_per_block < M ? m0 + rows_per_block : M;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (c < C) {
+    const float4 mu = ld4(mean + c);
+    auto one = [&](float4 g, float4 yv, float4 xv) {
+      if (RELU) g = relu_mask(g, yv);
+      acc[0] += g.x, acc[1] += g.y, acc[2] += g.z, acc[3] += g.w;
+      acc[4] += g.x * (xv.x - mu.x), acc[5] += g.y * (xv.y - mu.y);
+      acc[6] += g.z * (xv.z - mu.z), acc[7] += g.w * (xv.w - mu.w);
+    };
+    long m = m0 + rl;
+    const long step = (long)lanes * C;
+    const float *pd = dy + m * C + c, *px = x + m * C + c, *py = RELU ? y + m * C + c : nullptr;
+    for (; m + 3L * lanes < m1; m += 4L * lanes) {  // four independent rows in flight
+      float4 g[4], xv[4], yv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        g[u] = ld4(pd + u * step);
+        xv[u] = ld4(px + u * step);
+        yv[u] = RELU ? ld4(py + u * step) : g[u];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) one(g[u], yv[u], xv[u]);
+      pd += 4 * step, px += 4 * step;
+      if (RELU) py += 4 * step;
+    }
+    for (; m < m1; m += lanes) {
+      one(ld4(pd), RELU ? ld4(py) : make_float4(0, 0, 0, 0), ld4(px));
+      pd += step, px += step;
+      if (RELU) py += step;
+    }
+    const float4 rs = ld4(rstd + c);  // xhat = (x - mean) * rstd: the factor once per thread
+    acc[4] *= rs.x, acc[5] *= rs.y, acc[6] *= rs.z, acc[7] *= rs.w;
+  }
+  strip_reduce(acc, red, qwl, ql, rl);
+  if (rl == 0 && c < C) {
+    float* out = partial + (long)blockIdx.y * 2 * C + c;
+    st4(out, make_float4(acc[0], acc[1], acc[2], acc[3]));
+    st4(out + C, make_float4(acc[4], acc[5], acc[6], acc[7]));
+  }
+}
+
+// dbeta | dgamma = column sums of partial[slices][2C].  Same-address atomics from ~2000 blocks were
+// the whole cost of the small layers (~40 ns each, serial: 65 us for a 50 MB layer), hence partials
+// and this pass: one wave per four columns, lane = slice, then a wave sum.
+__global__ __launch_bounds__(256) void bn_bwd_finalize4_kernel(const float* __restrict__ partial,
+                                                               int slices, int C,
+                                                               float* __restrict__ dgamma,
+                                                               float* __restrict__ dbeta) {
+  const int col = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4, lane = threadIdx.x & 63;
+  if (col >= 2 * C) return;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int sl = lane; sl < slices; sl += 64) {
+    const float4 v = ld4(partial + (long)sl * 2 * C + col);
+    a.x += v.x, a.y += v.y, a.z += v.z, a.w += v.w;
+  }
+  a.x = wave_sum(a.x), a.y = wave_sum(a.y), a.z = wave_sum(a.z), a.w = wave_sum(a.w);
+  if (lane == 0) st4(col < C ? dbeta + col : dgamma + (col - C), a);
+}
+
+template <int RELU, int BATCH, int RES>
+__global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(
+    const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ x,
+    const float* __restrict__ mean, const float* __restrict__ rstd,
+    const float* __restrict__ gamma, const float* __restrict__ dgamma,
+    const float* __restrict__ dbeta, long M, int C, int qwl, int rows_per_block,
+    float* __restrict__ dx, float* __restrict__ dres) {
+  const int ql = threadIdx.x & ((1 << qwl) - 1), rl = threadIdx.x >> qwl, lanes = 256 >> qwl;
+  const int c = ((blockIdx.x << qwl) + ql) * 4;
+  if (c >= C) return;
+  const long m0 = (long)blockIdx.y * rows_per_block;
+  const long m1 = m0 + rows_per_block < M ? m0 + rows_per_block : M;
+  const float invM = 1.f / (float)M;
+  const float4 rs = ld4(rstd + c);
+  const float4 ga = gamma ? ld4(gamma + c) : make_float4(1.f, 1.f, 1.f, 1.f);
+  const float4 k = make_float4(ga.x * rs.x, ga.y * rs.y, ga.z * rs.z, ga.w * rs.w);
+  float4 a = make_float4(0, 0, 0, 0), b = a, mu = a;
+  if (BATCH) {
+    const float4 db = ld4(dbeta + c), dg = ld4(dgamma + c);
+    mu = ld4(mean + c);
+    a = make_float4(db.x * invM, db.y * invM, db.z * invM, db.w * invM);
+    b = make_float4(rs.x * dg.x * invM, rs.y * dg.y * invM, rs.z * dg.z * invM, rs.w * dg.w * invM);
+  }
+  auto one = [&](float4 g, float4 yv, float4 xv, long off) {
+    if (RELU) g = relu_mask(g, yv);
+    if (RES) st4(dres + off, g);
+    float4 v = g;
+    if (BATCH)
+      v = make_float4(g.x - a.x - (xv.x - mu.x) * b.x, g.y - a.y - (xv.y - mu.y) * b.y,
+                      g.z - a.z - (xv.z - mu.z) * b.z, g.w - a.w - (xv.w - mu.w) * b.w);
+    st4(dx + off, make_float4(k.x * v.x, k.y * v.y, k.z * v.z, k.w * v.w));
+  };
+  long m = m0 + rl;
+  const long step = (long)lanes * C;
+  long off = m * C + c;
+  for (; m + 3L * lanes < m1; m += 4L * lanes, off += 4 * step) {
+    float4 g[4], xv[4], yv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      g[u] = ld4(dy + off + u * step);
+      xv[u] = BATCH ? ld4(x + off + u * step) : g[u];
+      yv[u] = RELU ? ld4(y + off + u * step) : g[u];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) one(g[u], yv[u], xv[u], off + u * step);
+  }
+  for (; m < m1; m += lanes, off += step) {
+    const float4 g = ld4(dy + off);
+    one(g, RELU ? ld4(y + off) : g, BATCH ? ld4(x + off) : g, off);
   }
 }
 
@@ -152,6 +317,102 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(
     const float rs = rstd[sg];
     const float xh = (x[i] - mean[sg]) * rs;
     dx[i] = rs * (g * (gamma ? gamma[c] : 1.f) - s12[sg * 2] * inv - xh * s12[sg * 2 + 1] * inv);
+  }
+}
+
+// the *4 forms of the two kernels above: thread = 4 channels x one pixel lane
+template <int RELU>
+__global__ __launch_bounds__(256) void gn_bwd_partial4_kernel(
+    const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ x,
+    const float* __restrict__ mean, const float* __restrict__ rstd, int HW, int C, int groups,
+    int chunks, int qwl, float* __restrict__ partial) {
+  __shared__ float red[256][9];
+  const int ql = threadIdx.x & ((1 << qwl) - 1), pl = threadIdx.x >> qwl, lanes = 256 >> qwl;
+  const int n = blockIdx.x / chunks;
+  const int ch = blockIdx.x - n * chunks;
+  const int p0 = ch * GN_CHUNK;
+  const int p1 = min(HW, p0 + GN_CHUNK);
+  const int c = ((blockIdx.y << qwl) + ql) * 4;
+  const int cpg = C / groups;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (c < C) {
+    float mu[4], rs[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      mu[j] = mean[n * groups + (c + j) / cpg];
+      rs[j] = rstd[n * groups + (c + j) / cpg];
+    }
+    const long base = (long)n * HW * C + c;
+    for (int p = p0 + pl; p < p1; p += lanes) {
+      const long i = base + (long)p * C;
+      float4 g = ld4(dy + i);
+      if (RELU) g = relu_mask(g, ld4(y + i));
+      const float4 xv = ld4(x + i);
+      acc[0] += g.x, acc[1] += g.y, acc[2] += g.z, acc[3] += g.w;
+      acc[4] += g.x * (xv.x - mu[0]), acc[5] += g.y * (xv.y - mu[1]);
+      acc[6] += g.z * (xv.z - mu[2]), acc[7] += g.w * (xv.w - mu[3]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[4 + j] *= rs[j];
+  }
+  strip_reduce(acc, red, qwl, ql, pl);
+  if (pl == 0 && c < C) {
+    float* out = partial + (((long)n * chunks + ch) * C + c) * 2;
+    st4(out, make_float4(acc[0], acc[4], acc[1], acc[5]));
+    st4(out + 4, make_float4(acc[2], acc[6], acc[3], acc[7]));
+  }
+}
+
+template <int RELU, int RES>
+__global__ __launch_bounds__(256) void gn_bwd_apply4_kernel(
+    const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ x,
+    const float* __restrict__ mean, const float* __restrict__ rstd,
+    const float* __restrict__ gamma, const float* __restrict__ s12, int HW, int C, int groups,
+    int qwl, int pix_per_block, float* __restrict__ dx, float* __restrict__ dres) {
+  const int ql = threadIdx.x & ((1 << qwl) - 1), pl = threadIdx.x >> qwl, lanes = 256 >> qwl;
+  const int c = ((blockIdx.x << qwl) + ql) * 4;
+  if (c >= C) return;
+  const int n = blockIdx.z;
+  const int cpg = C / groups;
+  const float inv = 1.f / ((float)HW * (float)cpg);
+  float mu[4], rs[4], kg[4], a[4], b[4];  // dx = rs*gamma*g - rs*s1*inv - (x-mu) * rs*rs*s2*inv
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const long sg = (long)n * groups + (c + j) / cpg;
+    mu[j] = mean[sg];
+    rs[j] = rstd[sg];
+    kg[j] = gamma ? gamma[c + j] : 1.f;
+    a[j] = s12[sg * 2] * inv;
+    b[j] = rs[j] * s12[sg * 2 + 1] * inv;
+  }
+  const int p0 = blockIdx.y * pix_per_block;
+  const int p1 = min(HW, p0 + pix_per_block);
+  const long base = (long)n * HW * C + c;
+  auto one = [&](float4 g, float4 yv, float4 xv, long i) {
+    if (RELU) g = relu_mask(g, yv);
+    if (RES) st4(dres + i, g);
+    st4(dx + i, make_float4(rs[0] * (g.x * kg[0] - a[0] - (xv.x - mu[0]) * b[0]),
+                            rs[1] * (g.y * kg[1] - a[1] - (xv.y - mu[1]) * b[1]),
+                            rs[2] * (g.z * kg[2] - a[2] - (xv.z - mu[2]) * b[2]),
+                            rs[3] * (g.w * kg[3] - a[3] - (xv.w - mu[3]) * b[3])));
+  };
+  int p = p0 + pl;
+  for (; p + 3 * lanes < p1; p += 4 * lanes) {
+    float4 g[4], xv[4], yv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long i = base + (long)(p + u * lanes) * C;
+      g[u] = ld4(dy + i);
+      xv[u] = ld4(x + i);
+      yv[u] = RELU ? ld4(y + i) : g[u];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) one(g[u], yv[u], xv[u], base + (long)(p + u * lanes) * C);
+  }
+  for (; p < p1; p += lanes) {
+    const long i = base + (long)p * C;
+    const float4 g = ld4(dy + i);
+    one(g, RELU ? ld4(y + i) : g, ld4(x + i), i);
   }
 }
 
@@ -250,15 +511,67 @@ __global__ __launch_bounds__(256) void adaptive_avgpool_bwd_kernel(const float* 
 
 }  // namespace
 
+namespace {
+struct BnBwdPlan {
+  int qwl, strips, rpb, slices;
+};
+// ~2048 blocks (8 per CU), each lane at least 8 rows
+inline BnBwdPlan bn_bwd_plan(long M, int C) {
+  BnBwdPlan p;
+  p.qwl = strip_log2(C / 4);
+  p.strips = ceil_div(C / 4, 1 << p.qwl);
+  const int lanes = 256 >> p.qwl;
+  long slices = (2048 + p.strips - 1) / p.strips;
+  const long most = (M + 8L * lanes - 1) / (8L * lanes);
+  if (slices > most) slices = most;
+  if (slices < 1) slices = 1;
+  p.rpb = (int)((M + slices - 1) / slices);
+  p.slices = ceil_div(M, p.rpb);
+  return p;
+}
+}  // namespace
+
+extern "C" size_t vlnce_bn_bwd_workspace_floats(long M, int C) {
+  if (C <= 0 || C % 4 != 0 || M <= 0) return 0;
+  return (size_t)bn_bwd_plan(M, C).slices * 2 * C;
+}
+
 extern "C" int vlnce_bn_bwd(const float* dy, const float* y, const float* x, const float* mean,
                             const float* rstd, const float* gamma, long M, int C, int relu,
                             int use_batch_stats, float* dx, float* dres, float* dgamma,
-                            float* dbeta, vlnce_stream_t stream) {
+                            float* dbeta, float* workspace, vlnce_stream_t stream) {
   VLNCE_CHECK_ARG(dy && x && mean && rstd && dx && dgamma && dbeta, "bn_bwd: null argument");
   VLNCE_CHECK_ARG(!relu || y, "bn_bwd: ReLU backward needs the forward output y");
+  VLNCE_CHECK_ARG(C % 4 != 0 || workspace, "bn_bwd: C %% 4 == 0 needs the workspace");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  vlnce_zero(dgamma, 1, C, C, s);
-  vlnce_zero(dbeta, 1, C, C, s);
+  if (C % 4 == 0 && aligned16({dy, y, x, mean, rstd, gamma, dx, dres, dgamma, dbeta, workspace})) {
+    const BnBwdPlan pl = bn_bwd_plan(M, C);
+    const int qwl = pl.qwl, strips = pl.strips, rpb = pl.rpb;
+    const dim3 grid(strips, ceil_div(M, rpb));
+#define BN_R(R) hipLaunchKernelGGL(bn_bwd_reduce4_kernel<R>, grid, dim3(256), 0, s, dy, y, x, mean, \
+                                   rstd, M, C, qwl, rpb, workspace)
+    if (relu) BN_R(1); else BN_R(0);
+#undef BN_R
+    hipLaunchKernelGGL(bn_bwd_finalize4_kernel, dim3(ceil_div(2 * C / 4, 4)), dim3(256), 0, s,
+                       workspace, pl.slices, C, dgamma, dbeta);
+#define BN_A(R, B, D) hipLaunchKernelGGL((bn_bwd_apply4_kernel<R, B, D>), grid, dim3(256), 0, s, dy, y, \
+                                         x, mean, rstd, gamma, dgamma, dbeta, M, C, qwl, rpb, dx, dres)
+    const int sel = (relu ? 4 : 0) | (use_batch_stats ? 2 : 0) | (dres ? 1 : 0);
+    switch (sel) {
+      case 0: BN_A(0, 0, 0); break;
+      case 1: BN_A(0, 0, 1); break;
+      case 2: BN_A(0, 1, 0); break;
+      case 3: BN_A(0, 1, 1); break;
+      case 4: BN_A(1, 0, 0); break;
+      case 5: BN_A(1, 0, 1); break;
+      case 6: BN_A(1, 1, 0); break;
+      default: BN_A(1, 1, 1); break;
+    }
+#undef BN_A
+    VLNCE_CHECK_LAUNCH("bn_bwd");
+    return 0;
+  }
+  hipLaunchKernelGGL(zero2_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, s, dgamma, dbeta, C);
   const int col_blocks = ceil_div(C, 64);
   long slices = (1024 + col_blocks - 1) / col_blocks;
   if (slices > (M + 63) / 64) slices = (M + 63) / 64;
@@ -282,18 +595,45 @@ extern "C" int vlnce_gn_bwd(const float* dy, const float* y, const float* x, con
   VLNCE_CHECK_ARG(!relu || y, "gn_bwd: ReLU backward needs the forward output y");
   VLNCE_CHECK_ARG(groups > 0 && C % groups == 0, "gn_bwd: C %% groups != 0");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  vlnce_zero(dgamma, 1, C, C, s);
-  vlnce_zero(dbeta, 1, C, C, s);
+  hipLaunchKernelGGL(zero2_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, s, dgamma, dbeta, C);
   const int chunks = ceil_div(HW, GN_CHUNK);
   float* partial = workspace;
   float* s12 = workspace + (size_t)Nimg * chunks * C * 2;
-  hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3(Nimg * chunks), dim3(256), 0, s, dy, y, x, mean,
-                     rstd, HW, C, groups, chunks, relu, partial);
+  const bool quads = C % 4 == 0 && Nimg <= 65535 &&
+                     aligned16({dy, y, x, dx, dres, workspace});
+  const int qwl = quads ? strip_log2(C / 4) : 0, strips = quads ? ceil_div(C / 4, 1 << qwl) : 0;
+  if (quads) {
+    const dim3 grid(Nimg * chunks, strips);
+    if (relu)
+      hipLaunchKernelGGL(gn_bwd_partial4_kernel<1>, grid, dim3(256), 0, s, dy, y, x, mean, rstd, HW,
+                         C, groups, chunks, qwl, partial);
+    else
+      hipLaunchKernelGGL(gn_bwd_partial4_kernel<0>, grid, dim3(256), 0, s, dy, y, x, mean, rstd, HW,
+                         C, groups, chunks, qwl, partial);
+  } else {
+    hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3(Nimg * chunks), dim3(256), 0, s, dy, y, x, mean,
+                       rstd, HW, C, groups, chunks, relu, partial);
+  }
   hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(Nimg), dim3(256), (size_t)C * 2 * sizeof(float),
                      s, partial, C, groups, chunks, gamma, s12, dgamma, dbeta);
   const long total = (long)Nimg * HW * C;
-  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(grid_for(total)), dim3(256), 0, s, dy, y, x, mean,
-                     rstd, gamma, s12, total, HW, C, groups, relu, dx, dres);
+  if (quads) {
+    const int lanes = 256 >> qwl;
+    long slices = (4096 + (long)strips * Nimg - 1) / ((long)strips * Nimg);
+    const long most = (HW + 4L * lanes - 1) / (4L * lanes);
+    if (slices > most) slices = most;
+    if (slices < 1) slices = 1;
+    const int ppb = (int)((HW + slices - 1) / slices);
+    const dim3 grid(strips, ceil_div(HW, ppb), Nimg);
+#define GN_A(R, D) hipLaunchKernelGGL((gn_bwd_apply4_kernel<R, D>), grid, dim3(256), 0, s, dy, y, x, mean, \
+                                      rstd, gamma, s12, HW, C, groups, qwl, ppb, dx, dres)
+    if (relu) { if (dres) GN_A(1, 1); else GN_A(1, 0); }
+    else      { if (dres) GN_A(0, 1); else GN_A(0, 0); }
+#undef GN_A
+  } else {
+    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(grid_for(total)), dim3(256), 0, s, dy, y, x, mean,
+                       rstd, gamma, s12, total, HW, C, groups, relu, dx, dres);
+  }
   VLNCE_CHECK_LAUNCH("gn_bwd");
   return 0;
 }

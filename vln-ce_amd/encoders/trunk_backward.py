@@ -108,8 +108,10 @@ def bn_backward(dy, sv):
     dres = torch.empty_like(sv.raw) if sv.has_res else None
     dg = torch.empty(Cc, device=dev, dtype=torch.float32)
     db = torch.empty_like(dg)
-    L().bn_bwd(dy.contiguous(), sv.y, sv.raw, sv.mean, sv.rstd, sv.gamma.detach(), M, Cc, sv.relu,
-               sv.batch_stats, dx, dres, dg, db)
+    lib = L()
+    ws = torch.empty(max(lib.bn_bwd_workspace_floats(M, Cc), 1), device=dev, dtype=torch.float32)
+    lib.bn_bwd(dy.contiguous(), sv.y, sv.raw, sv.mean, sv.rstd, sv.gamma.detach(), M, Cc, sv.relu,
+               sv.batch_stats, dx, dres, dg, db, ws)
     return dx, dres, dg, db
 
 
