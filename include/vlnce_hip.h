@@ -199,6 +199,30 @@ long vlnce_conv2d_pack_bytes(const vlnce_conv_desc* d);
 int vlnce_conv2d_pack_weights(const float* w_ohwi, void* frag, const vlnce_conv_desc* d,
                               int format /* as vlnce_conv2d_split_weights */, vlnce_stream_t stream);
 
+/* Every weight image of a TRAINABLE trunk in one launch (ABI 143).  With
+ * MODEL.{RGB,DEPTH}_ENCODER.trainable (resnet_encoders.py:45-46,141-143) the filters change every
+ * optimizer step; per convolution the step needs the forward bank W[Cout,T,Cin] (T = KH*KW taps) and
+ * the data-gradient bank W'[Cin,T,Cout] with the taps reversed, each as fp32, as planes
+ * (vlnce_conv2d_split_weights' layout) and as fragments (vlnce_conv2d_pack_weights' layout) -- bit
+ * for bit what those entry points write for the permuted tensors.  A job names ONE of these outputs
+ * and reads the parameter where it lies, in nn.Conv2d's own [Cout, Cin, KH, KW] layout.
+ *   kind 0: fp32 [N,T,C];  1: planes [3][N*T*C];  2: fragments (N % 32 == 0 and C % 32 == 0)
+ *   with (N, C) = (Cout, Cin), or (Cin, Cout) when `transposed`; C % 8 == 0 throughout.
+ * vlnce_weight_job_items() = the work items of a job (-1: not eligible).  `jobs_dev` and
+ * `first_item_dev` (njobs + 1 running item counts, first_item[0] = 0) are DEVICE arrays the host
+ * builds once per trunk; total_items = first_item[njobs]. */
+typedef struct vlnce_weight_job {
+  const float* w_oihw;
+  void* dst;
+  int Cout, Cin, T;
+  int kind;
+  int transposed;
+  int format; /* plane format of kinds 1 and 2 (1 = three bf16 planes, 2 = fp16 planes) */
+} vlnce_weight_job;
+long vlnce_weight_job_items(const vlnce_weight_job* job);
+int vlnce_conv2d_prepare_weights(const vlnce_weight_job* jobs_dev, const long* first_item_dev,
+                                 int njobs, long total_items, vlnce_stream_t stream);
+
 /* Which kernel the calling thread's last vlnce_conv2d_fwd was dispatched to: the measurement
  * harness prices bf16-pipe launches (6 plane products per multiply) and fp32-MFMA launches
  * against their own peaks.  No reference counterpart. */

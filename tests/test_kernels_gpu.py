@@ -1567,3 +1567,34 @@ def test_stem7_from_frames(hip, case, fmt):
         M = want.numel() // Cout
         close((gacc[:, 0] / M).float(), (wacc[:, 0] / M).float(), 2e-5, what=f"{name} sum")
         close((gacc[:, 1] / M).float(), (wacc[:, 1] / M).float(), 3e-5, what=f"{name} sum of squares")
+
+
+def test_prepare_weights_matches_the_per_tensor_entry_points(hip):
+    """vlnce_conv2d_prepare_weights (all weight images of a trainable trunk in one launch) writes,
+    bit for bit, what the per-tensor path writes for the permuted tensors: OHWI fp32, planes,
+    fragments, in both formats, for the forward bank and for the data-gradient bank (taps reversed,
+    channels swapped)."""
+    torch.manual_seed(3)
+    params = [torch.randn(s, device=DEV) * 0.2 for s in
+              [(64, 32, 1, 1), (96, 64, 3, 3), (32, 128, 1, 1), (64, 64, 3, 3), (256, 64, 1, 1)]]
+    jobs, want = [], []
+    for p in params:
+        w = p.permute(0, 2, 3, 1).contiguous()
+        wt = w.flip(1, 2).permute(3, 1, 2, 0).contiguous()
+        for tr, bank in ((0, w), (1, wt)):
+            dst = torch.empty_like(bank)
+            jobs.append((p, dst, hip.WP_F32, tr, 0))
+            want.append(bank)
+            for fmt in (ops.PLANES_BF16X6, ops.PLANES_F16X3):
+                pl = torch.empty((3, p.numel()), device=DEV, dtype=torch.int16)
+                fr = torch.empty((p.numel() * 3,), device=DEV, dtype=torch.int16)
+                jobs += [(p, pl, hip.WP_PLANES, tr, fmt), (p, fr, hip.WP_FRAGMENTS, tr, fmt)]
+                want += [ops.split_weights(bank, fmt), ops.pack_weights(bank, fmt)]
+    plan = hip.weight_prep_plan(jobs)
+    hip.conv2d_prepare_weights(plan)
+    torch.cuda.synchronize()
+    for k, ((p, dst, kind, tr, fmt), ref) in enumerate(zip(jobs, want)):
+        assert torch.equal(dst.view(-1), ref.view(-1)), (k, tuple(p.shape), kind, tr, fmt)
+    with pytest.raises(ValueError):   # Cin = 3: not a job (the stems keep the per-tensor path)
+        hip.weight_prep_plan([(torch.randn(64, 3, 7, 7, device=DEV),
+                               torch.empty(64, 7, 7, 3, device=DEV), hip.WP_F32, 0, 0)])

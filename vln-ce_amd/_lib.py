@@ -40,6 +40,17 @@ class ConvDesc(C.Structure):
                 ("N", "H", "W", "Cin", "Cout", "KH", "KW", "stride", "pad", "Ho", "Wo", "ldx", "ldy")]
 
 
+class WeightJob(C.Structure):   # vlnce_weight_job
+    _fields_ = [("w_oihw", _P), ("dst", _P), ("Cout", _I), ("Cin", _I), ("T", _I), ("kind", _I),
+                ("transposed", _I), ("format", _I)]
+
+
+class WeightPrepPlan:
+    """the device-side job table of one vlnce_conv2d_prepare_weights launch (+ the tensors it
+    points into, kept alive)"""
+    __slots__ = ("table", "first_item", "njobs", "total", "keep")
+
+
 class Prologue(C.Structure):
     _fields_ = [("in_scale", _P), ("in_shift", _P), ("in_center", _P), ("in_relu", _I),
                 ("x2", _P), ("in2_scale", _P), ("in2_shift", _P), ("in2_center", _P),
@@ -71,6 +82,8 @@ _SIGNATURES = {
     "vlnce_embedding_bwd": (_I, [_P, _P, _P, _L, _I, _L, _L, _P]),
     "vlnce_conv2d_pack_bytes": (C.c_long, [C.POINTER(ConvDesc)]),
     "vlnce_conv2d_pack_weights": (_I, [_P, _P, C.POINTER(ConvDesc), _I, _P]),
+    "vlnce_weight_job_items": (C.c_long, [C.POINTER(WeightJob)]),
+    "vlnce_conv2d_prepare_weights": (_I, [_P, _P, _I, C.c_long, _P]),
     "vlnce_conv2d_tiles_m": (_I, [C.POINTER(ConvDesc)]),
     "vlnce_conv2d_tile_rows": (_I, [C.POINTER(ConvDesc)]),
     "vlnce_conv2d_bn_workspace_bytes": (C.c_long, [C.POINTER(ConvDesc)]),
@@ -407,6 +420,36 @@ class HipLib:
         d = self._desc(g)
         self._check(self.dll.vlnce_conv2d_pack_weights(_ptr(w), _ptr(frag), C.byref(d), int(fmt),
                                                        _stream()), "vlnce_conv2d_pack_weights")
+
+    WP_F32, WP_PLANES, WP_FRAGMENTS = 0, 1, 2
+
+    def weight_prep_plan(self, jobs):
+        """jobs: [(w_oihw parameter tensor, dst tensor, kind, transposed, format)] -> WeightPrepPlan
+        (the job table uploaded once; raises for a job the kernel does not take)"""
+        arr = (WeightJob * len(jobs))()
+        first = [0]
+        for j, (w, dst, kind, transposed, fmt) in zip(arr, jobs):
+            assert w.is_cuda and w.is_contiguous() and w.dtype == torch.float32 and w.dim() == 4
+            j.w_oihw, j.dst = w.data_ptr(), dst.data_ptr()
+            j.Cout, j.Cin, j.T = w.size(0), w.size(1), w.size(2) * w.size(3)
+            j.kind, j.transposed, j.format = int(kind), int(bool(transposed)), int(fmt or 0)
+            items = int(self.dll.vlnce_weight_job_items(C.byref(j)))
+            if items <= 0:
+                raise ValueError(f"weight_prep_plan: job not eligible: {tuple(w.shape)} kind={kind} "
+                                 f"transposed={transposed} format={fmt}")
+            first.append(first[-1] + items)
+        plan = WeightPrepPlan()
+        dev = jobs[0][1].device
+        plan.table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+        plan.first_item = torch.tensor(first, dtype=torch.int64).to(dev)
+        plan.njobs, plan.total = len(jobs), first[-1]
+        plan.keep = [(w, dst) for w, dst, *_ in jobs]
+        return plan
+
+    def conv2d_prepare_weights(self, plan):
+        self._check(self.dll.vlnce_conv2d_prepare_weights(_ptr(plan.table), _ptr(plan.first_item),
+                                                          plan.njobs, plan.total, _stream()),
+                    "vlnce_conv2d_prepare_weights")
 
     def gemm(self, A, lda, transA, B, ldb, transB, Cm, ldc, M, N, K, scale=None, shift=None,
              residual=None, ldr=0, act=0, accumulate=0):

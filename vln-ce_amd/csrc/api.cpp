@@ -30,7 +30,8 @@ extern "C" const char* vlnce_last_error(void) { return g_err; }
 // 142: plane format 2 (fp16 planes, three plane products per multiply): vlnce_prologue.w_format, a
 // `format` argument of vlnce_conv2d_split_weights / _pack_weights, `w_format` of vlnce_stem7_fwd;
 // option "conv_math" defaults to 2.
-// 143: vlnce_bn_bwd takes a workspace (vlnce_bn_bwd_workspace_floats): partial sums instead of atomics.
+// 143: vlnce_bn_bwd takes a workspace (vlnce_bn_bwd_workspace_floats): partial sums instead of atomics;
+// vlnce_conv2d_prepare_weights / vlnce_weight_job (all weight images of a trainable trunk in one launch).
 extern "C" int vlnce_version(void) { return 143; }
 
 // ---- dispatch options: one int per name, process-wide, relaxed atomics (a tuning / test knob,

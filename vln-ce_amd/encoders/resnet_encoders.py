@@ -38,6 +38,7 @@ class _WeightCache:
     def __init__(self):
         self._packed = {}
         self._folded = {}
+        self._prep = None
 
     @staticmethod
     def _key(*ts):
@@ -53,6 +54,64 @@ class _WeightCache:
             hit = (k, w)
             self._packed[id(conv)] = hit
         return hit[1]
+
+    def prepare_trainable(self, convs):
+        """Trainable trunks: every weight image the step needs -- OHWI fp32, planes and fragments in
+        the forward format, and the data-gradient bank (taps reversed, channels swapped) as fp32,
+        planes and fragments in format 1 -- written by ONE launch (vlnce_conv2d_prepare_weights)
+        into persistent buffers, and handed to conv() / ops.split_weights / ops.pack_weights /
+        trunk_backward.conv_backward through the caches those already consult.  Convolutions the
+        kernel does not take (the stems: Cin = 1 or 3) keep the per-tensor path."""
+        convs = [c for c in convs if c.weight.is_cuda and c.weight.is_contiguous()
+                 and c.weight.size(0) % 32 == 0 and c.weight.size(1) % 32 == 0]
+        if not convs or os.environ.get("VLNCE_WEIGHT_PREP", "1") == "0":
+            return
+        lib = ops.L()
+        fmt = ops.plane_format()
+        sig = (fmt,) + tuple((id(c), c.weight.data_ptr()) for c in convs)
+        st = self._prep
+        if st is None or st["sig"] != sig:
+            st = dict(sig=sig, key=None, rows=[], plan=None)
+            jobs = []
+            for c in convs:
+                p = c.weight
+                Cout, Cin, KH, KW = p.shape
+                dev = p.device
+
+                def i16(*shape):
+                    return torch.empty(shape, device=dev, dtype=torch.int16)
+                row = dict(conv=c,
+                           w=(torch.empty((Cout, KH, KW, Cin), device=dev) if KH * KW > 1 else None),
+                           split=i16(3, p.numel()), frag=i16(p.numel() * 3),
+                           wt=torch.empty((Cin, KH, KW, Cout), device=dev),
+                           split_t=i16(3, p.numel()), frag_t=i16(p.numel() * 3))
+                row["split"]._vlnce_fmt = row["frag"]._vlnce_fmt = fmt
+                row["split_t"]._vlnce_fmt = row["frag_t"]._vlnce_fmt = ops.PLANES_BF16X6
+                if row["w"] is not None:
+                    jobs.append((p, row["w"], lib.WP_F32, 0, 0))
+                jobs += [(p, row["split"], lib.WP_PLANES, 0, fmt),
+                         (p, row["frag"], lib.WP_FRAGMENTS, 0, fmt),
+                         (p, row["wt"], lib.WP_F32, 1, 0),
+                         (p, row["split_t"], lib.WP_PLANES, 1, ops.PLANES_BF16X6),
+                         (p, row["frag_t"], lib.WP_FRAGMENTS, 1, ops.PLANES_BF16X6)]
+                st["rows"].append(row)
+            st["plan"] = lib.weight_prep_plan(jobs)
+            self._prep = st
+        key = tuple(c.weight._version for c in convs)
+        if st["key"] == key:
+            return
+        lib.conv2d_prepare_weights(st["plan"])
+        st["key"] = key
+        for row in st["rows"]:
+            c = row["conv"]
+            w = row["w"] if row["w"] is not None else c.weight.detach().permute(0, 2, 3, 1)
+            wt = row["wt"]
+            w.__dict__["_vlnce_split"] = {fmt: (w._version, row["split"])}
+            w.__dict__["_vlnce_frag"] = {fmt: (w._version, row["frag"])}
+            wt.__dict__["_vlnce_split"] = {ops.PLANES_BF16X6: (wt._version, row["split_t"])}
+            wt.__dict__["_vlnce_frag"] = {ops.PLANES_BF16X6: (wt._version, row["frag_t"])}
+            w._vlnce_dgrad = wt
+            self._packed[id(c)] = (self._key(c.weight), w)
 
     def stem_s2d(self, conv):
         """7x7/s2/p3 stem taps regrouped for the space-to-depth formulation (ops.stem_weight_s2d)."""
@@ -433,6 +492,11 @@ class HipResNetTrunk(DropsGraphsOnApply, nn.Sequential):
     def trainable_params(self):
         return [p for p in self.parameters() if p.requires_grad]
 
+    def _all_convs(self):
+        if getattr(self, "_conv_list", None) is None:
+            self._conv_list = [m for m in self.modules() if isinstance(m, nn.Conv2d)]
+        return self._conv_list
+
     def _rec_conv_bn(self, x, conv, bn, relu, residual, tape, touched):
         w = self._cache.conv(conv)
         stride, pad = conv.stride[0], conv.padding[0]
@@ -447,6 +511,7 @@ class HipResNetTrunk(DropsGraphsOnApply, nn.Sequential):
     def run_recording(self, x):
         kids = list(self.children())
         tape, touched = [], []
+        self._cache.prepare_trainable(self._all_convs())
         sc, sh = self.input_scale
         x = ops.scale_shift_act(x, sc, sh)  # /255 (+mean/std) materialised: wgrad reads it
         x = self._rec_conv_bn(x, kids[0], kids[1], True, None, tape, touched)
@@ -813,6 +878,9 @@ def _depth_rec_conv_gn(self, x, conv, gn, relu, residual, tape):
 
 def _depth_run_recording(self, x):
     tape = []
+    if getattr(self, "_conv_list", None) is None:
+        self._conv_list = [m for m in self.modules() if isinstance(m, nn.Conv2d)]
+    self._cache.prepare_trainable(self._conv_list)
     x = ops.avgpool2x2(x)
     bb = self.backbone
     x = self._rec_conv_gn(x, bb.conv1[0], bb.conv1[1], True, None, tape)

@@ -40,7 +40,11 @@ def conv_backward(x, w_ohwi, dy, stride, pad, need_dx):
     N, H, W, _ = x.shape
     # flipped taps, in/out channels swapped: [Cin, KH, KW, Cout].  Gradient operands: three bf16
     # planes (fp32's exponent range); the fp16 planes of the forward would flush them
-    wt = w_ohwi.flip(1, 2).permute(3, 1, 2, 0).contiguous()
+    # (a trainable trunk's one-launch weight preparation leaves that bank, with its planes and
+    # fragments, on the forward tensor: _WeightCache.prepare_trainable)
+    wt = getattr(w_ohwi, "_vlnce_dgrad", None)
+    if wt is None:
+        wt = w_ohwi.flip(1, 2).permute(3, 1, 2, 0).contiguous()
     if stride == 1:
         dx = ops.conv2d_nhwc(dy, wt, 1, KH - 1 - pad, w_format=ops.PLANES_BF16X6)
     elif KH == 1:
