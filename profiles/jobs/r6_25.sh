@@ -5,7 +5,7 @@ mkdir -p $O
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace -d $O/kt -- python $GRAFT_REPO_ROOT/scripts/trainable_step.py 5 > $O/kt.log 2>&1
 cd $GRAFT_REPO_ROOT
-tail -1 $O/kt.log
+grep "ms/step" $O/kt.log
 python - <<P
 import sqlite3, glob, re
 db = sqlite3.connect(glob.glob('$O/kt/**/*.db', recursive=True)[0])

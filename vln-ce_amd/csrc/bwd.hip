@@ -482,6 +482,41 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
   }
 }
 
+// four channels per thread (C % 4 == 0): 16-byte dy / dx requests, one 4-byte arg-max word
+__global__ __launch_bounds__(256) void maxpool_bwd4_kernel(const float* __restrict__ dy,
+                                                           const uint8_t* __restrict__ arg,
+                                                           float* __restrict__ dx, int N, int H,
+                                                           int W, int C, int Ho, int Wo) {
+  const int cq = C / 4;
+  const long total = (long)N * H * W * cq;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cq) * 4;
+    long t = i / cq;
+    const int wi = (int)(t % W);
+    t /= W;
+    const int hi = (int)(t % H);
+    const int n = (int)(t / H);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int ho = hi / 2; ho <= (hi + 1) / 2; ++ho) {
+      if (ho >= Ho) continue;
+      const int r = hi + 1 - 2 * ho;
+      for (int wo = wi / 2; wo <= (wi + 1) / 2; ++wo) {
+        if (wo >= Wo) continue;
+        const unsigned tap = (unsigned)(r * 3 + (wi + 1 - 2 * wo));
+        const long o = (((long)n * Ho + ho) * Wo + wo) * C + c;
+        const unsigned a = *reinterpret_cast<const unsigned*>(arg + o);
+        const float4 g = ld4(dy + o);
+        if ((a & 255u) == tap) s.x += g.x;
+        if (((a >> 8) & 255u) == tap) s.y += g.y;
+        if (((a >> 16) & 255u) == tap) s.z += g.z;
+        if ((a >> 24) == tap) s.w += g.w;
+      }
+    }
+    st4(dx + (((long)n * H + hi) * W + wi) * C + c, s);
+  }
+}
+
 __global__ __launch_bounds__(256) void adaptive_avgpool_bwd_kernel(const float* __restrict__ dy,
                                                                    float* __restrict__ dx, int N,
                                                                    int H, int W, int C, int OH,
@@ -654,8 +689,13 @@ extern "C" int vlnce_maxpool3x3s2_argmax(const float* x, float* y, uint8_t* argm
 extern "C" int vlnce_maxpool3x3s2_bwd(const float* dy, const uint8_t* argmax, float* dx, int N,
                                       int H, int W, int C, int Ho, int Wo, vlnce_stream_t stream) {
   VLNCE_CHECK_ARG(dy && argmax && dx, "maxpool_bwd: null argument");
-  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for((long)N * H * W * C)), dim3(256), 0,
-                     reinterpret_cast<hipStream_t>(stream), dy, argmax, dx, N, H, W, C, Ho, Wo);
+  if (C % 4 == 0 && aligned16({dy, dx}) && (reinterpret_cast<uintptr_t>(argmax) & 3) == 0)
+    hipLaunchKernelGGL(maxpool_bwd4_kernel, dim3(grid_for((long)N * H * W * (C / 4), 16384)),
+                       dim3(256), 0, reinterpret_cast<hipStream_t>(stream), dy, argmax, dx, N, H, W,
+                       C, Ho, Wo);
+  else
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for((long)N * H * W * C)), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), dy, argmax, dx, N, H, W, C, Ho, Wo);
   VLNCE_CHECK_LAUNCH("maxpool_bwd");
   return 0;
 }

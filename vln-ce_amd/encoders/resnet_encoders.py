@@ -546,10 +546,10 @@ class HipResNetTrunk(DropsGraphsOnApply, nn.Sequential):
         block_begin, [downsample conv_bn], main_begin, conv_bn*, block_end."""
         grads = {}
 
-        def conv_bn_back(entry, dy, need_dx=True):
+        def conv_bn_back(entry, dy, need_dx=True, add=None):
             _, x_in, conv, bn, w, sv = entry
             draw, dres, dg, db = tb.bn_backward(dy, sv)
-            dx, dw = tb.conv_backward(x_in, w, draw, conv.stride[0], conv.padding[0], need_dx)
+            dx, dw = tb.conv_backward(x_in, w, draw, conv.stride[0], conv.padding[0], need_dx, add)
             for prm, g in ((conv.weight, dw), (bn.weight, dg), (bn.bias, db)):
                 if prm.requires_grad:
                     grads[id(prm)] = g
@@ -567,16 +567,19 @@ class HipResNetTrunk(DropsGraphsOnApply, nn.Sequential):
                 i -= 1
                 d_main, d_skip = conv_bn_back(tape[i], d)  # last conv: residual gradient
                 i -= 1
+                # the two branches' gradients meet at the block input: the LAST data-gradient
+                # convolution issued for the block adds the other branch in its epilogue
                 while tape[i][0] != "main_begin":
-                    d_main, _ = conv_bn_back(tape[i], d_main)
+                    first = tape[i - 1][0] == "main_begin"
+                    plain_skip = first and tape[i - 2][0] != "conv_bn"
+                    d_main, _ = conv_bn_back(tape[i], d_main, add=d_skip if plain_skip else None)
                     i -= 1
                 i -= 1  # past main_begin
                 if tape[i][0] == "conv_bn":  # downsample branch
-                    d_ds, _ = conv_bn_back(tape[i], d_skip)
-                    d = d_main + d_ds
+                    d, _ = conv_bn_back(tape[i], d_skip, add=d_main)
                     i -= 1
                 else:
-                    d = d_main + d_skip
+                    d = d_main
                 assert tape[i][0] == "block_begin"
                 i -= 1
             elif kind == "maxpool":
@@ -911,10 +914,10 @@ def _depth_run_recording(self, x):
 def _depth_backward_from_tape(self, tape, dout):
     grads = {}
 
-    def back(entry, dy, need_dx=True):
+    def back(entry, dy, need_dx=True, add=None):
         _, x_in, conv, gn, w, sv = entry
         draw, dres, dg, db = tb.gn_backward(dy, sv)
-        dx, dw = tb.conv_backward(x_in, w, draw, conv.stride[0], conv.padding[0], need_dx)
+        dx, dw = tb.conv_backward(x_in, w, draw, conv.stride[0], conv.padding[0], need_dx, add)
         for prm, g in ((conv.weight, dw), (gn.weight, dg), (gn.bias, db)):
             if prm.requires_grad:
                 grads[id(prm)] = g
@@ -928,16 +931,17 @@ def _depth_backward_from_tape(self, tape, dout):
             i -= 1
             d_main, d_skip = back(tape[i], d)
             i -= 1
-            while tape[i][0] != "main_begin":
-                d_main, _ = back(tape[i], d_main)
+            while tape[i][0] != "main_begin":   # (block-input sum in an epilogue: see the RGB trunk)
+                first = tape[i - 1][0] == "main_begin"
+                plain_skip = first and tape[i - 2][0] != "conv_gn"
+                d_main, _ = back(tape[i], d_main, add=d_skip if plain_skip else None)
                 i -= 1
             i -= 1
             if tape[i][0] == "conv_gn":
-                d_ds, _ = back(tape[i], d_skip)
-                d = d_main + d_ds
+                d, _ = back(tape[i], d_skip, add=d_main)
                 i -= 1
             else:
-                d = d_main + d_skip
+                d = d_main
             assert tape[i][0] == "block_begin"
             i -= 1
         elif kind == "maxpool":

@@ -11,6 +11,8 @@ layers in reverse on the hand-written backward kernels:
   BatchNorm / GroupNorm (+ReLU, +residual) : vlnce_bn_bwd / vlnce_gn_bwd
   max-pool (arg-max tap saved in forward), adaptive average pool.
 """
+import os
+
 import torch
 from torch.autograd import Function
 
@@ -21,13 +23,18 @@ def L():
     return ops.L()
 
 
+_SEPARATE_ADD = os.environ.get("VLNCE_DGRAD_ADD", "1") == "0"
+
+
 # ------------------------------------------------------------------ layer primitives
 def conv_raw(x, w_ohwi, stride, pad):
     return ops.conv2d_nhwc(x, w_ohwi, stride, pad)
 
 
-def conv_backward(x, w_ohwi, dy, stride, pad, need_dx):
-    """returns (dx | None, dW in OIHW)."""
+def conv_backward(x, w_ohwi, dy, stride, pad, need_dx, add=None):
+    """returns (dx | None, dW in OIHW).  `add` (the gradient arriving at the same tensor over the
+    block's other branch) is summed into dx by the data-gradient convolution's epilogue instead of
+    a separate pass over two block-input-sized tensors."""
     lib = L()
     g = ops.conv_geometry(x, w_ohwi, stride, pad)
     Cout, KH, KW, Cin = w_ohwi.shape
@@ -45,20 +52,29 @@ def conv_backward(x, w_ohwi, dy, stride, pad, need_dx):
     wt = getattr(w_ohwi, "_vlnce_dgrad", None)
     if wt is None:
         wt = w_ohwi.flip(1, 2).permute(3, 1, 2, 0).contiguous()
+    if add is not None:
+        if _SEPARATE_ADD:   # A/B knob (VLNCE_DGRAD_ADD=0): the sum as its own pass
+            dx, dw_oihw = conv_backward(x, w_ohwi, dy, stride, pad, True)
+            return dx + add, dw_oihw
+        add = add.contiguous()
     if stride == 1:
-        dx = ops.conv2d_nhwc(dy, wt, 1, KH - 1 - pad, w_format=ops.PLANES_BF16X6)
+        dx = ops.conv2d_nhwc(dy, wt, 1, KH - 1 - pad, residual=add, w_format=ops.PLANES_BF16X6)
     elif KH == 1:
         # 1x1 / stride s: only the sampled pixels receive gradient
         small = ops.conv2d_nhwc(dy, wt, 1, 0, w_format=ops.PLANES_BF16X6)
-        dx = torch.zeros((N, H, W, Cin), device=x.device, dtype=torch.float32)
-        dx[:, ::stride, ::stride] = small
+        if add is not None:
+            dx = add.clone()
+            dx[:, ::stride, ::stride] += small
+        else:
+            dx = torch.zeros((N, H, W, Cin), device=x.device, dtype=torch.float32)
+            dx[:, ::stride, ::stride] = small
     else:
         # general stride: dY zero-inserted on the stride grid, then a stride-1 correlation
         # with the flipped taps and padding KH-1-pad lands exactly on the input pixels
         Hu, Wu = H + 2 * pad - KH + 1, W + 2 * pad - KW + 1
         up = torch.zeros((N, Hu, Wu, Cout), device=x.device, dtype=torch.float32)
         up[:, ::stride, ::stride] = dy
-        dx = ops.conv2d_nhwc(up, wt, 1, KH - 1 - pad, w_format=ops.PLANES_BF16X6)
+        dx = ops.conv2d_nhwc(up, wt, 1, KH - 1 - pad, residual=add, w_format=ops.PLANES_BF16X6)
     return dx, dw_oihw
 
 
