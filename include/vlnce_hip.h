@@ -424,19 +424,27 @@ int vlnce_conv2d_wgrad(const float* x, const float* dy, float* dw_ohwi, const vl
  * dx = gamma*rstd*(g - dbeta/M - xhat*dgamma/M) with batch statistics, gamma*rstd*g with
  * running statistics (use_batch_stats = 0).  dres (may be NULL) receives g.  workspace (ABI 143):
  * vlnce_bn_bwd_workspace_floats(M, C) floats -- the per-block partial sums of the two reductions
- * (no same-address atomics); 0 floats / may be NULL when C % 4 != 0. */
+ * (no same-address atomics); 0 floats / may be NULL when C % 4 != 0.
+ * pow2 (ABI 143, may be NULL; needs C % 4 == 0): [2][P] floats, on return P copies of 2^k followed by P
+ * copies of 2^-k, with k the power of two at which dx fits the fp16 planes of plane format 2
+ * (bound(|dx|) * 2^k in (2^13, 2^14], the bound computed from the per-channel maxima of |g| and
+ * |x - mean| gathered by the reduction pass).  They are the prologue / epilogue vectors
+ * (vlnce_prologue.in_scale with a zero in_shift; vlnce_epilogue.scale) of the data-gradient
+ * convolution that reads dx, and the `dy_pow2` of vlnce_conv2d_wgrad: gradients live far below
+ * fp16's normal range, scaled by an exact power of two they take format 2's three plane products
+ * instead of format 1's six. */
 size_t vlnce_bn_bwd_workspace_floats(long M, int C);
 int vlnce_bn_bwd(const float* dy, const float* y, const float* x, const float* mean,
                  const float* rstd, const float* gamma, long M, int C, int relu,
                  int use_batch_stats, float* dx, float* dres, float* dgamma, float* dbeta,
-                 float* workspace, vlnce_stream_t stream);
+                 float* workspace, float* pow2, int P, vlnce_stream_t stream);
 /* GroupNorm backward (same conventions; mean/rstd are [N,groups]); workspace from
- * vlnce_gn_bwd_workspace_floats() floats. */
+ * vlnce_gn_bwd_workspace_floats() floats; pow2 / P as vlnce_bn_bwd. */
 size_t vlnce_gn_bwd_workspace_floats(int Nimg, int HW, int C, int groups);
 int vlnce_gn_bwd(const float* dy, const float* y, const float* x, const float* mean,
                  const float* rstd, const float* gamma, int Nimg, int HW, int C, int groups,
                  int relu, float* dx, float* dres, float* dgamma, float* dbeta, float* workspace,
-                 vlnce_stream_t stream);
+                 float* pow2, int P, vlnce_stream_t stream);
 /* max-pool forward that also records the arg-max tap (0..8), and its backward */
 int vlnce_maxpool3x3s2_argmax(const float* x, float* y, uint8_t* argmax, int N, int H, int W,
                               int C, int Ho, int Wo, vlnce_stream_t stream);

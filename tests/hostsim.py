@@ -9,6 +9,8 @@ fallback and raises when libvlnce_hip.so or a GPU is missing.
 Every method documents the contract of the kernel it stands in for; the GPU
 tests check the real kernels against the same contracts.
 """
+import math
+
 import torch
 import torch.nn.functional as F
 
@@ -568,7 +570,7 @@ class HostSim:
         return 1
 
     def bn_bwd(self, dy, y, x, mean, rstd, gamma, M, Cc, relu, use_batch_stats, dx, dres, dgamma,
-               dbeta, workspace=None):
+               dbeta, workspace=None, pow2=None):
         g = dy.reshape(M, Cc)
         if relu:
             g = g * (y.reshape(M, Cc) > 0)
@@ -579,14 +581,25 @@ class HostSim:
         k = (gamma if gamma is not None else 1.0) * rstd
         v = g - db / M - xh * dg / M if use_batch_stats else g
         dx.view(M, Cc).copy_(k * v)
+        self._fill_pow2(pow2, dx)
         if dres is not None:
             dres.view(M, Cc).copy_(g)
 
     def gn_bwd_workspace_floats(self, Nimg, HW, Cc, groups):
         return 1
 
+    @staticmethod
+    def _fill_pow2(pow2, dx):
+        """the simulator takes the true maximum where the kernels take an upper bound"""
+        if pow2 is None:
+            return
+        m = float(dx.abs().max())
+        up = 1.0 if not (m > 0) else 2.0 ** (14 - math.frexp(m)[1])
+        pow2[0].fill_(up)
+        pow2[1].fill_(1.0 / up)
+
     def gn_bwd(self, dy, y, x, mean, rstd, gamma, Nimg, HW, Cc, groups, relu, dx, dres, dgamma,
-               dbeta, workspace):
+               dbeta, workspace, pow2=None):
         cpg = Cc // groups
         g = dy.reshape(Nimg, HW, groups, cpg)
         if relu:
@@ -601,6 +614,7 @@ class HostSim:
         s2 = (g * ga * xh).sum((1, 3), keepdim=True)
         v = rstd.view(Nimg, 1, groups, 1) * (g * ga - s1 / cnt - xh * s2 / cnt)
         dx.view(Nimg, HW, groups, cpg).copy_(v)
+        self._fill_pow2(pow2, dx)
         if dres is not None:
             dres.view(Nimg, HW, groups, cpg).copy_(g)
 

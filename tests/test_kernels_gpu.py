@@ -4,6 +4,7 @@ random inputs.  Tolerance: 1e-4 relative to the output scale (fp32; the MFMA
 is an exact-fp32 fmaf chain, differences are summation order only).
 Shapes are the ones the policies issue scaled to a small
 batch, plus ragged edges (rows / channels / K not multiples of the tile)."""
+import math
 import os
 
 import pytest
@@ -1598,3 +1599,70 @@ def test_prepare_weights_matches_the_per_tensor_entry_points(hip):
     with pytest.raises(ValueError):   # Cin = 3: not a job (the stems keep the per-tensor path)
         hip.weight_prep_plan([(torch.randn(64, 3, 7, 7, device=DEV),
                                torch.empty(64, 7, 7, 3, device=DEV), hip.WP_F32, 0, 0)])
+
+
+@pytest.mark.parametrize("batch", [1, 0])
+def test_bn_bwd_power_of_two_bounds_dx(hip, batch):
+    """`pow2` of vlnce_bn_bwd / vlnce_gn_bwd: an exact power of two 2^k (and its inverse) with
+    max|dx| * 2^k <= 2^14 -- fp16's range with room to spare -- and not more than a few binades
+    below it (the bound comes from per-channel maxima, not from dx itself)."""
+    for scale in (1.0, 3e-7, 5e3):
+        M, Cc, P = 5000, 96, 128
+        x = rnd(M, Cc, seed=1) * 2 + 0.5
+        mean, rstd = x.mean(0), torch.rsqrt(x.var(0, unbiased=False) + 1e-5)
+        gamma = rnd(Cc, seed=2).abs() + 0.5
+        y = torch.relu((x - mean) * rstd * gamma + rnd(Cc, seed=3))
+        dy = rnd(M, Cc, seed=4) * scale
+        dx, dg, db = (torch.zeros(M, Cc, device=DEV), torch.zeros(Cc, device=DEV),
+                      torch.zeros(Cc, device=DEV))
+        pow2 = torch.zeros(2, P, device=DEV)
+        hip.bn_bwd(dy.to(DEV), y.to(DEV), x.to(DEV), mean.to(DEV), rstd.to(DEV), gamma.to(DEV), M, Cc,
+                   1, batch, dx, None, dg, db,
+                   torch.empty(hip.bn_bwd_workspace_floats(M, Cc), device=DEV), pow2)
+        up, down = pow2[0].cpu(), pow2[1].cpu()
+        assert (up == up[0]).all() and (down == down[0]).all() and float(up[0] * down[0]) == 1.0
+        assert math.frexp(float(up[0]))[0] == 0.5          # a power of two
+        top = float(dx.abs().max()) * float(up[0])
+        assert 2.0 ** 9 < top <= 2.0 ** 14, (scale, top)
+    # GroupNorm
+    N, HW, Cc, G = 3, 700, 64, 16
+    x = rnd(N, HW, Cc, seed=1) * 2 + 0.3
+    xg = x.view(N, HW, G, Cc // G)
+    mean, rstd = xg.mean((1, 3)).contiguous(), torch.rsqrt(xg.var((1, 3), unbiased=False) + 1e-5).contiguous()
+    gamma = rnd(Cc, seed=2).abs() + 0.5
+    y = torch.relu(((xg - mean.view(N, 1, G, 1)) * rstd.view(N, 1, G, 1)).reshape(N, HW, Cc) * gamma)
+    for scale in (1.0, 2e-8):
+        dy = rnd(N, HW, Cc, seed=4) * scale
+        dx, dg, db = torch.zeros(N, HW, Cc, device=DEV), torch.zeros(Cc, device=DEV), torch.zeros(Cc, device=DEV)
+        pow2 = torch.zeros(2, 80, device=DEV)
+        ws = torch.empty(hip.gn_bwd_workspace_floats(N, HW, Cc, G), device=DEV)
+        hip.gn_bwd(dy.to(DEV), y.contiguous().to(DEV), x.to(DEV), mean.to(DEV), rstd.to(DEV), gamma.to(DEV),
+                   N, HW, Cc, G, 1, dx, None, dg, db, ws, pow2)
+        up = float(pow2[0, 0])
+        assert math.frexp(up)[0] == 0.5 and float(pow2[1, 79]) * up == 1.0
+        top = float(dx.abs().max()) * up
+        assert 2.0 ** 9 < top <= 2.0 ** 14, (scale, top)
+
+
+@pytest.mark.parametrize("k,stride,pad", [(1, 1, 0), (3, 1, 1), (3, 2, 1), (1, 2, 0)])
+def test_data_gradient_on_fp16_planes_with_the_power_of_two(hip, k, stride, pad):
+    """conv_backward(..., pow2): the data gradient of a TINY dy (1e-7: below fp16's normal range) in
+    plane format 2, scaled by the exact power of two in the prologue and back in the epilogue,
+    against fp64 -- the accuracy of the forward's fp16 planes (2^-22), not a flush to zero."""
+    from vlnce_amd.encoders import trunk_backward as tb
+    N, H, W, Cin, Cout = 2, 14, 14, 64, 96
+    x = rnd(N, H, W, Cin, seed=1)
+    w = rnd(Cout, k, k, Cin, seed=2) * 0.1
+    Ho = (H + 2 * pad - k) // stride + 1
+    dy = rnd(N, Ho, Ho, Cout, seed=3) * 1e-7
+    ref = torch.nn.grad.conv2d_input((N, Cin, H, W), w.permute(0, 3, 1, 2).double(),
+                                     dy.permute(0, 3, 1, 2).double(), stride=stride, padding=pad)
+    ref = ref.permute(0, 2, 3, 1)
+    up = 2.0 ** (14 - math.frexp(float(dy.abs().max()))[1])
+    pow2 = torch.empty(2, 128, device=DEV)
+    pow2[0].fill_(up)
+    pow2[1].fill_(1.0 / up)
+    add = rnd(N, H, W, Cin, seed=4) * 1e-7
+    dx, _ = tb.conv_backward(x.to(DEV), w.to(DEV), dy.to(DEV), stride, pad, True, add.to(DEV), pow2)
+    err = float((dx.cpu().double() - ref - add.double()).abs().max()) / float(ref.abs().max())
+    assert err < 2e-6, err

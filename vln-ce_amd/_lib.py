@@ -134,10 +134,10 @@ _SIGNATURES = {
     "vlnce_mean_rows": (_I, [_P, _P, _I, _I, _I, _P]),
     "vlnce_mask_rows": (_I, [_P, _P, _P, _I, _I, _P]),
     "vlnce_conv2d_wgrad": (_I, [_P, _P, _P, C.POINTER(ConvDesc), _P]),
-    "vlnce_bn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
+    "vlnce_bn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P]),
     "vlnce_bn_bwd_workspace_floats": (C.c_size_t, [_L, _I]),
     "vlnce_gn_bwd_workspace_floats": (C.c_size_t, [_I, _I, _I, _I]),
-    "vlnce_gn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
+    "vlnce_gn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P]),
     "vlnce_maxpool3x3s2_argmax": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "vlnce_maxpool3x3s2_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "vlnce_adaptive_avgpool_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
@@ -697,20 +697,25 @@ class HipLib:
         return int(self.dll.vlnce_bn_bwd_workspace_floats(M, Cc))
 
     def bn_bwd(self, dy, y, x, mean, rstd, gamma, M, Cc, relu, use_batch_stats, dx, dres, dgamma,
-               dbeta, workspace=None):
+               dbeta, workspace=None, pow2=None):
+        """pow2: [2, P] floats or None -- on return P copies of 2^k, then P of 2^-k, the power of
+        two at which dx fits the fp16 planes (include/vlnce_hip.h)."""
         self._check(self.dll.vlnce_bn_bwd(_ptr(dy), _ptr(y), _ptr(x), _ptr(mean), _ptr(rstd),
                                           _ptr(gamma), M, Cc, int(relu), int(use_batch_stats),
                                           _ptr(dx), _ptr(dres), _ptr(dgamma), _ptr(dbeta),
-                                          _ptr(workspace), _stream()), "vlnce_bn_bwd")
+                                          _ptr(workspace), _ptr(pow2),
+                                          pow2.size(1) if pow2 is not None else 0, _stream()),
+                    "vlnce_bn_bwd")
 
     def gn_bwd_workspace_floats(self, Nimg, HW, Cc, groups):
         return int(self.dll.vlnce_gn_bwd_workspace_floats(Nimg, HW, Cc, groups))
 
     def gn_bwd(self, dy, y, x, mean, rstd, gamma, Nimg, HW, Cc, groups, relu, dx, dres, dgamma,
-               dbeta, workspace):
+               dbeta, workspace, pow2=None):
         self._check(self.dll.vlnce_gn_bwd(_ptr(dy), _ptr(y), _ptr(x), _ptr(mean), _ptr(rstd),
                                           _ptr(gamma), Nimg, HW, Cc, groups, int(relu), _ptr(dx),
                                           _ptr(dres), _ptr(dgamma), _ptr(dbeta), _ptr(workspace),
+                                          _ptr(pow2), pow2.size(1) if pow2 is not None else 0,
                                           _stream()), "vlnce_gn_bwd")
 
     def maxpool3x3s2_argmax(self, x, y, argmax, N, H, W, Cc, Ho, Wo):

@@ -99,7 +99,9 @@ __global__ __launch_bounds__(256) void zero2_kernel(float* __restrict__ a, float
   if (i < n) a[i] = 0.f, b[i] = 0.f;
 }
 
-// combine the row lanes of a block: acc[8] = {sum g (4 channels), sum g*xhat (4 channels)}
+// combine the row lanes of a block: acc[8] = {sum g (4 channels), sum g*xhat (4 channels)}, or
+// the running maxima (MAX)
+template <bool MAX = false>
 __device__ __forceinline__ void strip_reduce(float (&acc)[8], float (*red)[9], int qwl, int ql,
                                              int lane_row) {
   const int lanes = 256 >> qwl;
@@ -109,28 +111,47 @@ __device__ __forceinline__ void strip_reduce(float (&acc)[8], float (*red)[9], i
   if (lane_row == 0) {
     for (int l = 1; l < lanes; ++l)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc[j] += red[(l << qwl) + ql][j];
+      for (int j = 0; j < 8; ++j) {
+        const float v = red[(l << qwl) + ql][j];
+        acc[j] = MAX ? fmaxf(acc[j], v) : acc[j] + v;
+      }
   }
+}
+
+// 2^k with bound * 2^k in (2^13, 2^14]: the scale at which a gradient tensor whose magnitude is at
+// most `bound` enters the fp16 planes (format 2) with 2^28 of normal range below its largest value
+__device__ __forceinline__ float pow2_for_fp16_planes(float bound) {
+  if (!(bound > 0.f) || !isfinite(bound)) return 1.f;
+  int e;
+  frexpf(bound, &e);  // bound = m * 2^e, m in [0.5, 1)
+  int k = 14 - e;
+  k = k > 100 ? 100 : (k < -100 ? -100 : k);
+  return ldexpf(1.f, k);
 }
 
 template <int RELU>
 __global__ __launch_bounds__(256) void bn_bwd_reduce4_kernel(
     const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ x,
     const float* __restrict__ mean, const float* __restrict__ rstd, long M, int C, int qwl,
-    int rows_per_block, float* __restrict__ partial /* [slices][2][C] */) {
+    int rows_per_block, float* __restrict__ partial /* [slices][4][C] */) {
   __shared__ float red[256][9];
   const int ql = threadIdx.x & ((1 << qwl) - 1), rl = threadIdx.x >> qwl, lanes = 256 >> qwl;
   const int c = ((blockIdx.x << qwl) + ql) * 4;
   const long m0 = (long)blockIdx.y * rows_per_block;
   const long m1 = m0 + rows_per_block < M ? m0 + rows_per_block : M;
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float top[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // max |g|, max |x - mean| (4 channels)
   if (c < C) {
     const float4 mu = ld4(mean + c);
     auto one = [&](float4 g, float4 yv, float4 xv) {
       if (RELU) g = relu_mask(g, yv);
+      const float4 xc = make_float4(xv.x - mu.x, xv.y - mu.y, xv.z - mu.z, xv.w - mu.w);
       acc[0] += g.x, acc[1] += g.y, acc[2] += g.z, acc[3] += g.w;
-      acc[4] += g.x * (xv.x - mu.x), acc[5] += g.y * (xv.y - mu.y);
-      acc[6] += g.z * (xv.z - mu.z), acc[7] += g.w * (xv.w - mu.w);
+      acc[4] += g.x * xc.x, acc[5] += g.y * xc.y, acc[6] += g.z * xc.z, acc[7] += g.w * xc.w;
+      top[0] = fmaxf(top[0], fabsf(g.x)), top[1] = fmaxf(top[1], fabsf(g.y));
+      top[2] = fmaxf(top[2], fabsf(g.z)), top[3] = fmaxf(top[3], fabsf(g.w));
+      top[4] = fmaxf(top[4], fabsf(xc.x)), top[5] = fmaxf(top[5], fabsf(xc.y));
+      top[6] = fmaxf(top[6], fabsf(xc.z)), top[7] = fmaxf(top[7], fabsf(xc.w));
     };
     long m = m0 + rl;
     const long step = (long)lanes * C;
@@ -157,29 +178,61 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce4_kernel(
     acc[4] *= rs.x, acc[5] *= rs.y, acc[6] *= rs.z, acc[7] *= rs.w;
   }
   strip_reduce(acc, red, qwl, ql, rl);
+  __syncthreads();
+  strip_reduce<true>(top, red, qwl, ql, rl);
   if (rl == 0 && c < C) {
-    float* out = partial + (long)blockIdx.y * 2 * C + c;
+    float* out = partial + (long)blockIdx.y * 4 * C + c;
     st4(out, make_float4(acc[0], acc[1], acc[2], acc[3]));
     st4(out + C, make_float4(acc[4], acc[5], acc[6], acc[7]));
+    st4(out + 2 * C, make_float4(top[0], top[1], top[2], top[3]));
+    st4(out + 3 * C, make_float4(top[4], top[5], top[6], top[7]));
   }
 }
 
 // dbeta | dgamma = column sums of partial[slices][2C].  Same-address atomics from ~2000 blocks were
 // the whole cost of the small layers (~40 ns each, serial: 65 us for a 50 MB layer), hence partials
 // and this pass: one wave per four columns, lane = slice, then a wave sum.
+// columns [0,C) -> dbeta, [C,2C) -> dgamma (sums); [2C,4C) -> tops[2][C] (maxima of |g|, |x - mean|)
 __global__ __launch_bounds__(256) void bn_bwd_finalize4_kernel(const float* __restrict__ partial,
                                                                int slices, int C,
                                                                float* __restrict__ dgamma,
-                                                               float* __restrict__ dbeta) {
+                                                               float* __restrict__ dbeta,
+                                                               float* __restrict__ tops) {
   const int col = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4, lane = threadIdx.x & 63;
-  if (col >= 2 * C) return;
+  if (col >= 4 * C) return;
+  const bool mx = col >= 2 * C;
   float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int sl = lane; sl < slices; sl += 64) {
-    const float4 v = ld4(partial + (long)sl * 2 * C + col);
-    a.x += v.x, a.y += v.y, a.z += v.z, a.w += v.w;
+    const float4 v = ld4(partial + (long)sl * 4 * C + col);
+    if (mx) a.x = fmaxf(a.x, v.x), a.y = fmaxf(a.y, v.y), a.z = fmaxf(a.z, v.z), a.w = fmaxf(a.w, v.w);
+    else a.x += v.x, a.y += v.y, a.z += v.z, a.w += v.w;
   }
-  a.x = wave_sum(a.x), a.y = wave_sum(a.y), a.z = wave_sum(a.z), a.w = wave_sum(a.w);
-  if (lane == 0) st4(col < C ? dbeta + col : dgamma + (col - C), a);
+  if (mx) a.x = wave_max(a.x), a.y = wave_max(a.y), a.z = wave_max(a.z), a.w = wave_max(a.w);
+  else a.x = wave_sum(a.x), a.y = wave_sum(a.y), a.z = wave_sum(a.z), a.w = wave_sum(a.w);
+  if (lane == 0) st4(col < C ? dbeta + col : col < 2 * C ? dgamma + (col - C) : tops + (col - 2 * C), a);
+}
+
+// |dx| <= max_c |k_c| (max|g|_c + |a_c| + max|x - mean|_c |b_c|): an upper bound from the vectors
+// alone, within a small factor of the true maximum (a and b are the batch-statistics corrections);
+// -> pow2[0..P) = 2^k, pow2[P..2P) = 2^-k (per-channel vectors for a convolution's prologue /
+// epilogue, all equal).  One workgroup (block 0 of the apply kernel), ~3 us beside the others.
+__device__ void bn_bwd_pow2(const float* rstd, const float* gamma, const float* dgamma,
+                            const float* dbeta, const float* tops, int C, float invM, int batch,
+                            float* pow2, int P) {
+  __shared__ float wmax[4];
+  float m = 0.f;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const float rs = rstd[c], k = fabsf((gamma ? gamma[c] : 1.f) * rs);
+    float b = tops[c];
+    if (batch) b += fabsf(dbeta[c] * invM) + tops[C + c] * fabsf(rs * dgamma[c] * invM);
+    m = fmaxf(m, k * b);
+  }
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3])) * 1.0001f;
+  const float up = pow2_for_fp16_planes(m), down = 1.f / up;
+  for (int i = threadIdx.x; i < P; i += 256) pow2[i] = up, pow2[P + i] = down;
 }
 
 template <int RELU, int BATCH, int RES>
@@ -188,7 +241,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(
     const float* __restrict__ mean, const float* __restrict__ rstd,
     const float* __restrict__ gamma, const float* __restrict__ dgamma,
     const float* __restrict__ dbeta, long M, int C, int qwl, int rows_per_block,
-    float* __restrict__ dx, float* __restrict__ dres) {
+    float* __restrict__ dx, float* __restrict__ dres, const float* __restrict__ tops,
+    float* __restrict__ pow2, int P) {
+  if (pow2 && blockIdx.x == 0 && blockIdx.y == 0)
+    bn_bwd_pow2(rstd, gamma, dgamma, dbeta, tops, C, 1.f / (float)M, BATCH, pow2, P);
   const int ql = threadIdx.x & ((1 << qwl) - 1), rl = threadIdx.x >> qwl, lanes = 256 >> qwl;
   const int c = ((blockIdx.x << qwl) + ql) * 4;
   if (c >= C) return;
@@ -268,7 +324,9 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(
 __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(
     const float* __restrict__ partial, int C, int groups, int chunks,
     const float* __restrict__ gamma, float* __restrict__ s12 /* [N,groups,2] */,
-    float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    float* __restrict__ dgamma, float* __restrict__ dbeta,
+    const float* __restrict__ tops_partial, const float* __restrict__ rstd, float inv,
+    float* __restrict__ bound /* [N] or null */) {
   extern __shared__ float sh[];  // [C][2]
   const int n = blockIdx.x;
   const int cpg = C / groups;
@@ -295,6 +353,27 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(
     s12[((long)n * groups + g_) * 2] = s1;
     s12[((long)n * groups + g_) * 2 + 1] = s2;
   }
+  if (!bound) return;
+  // |dx| <= |rs| (max|g| |gamma| + |s1| inv + max|x - mean| |rs s2| inv) over the sample's channels
+  __syncthreads();  // (s12 of this sample: written by this block, read back below)
+  __shared__ float wmax[4];
+  float m = 0.f;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float tg = 0.f, tx = 0.f;
+    for (int ch = 0; ch < chunks; ++ch) {
+      const float* q = tops_partial + (((long)n * chunks + ch) * C + c) * 2;
+      tg = fmaxf(tg, q[0]);
+      tx = fmaxf(tx, q[1]);
+    }
+    const long sg = (long)n * groups + c / cpg;
+    const float rs = rstd[sg];
+    m = fmaxf(m, fabsf(rs) * (tg * fabsf(gamma ? gamma[c] : 1.f) + fabsf(s12[sg * 2]) * inv +
+                              tx * fabsf(rs * s12[sg * 2 + 1]) * inv));
+  }
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) bound[n] = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
 }
 
 // dx = rstd * (g*gamma - s1/cnt - xhat*s2/cnt)
@@ -325,9 +404,10 @@ template <int RELU>
 __global__ __launch_bounds__(256) void gn_bwd_partial4_kernel(
     const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ x,
     const float* __restrict__ mean, const float* __restrict__ rstd, int HW, int C, int groups,
-    int chunks, int qwl, float* __restrict__ partial) {
+    int chunks, int qwl, float* __restrict__ partial, float* __restrict__ tops_partial) {
   __shared__ float red[256][9];
   const int ql = threadIdx.x & ((1 << qwl) - 1), pl = threadIdx.x >> qwl, lanes = 256 >> qwl;
+  float top[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const int n = blockIdx.x / chunks;
   const int ch = blockIdx.x - n * chunks;
   const int p0 = ch * GN_CHUNK;
@@ -348,18 +428,31 @@ __global__ __launch_bounds__(256) void gn_bwd_partial4_kernel(
       float4 g = ld4(dy + i);
       if (RELU) g = relu_mask(g, ld4(y + i));
       const float4 xv = ld4(x + i);
+      const float4 xc = make_float4(xv.x - mu[0], xv.y - mu[1], xv.z - mu[2], xv.w - mu[3]);
       acc[0] += g.x, acc[1] += g.y, acc[2] += g.z, acc[3] += g.w;
-      acc[4] += g.x * (xv.x - mu[0]), acc[5] += g.y * (xv.y - mu[1]);
-      acc[6] += g.z * (xv.z - mu[2]), acc[7] += g.w * (xv.w - mu[3]);
+      acc[4] += g.x * xc.x, acc[5] += g.y * xc.y, acc[6] += g.z * xc.z, acc[7] += g.w * xc.w;
+      top[0] = fmaxf(top[0], fabsf(g.x)), top[1] = fmaxf(top[1], fabsf(g.y));
+      top[2] = fmaxf(top[2], fabsf(g.z)), top[3] = fmaxf(top[3], fabsf(g.w));
+      top[4] = fmaxf(top[4], fabsf(xc.x)), top[5] = fmaxf(top[5], fabsf(xc.y));
+      top[6] = fmaxf(top[6], fabsf(xc.z)), top[7] = fmaxf(top[7], fabsf(xc.w));
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[4 + j] *= rs[j];
   }
   strip_reduce(acc, red, qwl, ql, pl);
+  if (tops_partial) {
+    __syncthreads();
+    strip_reduce<true>(top, red, qwl, ql, pl);
+  }
   if (pl == 0 && c < C) {
     float* out = partial + (((long)n * chunks + ch) * C + c) * 2;
     st4(out, make_float4(acc[0], acc[4], acc[1], acc[5]));
     st4(out + 4, make_float4(acc[2], acc[6], acc[3], acc[7]));
+    if (tops_partial) {
+      out = tops_partial + (((long)n * chunks + ch) * C + c) * 2;
+      st4(out, make_float4(top[0], top[4], top[1], top[5]));
+      st4(out + 4, make_float4(top[2], top[6], top[3], top[7]));
+    }
   }
 }
 
@@ -368,7 +461,19 @@ __global__ __launch_bounds__(256) void gn_bwd_apply4_kernel(
     const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ x,
     const float* __restrict__ mean, const float* __restrict__ rstd,
     const float* __restrict__ gamma, const float* __restrict__ s12, int HW, int C, int groups,
-    int qwl, int pix_per_block, float* __restrict__ dx, float* __restrict__ dres) {
+    int qwl, int pix_per_block, float* __restrict__ dx, float* __restrict__ dres,
+    const float* __restrict__ bound, int Nimg, float* __restrict__ pow2, int P) {
+  if (pow2 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
+    __shared__ float wmax[4];
+    float m = 0.f;
+    for (int i = threadIdx.x; i < Nimg; i += 256) m = fmaxf(m, bound[i]);
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3])) * 1.0001f;
+    const float up = pow2_for_fp16_planes(m), down = 1.f / up;
+    for (int i = threadIdx.x; i < P; i += 256) pow2[i] = up, pow2[P + i] = down;
+  }
   const int ql = threadIdx.x & ((1 << qwl) - 1), pl = threadIdx.x >> qwl, lanes = 256 >> qwl;
   const int c = ((blockIdx.x << qwl) + ql) * 4;
   if (c >= C) return;
@@ -568,29 +673,33 @@ inline BnBwdPlan bn_bwd_plan(long M, int C) {
 
 extern "C" size_t vlnce_bn_bwd_workspace_floats(long M, int C) {
   if (C <= 0 || C % 4 != 0 || M <= 0) return 0;
-  return (size_t)bn_bwd_plan(M, C).slices * 2 * C;
+  return (size_t)bn_bwd_plan(M, C).slices * 4 * C + 2 * (size_t)C;
 }
 
 extern "C" int vlnce_bn_bwd(const float* dy, const float* y, const float* x, const float* mean,
                             const float* rstd, const float* gamma, long M, int C, int relu,
                             int use_batch_stats, float* dx, float* dres, float* dgamma,
-                            float* dbeta, float* workspace, vlnce_stream_t stream) {
+                            float* dbeta, float* workspace, float* pow2, int P,
+                            vlnce_stream_t stream) {
   VLNCE_CHECK_ARG(dy && x && mean && rstd && dx && dgamma && dbeta, "bn_bwd: null argument");
+  VLNCE_CHECK_ARG(!pow2 || (P > 0 && C % 4 == 0), "bn_bwd: pow2 needs P > 0 and C %% 4 == 0");
   VLNCE_CHECK_ARG(!relu || y, "bn_bwd: ReLU backward needs the forward output y");
   VLNCE_CHECK_ARG(C % 4 != 0 || workspace, "bn_bwd: C %% 4 == 0 needs the workspace");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (C % 4 == 0 && aligned16({dy, y, x, mean, rstd, gamma, dx, dres, dgamma, dbeta, workspace})) {
     const BnBwdPlan pl = bn_bwd_plan(M, C);
     const int qwl = pl.qwl, strips = pl.strips, rpb = pl.rpb;
+    float* tops = workspace + (size_t)pl.slices * 4 * C;
     const dim3 grid(strips, ceil_div(M, rpb));
 #define BN_R(R) hipLaunchKernelGGL(bn_bwd_reduce4_kernel<R>, grid, dim3(256), 0, s, dy, y, x, mean, \
                                    rstd, M, C, qwl, rpb, workspace)
     if (relu) BN_R(1); else BN_R(0);
 #undef BN_R
-    hipLaunchKernelGGL(bn_bwd_finalize4_kernel, dim3(ceil_div(2 * C / 4, 4)), dim3(256), 0, s,
-                       workspace, pl.slices, C, dgamma, dbeta);
+    hipLaunchKernelGGL(bn_bwd_finalize4_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, s, workspace,
+                       pl.slices, C, dgamma, dbeta, tops);
 #define BN_A(R, B, D) hipLaunchKernelGGL((bn_bwd_apply4_kernel<R, B, D>), grid, dim3(256), 0, s, dy, y, \
-                                         x, mean, rstd, gamma, dgamma, dbeta, M, C, qwl, rpb, dx, dres)
+                                         x, mean, rstd, gamma, dgamma, dbeta, M, C, qwl, rpb, dx, dres, \
+                                         tops, pow2, P)
     const int sel = (relu ? 4 : 0) | (use_batch_stats ? 2 : 0) | (dres ? 1 : 0);
     switch (sel) {
       case 0: BN_A(0, 0, 0); break;
@@ -606,6 +715,7 @@ extern "C" int vlnce_bn_bwd(const float* dy, const float* y, const float* x, con
     VLNCE_CHECK_LAUNCH("bn_bwd");
     return 0;
   }
+  VLNCE_CHECK_ARG(!pow2, "bn_bwd: pow2 needs 16-byte aligned tensors");
   hipLaunchKernelGGL(zero2_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, s, dgamma, dbeta, C);
   const int col_blocks = ceil_div(C, 64);
   long slices = (1024 + col_blocks - 1) / col_blocks;
@@ -623,17 +733,21 @@ extern "C" int vlnce_bn_bwd(const float* dy, const float* y, const float* x, con
 extern "C" int vlnce_gn_bwd(const float* dy, const float* y, const float* x, const float* mean,
                             const float* rstd, const float* gamma, int Nimg, int HW, int C,
                             int groups, int relu, float* dx, float* dres, float* dgamma,
-                            float* dbeta, float* workspace /* [N,chunks,C,2] + [N,groups,2] */,
-                            vlnce_stream_t stream) {
+                            float* dbeta,
+                            float* workspace /* [N,chunks,C,2] + [N,groups,2] + [N,chunks,C,2] + [N] */,
+                            float* pow2, int P, vlnce_stream_t stream) {
   VLNCE_CHECK_ARG(dy && x && mean && rstd && dx && dgamma && dbeta && workspace,
                   "gn_bwd: null argument");
   VLNCE_CHECK_ARG(!relu || y, "gn_bwd: ReLU backward needs the forward output y");
   VLNCE_CHECK_ARG(groups > 0 && C % groups == 0, "gn_bwd: C %% groups != 0");
+  VLNCE_CHECK_ARG(!pow2 || P > 0, "gn_bwd: pow2 needs P > 0");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(zero2_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, s, dgamma, dbeta, C);
   const int chunks = ceil_div(HW, GN_CHUNK);
   float* partial = workspace;
   float* s12 = workspace + (size_t)Nimg * chunks * C * 2;
+  float* tops_partial = s12 + (size_t)Nimg * groups * 2;
+  float* bound = tops_partial + (size_t)Nimg * chunks * C * 2;
   const bool quads = C % 4 == 0 && Nimg <= 65535 &&
                      aligned16({dy, y, x, dx, dres, workspace});
   const int qwl = quads ? strip_log2(C / 4) : 0, strips = quads ? ceil_div(C / 4, 1 << qwl) : 0;
@@ -641,16 +755,18 @@ extern "C" int vlnce_gn_bwd(const float* dy, const float* y, const float* x, con
     const dim3 grid(Nimg * chunks, strips);
     if (relu)
       hipLaunchKernelGGL(gn_bwd_partial4_kernel<1>, grid, dim3(256), 0, s, dy, y, x, mean, rstd, HW,
-                         C, groups, chunks, qwl, partial);
+                         C, groups, chunks, qwl, partial, pow2 ? tops_partial : nullptr);
     else
       hipLaunchKernelGGL(gn_bwd_partial4_kernel<0>, grid, dim3(256), 0, s, dy, y, x, mean, rstd, HW,
-                         C, groups, chunks, qwl, partial);
+                         C, groups, chunks, qwl, partial, pow2 ? tops_partial : nullptr);
   } else {
+    VLNCE_CHECK_ARG(!pow2, "gn_bwd: pow2 needs C %% 4 == 0 and 16-byte aligned tensors");
     hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3(Nimg * chunks), dim3(256), 0, s, dy, y, x, mean,
                        rstd, HW, C, groups, chunks, relu, partial);
   }
   hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(Nimg), dim3(256), (size_t)C * 2 * sizeof(float),
-                     s, partial, C, groups, chunks, gamma, s12, dgamma, dbeta);
+                     s, partial, C, groups, chunks, gamma, s12, dgamma, dbeta, tops_partial, rstd,
+                     1.f / ((float)HW * (float)(C / groups)), pow2 ? bound : nullptr);
   const long total = (long)Nimg * HW * C;
   if (quads) {
     const int lanes = 256 >> qwl;
@@ -661,7 +777,8 @@ extern "C" int vlnce_gn_bwd(const float* dy, const float* y, const float* x, con
     const int ppb = (int)((HW + slices - 1) / slices);
     const dim3 grid(strips, ceil_div(HW, ppb), Nimg);
 #define GN_A(R, D) hipLaunchKernelGGL((gn_bwd_apply4_kernel<R, D>), grid, dim3(256), 0, s, dy, y, x, mean, \
-                                      rstd, gamma, s12, HW, C, groups, qwl, ppb, dx, dres)
+                                      rstd, gamma, s12, HW, C, groups, qwl, ppb, dx, dres, bound, Nimg, \
+                                      pow2, P)
     if (relu) { if (dres) GN_A(1, 1); else GN_A(1, 0); }
     else      { if (dres) GN_A(0, 1); else GN_A(0, 0); }
 #undef GN_A
@@ -674,7 +791,7 @@ extern "C" int vlnce_gn_bwd(const float* dy, const float* y, const float* x, con
 }
 
 extern "C" size_t vlnce_gn_bwd_workspace_floats(int Nimg, int HW, int C, int groups) {
-  return (size_t)Nimg * ceil_div(HW, GN_CHUNK) * C * 2 + (size_t)Nimg * groups * 2;
+  return (size_t)Nimg * ceil_div(HW, GN_CHUNK) * C * 4 + (size_t)Nimg * groups * 2 + (size_t)Nimg;
 }
 
 extern "C" int vlnce_maxpool3x3s2_argmax(const float* x, float* y, uint8_t* argmax, int N, int H,

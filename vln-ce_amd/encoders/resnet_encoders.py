@@ -58,7 +58,7 @@ class _WeightCache:
     def prepare_trainable(self, convs):
         """Trainable trunks: every weight image the step needs -- OHWI fp32, planes and fragments in
         the forward format, and the data-gradient bank (taps reversed, channels swapped) as fp32,
-        planes and fragments in format 1 -- written by ONE launch (vlnce_conv2d_prepare_weights)
+        planes and fragments in the backward format (ops.GRAD_PLANES) -- written by ONE launch (vlnce_conv2d_prepare_weights)
         into persistent buffers, and handed to conv() / ops.split_weights / ops.pack_weights /
         trunk_backward.conv_backward through the caches those already consult.  Convolutions the
         kernel does not take (the stems: Cin = 1 or 3) keep the per-tensor path."""
@@ -68,7 +68,8 @@ class _WeightCache:
             return
         lib = ops.L()
         fmt = ops.plane_format()
-        sig = (fmt,) + tuple((id(c), c.weight.data_ptr()) for c in convs)
+        gfmt = ops.GRAD_PLANES if fmt == ops.PLANES_F16X3 else ops.PLANES_BF16X6
+        sig = (fmt, gfmt) + tuple((id(c), c.weight.data_ptr()) for c in convs)
         st = self._prep
         if st is None or st["sig"] != sig:
             st = dict(sig=sig, key=None, rows=[], plan=None)
@@ -86,14 +87,14 @@ class _WeightCache:
                            wt=torch.empty((Cin, KH, KW, Cout), device=dev),
                            split_t=i16(3, p.numel()), frag_t=i16(p.numel() * 3))
                 row["split"]._vlnce_fmt = row["frag"]._vlnce_fmt = fmt
-                row["split_t"]._vlnce_fmt = row["frag_t"]._vlnce_fmt = ops.PLANES_BF16X6
+                row["split_t"]._vlnce_fmt = row["frag_t"]._vlnce_fmt = gfmt
                 if row["w"] is not None:
                     jobs.append((p, row["w"], lib.WP_F32, 0, 0))
                 jobs += [(p, row["split"], lib.WP_PLANES, 0, fmt),
                          (p, row["frag"], lib.WP_FRAGMENTS, 0, fmt),
                          (p, row["wt"], lib.WP_F32, 1, 0),
-                         (p, row["split_t"], lib.WP_PLANES, 1, ops.PLANES_BF16X6),
-                         (p, row["frag_t"], lib.WP_FRAGMENTS, 1, ops.PLANES_BF16X6)]
+                         (p, row["split_t"], lib.WP_PLANES, 1, gfmt),
+                         (p, row["frag_t"], lib.WP_FRAGMENTS, 1, gfmt)]
                 st["rows"].append(row)
             st["plan"] = lib.weight_prep_plan(jobs)
             self._prep = st
@@ -108,8 +109,8 @@ class _WeightCache:
             wt = row["wt"]
             w.__dict__["_vlnce_split"] = {fmt: (w._version, row["split"])}
             w.__dict__["_vlnce_frag"] = {fmt: (w._version, row["frag"])}
-            wt.__dict__["_vlnce_split"] = {ops.PLANES_BF16X6: (wt._version, row["split_t"])}
-            wt.__dict__["_vlnce_frag"] = {ops.PLANES_BF16X6: (wt._version, row["frag_t"])}
+            wt.__dict__["_vlnce_split"] = {gfmt: (wt._version, row["split_t"])}
+            wt.__dict__["_vlnce_frag"] = {gfmt: (wt._version, row["frag_t"])}
             w._vlnce_dgrad = wt
             self._packed[id(c)] = (self._key(c.weight), w)
 
@@ -548,8 +549,10 @@ class HipResNetTrunk(DropsGraphsOnApply, nn.Sequential):
 
         def conv_bn_back(entry, dy, need_dx=True, add=None):
             _, x_in, conv, bn, w, sv = entry
-            draw, dres, dg, db = tb.bn_backward(dy, sv)
-            dx, dw = tb.conv_backward(x_in, w, draw, conv.stride[0], conv.padding[0], need_dx, add)
+            draw, dres, dg, db, pow2 = tb.bn_backward(
+                dy, sv, max(conv.in_channels, conv.out_channels) if need_dx else 0)
+            dx, dw = tb.conv_backward(x_in, w, draw, conv.stride[0], conv.padding[0], need_dx, add,
+                                      pow2)
             for prm, g in ((conv.weight, dw), (bn.weight, dg), (bn.bias, db)):
                 if prm.requires_grad:
                     grads[id(prm)] = g
@@ -916,8 +919,9 @@ def _depth_backward_from_tape(self, tape, dout):
 
     def back(entry, dy, need_dx=True, add=None):
         _, x_in, conv, gn, w, sv = entry
-        draw, dres, dg, db = tb.gn_backward(dy, sv)
-        dx, dw = tb.conv_backward(x_in, w, draw, conv.stride[0], conv.padding[0], need_dx, add)
+        draw, dres, dg, db, pow2 = tb.gn_backward(
+            dy, sv, max(conv.in_channels, conv.out_channels) if need_dx else 0)
+        dx, dw = tb.conv_backward(x_in, w, draw, conv.stride[0], conv.padding[0], need_dx, add, pow2)
         for prm, g in ((conv.weight, dw), (gn.weight, dg), (gn.bias, db)):
             if prm.requires_grad:
                 grads[id(prm)] = g

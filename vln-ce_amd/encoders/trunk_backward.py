@@ -31,10 +31,13 @@ def conv_raw(x, w_ohwi, stride, pad):
     return ops.conv2d_nhwc(x, w_ohwi, stride, pad)
 
 
-def conv_backward(x, w_ohwi, dy, stride, pad, need_dx, add=None):
+def conv_backward(x, w_ohwi, dy, stride, pad, need_dx, add=None, pow2=None):
     """returns (dx | None, dW in OIHW).  `add` (the gradient arriving at the same tensor over the
     block's other branch) is summed into dx by the data-gradient convolution's epilogue instead of
-    a separate pass over two block-input-sized tensors."""
+    a separate pass over two block-input-sized tensors.  `pow2` ([2, P >= max(Cin, Cout)], from
+    bn_backward / gn_backward): the power of two at which dy fits the fp16 planes -- with it the
+    data gradient runs in plane format 2 (three plane products), dy scaled in the prologue and the
+    result scaled back in the epilogue, both exactly."""
     lib = L()
     g = ops.conv_geometry(x, w_ohwi, stride, pad)
     Cout, KH, KW, Cin = w_ohwi.shape
@@ -54,14 +57,20 @@ def conv_backward(x, w_ohwi, dy, stride, pad, need_dx, add=None):
         wt = w_ohwi.flip(1, 2).permute(3, 1, 2, 0).contiguous()
     if add is not None:
         if _SEPARATE_ADD:   # A/B knob (VLNCE_DGRAD_ADD=0): the sum as its own pass
-            dx, dw_oihw = conv_backward(x, w_ohwi, dy, stride, pad, True)
+            dx, dw_oihw = conv_backward(x, w_ohwi, dy, stride, pad, True, None, pow2)
             return dx + add, dw_oihw
         add = add.contiguous()
+    if pow2 is not None:
+        zero = ops.zeros_vec(x.device, max(Cin, Cout))
+        how = dict(in_scale=pow2[0, :Cout], in_shift=zero[:Cout], scale=pow2[1, :Cin],
+                   shift=zero[:Cin], w_format=ops.PLANES_F16X3)
+    else:
+        how = dict(w_format=ops.PLANES_BF16X6)
     if stride == 1:
-        dx = ops.conv2d_nhwc(dy, wt, 1, KH - 1 - pad, residual=add, w_format=ops.PLANES_BF16X6)
+        dx = ops.conv2d_nhwc(dy, wt, 1, KH - 1 - pad, residual=add, **how)
     elif KH == 1:
         # 1x1 / stride s: only the sampled pixels receive gradient
-        small = ops.conv2d_nhwc(dy, wt, 1, 0, w_format=ops.PLANES_BF16X6)
+        small = ops.conv2d_nhwc(dy, wt, 1, 0, **how)
         if add is not None:
             dx = add.clone()
             dx[:, ::stride, ::stride] += small
@@ -74,7 +83,7 @@ def conv_backward(x, w_ohwi, dy, stride, pad, need_dx, add=None):
         Hu, Wu = H + 2 * pad - KH + 1, W + 2 * pad - KW + 1
         up = torch.zeros((N, Hu, Wu, Cout), device=x.device, dtype=torch.float32)
         up[:, ::stride, ::stride] = dy
-        dx = ops.conv2d_nhwc(up, wt, 1, KH - 1 - pad, residual=add, w_format=ops.PLANES_BF16X6)
+        dx = ops.conv2d_nhwc(up, wt, 1, KH - 1 - pad, residual=add, **how)
     return dx, dw_oihw
 
 
@@ -119,8 +128,18 @@ def bn_forward(raw, bn, relu, residual, stats, touched):
     return sv.y, sv
 
 
-def bn_backward(dy, sv):
-    """returns (d raw, d residual | None, dgamma, dbeta)."""
+def _pow2_buffer(raw, P):
+    """[2, P] for the norm-backward kernels' power-of-two output, or None where the backward
+    convolutions keep format 1 (VLNCE_GRAD_PLANES=bf16, the CPU simulator's tensors, C % 4 != 0)"""
+    if (not P or ops.GRAD_PLANES != ops.PLANES_F16X3 or raw.size(-1) % 4 != 0
+            or L().plane_format() != ops.PLANES_F16X3):
+        return None
+    return torch.empty((2, P), device=raw.device, dtype=torch.float32)
+
+
+def bn_backward(dy, sv, P=0):
+    """returns (d raw, d residual | None, dgamma, dbeta, pow2 | None); P = the longer channel count
+    of the convolution whose backward reads d raw (0: no power of two wanted)."""
     Cc = sv.raw.size(-1)
     M = sv.raw.numel() // Cc
     dev = sv.raw.device
@@ -130,9 +149,10 @@ def bn_backward(dy, sv):
     db = torch.empty_like(dg)
     lib = L()
     ws = torch.empty(max(lib.bn_bwd_workspace_floats(M, Cc), 1), device=dev, dtype=torch.float32)
+    pow2 = _pow2_buffer(sv.raw, P)
     lib.bn_bwd(dy.contiguous(), sv.y, sv.raw, sv.mean, sv.rstd, sv.gamma.detach(), M, Cc, sv.relu,
-               sv.batch_stats, dx, dres, dg, db, ws)
-    return dx, dres, dg, db
+               sv.batch_stats, dx, dres, dg, db, ws, pow2)
+    return dx, dres, dg, db, pow2
 
 
 class GNSaved:
@@ -162,7 +182,7 @@ def gn_forward(raw, gn, relu, residual):
     return sv.y, sv
 
 
-def gn_backward(dy, sv):
+def gn_backward(dy, sv, P=0):
     lib = L()
     N, H, W, Cc = sv.raw.shape
     dev = sv.raw.device
@@ -172,9 +192,10 @@ def gn_backward(dy, sv):
     db = torch.empty_like(dg)
     ws = torch.empty(lib.gn_bwd_workspace_floats(N, H * W, Cc, sv.groups), device=dev,
                      dtype=torch.float32)
+    pow2 = _pow2_buffer(sv.raw, P)
     lib.gn_bwd(dy.contiguous(), sv.y, sv.raw, sv.mean, sv.rstd, sv.gamma.detach(), N, H * W, Cc,
-               sv.groups, sv.relu, dx, dres, dg, db, ws)
-    return dx, dres, dg, db
+               sv.groups, sv.relu, dx, dres, dg, db, ws, pow2)
+    return dx, dres, dg, db, pow2
 
 
 def maxpool_forward(x):

@@ -50,6 +50,26 @@ def plane_format(w_format=None, w=None):
     return forced or L().plane_format()
 
 
+# Plane format of the trunks' BACKWARD convolutions (data gradient, weight gradient).  Gradients lie
+# far below fp16's normal range, so on their own they need format 1; the normalisation backward
+# kernels hand out the exact power of two that brings each gradient tensor to the top of fp16's
+# range (vlnce_bn_bwd / vlnce_gn_bwd `pow2`), and with it they take format 2's three plane products
+# instead of six.  VLNCE_GRAD_PLANES=bf16 keeps format 1 (no scaling).
+GRAD_PLANES = (PLANES_BF16X6 if os.environ.get("VLNCE_GRAD_PLANES", "f16") in ("bf16", "1")
+               else PLANES_F16X3)
+_ZEROS = {}
+
+
+def zeros_vec(device, n):
+    """a cached all-zero fp32 vector of at least n elements (the zero `in_shift` / `shift` beside a
+    power-of-two prologue / epilogue scale); never written"""
+    z = _ZEROS.get(device)
+    if z is None or z.numel() < n:
+        z = torch.zeros(max(4096, n), device=device, dtype=torch.float32)
+        _ZEROS[device] = z
+    return z[:n]
+
+
 F16_PLANES_MAX_WEIGHT = 16.0   # format 2 holds |w| < 32 (b1 * 2^11 in fp16); a factor of two in hand
 
 
