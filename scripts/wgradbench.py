@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--set", default="r50")
     ap.add_argument("--only", default="")
     ap.add_argument("--opt", default="")
+    ap.add_argument("--f16", action="store_true", help="fp16 planes with dy's power of two")
     args = ap.parse_args()
     for kv in filter(None, args.opt.split(",")):
         k_, v_ = kv.split("=")
@@ -38,15 +39,20 @@ def main():
         g = ops.conv_geometry(x, torch.empty(cout, k, k, cin), s, pad)
         dy = torch.randn(args.n, g["Ho"], g["Wo"], cout, device=dev) * 1e-3
         dw = torch.empty(cout, k, k, cin, device=dev)
+        pow2 = None
+        if args.f16:
+            import math
+            up = 2.0 ** (14 - math.frexp(float(dy.abs().max()))[1])
+            pow2 = torch.stack([torch.full((8,), up), torch.full((8,), 1.0 / up)]).to(dev)
         for _ in range(2):
-            ops.L().conv2d_wgrad(x, dy, dw, g)
+            ops.L().conv2d_wgrad(x, dy, dw, g, pow2)
         us = 1e30
         for _ in range(3):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             torch.cuda._sleep(int(2e7))
             e0.record()
             for _ in range(args.iters):
-                ops.L().conv2d_wgrad(x, dy, dw, g)
+                ops.L().conv2d_wgrad(x, dy, dw, g, pow2)
             e1.record()
             torch.cuda.synchronize()
             us = min(us, e0.elapsed_time(e1) * 1e3 / args.iters)

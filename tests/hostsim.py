@@ -557,7 +557,7 @@ class HostSim:
         dc_prev.copy_(dc * f * mk)
 
     # ---- backward of the visual trunks (contracts of csrc/bwd.hip, vlnce_conv2d_wgrad)
-    def conv2d_wgrad(self, x, dy, dw, g):
+    def conv2d_wgrad(self, x, dy, dw, g, dy_pow2=None):
         N, H, W, Cin, Cout = g["N"], g["H"], g["W"], g["Cin"], g["Cout"]
         xi = x.as_strided((N, H, W, Cin), (H * W * g["ldx"], W * g["ldx"], g["ldx"], 1))
         xi = xi.permute(0, 3, 1, 2).contiguous()

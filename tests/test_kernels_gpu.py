@@ -823,6 +823,17 @@ def test_conv2d_wgrad(hip, case):
     with hip.options(wgrad_tile=1):
         cpu3, gpu3 = both("conv2d_wgrad", dict(t, dw=torch.zeros_like(t["dw"])), dict(g=g))
     close(gpu3["dw"], cpu3["dw"], what="wgrad/" + name + "/fp32-MFMA")
+    # fp16 planes with the power of two of dy (what bn_bwd / gn_bwd hand out): tiny and huge dy
+    for scale in (1e-7, 1.0, 3e4):
+        dy = t["dy"] * scale
+        up = 2.0 ** (14 - math.frexp(float(dy.abs().max()))[1])
+        pow2 = torch.stack([torch.full((8,), up), torch.full((8,), 1.0 / up)])
+        t4 = dict(t, dy=dy, dw=torch.zeros_like(t["dw"]), dy_pow2=pow2)
+        cpu4, gpu4 = both("conv2d_wgrad", t4, dict(g=g))
+        close(gpu4["dw"], cpu4["dw"], what=f"wgrad/{name}/fp16 planes x{scale:g}")
+        ref = cpu4["dw"].double()   # (close() carries an absolute 1e-6: relative, for the tiny dy)
+        rel = float((gpu4["dw"].cpu().double() - ref).abs().max() / ref.abs().max())
+        assert rel < 1e-4, (name, scale, rel)
 
 
 @pytest.mark.parametrize("stride,k,pad", [(1, 3, 1), (2, 3, 1), (2, 1, 0), (1, 1, 0), (2, 7, 3)])

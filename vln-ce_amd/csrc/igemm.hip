@@ -1784,7 +1784,8 @@ extern "C" int vlnce_gemm(const float* A, int lda, int transA, const float* B, i
 
 // dW[Cout, KH, KW, Cin] = sum over output pixels of dY[m, co] * im2col(X)[m, (r,q,ci)]
 extern "C" int vlnce_conv2d_wgrad(const float* x, const float* dy, float* dw_ohwi,
-                                  const vlnce_conv_desc* d, vlnce_stream_t stream) {
+                                  const vlnce_conv_desc* d, const float* dy_pow2, int P,
+                                  vlnce_stream_t stream) {
   VLNCE_CHECK_ARG(x && dy && dw_ohwi && d, "conv2d_wgrad: null argument");
   const long Mrows = (long)d->N * d->Ho * d->Wo;
   VLNCE_CHECK_ARG(Mrows > 0 && Mrows < 0x7fffffffL, "conv2d_wgrad: bad shape");
@@ -1809,11 +1810,13 @@ extern "C" int vlnce_conv2d_wgrad(const float* x, const float* dy, float* dw_ohw
   p.ldc = p.N;
   VLNCE_CHECK_ARG(aligned16(dy) && aligned16(x) && aligned16(dw_ohwi),
                   "conv2d_wgrad: operands must be 16-byte aligned");
+  VLNCE_CHECK_ARG(!dy_pow2 || P > 0, "conv2d_wgrad: dy_pow2 needs P > 0");
   fill_epilogue(p, nullptr);
   // round 6: three bf16 planes on the 16-bit pipe (wgrad_x6_kernel) where it covers the layer;
   // option "wgrad_tile" = 1 keeps every layer on the fp32-MFMA kernel below (A/B)
   if (vlnce_opt(VLNCE_OPT_WGRAD_TILE) != 1)
-    if (const int rc = wgrad_x6_try_launch(x, dy, dw_ohwi, d, reinterpret_cast<hipStream_t>(stream)); rc >= 0)
+    if (const int rc = wgrad_x6_try_launch(x, dy, dw_ohwi, d, dy_pow2, dy_pow2 ? dy_pow2 + P : nullptr,
+                                           reinterpret_cast<hipStream_t>(stream)); rc >= 0)
       return rc;
   // option "wgrad_tile" = 128: 128x128 tiles where both output dimensions allow.  Measured slower on
   // the trainable-encoder step (46.7 vs 45.0 ms, profiles/archive/r03_g_*): fewer workgroups per

@@ -27,6 +27,13 @@
 // blockIdx.y owns a contiguous range of chunks (split over pixels: the output is small, the
 // reduction long) and adds its partial sums with fp32 atomics into a zeroed dW -- the arrangement
 // of the fp32-MFMA kernel it replaces.
+//
+// MATH_F16X3 form (`dy_pow2` given: the power of two 2^k at which dY tops out near 2^14, from the
+// normalisation backward that wrote dY -- vlnce_bn_bwd / vlnce_gn_bwd): THREE plane products per
+// multiply.  X takes the two-plane side of format 2 (|x| < 65504: activations), dY * 2^(k-10) the
+// three-plane side (|.| <= 16 < 32: that side's range), the accumulators leave through
+// 2^-11 * 2^(10-k), all exact.  Five plane images instead of six (51 KB), 12 MFMAs per wave and
+// chunk instead of 24, a shorter split.
 #include "igemm_shared.h"
 
 using namespace vlnce_detail;
@@ -48,17 +55,34 @@ struct WgradParams {
   int chunks_per_slice;        // 32-pixel chunks per blockIdx.y
   int tiles_n;
   long x_bytes, dy_bytes;
+  const float* dy_up;          // MATH_F16X3: device scalars 2^k, 2^-k
+  const float* dy_down;
 };
+
+// the three-plane side of format 2 for a pixel pair: {h * 2^11, (v - h) * 2^11, h}, h = fp16(v)
+// (split_weight<MATH_F16X3>'s planes, two values per word)
+__device__ __forceinline__ void split_pair_b_f16(float v0, float v1, unsigned (&w)[3]) {
+  typedef float f32x2_ __attribute__((ext_vector_type(2)));
+  typedef _Float16 f16x2_ __attribute__((ext_vector_type(2)));
+  const f32x2_ v = {v0, v1};
+  const f16x2_ h = __builtin_convertvector(v, f16x2_);
+  const float h0 = (float)h[0], h1 = (float)h[1];
+  const f32x2_ hi = {h0 * 2048.f, h1 * 2048.f}, lo = {(v0 - h0) * 2048.f, (v1 - h1) * 2048.f};
+  w[0] = __builtin_bit_cast(unsigned, __builtin_convertvector(hi, f16x2_));
+  w[1] = __builtin_bit_cast(unsigned, __builtin_convertvector(lo, f16x2_));
+  w[2] = __builtin_bit_cast(unsigned, h);
+}
 
 typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
 
-template <int TM>
+template <int TM, int MATH>
 __global__ __launch_bounds__(512) void wgrad_x6_kernel(WgradParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  typedef Planes<MATH_BF16X6> PL;
+  typedef Planes<MATH> PL;
+  constexpr bool F16 = MATH == MATH_F16X3;
+  constexpr int NXP = F16 ? 2 : 3;                  // plane images of X (dY: three in both forms)
   constexpr int MT = TM / 64;                       // 32-row blocks per wave (waves 2 x 4)
   constexpr int A_PLANE = TM * W6_PITCH, B_PLANE = W6_TN * W6_PITCH;
-  constexpr int STAGE = 3 * (A_PLANE + B_PLANE);
   extern __shared__ __attribute__((aligned(16))) char w6_lds[];   // [STAGE]
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -95,6 +119,8 @@ __global__ __launch_bounds__(512) void wgrad_x6_kernel(WgradParams p) {
   struct Raw {
     f32x4 a0, a1, b0, b1;
   };
+  // dY * 2^(k-10): at most 16, the three-plane side's range (exact: a power of two)
+  const float dy_scale = F16 ? *p.dy_up * (1.f / 1024.f) : 1.f;
   // (image, row, column) of this thread's two output pixels, walked 32 pixels per chunk in mixed
   // radix -- two integer divisions per pixel and chunk were a third of the thread's VALU work
   int q_img[2], q_ho[2], q_wo[2];
@@ -154,7 +180,8 @@ __global__ __launch_bounds__(512) void wgrad_x6_kernel(WgradParams p) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         unsigned w[3];
-        split_pair<MATH_BF16X6>(r.a0[e], r.a1[e], w);
+        if constexpr (F16) split_pair_b_f16(r.a0[e] * dy_scale, r.a1[e] * dy_scale, w);
+        else split_pair<MATH_BF16X6>(r.a0[e], r.a1[e], w);
 #pragma unroll
         for (int q = 0; q < 3; ++q)
           *reinterpret_cast<unsigned*>(dst + q * A_PLANE + e * W6_PITCH) = w[q];
@@ -164,10 +191,10 @@ __global__ __launch_bounds__(512) void wgrad_x6_kernel(WgradParams p) {
       char* dst = stage + 3 * A_PLANE + (c4 * 4) * W6_PITCH + pp * 4;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        unsigned w[3];
-        split_pair<MATH_BF16X6>(r.b0[e], r.b1[e], w);
+        unsigned w[NXP];
+        split_pair<MATH>(r.b0[e], r.b1[e], w);
 #pragma unroll
-        for (int q = 0; q < 3; ++q)
+        for (int q = 0; q < NXP; ++q)
           *reinterpret_cast<unsigned*>(dst + q * B_PLANE + e * W6_PITCH) = w[q];
       }
     }
@@ -190,19 +217,21 @@ __global__ __launch_bounds__(512) void wgrad_x6_kernel(WgradParams p) {
     const char* st = w6_lds;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      bf16x8 fa[MT][3], fb[3];
+      bf16x8 fa[MT][3], fb[NXP];
 #pragma unroll
       for (int q = 0; q < 3; ++q) {
-        fb[q] = *reinterpret_cast<const bf16x8*>(st + b_off + q * B_PLANE + s * 32);
+        if (q < NXP) fb[q] = *reinterpret_cast<const bf16x8*>(st + b_off + q * B_PLANE + s * 32);
 #pragma unroll
         for (int i = 0; i < MT; ++i)
           fa[i][q] = *reinterpret_cast<const bf16x8*>(st + a_off + q * A_PLANE + i * 32 * W6_PITCH + s * 32);
       }
+      // (F16: dY holds format 2's three-plane side, X its two-plane side)
 #pragma unroll
       for (int q = 0; q < PL::NP; ++q)
 #pragma unroll
         for (int i = 0; i < MT; ++i)
-          acc[i] = plane_mfma<MATH_BF16X6>(fa[i][PL::PA[q]], fb[PL::PB[q]], acc[i]);
+          acc[i] = plane_mfma<MATH>(fa[i][F16 ? PL::PB[q] : PL::PA[q]],
+                                    fb[F16 ? PL::PA[q] : PL::PB[q]], acc[i]);
     }
     // chunk c + 1 (in registers since the previous iteration) into the stage once every wave has
     // read chunk c out of it; chunk c + 2 requested
@@ -216,6 +245,7 @@ __global__ __launch_bounds__(512) void wgrad_x6_kernel(WgradParams p) {
 
   // ---- epilogue: accumulator register r of block i = row (r & 3) + 8 (r >> 2) + 4 half, column l31
   const int col = k0 + wn * 32 + l31;
+  const float post = F16 ? *p.dy_down * 0.5f : 1.f;   // 2^-11 * 2^(10 - k)
   if (col < p.K) {
 #pragma unroll
     for (int i = 0; i < MT; ++i)
@@ -224,19 +254,21 @@ __global__ __launch_bounds__(512) void wgrad_x6_kernel(WgradParams p) {
         const int row = co0 + wm * (MT * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
         if (row < p.Cout) {
           float* dst = p.dw + (long)row * p.K + col;
-          if (gridDim.y > 1) unsafeAtomicAdd(dst, acc[i][r]);
-          else *dst = acc[i][r];
+          const float v = F16 ? acc[i][r] * post : acc[i][r];
+          if (gridDim.y > 1) unsafeAtomicAdd(dst, v);
+          else *dst = v;
         }
       }
   }
 #endif
 }
 
-template <int TM>
+template <int TM, int MATH>
 int launch_w6(const WgradParams& p0, hipStream_t stream) {
   WgradParams p = p0;
-  constexpr int smem = 3 * (TM + W6_TN) * W6_PITCH;   // 61 KB (TM = 128): two workgroups per CU
-  auto kern = wgrad_x6_kernel<TM>;
+  // 61 KB (TM = 128; 51 KB with fp16 planes): two workgroups per CU
+  constexpr int smem = (3 * TM + (MATH == MATH_F16X3 ? 2 : 3) * W6_TN) * W6_PITCH;
+  auto kern = wgrad_x6_kernel<TM, MATH>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -274,7 +306,7 @@ int launch_w6(const WgradParams& p0, hipStream_t stream) {
 // kernel takes it).  Covered: Cin % 32 == 0, Cout % 32 == 0, 16-byte aligned operands, byte
 // offsets that fit 31 bits, option "conv_math" != 0.
 int wgrad_x6_try_launch(const float* x, const float* dy, float* dw, const vlnce_conv_desc* d,
-                        hipStream_t stream) {
+                        const float* dy_up, const float* dy_down, hipStream_t stream) {
   if (!conv_math()) return -1;
   if (d->Cin % 32 != 0 || d->Cout % 32 != 0) return -1;
   const int ldx = d->ldx ? d->ldx : d->Cin, ldy = d->ldy ? d->ldy : d->Cout;
@@ -304,7 +336,11 @@ int wgrad_x6_try_launch(const float* x, const float* dy, float* dw, const vlnce_
   p.ldy = ldy;
   p.x_bytes = x_bytes;
   p.dy_bytes = dy_bytes;
-  return d->Cout >= 128 ? launch_w6<128>(p, stream) : launch_w6<64>(p, stream);
+  p.dy_up = dy_up;
+  p.dy_down = dy_down;
+  if (dy_up && dy_down)
+    return d->Cout >= 128 ? launch_w6<128, MATH_F16X3>(p, stream) : launch_w6<64, MATH_F16X3>(p, stream);
+  return d->Cout >= 128 ? launch_w6<128, MATH_BF16X6>(p, stream) : launch_w6<64, MATH_BF16X6>(p, stream);
 }
 
 }  // namespace vlnce_detail

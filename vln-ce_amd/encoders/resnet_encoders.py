@@ -550,7 +550,7 @@ class HipResNetTrunk(DropsGraphsOnApply, nn.Sequential):
         def conv_bn_back(entry, dy, need_dx=True, add=None):
             _, x_in, conv, bn, w, sv = entry
             draw, dres, dg, db, pow2 = tb.bn_backward(
-                dy, sv, max(conv.in_channels, conv.out_channels) if need_dx else 0)
+                dy, sv, max(conv.in_channels, conv.out_channels) if need_dx else 4)
             dx, dw = tb.conv_backward(x_in, w, draw, conv.stride[0], conv.padding[0], need_dx, add,
                                       pow2)
             for prm, g in ((conv.weight, dw), (bn.weight, dg), (bn.bias, db)):
@@ -920,7 +920,7 @@ def _depth_backward_from_tape(self, tape, dout):
     def back(entry, dy, need_dx=True, add=None):
         _, x_in, conv, gn, w, sv = entry
         draw, dres, dg, db, pow2 = tb.gn_backward(
-            dy, sv, max(conv.in_channels, conv.out_channels) if need_dx else 0)
+            dy, sv, max(conv.in_channels, conv.out_channels) if need_dx else 4)
         dx, dw = tb.conv_backward(x_in, w, draw, conv.stride[0], conv.padding[0], need_dx, add, pow2)
         for prm, g in ((conv.weight, dw), (gn.weight, dg), (gn.bias, db)):
             if prm.requires_grad:

@@ -43,7 +43,7 @@ def conv_backward(x, w_ohwi, dy, stride, pad, need_dx, add=None, pow2=None):
     Cout, KH, KW, Cin = w_ohwi.shape
     dw = torch.empty_like(w_ohwi)
     dy = dy.contiguous()
-    lib.conv2d_wgrad(x, dy, dw, g)
+    lib.conv2d_wgrad(x, dy, dw, g, pow2)
     dw_oihw = dw.permute(0, 3, 1, 2).contiguous()
     if not need_dx:
         return None, dw_oihw
