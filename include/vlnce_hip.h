@@ -420,9 +420,10 @@ int vlnce_adaptive_avgpool(const float* x, float* y, int N, int H, int W, int C,
  * dy_pow2 / P (ABI 143, may be NULL / 0): the [2][P] power-of-two buffer vlnce_bn_bwd / vlnce_gn_bwd filled
  * for this dy (dy_pow2[0] = 2^k, dy_pow2[P] = 2^-k) -- with it the plane kernel runs in format 2:
  * x on the two-plane side (|x| < 65504), dy * 2^(k-10) on the three-plane side, three plane
- * products per multiply, the result scaled back exactly. */
+ * products per multiply, the result scaled back exactly.
+ * accumulate != 0 (ABI 143): dW += instead of dW = (the call does not zero dW). */
 int vlnce_conv2d_wgrad(const float* x, const float* dy, float* dw_ohwi, const vlnce_conv_desc* d,
-                       const float* dy_pow2, int P, vlnce_stream_t stream);
+                       const float* dy_pow2, int P, int accumulate, vlnce_stream_t stream);
 /* BatchNorm2d backward through y = act(x*gamma*rstd + (beta - mean*gamma*rstd) (+ residual)):
  * g = dy*[y>0] when relu; dbeta = sum g; dgamma = sum g*xhat;
  * dx = gamma*rstd*(g - dbeta/M - xhat*dgamma/M) with batch statistics, gamma*rstd*g with

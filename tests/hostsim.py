@@ -557,14 +557,17 @@ class HostSim:
         dc_prev.copy_(dc * f * mk)
 
     # ---- backward of the visual trunks (contracts of csrc/bwd.hip, vlnce_conv2d_wgrad)
-    def conv2d_wgrad(self, x, dy, dw, g, dy_pow2=None):
+    def conv2d_wgrad(self, x, dy, dw, g, dy_pow2=None, accumulate=False):
         N, H, W, Cin, Cout = g["N"], g["H"], g["W"], g["Cin"], g["Cout"]
         xi = x.as_strided((N, H, W, Cin), (H * W * g["ldx"], W * g["ldx"], g["ldx"], 1))
         xi = xi.permute(0, 3, 1, 2).contiguous()
         gy = dy.reshape(N, g["Ho"], g["Wo"], Cout).permute(0, 3, 1, 2).contiguous()
         gw = torch.nn.grad.conv2d_weight(xi, (Cout, Cin, g["KH"], g["KW"]), gy,
                                          stride=g["stride"], padding=g["pad"])
-        dw.view(Cout, g["KH"], g["KW"], Cin).copy_(gw.permute(0, 2, 3, 1))
+        if accumulate:
+            dw.view(Cout, g["KH"], g["KW"], Cin).add_(gw.permute(0, 2, 3, 1))
+        else:
+            dw.view(Cout, g["KH"], g["KW"], Cin).copy_(gw.permute(0, 2, 3, 1))
 
     def bn_bwd_workspace_floats(self, M, Cc):
         return 1

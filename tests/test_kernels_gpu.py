@@ -823,6 +823,11 @@ def test_conv2d_wgrad(hip, case):
     with hip.options(wgrad_tile=1):
         cpu3, gpu3 = both("conv2d_wgrad", dict(t, dw=torch.zeros_like(t["dw"])), dict(g=g))
     close(gpu3["dw"], cpu3["dw"], what="wgrad/" + name + "/fp32-MFMA")
+    # accumulate: dW += (a trunk's backward zeroes one arena for all its layers)
+    pre = rnd(Cout, k, k, Cin, seed=9)
+    cpu5, gpu5 = both("conv2d_wgrad", dict(t, dw=pre.clone()), dict(g=g, accumulate=True))
+    close(gpu5["dw"], cpu5["dw"], what="wgrad/" + name + "/accumulate")
+    assert float((cpu5["dw"] - pre - cpu["dw"]).abs().max()) < 1e-4 * float(cpu["dw"].abs().max())
     # fp16 planes with the power of two of dy (what bn_bwd / gn_bwd hand out): tiny and huge dy
     for scale in (1e-7, 1.0, 3e4):
         dy = t["dy"] * scale

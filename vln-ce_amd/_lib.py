@@ -133,7 +133,7 @@ _SIGNATURES = {
     "vlnce_lstm_gates_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "vlnce_mean_rows": (_I, [_P, _P, _I, _I, _I, _P]),
     "vlnce_mask_rows": (_I, [_P, _P, _P, _I, _I, _P]),
-    "vlnce_conv2d_wgrad": (_I, [_P, _P, _P, C.POINTER(ConvDesc), _P, _I, _P]),
+    "vlnce_conv2d_wgrad": (_I, [_P, _P, _P, C.POINTER(ConvDesc), _P, _I, _I, _P]),
     "vlnce_bn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P]),
     "vlnce_bn_bwd_workspace_floats": (C.c_size_t, [_L, _I]),
     "vlnce_gn_bwd_workspace_floats": (C.c_size_t, [_I, _I, _I, _I]),
@@ -688,13 +688,15 @@ class HipLib:
                     "vlnce_mask_rows")
 
     # ---- backward of the visual trunks
-    def conv2d_wgrad(self, x, dy, dw, g, dy_pow2=None):
-        """dy_pow2: the [2, P] power-of-two buffer bn_bwd / gn_bwd filled for this dy, or None"""
+    def conv2d_wgrad(self, x, dy, dw, g, dy_pow2=None, accumulate=False):
+        """dy_pow2: the [2, P] power-of-two buffer bn_bwd / gn_bwd filled for this dy, or None;
+        accumulate: dw += (the caller zeroed it)"""
         d = self._desc(g)
         self._check(self.dll.vlnce_conv2d_wgrad(_ptr(x), _ptr(dy), _ptr(dw), C.byref(d),
                                                 _ptr(dy_pow2),
                                                 dy_pow2.size(1) if dy_pow2 is not None else 0,
-                                                _stream()), "vlnce_conv2d_wgrad")
+                                                int(bool(accumulate)), _stream()),
+                    "vlnce_conv2d_wgrad")
 
     def bn_bwd_workspace_floats(self, M, Cc):
         return int(self.dll.vlnce_bn_bwd_workspace_floats(M, Cc))

@@ -1785,7 +1785,7 @@ extern "C" int vlnce_gemm(const float* A, int lda, int transA, const float* B, i
 // dW[Cout, KH, KW, Cin] = sum over output pixels of dY[m, co] * im2col(X)[m, (r,q,ci)]
 extern "C" int vlnce_conv2d_wgrad(const float* x, const float* dy, float* dw_ohwi,
                                   const vlnce_conv_desc* d, const float* dy_pow2, int P,
-                                  vlnce_stream_t stream) {
+                                  int accumulate, vlnce_stream_t stream) {
   VLNCE_CHECK_ARG(x && dy && dw_ohwi && d, "conv2d_wgrad: null argument");
   const long Mrows = (long)d->N * d->Ho * d->Wo;
   VLNCE_CHECK_ARG(Mrows > 0 && Mrows < 0x7fffffffL, "conv2d_wgrad: bad shape");
@@ -1816,7 +1816,7 @@ extern "C" int vlnce_conv2d_wgrad(const float* x, const float* dy, float* dw_ohw
   // option "wgrad_tile" = 1 keeps every layer on the fp32-MFMA kernel below (A/B)
   if (vlnce_opt(VLNCE_OPT_WGRAD_TILE) != 1)
     if (const int rc = wgrad_x6_try_launch(x, dy, dw_ohwi, d, dy_pow2, dy_pow2 ? dy_pow2 + P : nullptr,
-                                           reinterpret_cast<hipStream_t>(stream)); rc >= 0)
+                                           accumulate, reinterpret_cast<hipStream_t>(stream)); rc >= 0)
       return rc;
   // option "wgrad_tile" = 128: 128x128 tiles where both output dimensions allow.  Measured slower on
   // the trainable-encoder step (46.7 vs 45.0 ms, profiles/archive/r03_g_*): fewer workgroups per
@@ -1832,7 +1832,9 @@ extern "C" int vlnce_conv2d_wgrad(const float* x, const float* dy, float* dw_ohw
   p.splitk = sk < 2 ? 1 : (int)sk;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (p.splitk > 1) {
-    vlnce_zero(dw_ohwi, 1, p.M * p.N, (long)p.M * p.N, s);
+    if (!accumulate) vlnce_zero(dw_ohwi, 1, p.M * p.N, (long)p.M * p.N, s);
+  } else if (accumulate) {
+    p.accumulate = 1;
   }
   if (big) return launch<128, 128, 2, 2, A_TRANS, B_IM2COL>(p, s);
   return launch<64, 64, 2, 2, A_TRANS, B_IM2COL>(p, s);

@@ -445,6 +445,7 @@ int p3_try_launch(const IgemmParams& p, hipStream_t stream);
 int m3_try_launch(const IgemmParams& p, hipStream_t stream);   // conv_m3.hip
 // wgrad_x6.hip: the weight gradient on the 16-bit pipe (three bf16 planes); -1 = not covered
 int wgrad_x6_try_launch(const float* x, const float* dy, float* dw, const vlnce_conv_desc* d,
-                        const float* dy_up, const float* dy_down, hipStream_t stream);
+                        const float* dy_up, const float* dy_down, int accumulate,
+                        hipStream_t stream);
 
 }  // namespace vlnce_detail

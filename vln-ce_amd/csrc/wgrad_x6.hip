@@ -57,6 +57,7 @@ struct WgradParams {
   long x_bytes, dy_bytes;
   const float* dy_up;          // MATH_F16X3: device scalars 2^k, 2^-k
   const float* dy_down;
+  int accumulate;              // dW += (the caller zeroed it, or holds a sum to add to)
 };
 
 // the three-plane side of format 2 for a pixel pair: {h * 2^11, (v - h) * 2^11, h}, h = fp16(v)
@@ -255,7 +256,7 @@ __global__ __launch_bounds__(512) void wgrad_x6_kernel(WgradParams p) {
         if (row < p.Cout) {
           float* dst = p.dw + (long)row * p.K + col;
           const float v = F16 ? acc[i][r] * post : acc[i][r];
-          if (gridDim.y > 1) unsafeAtomicAdd(dst, v);
+          if (gridDim.y > 1 || p.accumulate) unsafeAtomicAdd(dst, v);
           else *dst = v;
         }
       }
@@ -294,7 +295,8 @@ int launch_w6(const WgradParams& p0, hipStream_t stream) {
   if (sk > 65535) sk = 65535;
   p.chunks_per_slice = ceil_div(chunks, sk);
   sk = ceil_div(chunks, p.chunks_per_slice);
-  if (sk > 1) vlnce_zero(p.dw, 1, (int)((long)p.Cout * p.K), (long)p.Cout * p.K, stream);
+  if (sk > 1 && !p.accumulate)
+    vlnce_zero(p.dw, 1, (int)((long)p.Cout * p.K), (long)p.Cout * p.K, stream);
   hipLaunchKernelGGL(kern, dim3((unsigned)tiles, (unsigned)sk), dim3(512), smem, stream, p);
   VLNCE_CHECK_LAUNCH("conv2d_wgrad (plane kernel)");
   return 0;
@@ -306,7 +308,8 @@ int launch_w6(const WgradParams& p0, hipStream_t stream) {
 // kernel takes it).  Covered: Cin % 32 == 0, Cout % 32 == 0, 16-byte aligned operands, byte
 // offsets that fit 31 bits, option "conv_math" != 0.
 int wgrad_x6_try_launch(const float* x, const float* dy, float* dw, const vlnce_conv_desc* d,
-                        const float* dy_up, const float* dy_down, hipStream_t stream) {
+                        const float* dy_up, const float* dy_down, int accumulate,
+                        hipStream_t stream) {
   if (!conv_math()) return -1;
   if (d->Cin % 32 != 0 || d->Cout % 32 != 0) return -1;
   const int ldx = d->ldx ? d->ldx : d->Cin, ldy = d->ldy ? d->ldy : d->Cout;
@@ -338,6 +341,7 @@ int wgrad_x6_try_launch(const float* x, const float* dy, float* dw, const vlnce_
   p.dy_bytes = dy_bytes;
   p.dy_up = dy_up;
   p.dy_down = dy_down;
+  p.accumulate = accumulate;
   if (dy_up && dy_down)
     return d->Cout >= 128 ? launch_w6<128, MATH_F16X3>(p, stream) : launch_w6<64, MATH_F16X3>(p, stream);
   return d->Cout >= 128 ? launch_w6<128, MATH_BF16X6>(p, stream) : launch_w6<64, MATH_BF16X6>(p, stream);
