@@ -1,0 +1,17 @@
+#!/bin/bash
+# conv_u3: raw rows requested two chunks per burst (U3_RAW_BATCH=2, default) vs one per chunk (variant rb1)
+O=gpurun_out/r6_33; mkdir -p $O
+RB1=$PWD/build/variants/libvlnce_rb1.so
+ls -la $RB1 | cut -c1-120
+for lib in default rb1; do
+  [ $lib = rb1 ] && export VLNCE_HIP_LIB=$RB1 || unset VLNCE_HIP_LIB
+  timeout 600 python scripts/convbench.py --mode train --pro --rotate 8 --only 1x1 > $O/conv_1x1_$lib.txt 2>&1
+  timeout 600 python scripts/convbench.py --mode train --pro --rotate 8 --only 1x1 --dual bn > $O/conv_dual_$lib.txt 2>&1
+  tail -1 $O/conv_1x1_$lib.txt; tail -1 $O/conv_dual_$lib.txt
+done
+for lib in default rb1 default rb1; do
+  [ $lib = rb1 ] && export VLNCE_HIP_LIB=$RB1 || unset VLNCE_HIP_LIB
+  timeout 600 python bench.py --steps 30 --warmup 4 2>/dev/null | tee $O/bench_$lib.json | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$lib', d['ms_per_step'], d['roofline']['kernel_ms_per_step'])"
+done
+unset VLNCE_HIP_LIB
+timeout 900 python -m pytest tests/test_kernels_gpu.py -q -x -k "conv" 2>&1 | tail -3

@@ -31,6 +31,7 @@
 // (one per SIMD), 168 VGPRs each, one workgroup per CU, persistent over a strided tile list; the
 // hand-over is per patch buffer (two of them) through LDS counters as in conv_x3_kernel.
 #include "igemm_shared.h"
+#include <type_traits>
 
 using namespace vlnce_detail;
 
@@ -40,6 +41,9 @@ namespace {
 // bytes per patch row: Planes<MATH>::ROW (208 = 13 x 16 B / 144 = 9 x 16 B: consecutive rows are
 // conflict-free for ds_read_b128)
 constexpr int P3_PRODUCERS = 4;  // producer waves
+#ifndef U3_RAW_BATCH
+#define U3_RAW_BATCH 1   // conv_u3_kernel: raw-row chunks per request burst (2: the round-6 experiment below)
+#endif
 constexpr int U3_MAX_CIN = 4096;   // conv_u3_kernel: input channels whose prologue vectors fit its LDS
 // patch rows the KxK producers address: 12 row groups of 32 (3 items of 128), their byte offsets in
 // twelve registers.  (Round 6, measured and dropped: with the 144-byte rows of the fp16 planes the LDS
@@ -1005,12 +1009,31 @@ __global__ __launch_bounds__(WAVES * 64) void conv_u3_kernel(IgemmParams p) {
   // ---------------------------------------------------------------- prologue of the stream
   // vector schedule: chunk k's vectors are channels (k % NC) * 32 ..; `cur` must hold chunk k's
   // when chunk k is transformed
-  Raw rx, ry;
+  //
+  // RB = 2 (round 6, single-input forms): raw rows requested TWO chunks at a time, every second
+  // chunk.  A wave has ONE in-order vmcnt queue: the B fragments of the next k-slab (L2 hits,
+  // needed half a chunk after they are requested) queue behind the raw rows requested just before
+  // them (HBM), so every chunk waits out part of an HBM latency with one chunk of rows in flight.
+  // Two chunks per burst put twice the bytes behind each such wait, for four raw sets in
+  // registers instead of two.  Measured per layer from HBM (scripts/convbench.py --rotate 8,
+  // profiles/r06_p_conv_u3_raw_batch_ab.txt): K >= 512 layers +7...15 % (1024 -> 512: 224 -> 258
+  // TF/s), 256 -> 1024 -6 %, the 1x1 layer list 2.184 -> 2.158 ms; the dual (block-end) forms
+  // measured 1-5 % SLOWER with it and keep one chunk per request; the step is unchanged within
+  // its noise (5.44-5.49 ms of conv launches either way), and the file compiles 40 % longer:
+  // NOT the default (-DU3_RAW_BATCH=2 builds it).
+  constexpr int RB = (U3_RAW_BATCH == 2 && DUAL == 0) ? 2 : 1;
+  Raw rx, ry, rz, rw;   // RB = 2: chunk j lives in set j % 4 (rx, ry, rz, rw); RB = 1: rx / ry alternate
   setup_tile(0);
   load_raw(rx);   // chunk 0
   advance_raw();
   load_raw(ry);   // chunk 1
   advance_raw();
+  if constexpr (RB == 2) {
+    load_raw(rz);   // chunks 2, 3
+    advance_raw();
+    load_raw(rw);
+    advance_raw();
+  }
   int m0 = 0, n0 = 0;
   tile_of(0, m0, n0);
   int vb[NT], vbn[NT];
@@ -1042,7 +1065,8 @@ __global__ __launch_bounds__(WAVES * 64) void conv_u3_kernel(IgemmParams p) {
 #endif
   // one K-chunk: MFMAs on patch (g & 1) / transform of `rn` (chunk g + 1) into patch ((g+1) & 1) /
   // raw loads of chunk g + 2 into `rf`.  Everything up to the transform is ONE basic block.
-  auto chunk = [&](int g, Raw& rn, Raw& rf) {
+  auto chunk = [&](int g, Raw& rn, Raw& rf, Raw& rf2, auto pair_tag) {
+    constexpr bool load_pair = decltype(pair_tag)::value;   // RB = 2: this chunk ends with a request burst
     const char* const pb = xsm + (g & 1) * PBUF;
     char* const pn = xsm + ((g + 1) & 1) * PBUF;
     const bool last_of_tile = c == NC - 1;
@@ -1053,7 +1077,7 @@ __global__ __launch_bounds__(WAVES * 64) void conv_u3_kernel(IgemmParams p) {
 #ifdef P3_DBG_TIME
     const long long d_0 = clock64();
 #endif
-    load_raw(rf);
+    if constexpr (RB == 1) load_raw(rf);
     loadB(b1, vb, ks3 + 3072);
     if constexpr (ADB) {
       readA(fa, pb, 0);
@@ -1116,7 +1140,14 @@ __global__ __launch_bounds__(WAVES * 64) void conv_u3_kernel(IgemmParams p) {
     const long long d_1 = clock64();
     d_blk += d_1 - d_0;
 #endif
-    advance_raw();
+    if constexpr (RB == 1) {
+      advance_raw();
+    } else if constexpr (load_pair) {
+      load_raw(rf);    // chunks g + 3, g + 4
+      advance_raw();
+      load_raw(rf2);
+      advance_raw();
+    }
     ks3 += 6144;
 #ifdef P3_DBG_TIME
     const long long d_2 = clock64();
@@ -1189,9 +1220,18 @@ __global__ __launch_bounds__(WAVES * 64) void conv_u3_kernel(IgemmParams p) {
     d_bar += clock64() - d_3;
 #endif
   };
-  for (int g = 0; g < G; g += 2) {
-    chunk(g, ry, rx);                    // transforms chunk g+1 (in ry), fetches chunk g+2 into rx
-    if (g + 1 < G) chunk(g + 1, rx, ry);
+  if constexpr (RB == 1) {
+    for (int g = 0; g < G; g += 2) {
+      chunk(g, ry, rx, rx, std::false_type{});   // transforms chunk g+1 (in ry), fetches chunk g+2 into rx
+      if (g + 1 < G) chunk(g + 1, rx, ry, ry, std::false_type{});
+    }
+  } else {
+    for (int g = 0; g < G; g += 4) {             // chunk g + 1 is transformed during chunk g
+      chunk(g, ry, rx, rx, std::false_type{});
+      if (g + 1 < G) chunk(g + 1, rz, rx, ry, std::true_type{});    // requests chunks g + 4, g + 5
+      if (g + 2 < G) chunk(g + 2, rw, rx, rx, std::false_type{});
+      if (g + 3 < G) chunk(g + 3, rx, rz, rw, std::true_type{});    // requests chunks g + 6, g + 7
+    }
   }
 #ifdef P3_DBG_TIME
   if (blockIdx.x == 8 && (tid == 0 || tid == (WAVES - 1) * 64)) {
