@@ -1077,8 +1077,16 @@ __global__ __launch_bounds__(WAVES * 64) void conv_u3_kernel(IgemmParams p) {
 #ifdef P3_DBG_TIME
     const long long d_0 = clock64();
 #endif
+#ifdef U3_RAW_FIRST
     if constexpr (RB == 1) load_raw(rf);
     loadB(b1, vb, ks3 + 3072);
+#else
+    // k-slab 1's B fragments BEFORE the raw rows of chunk g + 2: vmcnt retires in order, and the
+    // fragments (L2 hits, needed half a chunk from here) would otherwise wait out the HBM latency
+    // of rows that nobody reads before the next chunk
+    loadB(b1, vb, ks3 + 3072);
+    if constexpr (RB == 1) load_raw(rf);
+#endif
     if constexpr (ADB) {
       readA(fa, pb, 0);
       readA(fa1, pb, 1);
