@@ -1021,6 +1021,9 @@ __global__ __launch_bounds__(WAVES * 64) void conv_u3_kernel(IgemmParams p) {
   // measured 1-5 % SLOWER with it and keep one chunk per request; the step is unchanged within
   // its noise (5.44-5.49 ms of conv launches either way), and the file compiles 40 % longer:
   // NOT the default (-DU3_RAW_BATCH=2 builds it).
+  // (Also measured and dropped: the dual forms' side_out rows stored two chunks per burst instead
+  // of every chunk -- stores count in the same queue -- block ends 2.870 -> 2.946 ms, i.e. slower:
+  // profiles/r06_s_conv_u3_side_out_store_bursts.txt.)
   constexpr int RB = (U3_RAW_BATCH == 2 && DUAL == 0) ? 2 : 1;
   Raw rx, ry, rz, rw;   // RB = 2: chunk j lives in set j % 4 (rx, ry, rz, rw); RB = 1: rx / ry alternate
   setup_tile(0);
