@@ -41,6 +41,12 @@ namespace {
 // bytes per patch row: Planes<MATH>::ROW (208 = 13 x 16 B / 144 = 9 x 16 B: consecutive rows are
 // conflict-free for ds_read_b128)
 constexpr int P3_PRODUCERS = 4;  // producer waves
+#ifndef U3_B_AHEAD_64
+#define U3_B_AHEAD_64 2    // conv_u3_kernel: B fragments requested a chunk ahead (see BA in the kernel)
+#endif
+#ifndef U3_B_AHEAD_128
+#define U3_B_AHEAD_128 1
+#endif
 #ifndef U3_RAW_BATCH
 #define U3_RAW_BATCH 1   // conv_u3_kernel: raw-row chunks per request burst (2: the round-6 experiment below)
 #endif
@@ -952,7 +958,16 @@ __global__ __launch_bounds__(WAVES * 64) void conv_u3_kernel(IgemmParams p) {
   constexpr int HM = MT / 2;  // row blocks per half (two-wave form)
   static_assert(ADB || HM >= 1, "tile");
   bf16x8 fa[ADB ? MT : 1][NA], fa1[ADB ? MT : 1][NA], fh0[ADB ? 1 : HM][NA], fh1[ADB ? 1 : HM][NA];
+  // BA (B fragments ahead): 0 = k-slab 1's fragments requested at the start of their chunk and the
+  // next chunk's slab-0 fragments half a chunk ahead (one slab of lead: 6 * MT MFMAs against an L2
+  // round trip); 1 = slab 1's fragments a whole chunk ahead (a second set, alternating by chunk
+  // parity); 2 = both slabs' fragments a whole chunk ahead (two more sets: the 64-row forms have
+  // the registers).  Single-input forms only: 1x1 layer list 2.219 -> 2.158 ms from HBM (1024 ->
+  // 256: 179 -> 207 TF/s); the dual forms measured 3 % SLOWER with it (the 128-row ones spill 6-8
+  // registers) and keep one slab of lead (profiles/r06_u_conv_u3_b_fragments_a_chunk_ahead.txt).
+  constexpr int BA = (ADB || DUAL != 0) ? 0 : (BM == 64 ? U3_B_AHEAD_64 : U3_B_AHEAD_128);
   bf16x8 b0[NT][3], b1[NT][3];
+  bf16x8 b0x[BA == 2 ? NT : 1][3], b1x[BA >= 1 ? NT : 1][3];
   f32x16 acc[MT][NT];
   const int a_off = l31 * P3_ROW + half * 16;   // + i * 32 * P3_ROW + q * 64 + s * 32
   auto loadB = [&](bf16x8 (&b)[NT][3], const int (&vb)[NT], int soff) {
@@ -1049,6 +1064,7 @@ __global__ __launch_bounds__(WAVES * 64) void conv_u3_kernel(IgemmParams p) {
     vb_of(n1, vbn);
   }
   loadB(b0, vb, 0);
+  if constexpr (BA >= 1) loadB(b1, vb, 3072);
   transform(rx, xsm);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -1068,7 +1084,8 @@ __global__ __launch_bounds__(WAVES * 64) void conv_u3_kernel(IgemmParams p) {
 #endif
   // one K-chunk: MFMAs on patch (g & 1) / transform of `rn` (chunk g + 1) into patch ((g+1) & 1) /
   // raw loads of chunk g + 2 into `rf`.  Everything up to the transform is ONE basic block.
-  auto chunk = [&](int g, Raw& rn, Raw& rf, Raw& rf2, auto pair_tag) {
+  auto chunk = [&](int g, Raw& rn, Raw& rf, Raw& rf2, auto pair_tag, bf16x8 (&b0c)[NT][3],
+                   bf16x8 (&b1c)[NT][3], auto& b0n, auto& b1n) {
     constexpr bool load_pair = decltype(pair_tag)::value;   // RB = 2: this chunk ends with a request burst
     const char* const pb = xsm + (g & 1) * PBUF;
     char* const pn = xsm + ((g + 1) & 1) * PBUF;
@@ -1082,32 +1099,34 @@ __global__ __launch_bounds__(WAVES * 64) void conv_u3_kernel(IgemmParams p) {
 #endif
 #ifdef U3_RAW_FIRST
     if constexpr (RB == 1) load_raw(rf);
-    loadB(b1, vb, ks3 + 3072);
+    loadB(b1c, vb, ks3 + 3072);
 #else
     // k-slab 1's B fragments BEFORE the raw rows of chunk g + 2: vmcnt retires in order, and the
     // fragments (L2 hits, needed half a chunk from here) would otherwise wait out the HBM latency
     // of rows that nobody reads before the next chunk
-    loadB(b1, vb, ks3 + 3072);
+    if constexpr (BA == 0) loadB(b1c, vb, ks3 + 3072);
+    if constexpr (BA == 2) loadB(b0n, vb_s0, so_s0);              // the NEXT chunk's fragments
+    if constexpr (BA >= 1) loadB(b1n, vb_s0, so_s0 + 3072);
     if constexpr (RB == 1) load_raw(rf);
 #endif
     if constexpr (ADB) {
       readA(fa, pb, 0);
       readA(fa1, pb, 1);
-      mma(fa, b0);
-      loadB(b0, vb_s0, so_s0);
-      mma(fa1, b1);
+      mma(fa, b0c);
+      loadB(b0n, vb_s0, so_s0);
+      mma(fa1, b1c);
     } else {
       // the MT row blocks in two halves with a fragment set each: the reads of one half land
       // under the MFMAs of the other (no spare registers for a second full set)
       readH(fh0, pb, 0, 0);
       readH(fh1, pb, 0, 1);
-      mmaH(fh0, b0, 0);
+      mmaH(fh0, b0c, 0);
       readH(fh0, pb, 1, 0);
-      mmaH(fh1, b0, 1);
-      loadB(b0, vb_s0, so_s0);
+      mmaH(fh1, b0c, 1);
+      if constexpr (BA < 2) loadB(b0n, vb_s0, so_s0);
       readH(fh1, pb, 1, 1);
-      mmaH(fh0, b1, 0);
-      mmaH(fh1, b1, 1);
+      mmaH(fh0, b1c, 0);
+      mmaH(fh1, b1c, 1);
     }
     transform(rn, pn);
 #ifndef U3_NO_SCHED
@@ -1231,17 +1250,21 @@ __global__ __launch_bounds__(WAVES * 64) void conv_u3_kernel(IgemmParams p) {
     d_bar += clock64() - d_3;
 #endif
   };
+  auto& b0alt = [&]() -> auto& { if constexpr (BA == 2) return b0x; else return b0; }();
+  auto& b1alt = [&]() -> auto& { if constexpr (BA >= 1) return b1x; else return b1; }();
   if constexpr (RB == 1) {
     for (int g = 0; g < G; g += 2) {
-      chunk(g, ry, rx, rx, std::false_type{});   // transforms chunk g+1 (in ry), fetches chunk g+2 into rx
-      if (g + 1 < G) chunk(g + 1, rx, ry, ry, std::false_type{});
+      // (B sets by chunk parity: BA = 0 uses b0 / b1 throughout; BA = 1 alternates b1 / b1x;
+      // BA = 2 alternates both)
+      chunk(g, ry, rx, rx, std::false_type{}, b0, b1, b0alt, b1alt);
+      if (g + 1 < G) chunk(g + 1, rx, ry, ry, std::false_type{}, b0alt, b1alt, b0, b1);
     }
   } else {
     for (int g = 0; g < G; g += 4) {             // chunk g + 1 is transformed during chunk g
-      chunk(g, ry, rx, rx, std::false_type{});
-      if (g + 1 < G) chunk(g + 1, rz, rx, ry, std::true_type{});    // requests chunks g + 4, g + 5
-      if (g + 2 < G) chunk(g + 2, rw, rx, rx, std::false_type{});
-      if (g + 3 < G) chunk(g + 3, rx, rz, rw, std::true_type{});    // requests chunks g + 6, g + 7
+      chunk(g, ry, rx, rx, std::false_type{}, b0, b1, b0alt, b1alt);
+      if (g + 1 < G) chunk(g + 1, rz, rx, ry, std::true_type{}, b0alt, b1alt, b0, b1);   // requests chunks g + 4, g + 5
+      if (g + 2 < G) chunk(g + 2, rw, rx, rx, std::false_type{}, b0, b1, b0alt, b1alt);
+      if (g + 3 < G) chunk(g + 3, rx, rz, rw, std::true_type{}, b0alt, b1alt, b0, b1);   // requests chunks g + 6, g + 7
     }
   }
 #ifdef P3_DBG_TIME
