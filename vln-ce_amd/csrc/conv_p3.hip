@@ -552,6 +552,10 @@ __global__ __launch_bounds__((WM * WN + P3_PRODUCERS) * 64) void conv_p3_kernel(
     // 69 with neither -- against 58 us of pure MFMA issue at the 1.9 GHz the launch runs at
     // (profiles/r04_u_*): what the loop loses is the issue cost of its 9 memory instructions per
     // 12 MFMAs (768 B of operands per MFMA at these per-wave tiles), not their latency.)
+    // (Round 6, measured and dropped as well: the B fragments of the one- / two-block waves two
+    // (chunk, tap) steps ahead in four sets -- what paid in conv_u3: the 64-channel 3x3 layer
+    // 178 -> 156 TF/s with no spill, the other instances spill 198 registers under the 168-register
+    // cap of a 12-wave workgroup; profiles/r06_v_conv_p3_b_fragments_two_steps_ahead.txt.)
     bf16x8 fa[MT][NA];
     bf16x8 b0[NT][3], b1[NT][3];
     f32x16 acc[MT][NT];
